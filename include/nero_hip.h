@@ -1,0 +1,148 @@
+/* nero_hip.h -- C ABI of libnero_hip.so, the MI355X (gfx950) implementation of the NeRO Stage-I/II render-step hot path.
+ *
+ * The reference (liuyuan-pal/NeRO) is pure Python/PyTorch: it has no FFI for this path except two third-party CUDA
+ * extensions (`_raytracing.create_raytracer/trace`, raytracing/raytracer.py:19,49, and `nvdiffrast.torch.texture`,
+ * network/field.py:612).  The entry points below are therefore the boundary a maintainer binds with ctypes from the
+ * reference's own modules (INTEGRATION.md shows the stubs); each one cites the reference code it replaces.
+ *
+ * Conventions: every pointer is a DEVICE pointer to fp32 (or int32 where stated) unless marked host; matrices are
+ * row-major with an explicit leading dimension; every row count `n` may be any value >= 0 but all row buffers must be
+ * allocated for NERO_ROW_PAD(n) rows; every call is asynchronous on `stream` (a hipStream_t passed as void*); every
+ * function returns 0 on success or a negative error code, with a message available from nero_last_error().
+ * Nothing here allocates device memory or synchronises.
+ */
+#ifndef NERO_HIP_H
+#define NERO_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NERO_TILE_ROWS 64
+#define NERO_ROW_PAD(n) (((n) + 63) / 64 * 64)
+#define NERO_MAX_LAYERS 10
+#define NERO_HID 256              /* leading dimension of every saved hidden activation matrix */
+
+enum { NERO_ACT_NONE = 0, NERO_ACT_RELU = 1, NERO_ACT_SOFTPLUS100 = 2 };
+enum { NERO_OK = 0, NERO_ERR_ARG = -1, NERO_ERR_LAUNCH = -2, NERO_ERR_UNSUPPORTED = -3 };
+
+const char* nero_last_error(void);
+int nero_version(void);
+
+/* ---- weight packing -------------------------------------------------------------------------------------------
+ * Packs (a column window of) an effective weight matrix W[rows, ld] into the MFMA B-operand order used by the chain
+ * kernels:  out[((c*NT + nt)*64 + lane)*4 + t] = B[8c + 4(lane>>5) + t][32nt + (lane&31)] * scale, zero outside.
+ *   transpose == 0 ("forward" operand):  B[k][n] = W[n][col0 + k],  K = ncols,  N = nrows
+ *   transpose == 1 ("backward" operand): B[k][n] = W[k][col0 + n],  K = nrows,  N = ncols
+ * K is padded to a multiple of 8 (kpad), N to 32*nt_count.  Replaces the per-call cuBLAS operand handling inside
+ * nn.Linear (network/field.py:142, 266, 325-331). */
+int nero_pack_weight(const float* W, int nrows, int ld, int col0, int ncols, int transpose, float scale,
+                     int kpad, int nt_count, float* out, void* stream);
+
+/* ---- fused MLP chain ------------------------------------------------------------------------------------------
+ * One workgroup owns a tile of 64 rows and walks the whole layer list with the activations resident in LDS; every
+ * dense layer is computed with v_mfma_f32_32x32x2_f32.  Replaces the nn.Linear/softplus/ReLU sequences of
+ * SDFNetwork.forward (network/field.py:130-147), NeRFNetwork.forward (:258-283), make_predictor (:310-346). */
+typedef struct {
+    const float* w_main;   /* packed fwd operand [k_main/8][n_tiles][64][4]; input = current LDS activation tile      */
+    const float* w_aux;    /* packed fwd operand [k_aux/8][n_tiles][64][4];  input = aux tile (skip connections)      */
+    const float* bias;     /* [32*n_tiles] or NULL                                                                    */
+    float* save;           /* [rows_pad, 256] post-activation output, or NULL (forward-only evaluation)               */
+    const float* head_w;   /* optional VALU head evaluated on this layer's INPUT tile: [n_head][256] row-major        */
+    const float* head_b;   /* [n_head]                                                                                */
+    float* head_out;       /* [rows_pad, 4]                                                                           */
+    int k_main, k_aux;     /* multiples of 8 (0 = unused)                                                             */
+    int n_tiles;           /* output width / 32 (0 = head-only pseudo layer)                                          */
+    int n_head;            /* 0..4                                                                                    */
+    int act;               /* NERO_ACT_*                                                                              */
+    int head_k;            /* columns of the input tile the head reads (multiple of 4, <= 256)                        */
+} nero_fwd_layer;
+
+typedef struct {
+    const float* init;     /* [rows_pad, ld_init]: first k_init columns are loaded into the activation tile           */
+    const float* aux;      /* [rows_pad, ld_aux]: first k_aux columns are loaded into the aux tile                    */
+    int ld_init, k_init, ld_aux, k_aux;
+    int n_layers, aux_wide; /* aux_wide: 0 -> aux tile holds <= 40 columns (2 workgroups/CU), 1 -> <= 88              */
+    nero_fwd_layer layer[NERO_MAX_LAYERS];
+} nero_fwd_chain;
+
+int nero_mlp_forward(const nero_fwd_chain* chain /*host*/, int n_rows, void* stream);
+
+/* Tangent (forward-mode) pass of a softplus chain: same layer walk with  adot_l = sigma'(a_l) * (W_l adot_{l-1})  and
+ * inj_l = gbar_l * beta (1 - sigma'(a_l)) * zdot_l.  It is the "second-order" half of the backward of
+ * SDFNetwork.gradient (network/field.py:155-167, create_graph=True); SURVEY.md App. E. */
+typedef struct {
+    const float* w_main; const float* w_aux;
+    const float* a_saved;  /* [rows_pad,256] activations saved by the forward pass (for sigma')                       */
+    const float* gbar;     /* [rows_pad,256] first-order backward signal saved by the normal pass                     */
+    float* adot;           /* out [rows_pad,256]                                                                      */
+    float* inj;            /* out [rows_pad,256]                                                                      */
+    int k_main, k_aux, n_tiles, pad_;
+} nero_tan_layer;
+
+typedef struct {
+    const float* init; const float* aux;
+    int ld_init, k_init, ld_aux, k_aux;
+    int n_layers, aux_wide;
+    nero_tan_layer layer[NERO_MAX_LAYERS];
+} nero_tan_chain;
+
+int nero_mlp_tangent(const nero_tan_chain* chain /*host*/, int n_rows, void* stream);
+
+/* Reverse pass of a chain: delta_{l-1} = (delta_l W_l [+ dy_head W_head]) * act'(a_{l-1}) [+ inj_{l-1}], every delta_l
+ * written out for the weight-gradient GEMMs.  Replaces autograd's AddmmBackward / SoftplusBackward / ReluBackward
+ * chain for the same modules. */
+typedef struct {
+    const float* w_main_t; /* packed bwd operand [n_out/8][k_main/32][64][4]                                          */
+    const float* w_aux_t;  /* packed bwd operand [n_out/8][k_aux_tiles][64][4] or NULL                                */
+    const float* a_prev;   /* [rows_pad,256] saved activation of the layer's INPUT (NULL for the first layer)          */
+    const float* inj;      /* optional additive term for delta_{l-1} [rows_pad,256]                                   */
+    float* delta_prev;     /* out [rows_pad,256] (NULL for the first layer)                                           */
+    const float* head_w;   /* head on this layer's input tile: [n_head][256]                                          */
+    const float* head_dy;  /* [rows_pad,4]                                                                            */
+    int n_out;             /* K of the reverse GEMM (multiple of 8; 0 = head-only pseudo layer)                       */
+    int k_main_tiles, k_aux_tiles, n_head;
+    int act_prev;          /* activation that produced a_prev                                                         */
+    int pad_;
+} nero_bwd_layer;
+
+typedef struct {
+    const float* dy;       /* [rows_pad, ld_dy] gradient w.r.t. the LAST dense layer's pre-activation output, or NULL */
+    int ld_dy, k_dy;
+    float* d_init;         /* out [rows_pad, ld_dinit] gradient w.r.t. the init columns (NULL = not needed)           */
+    float* d_aux;          /* out [rows_pad, ld_daux]  gradient w.r.t. the aux columns, summed over the layers using it */
+    int ld_dinit, ld_daux, accumulate_dinit;
+    int n_layers, aux_wide;
+    nero_bwd_layer layer[NERO_MAX_LAYERS];   /* in FORWARD order; walked from n_layers-1 down to 0                    */
+} nero_bwd_chain;
+
+int nero_mlp_backward(const nero_bwd_chain* chain /*host*/, int n_rows, void* stream);
+
+/* ---- weight-gradient GEMM ------------------------------------------------------------------------------------
+ * dW[n][k] (+)= sum_r D0[r][n] * B0[r][k] (+ sum_r D1[r][n] * B1[r][k]),  db[n] (+)= sum_r D0[r][n]
+ * split over row slices; `partials` holds n_slices * (n_out_pad*k_pad + n_out_pad) floats of workspace and is reduced
+ * by the same call.  Output dW is row-major [n_out, ldw] written at column offset col0 (so skip-layer parts land in
+ * place), scaled by `scale`.  Replaces autograd's mm(grad.t(), input) per Linear. */
+typedef struct {
+    const float* d0; const float* b0;   /* [rows_pad, ldd0], [rows_pad, ldb0] */
+    const float* d1; const float* b1;   /* optional second pair (NULL)        */
+    int ldd0, ldb0, ldd1, ldb1;
+    int n_out, k_cols;                  /* logical sizes (<= 256 each)        */
+    float* dW; int ldw, col0;
+    float* db;                          /* [n_out] or NULL                    */
+    float scale;
+    int accumulate;                     /* 0: overwrite, 1: add into dW/db    */
+} nero_dw_job;
+
+int nero_dw_workspace_floats(int n_rows);
+int nero_dw_gemm(const nero_dw_job* job /*host*/, int n_rows, float* partials, void* stream);
+
+/* Head weight gradient: dWh[j][k] = sum_r dy[r][j] a[r][k] (+ extra[r][k] for j == 0 if extra != NULL), dbh[j] = sum_r dy[r][j]. */
+int nero_head_dw(const float* dy /*[rows,4]*/, const float* a /*[rows,256]*/, const float* extra, int n_head, int n_rows,
+                 float* dWh /*[n_head,256]*/, float* dbh, float* partials, int accumulate, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

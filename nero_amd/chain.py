@@ -1,0 +1,255 @@
+"""Host-side driver of the fused MLP-chain kernels (nero_amd/csrc/mlp_engine.hip): describes one network as a list of
+entries, packs its effective weights into the MFMA operand images once per step, and launches forward / reverse /
+weight-gradient passes through the C ABI (include/nero_hip.h).  No arithmetic happens here."""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+
+
+def _r8(x):
+    return (x + 7) // 8 * 8
+
+
+def _tiles(x):
+    return (x + 31) // 32
+
+
+def row_pad(n):
+    return (n + 63) // 64 * 64
+
+
+class Dense:
+    """one Linear: W [n_out, k_total] (row-major, autograd tensor allowed), columns [main_c0, main_c0+k_main) multiply the
+    resident activation tile, columns [aux_c0, aux_c0+k_aux) multiply the aux tile; `scale` is folded into the packed
+    operand (SDF skip: 1/sqrt(2))."""
+
+    def __init__(self, W, b, act, k_main, main_c0=0, k_aux=0, aux_c0=0, scale=1.0):
+        self.W, self.b, self.act = W, b, act
+        self.k_main, self.main_c0, self.k_aux, self.aux_c0, self.scale = k_main, main_c0, k_aux, aux_c0, scale
+        self.n_out = W.shape[0]
+
+
+class Head:
+    """VALU head evaluated on the INPUT tile of its entry: W [n_head<=4, k<=256]."""
+
+    def __init__(self, W, b):
+        self.W, self.b = W, b
+        self.n_head, self.k = W.shape
+
+
+class Chain:
+    def __init__(self, entries, k_init, k_aux=0, aux_wide=False, device='cuda'):
+        """entries: list of (Dense|None, Head|None).  k_init / k_aux: padded widths (multiples of 4) of the init / aux
+        matrices that are loaded into LDS."""
+        assert len(entries) <= L.MAX_LAYERS
+        self.entries, self.k_init, self.k_aux, self.aux_wide, self.device = entries, k_init, k_aux, aux_wide, device
+        self.dense_idx = [i for i, (d, _) in enumerate(entries) if d is not None]
+        self._packed = None
+
+    # ------------------------------------------------------------------------------------------------------------
+    def pack(self):
+        """(re)build the packed operand images from the current effective weights (call once per optimisation step)."""
+        st = L.stream_ptr()
+        sizes = []
+        for d, h in self.entries:
+            e = {}
+            if d is not None:
+                nt = _tiles(d.n_out)
+                e['fm'] = (_r8(d.k_main) // 8) * nt * 256 if d.k_main else 0
+                e['fa'] = (_r8(d.k_aux) // 8) * nt * 256 if d.k_aux else 0
+                e['bm'] = (_r8(d.n_out) // 8) * _tiles(d.k_main) * 256 if d.k_main else 0
+                e['ba'] = (_r8(d.n_out) // 8) * _tiles(d.k_aux) * 256 if d.k_aux else 0
+                e['bias'] = 32 * nt
+            if h is not None:
+                e['hw'] = 4 * L.HID
+                e['hb'] = 4
+            sizes.append(e)
+        total = sum(sum(e.values()) for e in sizes)
+        buf = torch.zeros(total, dtype=torch.float32, device=self.device)
+        off = 0
+        packed = []
+        for (d, h), e in zip(self.entries, sizes):
+            p = {}
+            for k, n in e.items():
+                p[k] = buf[off:off + n] if n else None
+                off += n
+            if d is not None:
+                W = d.W.detach()
+                assert W.stride(1) == 1
+                nt = _tiles(d.n_out)
+                if d.k_main:
+                    L.check(L.lib.nero_pack_weight(C.c_void_p(W.data_ptr()), d.n_out, W.stride(0), d.main_c0, d.k_main, 0,
+                                                   C.c_float(d.scale), _r8(d.k_main), nt, C.c_void_p(p['fm'].data_ptr()), st))
+                    L.check(L.lib.nero_pack_weight(C.c_void_p(W.data_ptr()), d.n_out, W.stride(0), d.main_c0, d.k_main, 1,
+                                                   C.c_float(d.scale), _r8(d.n_out), _tiles(d.k_main), C.c_void_p(p['bm'].data_ptr()), st))
+                if d.k_aux:
+                    L.check(L.lib.nero_pack_weight(C.c_void_p(W.data_ptr()), d.n_out, W.stride(0), d.aux_c0, d.k_aux, 0,
+                                                   C.c_float(d.scale), _r8(d.k_aux), nt, C.c_void_p(p['fa'].data_ptr()), st))
+                    L.check(L.lib.nero_pack_weight(C.c_void_p(W.data_ptr()), d.n_out, W.stride(0), d.aux_c0, d.k_aux, 1,
+                                                   C.c_float(d.scale), _r8(d.n_out), _tiles(d.k_aux), C.c_void_p(p['ba'].data_ptr()), st))
+                if d.b is not None:
+                    p['bias'][:d.n_out].copy_(d.b.detach())
+            if h is not None:
+                p['hw'].view(4, L.HID)[:h.n_head, :h.k].copy_(h.W.detach())
+                if h.b is not None:
+                    p['hb'][:h.n_head].copy_(h.b.detach())
+            packed.append(p)
+        self._packed, self._buf = packed, buf
+        return self
+
+    # ------------------------------------------------------------------------------------------------------------
+    def forward(self, init, aux, n_rows, save=True):
+        """-> dict(saves=[per dense entry: [rows_pad,256] or None], heads={entry: [rows_pad,4]})"""
+        assert self._packed is not None
+        rp = row_pad(n_rows)
+        ch = L.FwdChain()
+        ch.init, ch.ld_init, ch.k_init = L.ptr(init), (init.stride(0) if init is not None else 0), self.k_init
+        ch.aux, ch.ld_aux, ch.k_aux = L.ptr(aux), (aux.stride(0) if aux is not None else 0), self.k_aux
+        ch.n_layers, ch.aux_wide = len(self.entries), int(self.aux_wide)
+        if init is not None:
+            assert init.shape[0] >= rp and init.shape[1] >= self.k_init
+        if aux is not None:
+            assert aux.shape[0] >= rp and aux.shape[1] >= self.k_aux
+        nd = len(self.dense_idx)
+        last_dense = self.dense_idx[-1] if nd else -1
+        saves, heads = [None] * len(self.entries), {}
+        n_save = sum(1 for i in self.dense_idx if save or i == last_dense)
+        sbuf = torch.empty((n_save, rp, L.HID), dtype=torch.float32, device=self.device)
+        si = 0
+        for i, ((d, h), p) in enumerate(zip(self.entries, self._packed)):
+            fl = ch.layer[i]
+            if h is not None:
+                ho = torch.empty((rp, 4), dtype=torch.float32, device=self.device)
+                heads[i] = ho
+                fl.head_w, fl.head_b, fl.head_out = p['hw'].data_ptr(), p['hb'].data_ptr(), ho.data_ptr()
+                fl.n_head, fl.head_k = h.n_head, (h.k + 3) // 4 * 4
+            if d is not None:
+                fl.w_main = L.ptr(p['fm'])
+                fl.w_aux = L.ptr(p['fa'])
+                fl.bias = p['bias'].data_ptr()
+                fl.k_main, fl.k_aux = (_r8(d.k_main) if d.k_main else 0), (_r8(d.k_aux) if d.k_aux else 0)
+                fl.n_tiles, fl.act = _tiles(d.n_out), d.act
+                if save or i == last_dense:
+                    saves[i] = sbuf[si]
+                    si += 1
+                    fl.save = saves[i].data_ptr()
+        L.check(L.lib.nero_mlp_forward(C.byref(ch), n_rows, L.stream_ptr()))
+        return {'saves': saves, 'heads': heads, '_keep': (init, aux)}
+
+    # ------------------------------------------------------------------------------------------------------------
+    def backward(self, fwd, n_rows, dy=None, head_dys=None, need_dinit=False, need_daux=False, injs=None,
+                 dinit_out=None, accumulate_dinit=False):
+        """reverse pass.  dy: [rows_pad, >=n_out_last] gradient w.r.t. the last dense output (or w.r.t. the last
+        pseudo-entry's input tile).  head_dys: {entry: [rows_pad,4]}.  injs: {dense entry: [rows_pad,256]} added to the
+        delta of that entry's OUTPUT.  -> dict(deltas={entry: [rows_pad,256]}, d_init, d_aux)"""
+        head_dys = head_dys or {}
+        injs = injs or {}
+        rp = row_pad(n_rows)
+        saves = fwd['saves']
+        ch = L.BwdChain()
+        ch.n_layers, ch.aux_wide = len(self.entries), 0
+        last = len(self.entries) - 1
+        if dy is not None:
+            ch.dy, ch.ld_dy = dy.data_ptr(), dy.stride(0)
+            d_last = self.entries[last][0]
+            ch.k_dy = _r8(d_last.n_out) if d_last is not None else L.HID
+            assert dy.shape[1] >= ch.k_dy
+        d_init = d_aux = None
+        if need_dinit:
+            d_init = dinit_out if dinit_out is not None else torch.empty((rp, self.k_init), dtype=torch.float32, device=self.device)
+            ch.d_init, ch.ld_dinit, ch.accumulate_dinit = d_init.data_ptr(), d_init.stride(0), int(accumulate_dinit)
+        if need_daux:
+            d_aux = torch.zeros((rp, self.k_aux), dtype=torch.float32, device=self.device)
+            ch.d_aux, ch.ld_daux = d_aux.data_ptr(), d_aux.stride(0)
+        deltas = {}
+        n_delta = len(self.dense_idx)
+        dbuf = torch.empty((n_delta, rp, L.HID), dtype=torch.float32, device=self.device)
+        prev_dense = {}
+        pd = None
+        for i, (d, h) in enumerate(self.entries):
+            prev_dense[i] = pd
+            if d is not None:
+                pd = i
+        for k, i in enumerate(self.dense_idx):
+            deltas[i] = dbuf[k]
+        for i, ((d, h), p) in enumerate(zip(self.entries, self._packed)):
+            bl = ch.layer[i]
+            j = prev_dense[i]                      # dense entry that produced this entry's input tile
+            if d is not None:
+                bl.w_main_t = L.ptr(p['bm'])
+                bl.w_aux_t = L.ptr(p['ba']) if need_daux else None
+                bl.n_out = _r8(d.n_out)
+                bl.k_main_tiles = _tiles(d.k_main) if d.k_main else 0
+                bl.k_aux_tiles = _tiles(d.k_aux) if d.k_aux else 0
+            else:
+                bl.n_out = 0
+                bl.k_main_tiles = _tiles(self.entries[j][0].n_out)
+            if h is not None and i in head_dys:
+                bl.head_w, bl.head_dy, bl.n_head = p['hw'].data_ptr(), head_dys[i].data_ptr(), h.n_head
+            if j is not None:
+                bl.a_prev = saves[j].data_ptr()
+                bl.act_prev = self.entries[j][0].act
+                bl.delta_prev = deltas[j].data_ptr()
+                if j in injs:
+                    bl.inj = injs[j].data_ptr()
+        # the delta of the last dense entry is dy itself when that entry is the chain's last entry
+        if self.entries[last][0] is not None:
+            assert dy is not None and self.entries[last][0].act == L.ACT_NONE
+            deltas[last] = dy
+        L.check(L.lib.nero_mlp_backward(C.byref(ch), n_rows, L.stream_ptr()))
+        return {'deltas': deltas, 'd_init': d_init, 'd_aux': d_aux}
+
+    # ------------------------------------------------------------------------------------------------------------
+    def weight_grads(self, fwd, bwd, n_rows, init, aux, head_dys=None, workspace=None, second=None, head_extra=None):
+        """-> list per entry of dict(dW, db, dWh, dbh) (torch tensors shaped like the effective weights).
+        second: optional {dense entry: (D1 [rows,256], B1_main [rows,256] or init-like, B1_aux)} extra operand pair
+        accumulated into the same dW (SDF double-backward)."""
+        head_dys = head_dys or {}
+        second = second or {}
+        head_extra = head_extra or {}
+        if workspace is None:
+            workspace = torch.empty(L.lib.nero_dw_workspace_floats(max(n_rows, 1)), dtype=torch.float32, device=self.device)
+        st = L.stream_ptr()
+        out = []
+        prev = None
+        for i, (d, h) in enumerate(self.entries):
+            g = {}
+            if h is not None and i in head_dys:
+                a_in = fwd['saves'][prev]
+                g['dWh'] = torch.empty((4, L.HID), dtype=torch.float32, device=self.device)
+                g['dbh'] = torch.empty(4, dtype=torch.float32, device=self.device)
+                L.check(L.lib.nero_head_dw(C.c_void_p(head_dys[i].data_ptr()), C.c_void_p(a_in.data_ptr()),
+                                           C.c_void_p(L.ptr(head_extra.get(i))), h.n_head, n_rows,
+                                           C.c_void_p(g['dWh'].data_ptr()), C.c_void_p(g['dbh'].data_ptr()),
+                                           C.c_void_p(workspace.data_ptr()), 0, st))
+                g['dWh'] = g['dWh'][:h.n_head, :h.k]
+                g['dbh'] = g['dbh'][:h.n_head]
+            if d is not None:
+                delta = bwd['deltas'][i]
+                dW = torch.empty_like(d.W.detach())
+                db = torch.empty(d.n_out, dtype=torch.float32, device=self.device)
+                main_in = init if prev is None else fwd['saves'][prev]
+                sec = second.get(i)
+                parts = []
+                if d.k_main:
+                    parts.append((main_in, d.k_main, d.main_c0, 0))
+                if d.k_aux:
+                    parts.append((aux, d.k_aux, d.aux_c0, 1))
+                for pi, (Bm, kc, c0, which) in enumerate(parts):
+                    job = L.DwJob()
+                    job.d0, job.ldd0, job.b0, job.ldb0 = delta.data_ptr(), delta.stride(0), Bm.data_ptr(), Bm.stride(0)
+                    if sec is not None:
+                        D1, B1 = sec[0], sec[1 + which]
+                        job.d1, job.ldd1, job.b1, job.ldb1 = D1.data_ptr(), D1.stride(0), B1.data_ptr(), B1.stride(0)
+                    job.n_out, job.k_cols = d.n_out, kc
+                    job.dW, job.ldw, job.col0 = dW.data_ptr(), dW.stride(0), c0
+                    job.db = db.data_ptr() if pi == 0 else None
+                    job.scale, job.accumulate = d.scale, 0
+                    L.check(L.lib.nero_dw_gemm(C.byref(job), n_rows, C.c_void_p(workspace.data_ptr()), st))
+                g['dW'], g['db'] = dW, db
+                prev = i
+            out.append(g)
+        return out

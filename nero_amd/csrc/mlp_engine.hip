@@ -1,0 +1,587 @@
+// mlp_engine.hip -- fused MLP-chain kernels for gfx950 (MI355X): forward, tangent (forward-mode), reverse and
+// weight-gradient GEMM, all on v_mfma_f32_32x32x2_f32 (exact fp32, 157 TFLOP/s dense peak).
+//
+// Design: one 256-thread workgroup owns a tile of 64 rows (ray samples) and walks the whole layer list
+// of one network with the activations resident in LDS ([64][260] fp32, row stride 260 -> conflict-free ds_read_b128
+// A fragments).  The four waves split the output columns (2 column tiles of 32 each); B fragments (weights) are read
+// straight from the L2-resident packed weight image with one coalesced 16-byte load per lane per 8 k-values -- weights
+// are never shared between waves, so staging them through LDS would buy nothing.  Two workgroups per CU overlap one
+// tile's VALU epilogue (bias, softplus, stores) with the other's MFMA stream.
+//
+// k-ordering inside a chunk of 8: MFMA t (t=0..3) consumes k = 8c + 4h + t from lane half h, which makes the A fragment
+// 4 contiguous floats per lane (one ds_read_b128) and the packed B image a plain float4 per lane.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/nero_hip.h"
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int LDA = 260;          // activation tile row stride (floats)
+constexpr int LDX_NARROW = 44;    // aux tile row stride, <= 40 columns
+constexpr int LDX_WIDE = 92;      // aux tile row stride, <= 88 columns
+constexpr float BETA = 100.0f;
+
+struct WaveTiles { int ct0, n; };
+
+__device__ __forceinline__ WaveTiles wave_tiles(int nt, int wave) {
+    int per = nt > 4 ? 2 : 1;
+    int ct0 = wave * per;
+    int n = nt - ct0;
+    n = n < 0 ? 0 : (n > per ? per : n);
+    return {ct0, n};
+}
+
+// acc[rt][ct] += A[64 x 8*nchunks] (LDS, stride lds) * B (packed), for this wave's column tiles.
+__device__ __forceinline__ void gemm_part(f32x16 (&acc)[2][2], const float* tile, int lds, int nchunks,
+                                          const float* __restrict__ wpack, int nt, WaveTiles wt, int lane) {
+    if (nchunks <= 0 || wt.n == 0) return;
+    const int i = lane & 31, h = lane >> 5;
+    const float* a0p = tile + i * lds + 4 * h;
+    const float* a1p = a0p + 32 * lds;
+    const float4* bp = reinterpret_cast<const float4*>(wpack) + (size_t)wt.ct0 * 64 + lane;
+    const size_t bstride = (size_t)nt * 64;          // float4 per chunk
+    if (wt.n == 2) {
+#pragma unroll 2
+        for (int c = 0; c < nchunks; ++c) {
+            float4 b0 = bp[c * bstride], b1 = bp[c * bstride + 64];
+            float4 a0 = *reinterpret_cast<const float4*>(a0p + 8 * c);
+            float4 a1 = *reinterpret_cast<const float4*>(a1p + 8 * c);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b1.x, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b1.y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b1.z, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b0.z, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b1.w, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc[1][1], 0, 0, 0);
+        }
+    } else {
+#pragma unroll 2
+        for (int c = 0; c < nchunks; ++c) {
+            float4 b0 = bp[c * bstride];
+            float4 a0 = *reinterpret_cast<const float4*>(a0p + 8 * c);
+            float4 a1 = *reinterpret_cast<const float4*>(a1p + 8 * c);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, acc[1][0], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, acc[1][0], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b0.z, acc[1][0], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, acc[1][0], 0, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[r][c][v] = 0.f;
+}
+
+// C/D layout of the 32x32 MFMA: col = lane&31, row = (v&3) + 8*(v>>2) + 4*(lane>>5)
+#define FOR_EACH_ACC(WT, BODY)                                                                   \
+    _Pragma("unroll") for (int rt = 0; rt < 2; ++rt) _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) {          \
+        if (ct < (WT).n) {                                                                       \
+            const int col = 32 * ((WT).ct0 + ct) + (lane & 31);                                  \
+            _Pragma("unroll") for (int v = 0; v < 16; ++v) {                                     \
+                const int row = 32 * rt + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);              \
+                float x = acc[rt][ct][v];                                                        \
+                BODY                                                                             \
+                acc[rt][ct][v] = x;                                                              \
+            }                                                                                    \
+        }                                                                                        \
+    }
+
+__device__ __forceinline__ float softplus100(float x) {
+    float bx = BETA * x;
+    return bx > 20.f ? x : log1pf(expf(bx)) * (1.0f / BETA);
+}
+// sigma'(z) recovered from a = softplus(z):  1 - exp(-beta a)  (== 1 in torch's linear region beta z > 20)
+__device__ __forceinline__ float softplus100_grad_from_out(float a) {
+    float ba = BETA * a;
+    return ba > 20.f ? 1.f : -expm1f(-ba);
+}
+
+// copy [64][k] from a row-major global matrix into an LDS tile (k multiple of 4, rows clamped to n_rows-1)
+__device__ __forceinline__ void load_tile(float* tile, int lds, const float* __restrict__ src, int ld, int k, int row0,
+                                          int n_rows, int tid) {
+    const int k4 = k >> 2;
+    for (int idx = tid; idx < 64 * k4; idx += 256) {
+        int r = idx / k4, c4 = idx - r * k4;
+        int gr = row0 + r;
+        gr = gr < n_rows ? gr : (n_rows - 1);
+        float4 v = *reinterpret_cast<const float4*>(src + (size_t)gr * ld + 4 * c4);
+        *reinterpret_cast<float4*>(tile + r * lds + 4 * c4) = v;
+    }
+}
+
+// VALU head on the current activation tile: out[r][j] = b[j] + sum_k tile[r][k] * W[j][k], k < hk
+__device__ __forceinline__ void eval_head(const float* tile, const float* __restrict__ w, const float* __restrict__ b,
+                                          float* __restrict__ out, int n_head, int hk, int row0, int tid) {
+    const int r = tid >> 2, q = tid & 3;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* arow = tile + r * LDA + q;
+    for (int i = 0; i < (hk >> 2); ++i) {
+        float a = arow[4 * i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < n_head) s[j] = fmaf(a, w[j * NERO_HID + 4 * i + q], s[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s[j] += __shfl_xor(s[j], 1);
+        s[j] += __shfl_xor(s[j], 2);
+    }
+    if (q == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < n_head) out[(size_t)(row0 + r) * 4 + j] = s[j] + (b ? b[j] : 0.f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward chain
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool WIDE>
+__global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(nero_fwd_chain ch, int n_rows) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int LDX = WIDE ? LDX_WIDE : LDX_NARROW;
+    float* act = smem;
+    float* aux = smem + 64 * LDA;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = blockIdx.x * 64;
+    if (ch.init) load_tile(act, LDA, ch.init, ch.ld_init, ch.k_init, row0, n_rows, tid);
+    if (ch.aux) load_tile(aux, LDX, ch.aux, ch.ld_aux, ch.k_aux, row0, n_rows, tid);
+    __syncthreads();
+    for (int l = 0; l < ch.n_layers; ++l) {
+        const nero_fwd_layer& L = ch.layer[l];
+        if (L.n_head > 0) eval_head(act, L.head_w, L.head_b, L.head_out, L.n_head, L.head_k, row0, tid);
+        if (L.n_tiles == 0) continue;
+        f32x16 acc[2][2];
+        zero_acc(acc);
+        const WaveTiles wt = wave_tiles(L.n_tiles, wave);
+        gemm_part(acc, act, LDA, L.k_main >> 3, L.w_main, L.n_tiles, wt, lane);
+        gemm_part(acc, aux, LDX, L.k_aux >> 3, L.w_aux, L.n_tiles, wt, lane);
+        __syncthreads();                               // every wave is done reading the input tile
+        const float* __restrict__ bias = L.bias;
+        float* __restrict__ save = L.save;
+        const int actk = L.act;
+        FOR_EACH_ACC(wt, {
+            float y = x + (bias ? bias[col] : 0.f);
+            if (actk == NERO_ACT_RELU) y = fmaxf(y, 0.f);
+            else if (actk == NERO_ACT_SOFTPLUS100) y = softplus100(y);
+            act[row * LDA + col] = y;
+            if (save) save[(size_t)(row0 + row) * NERO_HID + col] = y;
+        })
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// tangent chain (softplus networks):  adot_l = s_l * (W_l adot_{l-1}),  inj_l = gbar_l * beta (1-s_l) * zdot_l
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool WIDE>
+__global__ __launch_bounds__(256, 2) void mlp_tan_kernel(nero_tan_chain ch, int n_rows) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int LDX = WIDE ? LDX_WIDE : LDX_NARROW;
+    float* act = smem;
+    float* aux = smem + 64 * LDA;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = blockIdx.x * 64;
+    if (ch.init) load_tile(act, LDA, ch.init, ch.ld_init, ch.k_init, row0, n_rows, tid);
+    if (ch.aux) load_tile(aux, LDX, ch.aux, ch.ld_aux, ch.k_aux, row0, n_rows, tid);
+    __syncthreads();
+    for (int l = 0; l < ch.n_layers; ++l) {
+        const nero_tan_layer& L = ch.layer[l];
+        f32x16 acc[2][2];
+        zero_acc(acc);
+        const WaveTiles wt = wave_tiles(L.n_tiles, wave);
+        gemm_part(acc, act, LDA, L.k_main >> 3, L.w_main, L.n_tiles, wt, lane);
+        gemm_part(acc, aux, LDX, L.k_aux >> 3, L.w_aux, L.n_tiles, wt, lane);
+        __syncthreads();
+        const float* __restrict__ asv = L.a_saved;
+        const float* __restrict__ gb = L.gbar;
+        float* __restrict__ adot = L.adot;
+        float* __restrict__ inj = L.inj;
+        FOR_EACH_ACC(wt, {
+            const size_t g = (size_t)(row0 + row) * NERO_HID + col;
+            const float a = asv[g];
+            const float s = softplus100_grad_from_out(a);
+            const float ad = s * x;
+            act[row * LDA + col] = ad;
+            const bool live = (row0 + row) < n_rows;
+            adot[g] = live ? ad : 0.f;
+            // sigma''/sigma' = beta (1 - s); zero in the linear region (torch: softplus double-backward is 0 there)
+            const float r2 = (BETA * a > 20.f) ? 0.f : BETA * (1.f - s);
+            inj[g] = live ? gb[g] * r2 * x : 0.f;
+        })
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// reverse chain
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool WIDE>
+__global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(nero_bwd_chain ch, int n_rows) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* act = smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = blockIdx.x * 64;
+    if (ch.dy) load_tile(act, LDA, ch.dy, ch.ld_dy, ch.k_dy, row0, n_rows, tid);
+    __syncthreads();
+    for (int l = ch.n_layers - 1; l >= 0; --l) {
+        const nero_bwd_layer& L = ch.layer[l];
+        const bool first = (L.a_prev == nullptr);
+        if (first && ch.d_init == nullptr && !(ch.d_aux && L.w_aux_t)) break;
+        f32x16 acc[2][2];
+        zero_acc(acc);
+        const int nt = L.k_main_tiles;
+        const WaveTiles wt = wave_tiles(nt, wave);
+        if (L.n_out > 0) {
+            gemm_part(acc, act, LDA, L.n_out >> 3, L.w_main_t, nt, wt, lane);
+        } else if (ch.dy) {
+            // head-only pseudo layer: the tile already is the gradient w.r.t. this layer's input
+            FOR_EACH_ACC(wt, { x = act[row * LDA + col]; })
+        }
+        // gradient w.r.t. the aux columns of this layer (skip connections), written straight out
+        if (ch.d_aux && L.w_aux_t && L.n_out > 0) {
+            f32x16 acx[2][2];
+            zero_acc(acx);
+            const WaveTiles wx = wave_tiles(L.k_aux_tiles, wave);
+            gemm_part(acx, act, LDA, L.n_out >> 3, L.w_aux_t, L.k_aux_tiles, wx, lane);
+            float* __restrict__ dax = ch.d_aux;
+            const int ldx = ch.ld_daux;
+            {
+                f32x16 (&acc)[2][2] = acx;
+                FOR_EACH_ACC(wx, { if (col < ldx) dax[(size_t)(row0 + row) * ldx + col] = x; })
+            }
+        }
+        __syncthreads();
+        if (first) {
+            if (ch.d_init) {
+                float* __restrict__ di = ch.d_init;
+                const int ldi = ch.ld_dinit;
+                const bool accum = ch.accumulate_dinit != 0;
+                FOR_EACH_ACC(wt, {
+                    if (col < ldi) {
+                        const size_t g = (size_t)(row0 + row) * ldi + col;
+                        di[g] = accum ? di[g] + x : x;
+                    }
+                })
+            }
+            break;
+        }
+        const float* __restrict__ ap = L.a_prev;
+        const float* __restrict__ inj = L.inj;
+        float* __restrict__ dprev = L.delta_prev;
+        const float* __restrict__ hw = L.head_w;
+        const float* __restrict__ hdy = L.head_dy;
+        const int nh = L.n_head, actp = L.act_prev;
+        FOR_EACH_ACC(wt, {
+            const size_t g = (size_t)(row0 + row) * NERO_HID + col;
+            float gsum = x;
+            if (nh > 0) {
+                const float4 dyh = *reinterpret_cast<const float4*>(hdy + (size_t)(row0 + row) * 4);
+                gsum = fmaf(dyh.x, hw[col], gsum);
+                if (nh > 1) gsum = fmaf(dyh.y, hw[NERO_HID + col], gsum);
+                if (nh > 2) gsum = fmaf(dyh.z, hw[2 * NERO_HID + col], gsum);
+                if (nh > 3) gsum = fmaf(dyh.w, hw[3 * NERO_HID + col], gsum);
+            }
+            const float a = ap[g];
+            float d;
+            if (actp == NERO_ACT_RELU) d = a > 0.f ? gsum : 0.f;
+            else if (actp == NERO_ACT_SOFTPLUS100) d = gsum * softplus100_grad_from_out(a);
+            else d = gsum;
+            if (inj) d += inj[g];
+            if (row0 + row >= n_rows) d = 0.f;
+            act[row * LDA + col] = d;
+            if (dprev) dprev[g] = d;
+        })
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// weight-gradient GEMM:  C[n][k] = sum_r D[r][n] B[r][k]   (split over row slices, fixed-order reduction)
+// 512 threads = 8 waves in a 4(n) x 2(k) grid; each wave owns a 64x128 block = 2x4 tiles of 32x32 (128 acc VGPRs).
+// Row chunks of 32 are staged through LDS with coalesced 16-byte loads.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int DW_RC = 32;           // rows per staged chunk
+constexpr int DW_LD = 256;
+
+__device__ __forceinline__ void dw_stage(float* dst, const float* __restrict__ src, int ld, int cols, int r0, int r1, int tid) {
+    // rows [r0, r0+32) of src -> dst[32][256]; columns >= cols are zero; rows >= r1 are zero
+    const int c4n = DW_LD >> 2;
+    for (int idx = tid; idx < DW_RC * c4n; idx += 512) {
+        int r = idx / c4n, c4 = idx - r * c4n;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        int gr = r0 + r;
+        if (gr < r1 && 4 * c4 < cols) {
+            const float* p = src + (size_t)gr * ld + 4 * c4;
+            if (4 * c4 + 3 < cols) v = *reinterpret_cast<const float4*>(p);
+            else { v.x = p[0]; if (4 * c4 + 1 < cols) v.y = p[1]; if (4 * c4 + 2 < cols) v.z = p[2]; }
+        }
+        *reinterpret_cast<float4*>(dst + r * DW_LD + 4 * c4) = v;
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void dw_gemm_kernel(nero_dw_job job, int n_rows, int rows_per_slice, float* __restrict__ partials,
+                                                          int n_pad, int k_pad) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sD = smem;                    // [32][256]
+    float* sB = smem + DW_RC * DW_LD;    // [32][256]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int i = lane & 31, h = lane >> 5;
+    const int r_begin = blockIdx.x * rows_per_slice;
+    int r_end = r_begin + rows_per_slice;
+    r_end = r_end < n_rows ? r_end : n_rows;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
+    float bsum = 0.f;                    // bias gradient: thread tid < 256 owns column tid of D0
+    const int n_tiles = n_pad >> 5, k_tiles = k_pad >> 5;
+    const bool wave_live = (2 * wn < n_tiles) && (4 * wk < k_tiles);
+    for (int pair = 0; pair < 2; ++pair) {
+        const float* D = pair == 0 ? job.d0 : job.d1;
+        const float* B = pair == 0 ? job.b0 : job.b1;
+        if (!D) continue;
+        const int ldd = pair == 0 ? job.ldd0 : job.ldd1, ldb = pair == 0 ? job.ldb0 : job.ldb1;
+        for (int r0 = r_begin; r0 < r_end; r0 += DW_RC) {
+            __syncthreads();
+            dw_stage(sD, D, ldd, job.n_out, r0, r_end, tid);
+            dw_stage(sB, B, ldb, job.k_cols, r0, r_end, tid);
+            __syncthreads();
+            if (pair == 0 && tid < 256) {
+#pragma unroll 8
+                for (int r = 0; r < DW_RC; ++r) bsum += sD[r * DW_LD + tid];
+            }
+            if (wave_live) {
+#pragma unroll 4
+                for (int j = 0; j < DW_RC / 2; ++j) {
+                    const float* dr = sD + (2 * j + h) * DW_LD + 64 * wn + i;
+                    const float* br = sB + (2 * j + h) * DW_LD + 128 * wk + i;
+                    float a0 = dr[0], a1 = dr[32];
+                    float b0 = br[0], b1 = br[32], b2 = br[64], b3 = br[96];
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b2, acc[0][2], 0, 0, 0);
+                    acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b3, acc[0][3], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                    acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b2, acc[1][2], 0, 0, 0);
+                    acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b3, acc[1][3], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // write this slice's partial C (row-major [n_pad][k_pad]) and bias partial
+    float* __restrict__ P = partials + (size_t)blockIdx.x * ((size_t)n_pad * k_pad + n_pad);
+    if (wave_live) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int nt = 2 * wn + a, kt = 4 * wk + b;
+                if (nt < n_tiles && kt < k_tiles) {
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const int row = 32 * nt + (v & 3) + 8 * (v >> 2) + 4 * h;
+                        P[(size_t)row * k_pad + 32 * kt + i] = acc[a][b][v];
+                    }
+                }
+            }
+    }
+    if (tid < n_pad) P[(size_t)n_pad * k_pad + tid] = bsum;
+}
+
+__global__ void dw_reduce_kernel(nero_dw_job job, const float* __restrict__ partials, int n_slices, int n_pad, int k_pad) {
+    const size_t per = (size_t)n_pad * k_pad + n_pad;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = job.n_out * job.k_cols;
+    if (idx < total) {
+        const int n = idx / job.k_cols, k = idx - n * job.k_cols;
+        float s = 0.f;
+        for (int sl = 0; sl < n_slices; ++sl) s += partials[sl * per + (size_t)n * k_pad + k];
+        float* o = job.dW + (size_t)n * job.ldw + job.col0 + k;
+        *o = job.accumulate ? *o + s * job.scale : s * job.scale;
+    } else if (idx < total + job.n_out && job.db) {
+        const int n = idx - total;
+        float s = 0.f;
+        for (int sl = 0; sl < n_slices; ++sl) s += partials[sl * per + (size_t)n_pad * k_pad + n];
+        job.db[n] = job.accumulate ? job.db[n] + s : s;
+    }
+}
+
+// head weight gradient: thread k (256) accumulates dWh[j][k] over the slice's rows
+__global__ __launch_bounds__(256) void head_dw_kernel(const float* __restrict__ dy, const float* __restrict__ a,
+                                                      const float* __restrict__ extra, int n_head, int n_rows,
+                                                      int rows_per_slice, float* __restrict__ partials) {
+    const int k = threadIdx.x;
+    const int r_begin = blockIdx.x * rows_per_slice;
+    int r_end = r_begin + rows_per_slice;
+    r_end = r_end < n_rows ? r_end : n_rows;
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = r_begin; r < r_end; ++r) {
+        const float4 d = *reinterpret_cast<const float4*>(dy + (size_t)r * 4);
+        const float av = a[(size_t)r * NERO_HID + k];
+        s[0] = fmaf(d.x, av, s[0]); s[1] = fmaf(d.y, av, s[1]); s[2] = fmaf(d.z, av, s[2]); s[3] = fmaf(d.w, av, s[3]);
+        if (extra) s[0] += extra[(size_t)r * NERO_HID + k];
+        sb[0] += d.x; sb[1] += d.y; sb[2] += d.z; sb[3] += d.w;
+    }
+    float* P = partials + (size_t)blockIdx.x * (4 * NERO_HID + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) P[j * NERO_HID + k] = s[j];
+    if (k < 4) P[4 * NERO_HID + k] = sb[k];
+    (void)n_head;
+}
+
+__global__ void head_dw_reduce_kernel(const float* __restrict__ partials, int n_slices, int n_head, float* __restrict__ dWh,
+                                      float* __restrict__ dbh, int accumulate) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t per = 4 * NERO_HID + 4;
+    if (idx < n_head * NERO_HID) {
+        float s = 0.f;
+        for (int sl = 0; sl < n_slices; ++sl) s += partials[sl * per + idx];
+        dWh[idx] = accumulate ? dWh[idx] + s : s;
+    } else if (idx < n_head * NERO_HID + n_head && dbh) {
+        const int j = idx - n_head * NERO_HID;
+        float s = 0.f;
+        for (int sl = 0; sl < n_slices; ++sl) s += partials[sl * per + 4 * NERO_HID + j];
+        dbh[j] = accumulate ? dbh[j] + s : s;
+    }
+}
+
+__global__ void pack_weight_kernel(const float* __restrict__ W, int nrows, int ld, int col0, int ncols, int transpose,
+                                   float scale, int kpad, int nt_count, float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = (kpad >> 3) * nt_count * 64 * 4;
+    if (idx >= total) return;
+    const int t = idx & 3, lane = (idx >> 2) & 63;
+    const int rest = idx >> 8;
+    const int nt = rest % nt_count, c = rest / nt_count;
+    const int k = 8 * c + 4 * (lane >> 5) + t, n = 32 * nt + (lane & 31);
+    float v = 0.f;
+    if (!transpose) { if (k < ncols && n < nrows) v = W[(size_t)n * ld + col0 + k]; }
+    else            { if (k < nrows && n < ncols) v = W[(size_t)k * ld + col0 + n]; }
+    out[idx] = v * scale;
+}
+
+constexpr int DW_MAX_SLICES = 512;
+
+inline int dw_rows_per_slice(int n_rows) {
+    int rps = (n_rows + DW_MAX_SLICES - 1) / DW_MAX_SLICES;
+    rps = (rps + DW_RC - 1) / DW_RC * DW_RC;
+    return rps < DW_RC ? DW_RC : rps;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nero_pack_weight(const float* W, int nrows, int ld, int col0, int ncols, int transpose, float scale, int kpad,
+                     int nt_count, float* out, void* stream) {
+    if (!W || !out || kpad % 8 || nt_count <= 0) return nero_fail(NERO_ERR_ARG, "nero_pack_weight: bad argument");
+    const int total = (kpad >> 3) * nt_count * 256;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, nrows, ld, col0,
+                       ncols, transpose, scale, kpad, nt_count, out);
+    return nero_check_launch("nero_pack_weight");
+}
+
+static int lds_bytes(int wide) { return (64 * LDA + 64 * (wide ? LDX_WIDE : LDX_NARROW)) * (int)sizeof(float); }
+
+int nero_mlp_forward(const nero_fwd_chain* ch, int n_rows, void* stream) {
+    if (!ch || n_rows < 0 || ch->n_layers > NERO_MAX_LAYERS) return nero_fail(NERO_ERR_ARG, "nero_mlp_forward: bad argument");
+    if (n_rows == 0) return NERO_OK;
+    if (ch->k_aux > (ch->aux_wide ? 88 : 40) || ch->k_init > 256 || (ch->k_init & 3) || (ch->k_aux & 3))
+        return nero_fail(NERO_ERR_ARG, "nero_mlp_forward: init/aux width out of range");
+    const dim3 grid((n_rows + 63) / 64), block(256);
+    if (ch->aux_wide) {
+        NERO_ONCE(hipFuncSetAttribute((const void*)mlp_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(1)));
+        hipLaunchKernelGGL(mlp_fwd_kernel<true>, grid, block, lds_bytes(1), (hipStream_t)stream, *ch, n_rows);
+    } else {
+        NERO_ONCE(hipFuncSetAttribute((const void*)mlp_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(0)));
+        hipLaunchKernelGGL(mlp_fwd_kernel<false>, grid, block, lds_bytes(0), (hipStream_t)stream, *ch, n_rows);
+    }
+    return nero_check_launch("nero_mlp_forward");
+}
+
+int nero_mlp_tangent(const nero_tan_chain* ch, int n_rows, void* stream) {
+    if (!ch || n_rows < 0 || ch->n_layers > NERO_MAX_LAYERS) return nero_fail(NERO_ERR_ARG, "nero_mlp_tangent: bad argument");
+    if (n_rows == 0) return NERO_OK;
+    const dim3 grid((n_rows + 63) / 64), block(256);
+    if (ch->aux_wide) {
+        NERO_ONCE(hipFuncSetAttribute((const void*)mlp_tan_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(1)));
+        hipLaunchKernelGGL(mlp_tan_kernel<true>, grid, block, lds_bytes(1), (hipStream_t)stream, *ch, n_rows);
+    } else {
+        NERO_ONCE(hipFuncSetAttribute((const void*)mlp_tan_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(0)));
+        hipLaunchKernelGGL(mlp_tan_kernel<false>, grid, block, lds_bytes(0), (hipStream_t)stream, *ch, n_rows);
+    }
+    return nero_check_launch("nero_mlp_tangent");
+}
+
+int nero_mlp_backward(const nero_bwd_chain* ch, int n_rows, void* stream) {
+    if (!ch || n_rows < 0 || ch->n_layers > NERO_MAX_LAYERS) return nero_fail(NERO_ERR_ARG, "nero_mlp_backward: bad argument");
+    if (n_rows == 0) return NERO_OK;
+    const dim3 grid((n_rows + 63) / 64), block(256);
+    NERO_ONCE(hipFuncSetAttribute((const void*)mlp_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(0)));
+    hipLaunchKernelGGL(mlp_bwd_kernel<false>, grid, block, lds_bytes(0), (hipStream_t)stream, *ch, n_rows);
+    return nero_check_launch("nero_mlp_backward");
+}
+
+int nero_dw_workspace_floats(int n_rows) {
+    const int rps = dw_rows_per_slice(n_rows < 1 ? 1 : n_rows);
+    const int slices = ((n_rows < 1 ? 1 : n_rows) + rps - 1) / rps;
+    return slices * (256 * 256 + 256);
+}
+
+int nero_dw_gemm(const nero_dw_job* job, int n_rows, float* partials, void* stream) {
+    if (!job || !job->d0 || !job->b0 || !job->dW || !partials || job->n_out > 256 || job->k_cols > 256 || job->n_out <= 0 || job->k_cols <= 0)
+        return nero_fail(NERO_ERR_ARG, "nero_dw_gemm: bad argument");
+    const int n_pad = (job->n_out + 31) / 32 * 32, k_pad = (job->k_cols + 31) / 32 * 32;
+    const int rows = n_rows < 1 ? 1 : n_rows;
+    const int rps = dw_rows_per_slice(rows);
+    const int slices = (rows + rps - 1) / rps;
+    const int lds = 2 * DW_RC * DW_LD * (int)sizeof(float);
+    hipLaunchKernelGGL(dw_gemm_kernel, dim3(slices), dim3(512), lds, (hipStream_t)stream, *job, n_rows, rps, partials, n_pad, k_pad);
+    const int total = job->n_out * job->k_cols + job->n_out;
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, *job, partials, slices, n_pad, k_pad);
+    return nero_check_launch("nero_dw_gemm");
+}
+
+int nero_head_dw(const float* dy, const float* a, const float* extra, int n_head, int n_rows, float* dWh, float* dbh,
+                 float* partials, int accumulate, void* stream) {
+    if (!dy || !a || !dWh || !partials || n_head < 1 || n_head > 4) return nero_fail(NERO_ERR_ARG, "nero_head_dw: bad argument");
+    const int rows = n_rows < 1 ? 1 : n_rows;
+    int rps = (rows + 1023) / 1024;
+    rps = rps < 16 ? 16 : rps;
+    const int slices = (rows + rps - 1) / rps;
+    hipLaunchKernelGGL(head_dw_kernel, dim3(slices), dim3(256), 0, (hipStream_t)stream, dy, a, extra, n_head, n_rows, rps, partials);
+    const int total = n_head * NERO_HID + n_head;
+    hipLaunchKernelGGL(head_dw_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials, slices, n_head, dWh, dbh, accumulate);
+    return nero_check_launch("nero_head_dw");
+}
+
+}  // extern "C"

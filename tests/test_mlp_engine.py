@@ -1,0 +1,116 @@
+"""GPU tier: the fused MLP-chain kernels (forward / reverse / weight-gradient GEMM) against plain fp64 torch math
+of the same layers.  Tolerances: 2e-5 rel (fp32 accumulation-order noise over K<=340)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def _mk(n_out, n_in, g, scale=1.0):
+    W = (torch.randn(n_out, n_in, generator=g) * scale / math.sqrt(n_in)).cuda()
+    b = (torch.randn(n_out, generator=g) * 0.1).cuda()
+    return W, b
+
+
+@pytest.mark.parametrize('n_rows', [64, 1000])
+def test_predictor_chain_fwd_bwd(n_rows):
+    from nero_amd import _lib as L
+    from nero_amd.chain import Chain, Dense, Head, row_pad
+    g = torch.Generator().manual_seed(0)
+    k_in = 123
+    W0, b0 = _mk(256, k_in, g, 2.0)
+    W1, b1 = _mk(256, 256, g, 2.0)
+    W2, b2 = _mk(256, 256, g, 2.0)
+    W3, b3 = _mk(3, 256, g, 2.0)
+    rp = row_pad(n_rows)
+    kp = 128
+    X = torch.zeros(rp, kp, device='cuda')
+    X[:n_rows, :k_in] = torch.randn(n_rows, k_in, generator=g).cuda()
+    ch = Chain([(Dense(W0, b0, L.ACT_RELU, k_in), None), (Dense(W1, b1, L.ACT_RELU, 256), None),
+                (Dense(W2, b2, L.ACT_RELU, 256), None), (None, Head(W3, b3))], k_init=kp).pack()
+    fwd = ch.forward(X, None, n_rows)
+    Ws = [w.double().cpu().requires_grad_(True) for w in (W0, W1, W2, W3)]
+    bs = [b.double().cpu().requires_grad_(True) for b in (b0, b1, b2, b3)]
+    x = X[:n_rows, :k_in].double().cpu().requires_grad_(True)
+    h = x
+    for i in range(3):
+        h = F.relu(F.linear(h, Ws[i], bs[i]))
+    y = F.linear(h, Ws[3], bs[3])
+    assert rel(fwd['heads'][3][:n_rows, :3], y) < 2e-5
+    assert rel(fwd['saves'][2][:n_rows], h) < 2e-5
+    dy = torch.zeros(rp, 4, device='cuda')
+    dy[:n_rows, :3] = torch.randn(n_rows, 3, generator=g).cuda()
+    y.backward(dy[:n_rows, :3].double().cpu())
+    bwd = ch.backward(fwd, n_rows, head_dys={3: dy}, need_dinit=True)
+    assert rel(bwd['d_init'][:n_rows, :k_in], x.grad) < 2e-5
+    gr = ch.weight_grads(fwd, bwd, n_rows, X, None, head_dys={3: dy})
+    for i in range(3):
+        assert rel(gr[i]['dW'], Ws[i].grad) < 2e-5, i
+        assert rel(gr[i]['db'], bs[i].grad) < 2e-5, i
+    assert rel(gr[3]['dWh'], Ws[3].grad) < 2e-5
+    assert rel(gr[3]['dbh'], bs[3].grad) < 2e-5
+
+
+def sdf_entries(P):
+    from nero_amd import _lib as L
+    from nero_amd.chain import Dense, Head
+    e = []
+    for l in range(9):
+        W, b = P[f'sdf_network.lin{l}.weight'], P[f'sdf_network.lin{l}.bias']
+        if l == 0:
+            e.append((Dense(W, b, L.ACT_SOFTPLUS100, 39), None))
+        elif l == 4:
+            e.append((Dense(W, b, L.ACT_SOFTPLUS100, 217, 0, 39, 217, 1.0 / math.sqrt(2)), None))
+        elif l == 8:
+            e.append((Dense(W[1:], b[1:], L.ACT_NONE, 256), Head(W[0:1], b[0:1])))
+        else:
+            e.append((Dense(W, b, L.ACT_SOFTPLUS100, 256), None))
+    return e
+
+
+def test_sdf_chain_forward_and_first_order_backward():
+    from nero_amd.chain import Chain, row_pad
+    from oracle import nero_oracle as O
+    from tests.helpers import build_case_model, load_golden
+    _, meta = load_golden('bell_s25000')
+    net = build_case_model(meta).cuda()
+    P = O.effective_params({k: v.detach() for k, v in net.state_dict().items()})
+    n = 777
+    g = torch.Generator().manual_seed(1)
+    x = (torch.rand(n, 3, generator=g) * 1.6 - 0.8)
+    rp = row_pad(n)
+    pe = torch.zeros(rp, 40, device='cuda')
+    pe[:n, :39] = O.pos_enc(x, 6).cuda()
+    ch = Chain(sdf_entries(P), k_init=40, k_aux=40).pack()
+    fwd = ch.forward(pe, pe, n)
+    Pd = {k: v.double().cpu() for k, v in P.items()}
+    y = O.sdf_network(Pd, x.double())
+    assert rel(fwd['heads'][8][:n, 0], y[:, 0]) < 2e-5
+    assert rel(fwd['saves'][8][:n], y[:, 1:]) < 2e-5
+    dfeat = torch.zeros(rp, 256, device='cuda')
+    dfeat[:n] = torch.randn(n, 256, generator=g).cuda() * 0.1
+    dsdf = torch.zeros(rp, 4, device='cuda')
+    dsdf[:n, 0] = torch.randn(n, generator=g).cuda()
+    Wl = {k: v.clone().requires_grad_(True) for k, v in Pd.items() if k.startswith('sdf_network')}
+    y2 = O.sdf_network(Wl, x.double())
+    ((y2[:, 0] * dsdf[:n, 0].double().cpu()).sum() + (y2[:, 1:] * dfeat[:n].double().cpu()).sum()).backward()
+    bwd = ch.backward(fwd, n, dy=dfeat, head_dys={8: dsdf})
+    gr = ch.weight_grads(fwd, bwd, n, pe, pe, head_dys={8: dsdf})
+    for l in range(9):
+        ref_w = Wl[f'sdf_network.lin{l}.weight'].grad
+        ref_b = Wl[f'sdf_network.lin{l}.bias'].grad
+        if l == 8:
+            assert rel(gr[l]['dW'], ref_w[1:]) < 5e-5
+            assert rel(gr[l]['dWh'], ref_w[0:1]) < 5e-5
+            assert rel(gr[l]['db'], ref_b[1:]) < 5e-5
+        else:
+            assert rel(gr[l]['dW'], ref_w) < 5e-5, l
+            assert rel(gr[l]['db'], ref_b) < 5e-5, l
