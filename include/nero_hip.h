@@ -142,6 +142,17 @@ int nero_dw_gemm(const nero_dw_job* job /*host*/, int n_rows, float* partials, v
 int nero_head_dw(const float* dy /*[rows,4]*/, const float* a /*[rows,256]*/, const float* extra, int n_head, int n_rows,
                  float* dWh /*[n_head,256]*/, float* dbh, float* partials, int accumulate, void* stream);
 
+/* ---- encodings --------------------------------------------------------------------------------------------------
+ * Positional encoding rows [x, sin(2^k x), cos(2^k x)]_{k<n_freq}, zero padded to ldo, rows >= n zero
+ * (Embedder, network/field.py:14-58). */
+int nero_encode_pe(const float* x, int ldx, int dim, int n_freq, int n, float* out, int ldo, void* stream);
+/* out[r,0:3] = J_e(x_r)^T (e0[r] + e1[r])  -- input gradient of the SDF network through its PE-6 (the NORMAL,
+ * SDFNetwork.gradient, network/field.py:155-167).  e1 may be NULL. */
+int nero_pe_vjp(const float* x, int ldx, const float* e0, int ld0, const float* e1, int ld1, int n_freq, int n,
+                float* out, int ldo, void* stream);
+/* out[r] = J_e(x_r) t_r  (tangent of the PE; seeds the second-order pass), zero padded like nero_encode_pe. */
+int nero_pe_jvp(const float* x, int ldx, const float* t, int ldt, int n_freq, int n, float* out, int ldo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

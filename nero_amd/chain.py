@@ -141,7 +141,7 @@ class Chain:
 
     # ------------------------------------------------------------------------------------------------------------
     def backward(self, fwd, n_rows, dy=None, head_dys=None, need_dinit=False, need_daux=False, injs=None,
-                 dinit_out=None, accumulate_dinit=False):
+                 dinit_out=None, accumulate_dinit=False, skip_last_dense=False):
         """reverse pass.  dy: [rows_pad, >=n_out_last] gradient w.r.t. the last dense output (or w.r.t. the last
         pseudo-entry's input tile).  head_dys: {entry: [rows_pad,4]}.  injs: {dense entry: [rows_pad,256]} added to the
         delta of that entry's OUTPUT.  -> dict(deltas={entry: [rows_pad,256]}, d_init, d_aux)"""
@@ -178,7 +178,7 @@ class Chain:
         for i, ((d, h), p) in enumerate(zip(self.entries, self._packed)):
             bl = ch.layer[i]
             j = prev_dense[i]                      # dense entry that produced this entry's input tile
-            if d is not None:
+            if d is not None and not (skip_last_dense and i == last):
                 bl.w_main_t = L.ptr(p['bm'])
                 bl.w_aux_t = L.ptr(p['ba']) if need_daux else None
                 bl.n_out = _r8(d.n_out)
@@ -196,7 +196,7 @@ class Chain:
                 if j in injs:
                     bl.inj = injs[j].data_ptr()
         # the delta of the last dense entry is dy itself when that entry is the chain's last entry
-        if self.entries[last][0] is not None:
+        if self.entries[last][0] is not None and not skip_last_dense:
             assert dy is not None and self.entries[last][0].act == L.ACT_NONE
             deltas[last] = dy
         L.check(L.lib.nero_mlp_backward(C.byref(ch), n_rows, L.stream_ptr()))

@@ -1,0 +1,122 @@
+"""SDF field on the HIP engine: value + feature + normal (first-order input gradient) in the forward direction and the
+second-order weight gradient in the reverse direction:
+
+  forward :  z_l = W_l abar_{l-1} + b_l ; a_l = softplus100(z_l)                      (chain forward, saves a_l)
+  normal  :  gbar_{l-1} = (W_l^T gbar_l) * s_{l-1},  gbar seeded by the sdf row of W_8 (chain reverse, saves gbar_l)
+             n = J_e^T ebar
+  reverse :  given dL/dsdf, dL/dfeat, dL/dn:
+             tangent   adot_l = s_l * (W_l adot_{l-1}),  adot_{-1} = J_e dL/dn        (chain tangent)
+             zhat_{l-1} = (W_l^T zhat_l) * s_{l-1} + gbar_{l-1} * beta (1-s_{l-1}) * zdot_{l-1}
+             dW_l = zhat_l abar_{l-1}^T + gbar_l adotbar_{l-1}^T ,  db_l = sum zhat_l
+Replaces SDFNetwork.forward/.gradient (network/field.py:130-167) and autograd's double backward through them.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+from .chain import Chain, Dense, Head, row_pad, _r8, _tiles
+
+N_FREQ, D_PE, LD_PE = 6, 39, 40
+
+
+def sdf_entries(eff):
+    """eff: list of 9 (W, b) effective weights."""
+    e = []
+    for l, (W, b) in enumerate(eff):
+        if l == 0:
+            e.append((Dense(W, b, L.ACT_SOFTPLUS100, D_PE), None))
+        elif l == 4:
+            e.append((Dense(W, b, L.ACT_SOFTPLUS100, 256 - D_PE, 0, D_PE, 256 - D_PE, 1.0 / math.sqrt(2)), None))
+        elif l == 8:
+            e.append((Dense(W[1:], b[1:], L.ACT_NONE, 256), Head(W[0:1], b[0:1])))
+        else:
+            e.append((Dense(W, b, L.ACT_SOFTPLUS100, 256), None))
+    return e
+
+
+def encode_pe(x, n, dim, n_freq, ld):
+    out = torch.empty((row_pad(n), ld), dtype=torch.float32, device=x.device)
+    L.check(L.lib.nero_encode_pe(C.c_void_p(x.data_ptr()), x.stride(0), dim, n_freq, n, C.c_void_p(out.data_ptr()), ld, L.stream_ptr()))
+    return out
+
+
+class SDFField:
+    def __init__(self, eff, device='cuda'):
+        self.device = device
+        self.full = Chain(sdf_entries(eff), k_init=LD_PE, k_aux=LD_PE, device=device)
+        self.value_only = Chain(self.full.entries[:8] + [(None, self.full.entries[8][1])], k_init=LD_PE, k_aux=LD_PE, device=device)
+        self._ones = None
+
+    def pack(self):
+        self.full.pack()
+        self.value_only._packed = self.full._packed[:8] + [{k: v for k, v in self.full._packed[8].items() if k in ('hw', 'hb')}]
+        return self
+
+    # -- no-grad value evaluation (sampler, occ-loss march, mesh extraction) --------------------------------------
+    def sdf_from_pe(self, pe, n):
+        """pe: [rows_pad, 40] -> [rows_pad, 4] tensor whose column 0 is the sdf"""
+        return self.value_only.forward(pe, pe, n, save=False)['heads'][8]
+
+    def sdf(self, x):
+        n = x.shape[0]
+        return self.sdf_from_pe(encode_pe(x.contiguous(), n, 3, N_FREQ, LD_PE), n)[:n, 0:1]
+
+    # -- value + feature + normal ----------------------------------------------------------------------------------
+    def forward_normal(self, x, n, pe=None):
+        """x [n,>=3] contiguous rows (ld = x.stride(0)).  -> ctx dict with sdf [rows_pad,4](col 0), feat [rows_pad,256],
+        normal [n,3]"""
+        rp = row_pad(n)
+        if pe is None:
+            pe = encode_pe(x, n, 3, N_FREQ, LD_PE)
+        fwd = self.full.forward(pe, pe, n, save=True)
+        if self._ones is None or self._ones.shape[0] < rp:
+            self._ones = torch.zeros((rp, 4), dtype=torch.float32, device=self.device)
+            self._ones[:, 0] = 1.0
+        nb = self.full.backward(fwd, n, dy=None, head_dys={8: self._ones}, need_dinit=True, need_daux=True, skip_last_dense=True)
+        normal = torch.empty((n, 3), dtype=torch.float32, device=self.device)
+        L.check(L.lib.nero_pe_vjp(C.c_void_p(x.data_ptr()), x.stride(0), C.c_void_p(nb['d_init'].data_ptr()), nb['d_init'].stride(0),
+                                  C.c_void_p(nb['d_aux'].data_ptr()), nb['d_aux'].stride(0), N_FREQ, n,
+                                  C.c_void_p(normal.data_ptr()), 3, L.stream_ptr()))
+        return {'x': x, 'n': n, 'pe': pe, 'fwd': fwd, 'gbar': nb['deltas'], 'sdf4': fwd['heads'][8], 'feat': fwd['saves'][8],
+                'normal': normal}
+
+    # -- reverse of (sdf, feat, normal) w.r.t. the weights -----------------------------------------------------------
+    def backward(self, ctx, d_sdf4, d_feat, d_normal, workspace=None):
+        """d_sdf4 [rows_pad,4] (col 0 used), d_feat [rows_pad,256], d_normal [n,3] or None.
+        -> list of 9 (dW [n_out,k], db [n_out]) for lin0..lin8 (lin8 with all 257 rows)."""
+        n, x, pe, fwd, gbar = ctx['n'], ctx['x'], ctx['pe'], ctx['fwd'], ctx['gbar']
+        rp = row_pad(n)
+        ch = self.full
+        injs, second, head_extra = {}, {}, {}
+        if d_normal is not None:
+            ehat = torch.empty((rp, LD_PE), dtype=torch.float32, device=self.device)
+            L.check(L.lib.nero_pe_jvp(C.c_void_p(x.data_ptr()), x.stride(0), C.c_void_p(d_normal.data_ptr()), d_normal.stride(0),
+                                      N_FREQ, n, C.c_void_p(ehat.data_ptr()), LD_PE, L.stream_ptr()))
+            tc = L.TanChain()
+            tc.init, tc.ld_init, tc.k_init = ehat.data_ptr(), LD_PE, LD_PE
+            tc.aux, tc.ld_aux, tc.k_aux = ehat.data_ptr(), LD_PE, LD_PE
+            tc.n_layers, tc.aux_wide = 8, 0
+            tbuf = torch.empty((2, 8, rp, L.HID), dtype=torch.float32, device=self.device)
+            for l in range(8):
+                d, p = ch.entries[l][0], ch._packed[l]
+                tl = tc.layer[l]
+                tl.w_main, tl.w_aux = L.ptr(p['fm']), L.ptr(p['fa'])
+                tl.a_saved, tl.gbar = fwd['saves'][l].data_ptr(), gbar[l].data_ptr()
+                tl.adot, tl.inj = tbuf[0, l].data_ptr(), tbuf[1, l].data_ptr()
+                tl.k_main, tl.k_aux, tl.n_tiles = _r8(d.k_main), (_r8(d.k_aux) if d.k_aux else 0), _tiles(d.n_out)
+                injs[l] = tbuf[1, l]
+            L.check(L.lib.nero_mlp_tangent(C.byref(tc), n, L.stream_ptr()))
+            for l in range(8):
+                second[l] = (gbar[l], ehat if l == 0 else tbuf[0, l - 1], ehat)
+            head_extra[8] = tbuf[0, 7]
+        bwd = ch.backward(fwd, n, dy=d_feat, head_dys={8: d_sdf4}, injs=injs)
+        gr = ch.weight_grads(fwd, bwd, n, pe, pe, head_dys={8: d_sdf4}, workspace=workspace, second=second, head_extra=head_extra)
+        out = []
+        for l in range(9):
+            if l == 8:
+                out.append((torch.cat([gr[8]['dWh'], gr[8]['dW']], 0), torch.cat([gr[8]['dbh'], gr[8]['db']], 0)))
+            else:
+                out.append((gr[l]['dW'], gr[l]['db']))
+        return out
