@@ -153,6 +153,63 @@ int nero_pe_vjp(const float* x, int ldx, const float* e0, int ld0, const float* 
 /* out[r] = J_e(x_r) t_r  (tangent of the PE; seeds the second-order pass), zero padded like nero_encode_pe. */
 int nero_pe_jvp(const float* x, int ldx, const float* t, int ldt, int n_freq, int n, float* out, int ldo, void* stream);
 
+/* ---- hierarchical sampling (NeROShapeRenderer.sample_ray / upsample / cat_z_vals, network/renderer.py:355-443;
+ *      sample_pdf, network/field.py:399-429).  Per-ray tables: z [R, ldz], sdf [R, lds]. ------------------------------- */
+int nero_coarse_z(const float* near, const float* far, const float* rand1 /*[R] or NULL*/, int R, int n, float* z, int ldz, void* stream);
+int nero_background_z(const float* far, const float* rand_bg /*[R,n_bg] or NULL*/, int R, int n_bg, float* z, int ldz, int col0, void* stream);
+/* PE-6 rows (ld 40) of the points o + d*z[r, col0+j], row = r*ncols + j */
+int nero_ray_points_pe(const float* o, const float* d, const float* z, int ldz, int col0, int ncols, int R, float* pe, void* stream);
+/* one up-sampling round: m new z per ray from the NeuS section weights of (z, sdf)[0..n).  inv_s = min(exp(10*variance), cap),
+ * or cap when variance == NULL.  w_out [R,n-1] / inds_out int32 [R,m] optional (tests). */
+int nero_upsample(const float* o, const float* d, const float* z, int ldz, const float* sdf, int lds, int n,
+                  const float* variance, float inv_s_cap, int m, int R, float* z_new, float* w_out, int* inds_out, void* stream);
+/* deterministic inverse-CDF sampling from given bins/weights; inds = searchsorted(cdf, u, right=True) (bit-exact contract) */
+int nero_sample_pdf(const float* bins, int ldb, const float* w, int ldw, int n, int m, int R, float* out, int* inds_out, void* stream);
+/* stable in-place merge of sorted z[r,0..n) with sorted z_new[r,0..m); sdf permuted alike (sdf/sdf_new may be NULL);
+ * sdf_new is read with stride ldsn; index_out int32 [R,n+m] optional = position in the concatenation [z, z_new] */
+int nero_merge_sorted(float* z, int ldz, int n, float* sdf, int lds, const float* z_new, int m, const float* sdf_new, int ldsn,
+                      int R, int* index_out, void* stream);
+int nero_scatter_sdf(const float* src, int ld_src, int R, int n, float* sdf, int lds, void* stream);
+
+/* ---- render preparation (render_core, network/renderer.py:550-565): mid points, section lengths, inner/outer split ---- */
+/* pts4 [R*T,4] = (x,y,z,dist); ray_counts/ray_off int32 [R]; counts int32 [2] = (#inner, #outer) */
+int nero_render_prep(const float* o, const float* d, const float* z, int R, int T, float* pts4, int* ray_counts, int* ray_off,
+                     int* counts, void* stream);
+int nero_compact(const float* pts4, const int* ray_off, int R, int T, int* inner_idx, int* outer_idx, void* stream);
+int nero_gather_inner(const float* pts4, const int* idx, int n, float* x4 /*[rows,4]*/, float* pe /*[rows,40]*/, void* stream);
+int nero_gather_outer(const float* pts4, const float* d, const int* idx, int T, int n, float* pe88, float* pev32, float* dist, void* stream);
+
+/* ---- inner samples: NeuS alpha + shading frame + eikonal term (compute_sdf_alpha, network/renderer.py:484-512, 574) ---- */
+/* geo [rows,8] = { nhat(3), NoV, refl(3), |grad| };  variance: device pointer to deviation_network.variance */
+int nero_sdf_alpha_fwd(const float* sdf4, const float* grad, const float* x4, const int* idx, const float* d, int T,
+                       const float* variance, float anneal, int n, float* alpha, float* geo, float* gerr, void* stream);
+int nero_sdf_alpha_bwd(const float* sdf4, const float* grad, const float* x4, const int* idx, const float* d, int T,
+                       const float* variance, float anneal, int n, const float* d_alpha, const float* d_gerr, const float* d_geo,
+                       float* d_sdf4, float* d_grad, float* dinv /*[rows_pad] per-sample d inv_s*/, void* stream);
+
+/* ---- split-sum shader algebra (AppShadingNetwork.forward, network/field.py:591-651; IDE utils/ref_utils.py:53-117;
+ *      dr.texture field.py:612; linear_to_srgb utils/raw_utils.py:4-10) ------------------------------------------------ */
+int nero_shade_encode(const float* x4, const float* geo, const float* m_raw, const float* r_raw, const float* a_raw, int n,
+                      float* mat /*[rows,8]*/, float* Xd /*[rows,72]*/, float* Xs /*[rows,72]*/, float* Xi /*[rows,128]*/,
+                      float* Xo /*[rows,96]*/, void* stream);
+int nero_shade_combine_fwd(const float* geo, const float* mat, const float* Ld, const float* Ls, const float* Li, const float* Lo,
+                           const float* lut /*[256,256,2]*/, float exp_max, int n, float* color /*[n,3]*/, float* occ_prob, void* stream);
+int nero_shade_combine_bwd(const float* geo, const float* mat, const float* Ld, const float* Ls, const float* Li, const float* Lo,
+                           const float* lut, float exp_max, int n, const float* d_color, const float* d_occ /*or NULL*/, float* dLd,
+                           float* dLs, float* dLi, float* dLo, float* dmat /*[rows,8]*/, float* d_geo /*[rows,8]*/, void* stream);
+int nero_shade_encode_bwd(const float* geo, const float* mat, const float* dXd, const float* dXs, const float* dXi, const float* dmat,
+                          int n, float* d_geo, float* dm_raw, float* dr_raw, float* da_raw, void* stream);
+
+/* ---- NeRF++ head (compute_density_alpha, network/renderer.py:514-520) and compositing (renderer.py:578-579) ----------- */
+int nero_nerf_head_fwd(const float* sig4, const float* rgb4, const float* dist, int n, float* alpha, float* color, void* stream);
+int nero_nerf_head_bwd(const float* sig4, const float* rgb4, const float* dist, int n, const float* d_alpha, const float* d_color,
+                       float* d_sig4, float* d_rgb4, void* stream);
+int nero_scatter_samples(const float* a, const float* c, const int* idx, int n, float* alphaRT, float* colorRT, void* stream);
+int nero_composite_fwd(const float* alphaRT, const float* colorRT, int R, int T, float* weights, float* rgb, void* stream);
+int nero_composite_bwd(const float* alphaRT, const float* colorRT, const float* weights, const float* d_rgb, int R, int T,
+                       float* d_alphaRT, float* d_colorRT, void* stream);
+int nero_gather_sample_grads(const float* d_alphaRT, const float* d_colorRT, const int* idx, int n, float* d_a, float* d_c, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

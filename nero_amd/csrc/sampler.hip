@@ -1,0 +1,422 @@
+// sampler.hip -- hierarchical ray sampling for Stage I (gfx950): coarse z, NeuS section weights, deterministic
+// inverse-CDF importance samples, sorted merge, background z, and the inner/outer sample compaction.
+// Replaces NeROShapeRenderer.sample_ray / upsample / cat_z_vals (network/renderer.py:355-443) and sample_pdf
+// (network/field.py:399-429).  Scans run in the order the oracle states (sequential, float64 running value rounded to
+// float32 per element) so that integer outputs (searchsorted indices, merge permutation) are bit-exact under teacher forcing.
+// One thread owns one ray: the per-ray state is <= 128 floats and the whole stage is a few hundred microseconds; the
+// SDF evaluations between rounds (the real cost) go through the MLP-chain kernel.
+#include <hip/hip_runtime.h>
+#include "../../include/nero_hip.h"
+#include "common.h"
+
+#pragma clang fp contract(off)      // keep a*b+c un-fused: the oracle's float32 steps are stated without FMA
+
+namespace {
+
+constexpr int MAXS = 160;   // max z-values per ray handled by the per-thread buffers
+
+// torch.linspace(start, end, steps)[i] in float32 (ATen: symmetric evaluation around the midpoint)
+__device__ __forceinline__ float linspace_f32(float start, float end, int steps, int i) {
+    if (steps == 1) return start;
+    const float step = (end - start) / (float)(steps - 1);
+    const int half = steps / 2;
+    return i < half ? start + step * (float)i : end - step * (float)(steps - i - 1);
+}
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+// z[r, i] = near + (far-near) * lin(0,1,n)[i] (+ (rand1-0.5)*2/n)          (renderer.py:411-417)
+__global__ void coarse_z_kernel(const float* __restrict__ near, const float* __restrict__ far, const float* __restrict__ rand1,
+                                int R, int n, float* __restrict__ z, int ldz) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= R * n) return;
+    const int r = idx / n, i = idx - r * n;
+    float v = near[r] + (far[r] - near[r]) * linspace_f32(0.f, 1.f, n, i);
+    if (rand1) v = v + (rand1[r] - 0.5f) * 2.0f / (float)n;
+    z[(size_t)r * ldz + i] = v;
+}
+
+// z_bg[r, j] = far / flip(zo)[j] + 1/n_bg, zo = lin(1e-3, 1-1/(n_bg+1), n_bg) optionally stratified-jittered (renderer.py:413-425)
+__global__ void background_z_kernel(const float* __restrict__ far, const float* __restrict__ rand_bg, int R, int nb,
+                                    float* __restrict__ z, int ldz, int col0) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= R * nb) return;
+    const int r = idx / nb, j = idx - r * nb;
+    const int k = nb - 1 - j;                          // flip
+    const float end = 1.0f - 1.0f / ((float)nb + 1.0f);
+    float zo = linspace_f32(1e-3f, end, nb, k);
+    if (rand_bg) {
+        const float prev = k > 0 ? linspace_f32(1e-3f, end, nb, k - 1) : zo;
+        const float next = k < nb - 1 ? linspace_f32(1e-3f, end, nb, k + 1) : zo;
+        const float lower = k > 0 ? 0.5f * (zo + prev) : zo;
+        const float upper = k < nb - 1 ? 0.5f * (next + zo) : zo;
+        zo = lower + (upper - lower) * rand_bg[(size_t)r * nb + k];
+    }
+    z[(size_t)r * ldz + col0 + j] = far[r] / zo + 1.0f / (float)nb;
+}
+
+// PE-6 rows of the points o + d * z[r, col0 + j], row = r*ncols + j, zero padded to 40 columns / row_pad rows
+__global__ void ray_points_pe_kernel(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ z, int ldz,
+                                     int col0, int ncols, int R, int n_pad, float* __restrict__ pe) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_pad) return;
+    float* out = pe + (size_t)row * 40;
+    if (row >= R * ncols) { for (int c = 0; c < 40; ++c) out[c] = 0.f; return; }
+    const int r = row / ncols, j = row - r * ncols;
+    const float t = z[(size_t)r * ldz + col0 + j];
+    float p[3];
+    for (int c = 0; c < 3; ++c) { p[c] = o[r * 3 + c] + d[r * 3 + c] * t; out[c] = p[c]; }
+    float f = 1.f;
+    int q = 3;
+    for (int k = 0; k < 6; ++k) {
+        for (int c = 0; c < 3; ++c) out[q + c] = sinf(p[c] * f);
+        for (int c = 0; c < 3; ++c) out[q + 3 + c] = cosf(p[c] * f);
+        q += 6;
+        f *= 2.f;
+    }
+    out[39] = 0.f;
+}
+
+// deterministic inverse-CDF sampling of `m` values from bins z[0..n) with weights w[0..n-1)   (field.py:399-429, det=True)
+__device__ void sample_pdf_det(const float* zb, const float* w, int n, int m, float* out, int* inds_out) {
+    float cdf[MAXS];
+    // scans: float64 running value, rounded to float32 only where an element is stored (torch-CPU cumsum semantics)
+    double acc = 0.0;
+    for (int i = 0; i < n - 1; ++i) acc += (double)(w[i] + 1e-5f);
+    const float norm = (float)acc;
+    cdf[0] = 0.f;
+    acc = 0.0;
+    for (int i = 0; i < n - 1; ++i) {
+        const float pdf = (w[i] + 1e-5f) / norm;
+        acc += (double)pdf;
+        cdf[i + 1] = (float)acc;
+    }
+    const float u0 = 0.5f / (float)m, u1 = 1.0f - 0.5f / (float)m;
+    int idx = 0;
+    for (int j = 0; j < m; ++j) {
+        const float u = linspace_f32(u0, u1, m, j);
+        while (idx < n && cdf[idx] <= u) ++idx;        // searchsorted(right=True): first index with cdf > u
+        const int below = idx - 1 > 0 ? idx - 1 : 0;
+        const int above = idx < n - 1 ? idx : n - 1;
+        float denom = cdf[above] - cdf[below];
+        if (denom < 1e-5f) denom = 1.f;
+        const float t = (u - cdf[below]) / denom;
+        out[j] = zb[below] + t * (zb[above] - zb[below]);
+        if (inds_out) inds_out[j] = idx;
+    }
+}
+
+// one up-sampling round: NeuS section weights from (z, sdf) -> m new z          (renderer.py:355-385)
+__global__ void upsample_kernel(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ z, int ldz,
+                                const float* __restrict__ sdf, int lds, int n, const float* __restrict__ variance, float inv_s_cap,
+                                int m, int R, float* __restrict__ z_new, float* __restrict__ w_out, int* __restrict__ inds_out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    // renderer.py:434-438: inv_s = min(exp(10 v), 64*2^i) (clip_sample_variance) or the fixed 64*2^i (variance == NULL)
+    const float inv_s = variance ? fminf(expf(variance[0] * 10.0f), inv_s_cap) : inv_s_cap;
+    float zl[MAXS], w[MAXS];
+    const float ox = o[r * 3], oy = o[r * 3 + 1], oz = o[r * 3 + 2];
+    const float dx = d[r * 3], dy = d[r * 3 + 1], dz_ = d[r * 3 + 2];
+    for (int i = 0; i < n; ++i) zl[i] = z[(size_t)r * ldz + i];
+    double T = 1.0;
+    float prev_cos = 0.f;
+    float px = ox + dx * zl[0], py = oy + dy * zl[0], pz = oz + dz_ * zl[0];
+    float rad_prev = sqrtf(px * px + py * py + pz * pz);
+    float s_prev = sdf[(size_t)r * lds];
+    for (int i = 0; i < n - 1; ++i) {
+        px = ox + dx * zl[i + 1]; py = oy + dy * zl[i + 1]; pz = oz + dz_ * zl[i + 1];
+        const float rad_next = sqrtf(px * px + py * py + pz * pz);
+        const float s_next = sdf[(size_t)r * lds + i + 1];
+        const float inside = (rad_prev < 1.0f || rad_next < 1.0f) ? 1.f : 0.f;
+        const float dist = zl[i + 1] - zl[i];
+        const float mid = (s_prev + s_next) * 0.5f;
+        const float cosv = (s_next - s_prev) / (dist + 1e-5f);
+        float c = fminf(prev_cos, cosv);
+        c = fminf(fmaxf(c, -1e3f), 0.f) * inside;
+        prev_cos = cosv;
+        const float pe_ = mid - c * dist * 0.5f, ne_ = mid + c * dist * 0.5f;
+        const float pc = sigmoid_f(pe_ * inv_s), nc = sigmoid_f(ne_ * inv_s);
+        const float alpha = (pc - nc + 1e-5f) / (pc + 1e-5f);
+        w[i] = alpha * (float)T;
+        T *= (double)(1.0f - alpha + 1e-7f);
+        rad_prev = rad_next;
+        s_prev = s_next;
+    }
+    if (w_out) for (int i = 0; i < n - 1; ++i) w_out[(size_t)r * (n - 1) + i] = w[i];
+    float zn[32];
+    int ind[32];
+    sample_pdf_det(zl, w, n, m, zn, inds_out ? ind : nullptr);
+    for (int j = 0; j < m; ++j) {
+        z_new[(size_t)r * m + j] = zn[j];
+        if (inds_out) inds_out[(size_t)r * m + j] = ind[j];
+    }
+}
+
+// standalone sample_pdf (tests / occ-loss march): bins [R,n], weights [R,n-1] -> samples [R,m]
+__global__ void sample_pdf_kernel(const float* __restrict__ bins, int ldb, const float* __restrict__ w, int ldw, int n, int m, int R,
+                                  float* __restrict__ out, int* __restrict__ inds_out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    float zl[MAXS], wl[MAXS], zn[32];
+    int ind[32];
+    for (int i = 0; i < n; ++i) zl[i] = bins[(size_t)r * ldb + i];
+    for (int i = 0; i < n - 1; ++i) wl[i] = w[(size_t)r * ldw + i];
+    sample_pdf_det(zl, wl, n, m, zn, inds_out ? ind : nullptr);
+    for (int j = 0; j < m; ++j) {
+        out[(size_t)r * m + j] = zn[j];
+        if (inds_out) inds_out[(size_t)r * m + j] = ind[j];
+    }
+}
+
+// stable merge of the sorted lists z[r, 0..n) and z_new[r, 0..m) (ties: z first), in place in z; sdf permuted alike
+// (renderer.py:387-401: cat + sort + gather)
+__global__ void merge_sorted_kernel(float* __restrict__ z, int ldz, int n, float* __restrict__ sdf, int lds,
+                                    const float* __restrict__ z_new, int m, const float* __restrict__ sdf_new, int ldsn,
+                                    int R, int* __restrict__ index_out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    float za[MAXS], sa[MAXS];
+    const bool hs = sdf != nullptr && sdf_new != nullptr;
+    for (int i = 0; i < n; ++i) { za[i] = z[(size_t)r * ldz + i]; if (hs) sa[i] = sdf[(size_t)r * lds + i]; }
+    int i = 0, j = 0;
+    for (int k = 0; k < n + m; ++k) {
+        const float zn = j < m ? z_new[(size_t)r * m + j] : 0.f;
+        const bool take_old = (j >= m) || (i < n && za[i] <= zn);
+        if (take_old) {
+            z[(size_t)r * ldz + k] = za[i];
+            if (hs) sdf[(size_t)r * lds + k] = sa[i];
+            if (index_out) index_out[(size_t)r * (n + m) + k] = i;
+            ++i;
+        } else {
+            z[(size_t)r * ldz + k] = zn;
+            if (hs) sdf[(size_t)r * lds + k] = sdf_new[((size_t)r * m + j) * ldsn];
+            if (index_out) index_out[(size_t)r * (n + m) + k] = n + j;
+            ++j;
+        }
+    }
+}
+
+// copy a strided column (head output [rows,4] col 0) into the per-ray sdf table
+__global__ void scatter_sdf_kernel(const float* __restrict__ src, int lds_src, int R, int n, float* __restrict__ sdf, int lds) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= R * n) return;
+    const int r = idx / n, i = idx - r * n;
+    sdf[(size_t)r * lds + i] = src[(size_t)idx * lds_src];
+}
+
+// ---- render preparation: section lengths, mid points, inner/outer split (renderer.py:550-565) ---------------------
+// pts4[r*T+i] = (x, y, z, dist); flag = |p| <= 1.  One thread per ray keeps the sample order (ray-major), exactly the
+// order boolean-mask indexing produces in the reference.
+__global__ void render_prep_kernel(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ z, int R, int T,
+                                   float* __restrict__ pts4, int* __restrict__ ray_counts) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    int cnt = 0;
+    const float ox = o[r * 3], oy = o[r * 3 + 1], oz = o[r * 3 + 2];
+    const float dx = d[r * 3], dy = d[r * 3 + 1], dz_ = d[r * 3 + 2];
+    float zc = z[(size_t)r * T];
+    float last = 0.f;
+    for (int i = 0; i < T; ++i) {
+        float dist;
+        float zn = zc;
+        if (i < T - 1) { zn = z[(size_t)r * T + i + 1]; dist = zn - zc; last = dist; } else dist = last;
+        const float mid = zc + dist * 0.5f;
+        const float x = ox + dx * mid, y = oy + dy * mid, zz = oz + dz_ * mid;
+        float4 v = make_float4(x, y, zz, dist);
+        reinterpret_cast<float4*>(pts4)[(size_t)r * T + i] = v;
+        cnt += (sqrtf(x * x + y * y + zz * zz) <= 1.0f) ? 1 : 0;
+        zc = zn;
+    }
+    ray_counts[r] = cnt;
+}
+
+// exclusive scan of the per-ray inner counts (single workgroup), totals to counts[0] (inner) / counts[1] (outer)
+__global__ void ray_scan_kernel(const int* __restrict__ ray_counts, int R, int T, int* __restrict__ ray_off_in, int* __restrict__ counts) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (R + 1023) / 1024;
+    int s = 0;
+    for (int k = 0; k < per; ++k) { const int r = tid * per + k; if (r < R) s += ray_counts[r]; }
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int base = part[tid] - s;
+    for (int k = 0; k < per; ++k) {
+        const int r = tid * per + k;
+        if (r < R) { ray_off_in[r] = base; base += ray_counts[r]; }
+    }
+    if (tid == 1023) { counts[0] = part[1023]; counts[1] = R * T - part[1023]; }
+}
+
+// inner_idx / outer_idx: flat sample ids in (ray, sample) order; slot[s] = position of sample s in its list
+__global__ void compact_kernel(const float* __restrict__ pts4, const int* __restrict__ ray_off_in, int R, int T,
+                               int* __restrict__ inner_idx, int* __restrict__ outer_idx) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    int ki = ray_off_in[r];
+    int ko = r * T - ki;
+    for (int i = 0; i < T; ++i) {
+        const float4 v = reinterpret_cast<const float4*>(pts4)[(size_t)r * T + i];
+        const bool in = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z) <= 1.0f;
+        if (in) inner_idx[ki++] = r * T + i; else outer_idx[ko++] = r * T + i;
+    }
+}
+
+// inner rows: x4[k] = pts4[inner_idx[k]], pe[k] = PE-6(xyz)
+__global__ void gather_inner_kernel(const float* __restrict__ pts4, const int* __restrict__ idx, int n, int n_pad,
+                                    float* __restrict__ x4, float* __restrict__ pe) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_pad) return;
+    float* out = pe + (size_t)k * 40;
+    if (k >= n) { for (int c = 0; c < 40; ++c) out[c] = 0.f; reinterpret_cast<float4*>(x4)[k] = make_float4(0, 0, 0, 0); return; }
+    const float4 v = reinterpret_cast<const float4*>(pts4)[idx[k]];
+    reinterpret_cast<float4*>(x4)[k] = v;
+    const float p[3] = {v.x, v.y, v.z};
+    for (int c = 0; c < 3; ++c) out[c] = p[c];
+    float f = 1.f;
+    int q = 3;
+    for (int j = 0; j < 6; ++j) {
+        for (int c = 0; c < 3; ++c) out[q + c] = sinf(p[c] * f);
+        for (int c = 0; c < 3; ++c) out[q + 3 + c] = cosf(p[c] * f);
+        q += 6;
+        f *= 2.f;
+    }
+    out[39] = 0.f;
+}
+
+// outer rows (NeRF++ inverted-sphere parametrisation, renderer.py:514-517): pe88 = PE-10([p/|p|, 1/|p|]) (84 + 4 pad),
+// pev32 = PE-4(view = -normalize(d)) (27 + 5 pad), dist[k]
+__global__ void gather_outer_kernel(const float* __restrict__ pts4, const float* __restrict__ d, const int* __restrict__ idx, int T,
+                                    int n, int n_pad, float* __restrict__ pe88, float* __restrict__ pev32, float* __restrict__ dist) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_pad) return;
+    float* o1 = pe88 + (size_t)k * 88;
+    float* o2 = pev32 + (size_t)k * 32;
+    if (k >= n) { for (int c = 0; c < 88; ++c) o1[c] = 0.f; for (int c = 0; c < 32; ++c) o2[c] = 0.f; dist[k] = 0.f; return; }
+    const int s = idx[k];
+    const float4 v = reinterpret_cast<const float4*>(pts4)[s];
+    const int r = s / T;
+    const float nrm = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    const float p[4] = {v.x / nrm, v.y / nrm, v.z / nrm, 1.0f / nrm};
+    for (int c = 0; c < 4; ++c) o1[c] = p[c];
+    float f = 1.f;
+    int q = 4;
+    for (int j = 0; j < 10; ++j) {
+        for (int c = 0; c < 4; ++c) o1[q + c] = sinf(p[c] * f);
+        for (int c = 0; c < 4; ++c) o1[q + 4 + c] = cosf(p[c] * f);
+        q += 8;
+        f *= 2.f;
+    }
+    for (; q < 88; ++q) o1[q] = 0.f;
+    const float dxr = d[r * 3], dyr = d[r * 3 + 1], dzr = d[r * 3 + 2];
+    const float dn = fmaxf(sqrtf(dxr * dxr + dyr * dyr + dzr * dzr), 1e-12f);
+    const float w[3] = {-(dxr / dn), -(dyr / dn), -(dzr / dn)};
+    for (int c = 0; c < 3; ++c) o2[c] = w[c];
+    f = 1.f;
+    q = 3;
+    for (int j = 0; j < 4; ++j) {
+        for (int c = 0; c < 3; ++c) o2[q + c] = sinf(w[c] * f);
+        for (int c = 0; c < 3; ++c) o2[q + 3 + c] = cosf(w[c] * f);
+        q += 6;
+        f *= 2.f;
+    }
+    for (; q < 32; ++q) o2[q] = 0.f;
+    dist[k] = v.w;
+}
+
+}  // namespace
+
+#define GRID1D(n) dim3(((n) + 255) / 256), dim3(256), 0, (hipStream_t)stream
+
+extern "C" {
+
+int nero_coarse_z(const float* near, const float* far, const float* rand1, int R, int n, float* z, int ldz, void* stream) {
+    if (!near || !far || !z || n > MAXS) return nero_fail(NERO_ERR_ARG, "nero_coarse_z: bad argument");
+    if (R == 0) return NERO_OK;
+    hipLaunchKernelGGL(coarse_z_kernel, GRID1D(R * n), near, far, rand1, R, n, z, ldz);
+    return nero_check_launch("nero_coarse_z");
+}
+
+int nero_background_z(const float* far, const float* rand_bg, int R, int n_bg, float* z, int ldz, int col0, void* stream) {
+    if (!far || !z) return nero_fail(NERO_ERR_ARG, "nero_background_z: bad argument");
+    if (R == 0 || n_bg == 0) return NERO_OK;
+    hipLaunchKernelGGL(background_z_kernel, GRID1D(R * n_bg), far, rand_bg, R, n_bg, z, ldz, col0);
+    return nero_check_launch("nero_background_z");
+}
+
+int nero_ray_points_pe(const float* o, const float* d, const float* z, int ldz, int col0, int ncols, int R, float* pe, void* stream) {
+    if (!o || !d || !z || !pe) return nero_fail(NERO_ERR_ARG, "nero_ray_points_pe: bad argument");
+    const int n_pad = NERO_ROW_PAD(R * ncols);
+    if (n_pad == 0) return NERO_OK;
+    hipLaunchKernelGGL(ray_points_pe_kernel, GRID1D(n_pad), o, d, z, ldz, col0, ncols, R, n_pad, pe);
+    return nero_check_launch("nero_ray_points_pe");
+}
+
+int nero_upsample(const float* o, const float* d, const float* z, int ldz, const float* sdf, int lds, int n,
+                  const float* variance, float inv_s_cap, int m, int R, float* z_new, float* w_out, int* inds_out, void* stream) {
+    if (!o || !d || !z || !sdf || !z_new || n > MAXS || n < 2 || m > 32) return nero_fail(NERO_ERR_ARG, "nero_upsample: bad argument");
+    if (R == 0) return NERO_OK;
+    hipLaunchKernelGGL(upsample_kernel, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, o, d, z, ldz, sdf, lds, n, variance, inv_s_cap, m, R, z_new, w_out, inds_out);
+    return nero_check_launch("nero_upsample");
+}
+
+int nero_sample_pdf(const float* bins, int ldb, const float* w, int ldw, int n, int m, int R, float* out, int* inds_out, void* stream) {
+    if (!bins || !w || !out || n > MAXS || n < 2 || m > 32) return nero_fail(NERO_ERR_ARG, "nero_sample_pdf: bad argument");
+    if (R == 0) return NERO_OK;
+    hipLaunchKernelGGL(sample_pdf_kernel, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, bins, ldb, w, ldw, n, m, R, out, inds_out);
+    return nero_check_launch("nero_sample_pdf");
+}
+
+int nero_merge_sorted(float* z, int ldz, int n, float* sdf, int lds, const float* z_new, int m, const float* sdf_new, int ldsn,
+                      int R, int* index_out, void* stream) {
+    if (!z || !z_new || n + m > MAXS) return nero_fail(NERO_ERR_ARG, "nero_merge_sorted: bad argument");
+    if (R == 0) return NERO_OK;
+    hipLaunchKernelGGL(merge_sorted_kernel, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, z, ldz, n, sdf, lds, z_new, m, sdf_new, ldsn, R, index_out);
+    return nero_check_launch("nero_merge_sorted");
+}
+
+int nero_scatter_sdf(const float* src, int ld_src, int R, int n, float* sdf, int lds, void* stream) {
+    if (!src || !sdf) return nero_fail(NERO_ERR_ARG, "nero_scatter_sdf: bad argument");
+    if (R * n == 0) return NERO_OK;
+    hipLaunchKernelGGL(scatter_sdf_kernel, GRID1D(R * n), src, ld_src, R, n, sdf, lds);
+    return nero_check_launch("nero_scatter_sdf");
+}
+
+int nero_render_prep(const float* o, const float* d, const float* z, int R, int T, float* pts4, int* ray_counts, int* ray_off,
+                     int* counts, void* stream) {
+    if (!o || !d || !z || !pts4 || !ray_counts || !ray_off || !counts) return nero_fail(NERO_ERR_ARG, "nero_render_prep: bad argument");
+    if (R == 0) return NERO_OK;
+    hipLaunchKernelGGL(render_prep_kernel, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, o, d, z, R, T, pts4, ray_counts);
+    hipLaunchKernelGGL(ray_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ray_counts, R, T, ray_off, counts);
+    return nero_check_launch("nero_render_prep");
+}
+
+int nero_compact(const float* pts4, const int* ray_off, int R, int T, int* inner_idx, int* outer_idx, void* stream) {
+    if (!pts4 || !ray_off || !inner_idx || !outer_idx) return nero_fail(NERO_ERR_ARG, "nero_compact: bad argument");
+    if (R == 0) return NERO_OK;
+    hipLaunchKernelGGL(compact_kernel, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, pts4, ray_off, R, T, inner_idx, outer_idx);
+    return nero_check_launch("nero_compact");
+}
+
+int nero_gather_inner(const float* pts4, const int* idx, int n, float* x4, float* pe, void* stream) {
+    const int n_pad = NERO_ROW_PAD(n);
+    if (n_pad == 0) return NERO_OK;
+    if (!pts4 || !idx || !x4 || !pe) return nero_fail(NERO_ERR_ARG, "nero_gather_inner: bad argument");
+    hipLaunchKernelGGL(gather_inner_kernel, GRID1D(n_pad), pts4, idx, n, n_pad, x4, pe);
+    return nero_check_launch("nero_gather_inner");
+}
+
+int nero_gather_outer(const float* pts4, const float* d, const int* idx, int T, int n, float* pe88, float* pev32, float* dist, void* stream) {
+    const int n_pad = NERO_ROW_PAD(n);
+    if (n_pad == 0) return NERO_OK;
+    if (!pts4 || !d || !idx || !pe88 || !pev32 || !dist) return nero_fail(NERO_ERR_ARG, "nero_gather_outer: bad argument");
+    hipLaunchKernelGGL(gather_outer_kernel, GRID1D(n_pad), pts4, d, idx, T, n, n_pad, pe88, pev32, dist);
+    return nero_check_launch("nero_gather_outer");
+}
+
+}  // extern "C"

@@ -1,0 +1,602 @@
+// shade.hip -- the elementwise half of the Stage-I render step on gfx950: NeuS alpha from (sdf, normal), split-sum
+// shading algebra around the light/material MLPs (IDE / PE encoders, FG-LUT bilinear fetch, sRGB, exp/sigmoid heads),
+// NeRF++ head, alpha compositing -- forward and hand-derived backward.  One thread per sample / per ray; all of it is
+// HBM-bound glue around the MLP-chain kernels.  Replaces compute_sdf_alpha (network/renderer.py:484-512),
+// AppShadingNetwork.forward (network/field.py:591-651), generate_ide_fn (utils/ref_utils.py:53-117), dr.texture
+// (field.py:612), linear_to_srgb (utils/raw_utils.py:4-10), compute_density_alpha (renderer.py:514-520) and the
+// compositing lines of render_core (renderer.py:578-579), plus everything autograd derived from them.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "../../include/nero_hip.h"
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------------------
+// IDE tables (deg_view = 5): 36 (m,l) pairs, l in {1,2,4,8,16}, polynomial coefficients mat[k][i], k <= 16
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int IDE_N = 36;
+__constant__ float c_ide_mat[17 * IDE_N];
+__constant__ int c_ide_m[IDE_N];
+__constant__ int c_ide_l[IDE_N];
+
+double fact(int n) { double r = 1.0; for (int i = 2; i <= n; ++i) r *= i; return r; }
+double gen_binom(double a, int k) { double p = 1.0; for (int i = 0; i < k; ++i) p *= (a - i); return p / fact(k); }
+double assoc_legendre_coeff(int l, int m, int k) {
+    return ((m & 1) ? -1.0 : 1.0) * pow(2.0, l) * fact(l) / fact(k) / fact(l - k - m) * gen_binom(0.5 * (l + k + m - 1.0), l);
+}
+double sph_harm_coeff(int l, int m, int k) {
+    return sqrt((2.0 * l + 1.0) * fact(l - m) / (4.0 * M_PI * fact(l + m))) * assoc_legendre_coeff(l, m, k);
+}
+
+int init_ide_tables() {
+    static bool done = false;
+    if (done) return 0;
+    float mat[17 * IDE_N];
+    int ms[IDE_N], ls[IDE_N];
+    for (int i = 0; i < 17 * IDE_N; ++i) mat[i] = 0.f;
+    int i = 0;
+    for (int e = 0; e < 5; ++e) {
+        const int l = 1 << e;
+        for (int m = 0; m <= l; ++m, ++i) {
+            ms[i] = m; ls[i] = l;
+            for (int k = 0; k <= l - m; ++k) mat[k * IDE_N + i] = (float)sph_harm_coeff(l, m, k);
+        }
+    }
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c_ide_mat), mat, sizeof(mat)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c_ide_m), ms, sizeof(ms)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c_ide_l), ls, sizeof(ls)) != hipSuccess) return -1;
+    done = true;
+    return 0;
+}
+
+// out[0..36) = Re, out[36..72) = Im of (x+iy)^m * P_i(z) * exp(-l(l+1)/2 * kinv)
+__device__ void ide_forward(float x, float y, float z, float kinv, float* __restrict__ out) {
+    float zp[17], re[17], im[17];
+    zp[0] = 1.f; re[0] = 1.f; im[0] = 0.f;
+    for (int k = 1; k <= 16; ++k) {
+        zp[k] = zp[k - 1] * z;
+        re[k] = re[k - 1] * x - im[k - 1] * y;
+        im[k] = re[k - 1] * y + im[k - 1] * x;
+    }
+    for (int i = 0; i < IDE_N; ++i) {
+        const int m = c_ide_m[i], l = c_ide_l[i];
+        float poly = 0.f;
+        for (int k = 0; k <= l - m; ++k) poly = fmaf(zp[k], c_ide_mat[k * IDE_N + i], poly);
+        const float att = expf(-0.5f * (float)(l * (l + 1)) * kinv);
+        out[i] = re[m] * poly * att;
+        out[IDE_N + i] = im[m] * poly * att;
+    }
+}
+
+// gradient of sum(g * ide(x,y,z,kinv)) w.r.t. (x,y,z,kinv); accumulates into dx,dy,dz,dk
+__device__ void ide_backward(float x, float y, float z, float kinv, const float* __restrict__ g, float& dx, float& dy, float& dz, float& dk) {
+    float zp[17], re[17], im[17], dre[17], dim_[17];
+    zp[0] = 1.f; re[0] = 1.f; im[0] = 0.f;
+    for (int k = 1; k <= 16; ++k) {
+        zp[k] = zp[k - 1] * z;
+        re[k] = re[k - 1] * x - im[k - 1] * y;
+        im[k] = re[k - 1] * y + im[k - 1] * x;
+    }
+    for (int k = 0; k <= 16; ++k) { dre[k] = 0.f; dim_[k] = 0.f; }
+    float gz = 0.f, gk = 0.f;
+    for (int i = 0; i < IDE_N; ++i) {
+        const int m = c_ide_m[i], l = c_ide_l[i];
+        float poly = 0.f, dpoly = 0.f;
+        for (int k = 0; k <= l - m; ++k) {
+            const float c = c_ide_mat[k * IDE_N + i];
+            poly = fmaf(zp[k], c, poly);
+            if (k > 0) dpoly = fmaf((float)k * zp[k - 1], c, dpoly);
+        }
+        const float sig = 0.5f * (float)(l * (l + 1));
+        const float att = expf(-sig * kinv);
+        const float gr = g[i], gi = g[IDE_N + i];
+        const float s = gr * re[m] + gi * im[m];
+        gz += s * att * dpoly;
+        gk += s * poly * (-sig * att);
+        dre[m] += gr * poly * att;
+        dim_[m] += gi * poly * att;
+    }
+    // w^m = re + i im:  d re_m/dx = m re_{m-1}, d im_m/dx = m im_{m-1}, d re_m/dy = -m im_{m-1}, d im_m/dy = m re_{m-1}
+    float gx = 0.f, gy = 0.f;
+    for (int m = 1; m <= 16; ++m) {
+        gx += (float)m * (dre[m] * re[m - 1] + dim_[m] * im[m - 1]);
+        gy += (float)m * (-dre[m] * im[m - 1] + dim_[m] * re[m - 1]);
+    }
+    dx += gx; dy += gy; dz += gz; dk += gk;
+}
+
+__device__ __forceinline__ void pe3(const float* p, int n_freq, float* out) {
+    for (int c = 0; c < 3; ++c) out[c] = p[c];
+    float f = 1.f;
+    int q = 3;
+    for (int k = 0; k < n_freq; ++k) {
+        for (int c = 0; c < 3; ++c) out[q + c] = sinf(p[c] * f);
+        for (int c = 0; c < 3; ++c) out[q + 3 + c] = cosf(p[c] * f);
+        q += 6;
+        f *= 2.f;
+    }
+}
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+constexpr float SRGB_EPS = 1.1920928955078125e-07f;
+__device__ __forceinline__ float srgb_f(float x) {
+    return x <= 0.0031308f ? (323.f / 25.f) * x : (211.f * powf(fmaxf(x, SRGB_EPS), 5.f / 12.f) - 11.f) / 200.f;
+}
+__device__ __forceinline__ float srgb_grad(float x) {
+    if (x <= 0.0031308f) return 323.f / 25.f;
+    return x >= SRGB_EPS ? (211.f / 200.f) * (5.f / 12.f) * powf(x, -7.f / 12.f) : 0.f;
+}
+
+// bilinear clamp fetch of the FG table lut[256(v)][256(u)][2]; returns d/du, d/dv too
+__device__ __forceinline__ void fg_fetch(const float* __restrict__ lut, float u, float v, float& f0, float& f1,
+                                         float& df0du, float& df1du, float& df0dv, float& df1dv) {
+    const float W = 256.f;
+    float uu = u * W - 0.5f, vv = v * W - 0.5f;
+    const float gu = (uu >= 0.f && uu <= W - 1.f) ? W : 0.f, gv = (vv >= 0.f && vv <= W - 1.f) ? W : 0.f;
+    uu = fminf(fmaxf(uu, 0.f), W - 1.f);
+    vv = fminf(fmaxf(vv, 0.f), W - 1.f);
+    const float u0 = fminf(floorf(uu), W - 2.f), v0 = fminf(floorf(vv), W - 2.f);
+    const float fu = uu - u0, fv = vv - v0;
+    const int iu = (int)u0, iv = (int)v0;
+    const float2 t00 = reinterpret_cast<const float2*>(lut)[iv * 256 + iu];
+    const float2 t01 = reinterpret_cast<const float2*>(lut)[iv * 256 + iu + 1];
+    const float2 t10 = reinterpret_cast<const float2*>(lut)[(iv + 1) * 256 + iu];
+    const float2 t11 = reinterpret_cast<const float2*>(lut)[(iv + 1) * 256 + iu + 1];
+    f0 = (t00.x * (1 - fu) + t01.x * fu) * (1 - fv) + (t10.x * (1 - fu) + t11.x * fu) * fv;
+    f1 = (t00.y * (1 - fu) + t01.y * fu) * (1 - fv) + (t10.y * (1 - fu) + t11.y * fu) * fv;
+    df0du = ((t01.x - t00.x) * (1 - fv) + (t11.x - t10.x) * fv) * gu;
+    df1du = ((t01.y - t00.y) * (1 - fv) + (t11.y - t10.y) * fv) * gu;
+    df0dv = ((t10.x * (1 - fu) + t11.x * fu) - (t00.x * (1 - fu) + t01.x * fu)) * gv;
+    df1dv = ((t10.y * (1 - fu) + t11.y * fu) - (t00.y * (1 - fu) + t01.y * fu)) * gv;
+}
+
+__device__ __forceinline__ void ray_dir(const float* __restrict__ d, int r, float* dh) {
+    const float x = d[r * 3], y = d[r * 3 + 1], z = d[r * 3 + 2];
+    const float n = fmaxf(sqrtf(x * x + y * y + z * z), 1e-12f);
+    dh[0] = x / n; dh[1] = y / n; dh[2] = z / n;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// inner geometry: alpha, shading frame, eikonal term                                     (renderer.py:484-512, 574)
+// geo[k] = { nhat(3), NoV, refl(3), |grad| }
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float inv_s_from(const float* variance) {
+    return fminf(fmaxf(expf(variance[0] * 10.0f), 1e-6f), 1e6f);
+}
+
+__global__ void sdf_alpha_fwd_kernel(const float* __restrict__ sdf4, const float* __restrict__ grad, const float* __restrict__ x4,
+                                     const int* __restrict__ idx, const float* __restrict__ d, int T, const float* __restrict__ variance,
+                                     float anneal, int n, float* __restrict__ alpha, float* __restrict__ geo, float* __restrict__ gerr) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float s = inv_s_from(variance);
+    float dh[3];
+    ray_dir(d, idx[k] / T, dh);
+    const float g[3] = {grad[k * 3], grad[k * 3 + 1], grad[k * 3 + 2]};
+    const float sdf = sdf4[(size_t)k * 4], dist = x4[(size_t)k * 4 + 3];
+    const float tc = dh[0] * g[0] + dh[1] * g[1] + dh[2] * g[2];
+    const float ic = -(fmaxf(-tc * 0.5f + 0.5f, 0.f) * (1.0f - anneal) + fmaxf(-tc, 0.f) * anneal);
+    const float en = sdf + ic * dist * 0.5f, ep = sdf - ic * dist * 0.5f;
+    const float pc = sigmoid_f(ep * s), nc = sigmoid_f(en * s);
+    const float raw = (pc - nc + 1e-5f) / (pc + 1e-5f);
+    alpha[k] = fminf(fmaxf(raw, 0.f), 1.f);
+    const float gn = sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+    const float gd = fmaxf(gn, 1e-12f);
+    const float nh[3] = {g[0] / gd, g[1] / gd, g[2] / gd};
+    const float nov = -(nh[0] * dh[0] + nh[1] * dh[1] + nh[2] * dh[2]);
+    float* o = geo + (size_t)k * 8;
+    o[0] = nh[0]; o[1] = nh[1]; o[2] = nh[2]; o[3] = nov;
+    o[4] = nov * nh[0] * 2.f + dh[0]; o[5] = nov * nh[1] * 2.f + dh[1]; o[6] = nov * nh[2] * 2.f + dh[2];
+    o[7] = gn;
+    gerr[k] = (gn - 1.0f) * (gn - 1.0f);
+}
+
+// d_geo[k] = { d_nhat(3), d_NoV, d_refl(3), - } from the shader (may be NULL);  outputs d_sdf4[k*4], d_grad[k*3],
+// per-thread d_inv_s into dinv[k] (summed by the caller)
+__global__ void sdf_alpha_bwd_kernel(const float* __restrict__ sdf4, const float* __restrict__ grad, const float* __restrict__ x4,
+                                     const int* __restrict__ idx, const float* __restrict__ d, int T, const float* __restrict__ variance,
+                                     float anneal, int n, int n_pad, const float* __restrict__ d_alpha, const float* __restrict__ d_gerr,
+                                     const float* __restrict__ d_geo, float* __restrict__ d_sdf4, float* __restrict__ d_grad,
+                                     float* __restrict__ dinv) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_pad) return;
+    if (k >= n) { reinterpret_cast<float4*>(d_sdf4)[k] = make_float4(0, 0, 0, 0); dinv[k] = 0.f; return; }
+    const float s = inv_s_from(variance);
+    float dh[3];
+    ray_dir(d, idx[k] / T, dh);
+    const float g[3] = {grad[k * 3], grad[k * 3 + 1], grad[k * 3 + 2]};
+    const float sdf = sdf4[(size_t)k * 4], dist = x4[(size_t)k * 4 + 3];
+    const float tc = dh[0] * g[0] + dh[1] * g[1] + dh[2] * g[2];
+    const float ic = -(fmaxf(-tc * 0.5f + 0.5f, 0.f) * (1.0f - anneal) + fmaxf(-tc, 0.f) * anneal);
+    const float en = sdf + ic * dist * 0.5f, ep = sdf - ic * dist * 0.5f;
+    const float pc = sigmoid_f(ep * s), nc = sigmoid_f(en * s);
+    const float den = pc + 1e-5f;
+    const float raw = (pc - nc + 1e-5f) / den;
+    const float draw = (raw >= 0.f && raw <= 1.f) ? d_alpha[k] : 0.f;
+    const float dpc = draw * nc / (den * den), dnc = -draw / den;
+    const float dps = dpc * pc * (1.f - pc), dns = dnc * nc * (1.f - nc);
+    const float dep = s * dps, den_ = s * dns;
+    dinv[k] = ep * dps + en * dns;
+    reinterpret_cast<float4*>(d_sdf4)[k] = make_float4(dep + den_, 0.f, 0.f, 0.f);
+    const float dic = (den_ - dep) * dist * 0.5f;
+    const float dic_dtc = ((-tc * 0.5f + 0.5f) > 0.f ? 0.5f * (1.0f - anneal) : 0.f) + ((-tc) > 0.f ? anneal : 0.f);
+    const float dtc = dic * dic_dtc;
+    float dg[3] = {dtc * dh[0], dtc * dh[1], dtc * dh[2]};
+    const float gn = sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+    const float gd = fmaxf(gn, 1e-12f);
+    const float nh[3] = {g[0] / gd, g[1] / gd, g[2] / gd};
+    // eikonal: (|g|-1)^2
+    const float de = d_gerr ? d_gerr[k] * 2.f * (gn - 1.0f) : 0.f;
+    for (int c = 0; c < 3; ++c) dg[c] += de * nh[c];
+    if (d_geo) {
+        const float* q = d_geo + (size_t)k * 8;
+        const float v[3] = {-dh[0], -dh[1], -dh[2]};
+        const float nov = nh[0] * v[0] + nh[1] * v[1] + nh[2] * v[2];
+        const float drn = q[4] * nh[0] + q[5] * nh[1] + q[6] * nh[2];
+        float dn[3];
+        for (int c = 0; c < 3; ++c) dn[c] = q[c] + q[4 + c] * 2.f * nov + (q[3] + 2.f * drn) * v[c];
+        const float dot = dn[0] * nh[0] + dn[1] * nh[1] + dn[2] * nh[2];
+        if (gn >= 1e-12f)
+            for (int c = 0; c < 3; ++c) dg[c] += (dn[c] - nh[c] * dot) / gd;
+    }
+    for (int c = 0; c < 3; ++c) d_grad[k * 3 + c] = dg[c];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// light-MLP input encodings (field.py:554-589):  Xd = IDE(n,1) [72], Xs = IDE(refl, rough) [72],
+// Xi = [PE8(p)(51), IDE(refl,rough)(72), pad] ld 128,  Xo = [PE8(p)(51), PE6(refl)(39), pad] ld 96
+// mat[k] = { metallic, roughness, albedo(3), -, -, - } (after sigmoid) is written here too.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void shade_encode_kernel(const float* __restrict__ x4, const float* __restrict__ geo, const float* __restrict__ m_raw,
+                                    const float* __restrict__ r_raw, const float* __restrict__ a_raw, int n, int n_pad,
+                                    float* __restrict__ mat, float* __restrict__ Xd, float* __restrict__ Xs, float* __restrict__ Xi,
+                                    float* __restrict__ Xo) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_pad) return;
+    float* xd = Xd + (size_t)k * 72; float* xs = Xs + (size_t)k * 72; float* xi = Xi + (size_t)k * 128; float* xo = Xo + (size_t)k * 96;
+    if (k >= n) {
+        for (int c = 0; c < 72; ++c) { xd[c] = 0.f; xs[c] = 0.f; }
+        for (int c = 0; c < 128; ++c) xi[c] = 0.f;
+        for (int c = 0; c < 96; ++c) xo[c] = 0.f;
+        return;
+    }
+    const float* q = geo + (size_t)k * 8;
+    const float m = sigmoid_f(m_raw[(size_t)k * 4]), r = sigmoid_f(r_raw[(size_t)k * 4]);
+    float* mo = mat + (size_t)k * 8;
+    mo[0] = m; mo[1] = r;
+    for (int c = 0; c < 3; ++c) mo[2 + c] = sigmoid_f(a_raw[(size_t)k * 4 + c]);
+    mo[5] = 0.f; mo[6] = 0.f; mo[7] = 0.f;
+    float e[72];
+    ide_forward(q[0], q[1], q[2], 1.0f, e);
+    for (int c = 0; c < 72; ++c) xd[c] = e[c];
+    ide_forward(q[4], q[5], q[6], r, e);
+    for (int c = 0; c < 72; ++c) { xs[c] = e[c]; xi[51 + c] = e[c]; }
+    float pe[51];
+    const float p[3] = {x4[(size_t)k * 4], x4[(size_t)k * 4 + 1], x4[(size_t)k * 4 + 2]};
+    pe3(p, 8, pe);
+    for (int c = 0; c < 51; ++c) { xi[c] = pe[c]; xo[c] = pe[c]; }
+    for (int c = 123; c < 128; ++c) xi[c] = 0.f;
+    const float rf[3] = {q[4], q[5], q[6]};
+    pe3(rf, 6, pe);
+    for (int c = 0; c < 39; ++c) xo[51 + c] = pe[c];
+    for (int c = 90; c < 96; ++c) xo[c] = 0.f;
+}
+
+// combine (field.py:601-623).  light heads are RAW outputs [rows,4]: diff(3), direct(3), indirect(3), occ(1).
+// color[k*3..], occ_prob[k] (unclamped, for the occ loss)
+__global__ void shade_combine_fwd_kernel(const float* __restrict__ geo, const float* __restrict__ mat, const float* __restrict__ Ld,
+                                         const float* __restrict__ Ls, const float* __restrict__ Li, const float* __restrict__ Lo,
+                                         const float* __restrict__ lut, float exp_max, int n, float* __restrict__ color,
+                                         float* __restrict__ occ_prob) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float* mo = mat + (size_t)k * 8;
+    const float m = mo[0], r = mo[1];
+    const float nov = geo[(size_t)k * 8 + 3];
+    float f0, f1, a0, a1, a2, a3;
+    fg_fetch(lut, fminf(fmaxf(nov, 0.f), 1.f), fminf(fmaxf(r, 0.f), 1.f), f0, f1, a0, a1, a2, a3);
+    const float occ = Lo[(size_t)k * 4] * 0.5f + 0.5f;
+    const float oc = fminf(fmaxf(occ, 0.f), 1.f);
+    occ_prob[k] = occ;
+    for (int c = 0; c < 3; ++c) {
+        const float a = mo[2 + c];
+        const float dl = expf(fminf(Ld[(size_t)k * 4 + c], exp_max));
+        const float direct = expf(fminf(Ls[(size_t)k * 4 + c], exp_max));
+        const float indirect = expf(fminf(Li[(size_t)k * 4 + c], exp_max));
+        const float sl = indirect * oc + direct * (1.f - oc);
+        const float da = (1.f - m) * a, sa = 0.04f * (1.f - m) + m * a;
+        const float lin = da * dl + (sa * f0 + f1) * sl;
+        color[(size_t)k * 3 + c] = fminf(fmaxf(srgb_f(lin), 0.f), 1.f);
+    }
+}
+
+// backward of combine: writes the gradients of the RAW head outputs (dLd, dLs, dLi, dLo [rows,4]), the partial
+// material grads dmat[k] = { d_metallic, d_rough(LUT part), d_albedo(3) } and d_geo[k][3] = d_NoV (LUT part)
+__global__ void shade_combine_bwd_kernel(const float* __restrict__ geo, const float* __restrict__ mat, const float* __restrict__ Ld,
+                                         const float* __restrict__ Ls, const float* __restrict__ Li, const float* __restrict__ Lo,
+                                         const float* __restrict__ lut, float exp_max, int n, int n_pad,
+                                         const float* __restrict__ d_color, const float* __restrict__ d_occ,
+                                         float* __restrict__ dLd, float* __restrict__ dLs, float* __restrict__ dLi, float* __restrict__ dLo,
+                                         float* __restrict__ dmat, float* __restrict__ d_geo) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_pad) return;
+    float4 z4 = make_float4(0, 0, 0, 0);
+    if (k >= n) {
+        reinterpret_cast<float4*>(dLd)[k] = z4; reinterpret_cast<float4*>(dLs)[k] = z4;
+        reinterpret_cast<float4*>(dLi)[k] = z4; reinterpret_cast<float4*>(dLo)[k] = z4;
+        return;
+    }
+    const float* mo = mat + (size_t)k * 8;
+    const float m = mo[0], r = mo[1];
+    const float nov = geo[(size_t)k * 8 + 3];
+    float f0, f1, df0du, df1du, df0dv, df1dv;
+    fg_fetch(lut, fminf(fmaxf(nov, 0.f), 1.f), fminf(fmaxf(r, 0.f), 1.f), f0, f1, df0du, df1du, df0dv, df1dv);
+    const float occ = Lo[(size_t)k * 4] * 0.5f + 0.5f;
+    const float oc = fminf(fmaxf(occ, 0.f), 1.f);
+    float d_m = 0.f, d_f0 = 0.f, d_f1 = 0.f, d_oc = 0.f;
+    float ld[4] = {0, 0, 0, 0}, ls[4] = {0, 0, 0, 0}, li[4] = {0, 0, 0, 0};
+    float da_out[3];
+    for (int c = 0; c < 3; ++c) {
+        const float a = mo[2 + c];
+        const float rd = Ld[(size_t)k * 4 + c], rs = Ls[(size_t)k * 4 + c], ri = Li[(size_t)k * 4 + c];
+        const float dl = expf(fminf(rd, exp_max)), direct = expf(fminf(rs, exp_max)), indirect = expf(fminf(ri, exp_max));
+        const float sl = indirect * oc + direct * (1.f - oc);
+        const float dalb = (1.f - m) * a, salb = 0.04f * (1.f - m) + m * a;
+        const float sref = salb * f0 + f1;
+        const float lin = dalb * dl + sref * sl;
+        const float sg = srgb_f(lin);
+        const float dlin = (sg >= 0.f && sg <= 1.f) ? d_color[(size_t)k * 3 + c] * srgb_grad(lin) : 0.f;
+        const float d_dalb = dlin * dl, d_dl = dlin * dalb, d_sref = dlin * sl, d_sl = dlin * sref;
+        const float d_salb = d_sref * f0;
+        d_f0 += d_sref * salb;
+        d_f1 += d_sref;
+        d_m += -a * d_dalb + (a - 0.04f) * d_salb;
+        da_out[c] = (1.f - m) * d_dalb + m * d_salb;
+        ld[c] = rd <= exp_max ? d_dl * dl : 0.f;
+        li[c] = ri <= exp_max ? d_sl * oc * indirect : 0.f;
+        ls[c] = rs <= exp_max ? d_sl * (1.f - oc) * direct : 0.f;
+        d_oc += d_sl * (indirect - direct);
+    }
+    float d_occ_tot = (occ >= 0.f && occ <= 1.f) ? d_oc : 0.f;
+    if (d_occ) d_occ_tot += d_occ[k];
+    reinterpret_cast<float4*>(dLd)[k] = make_float4(ld[0], ld[1], ld[2], 0.f);
+    reinterpret_cast<float4*>(dLs)[k] = make_float4(ls[0], ls[1], ls[2], 0.f);
+    reinterpret_cast<float4*>(dLi)[k] = make_float4(li[0], li[1], li[2], 0.f);
+    reinterpret_cast<float4*>(dLo)[k] = make_float4(0.5f * d_occ_tot, 0.f, 0.f, 0.f);
+    const float d_u = (nov >= 0.f && nov <= 1.f) ? d_f0 * df0du + d_f1 * df1du : 0.f;
+    const float d_v = (r >= 0.f && r <= 1.f) ? d_f0 * df0dv + d_f1 * df1dv : 0.f;
+    float* dm = dmat + (size_t)k * 8;
+    dm[0] = d_m; dm[1] = d_v; dm[2] = da_out[0]; dm[3] = da_out[1]; dm[4] = da_out[2];
+    d_geo[(size_t)k * 8 + 3] = d_u;
+}
+
+// backward of the encodings: dXd, dXs [rows,72], dXi [rows,128] (cols 51..122 = IDE part) -> d_geo (d_nhat, d_refl; d_NoV
+// already there), total roughness gradient; then the RAW material head gradients dm_raw/dr_raw/da_raw [rows,4]
+__global__ void shade_encode_bwd_kernel(const float* __restrict__ geo, const float* __restrict__ mat, const float* __restrict__ dXd,
+                                        const float* __restrict__ dXs, const float* __restrict__ dXi, const float* __restrict__ dmat,
+                                        int n, int n_pad, float* __restrict__ d_geo, float* __restrict__ dm_raw,
+                                        float* __restrict__ dr_raw, float* __restrict__ da_raw) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_pad) return;
+    float4 z4 = make_float4(0, 0, 0, 0);
+    if (k >= n) {
+        reinterpret_cast<float4*>(dm_raw)[k] = z4; reinterpret_cast<float4*>(dr_raw)[k] = z4; reinterpret_cast<float4*>(da_raw)[k] = z4;
+        return;
+    }
+    const float* q = geo + (size_t)k * 8;
+    const float* mo = mat + (size_t)k * 8;
+    const float* dm = dmat + (size_t)k * 8;
+    const float m = mo[0], r = mo[1];
+    float g[72];
+    float dnx = 0.f, dny = 0.f, dnz = 0.f, dk1 = 0.f;
+    for (int c = 0; c < 72; ++c) g[c] = dXd[(size_t)k * 72 + c];
+    ide_backward(q[0], q[1], q[2], 1.0f, g, dnx, dny, dnz, dk1);
+    float drx = 0.f, dry = 0.f, drz = 0.f, dkr = 0.f;
+    for (int c = 0; c < 72; ++c) g[c] = dXs[(size_t)k * 72 + c] + dXi[(size_t)k * 128 + 51 + c];
+    ide_backward(q[4], q[5], q[6], r, g, drx, dry, drz, dkr);
+    float* o = d_geo + (size_t)k * 8;
+    o[0] = dnx; o[1] = dny; o[2] = dnz;
+    o[4] = drx; o[5] = dry; o[6] = drz; o[7] = 0.f;
+    const float d_r = dm[1] + dkr;
+    reinterpret_cast<float4*>(dm_raw)[k] = make_float4(dm[0] * m * (1.f - m), 0.f, 0.f, 0.f);
+    reinterpret_cast<float4*>(dr_raw)[k] = make_float4(d_r * r * (1.f - r), 0.f, 0.f, 0.f);
+    reinterpret_cast<float4*>(da_raw)[k] = make_float4(dm[2] * mo[2] * (1.f - mo[2]), dm[3] * mo[3] * (1.f - mo[3]), dm[4] * mo[4] * (1.f - mo[4]), 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// NeRF++ head (renderer.py:346-347, 518-519): alpha = 1 - exp(-softplus(sigma) dist), color = sRGB(exp(min(rgb,5)))
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void nerf_head_fwd_kernel(const float* __restrict__ sig4, const float* __restrict__ rgb4, const float* __restrict__ dist,
+                                     int n, float* __restrict__ alpha, float* __restrict__ color) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float s = sig4[(size_t)k * 4];
+    const float sp = s > 20.f ? s : log1pf(expf(s));
+    alpha[k] = 1.0f - expf(-sp * dist[k]);
+    for (int c = 0; c < 3; ++c) color[(size_t)k * 3 + c] = srgb_f(expf(fminf(rgb4[(size_t)k * 4 + c], 5.0f)));
+}
+
+__global__ void nerf_head_bwd_kernel(const float* __restrict__ sig4, const float* __restrict__ rgb4, const float* __restrict__ dist,
+                                     int n, int n_pad, const float* __restrict__ d_alpha, const float* __restrict__ d_color,
+                                     float* __restrict__ d_sig4, float* __restrict__ d_rgb4) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_pad) return;
+    if (k >= n) { reinterpret_cast<float4*>(d_sig4)[k] = make_float4(0, 0, 0, 0); reinterpret_cast<float4*>(d_rgb4)[k] = make_float4(0, 0, 0, 0); return; }
+    const float s = sig4[(size_t)k * 4];
+    const float sp = s > 20.f ? s : log1pf(expf(s));
+    const float dsp = s > 20.f ? 1.f : sigmoid_f(s);
+    const float ds = d_alpha[k] * expf(-sp * dist[k]) * dist[k] * dsp;
+    reinterpret_cast<float4*>(d_sig4)[k] = make_float4(ds, 0.f, 0.f, 0.f);
+    float o[3];
+    for (int c = 0; c < 3; ++c) {
+        const float raw = rgb4[(size_t)k * 4 + c];
+        const float e = expf(fminf(raw, 5.0f));
+        o[c] = raw <= 5.0f ? d_color[(size_t)k * 3 + c] * srgb_grad(e) * e : 0.f;
+    }
+    reinterpret_cast<float4*>(d_rgb4)[k] = make_float4(o[0], o[1], o[2], 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// compositing (renderer.py:578-579): scatter the compact inner/outer results into [R,T], w_i = a_i prod_{j<i}(1-a_j+1e-7)
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void scatter_samples_kernel(const float* __restrict__ a, const float* __restrict__ c, const int* __restrict__ idx, int n,
+                                       float* __restrict__ alphaRT, float* __restrict__ colorRT) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int s = idx[k];
+    alphaRT[s] = a[k];
+    for (int q = 0; q < 3; ++q) colorRT[(size_t)s * 3 + q] = c[(size_t)k * 3 + q];
+}
+
+__global__ void composite_fwd_kernel(const float* __restrict__ alphaRT, const float* __restrict__ colorRT, int R, int T,
+                                     float* __restrict__ weights, float* __restrict__ rgb) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    float Tr = 1.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    for (int i = 0; i < T; ++i) {
+        const float a = alphaRT[(size_t)r * T + i];
+        const float w = a * Tr;
+        weights[(size_t)r * T + i] = w;
+        const float* c = colorRT + ((size_t)r * T + i) * 3;
+        c0 += c[0] * w; c1 += c[1] * w; c2 += c[2] * w;
+        Tr *= (1.0f - a + 1e-7f);
+    }
+    rgb[r * 3] = c0; rgb[r * 3 + 1] = c1; rgb[r * 3 + 2] = c2;
+}
+
+// d_rgb [R,3] -> d_alphaRT [R,T], d_colorRT [R,T,3]
+__global__ void composite_bwd_kernel(const float* __restrict__ alphaRT, const float* __restrict__ colorRT,
+                                     const float* __restrict__ weights, const float* __restrict__ d_rgb, int R, int T,
+                                     float* __restrict__ d_alphaRT, float* __restrict__ d_colorRT) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float g0 = d_rgb[r * 3], g1 = d_rgb[r * 3 + 1], g2 = d_rgb[r * 3 + 2];
+    float S = 0.f;                                   // sum_{j>i} dw_j w_j
+    for (int i = T - 1; i >= 0; --i) {
+        const size_t s = (size_t)r * T + i;
+        const float a = alphaRT[s], w = weights[s];
+        const float* c = colorRT + s * 3;
+        const float dw = c[0] * g0 + c[1] * g1 + c[2] * g2;
+        d_colorRT[s * 3] = w * g0; d_colorRT[s * 3 + 1] = w * g1; d_colorRT[s * 3 + 2] = w * g2;
+        // T_i = w_i / a_i is unstable for a_i -> 0; recompute transmittance by the forward product instead
+        d_alphaRT[s] = -S / (1.0f - a + 1e-7f);      // + dw * T_i added in the second sweep
+        S += dw * w;
+    }
+    float Tr = 1.f;
+    for (int i = 0; i < T; ++i) {
+        const size_t s = (size_t)r * T + i;
+        const float a = alphaRT[s];
+        const float* c = colorRT + s * 3;
+        const float dw = c[0] * g0 + c[1] * g1 + c[2] * g2;
+        d_alphaRT[s] += dw * Tr;
+        Tr *= (1.0f - a + 1e-7f);
+    }
+}
+
+__global__ void gather_sample_grads_kernel(const float* __restrict__ d_alphaRT, const float* __restrict__ d_colorRT,
+                                           const int* __restrict__ idx, int n, float* __restrict__ d_a, float* __restrict__ d_c) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int s = idx[k];
+    d_a[k] = d_alphaRT[s];
+    for (int q = 0; q < 3; ++q) d_c[(size_t)k * 3 + q] = d_colorRT[(size_t)s * 3 + q];
+}
+
+}  // namespace
+
+#define GRID1D(n) dim3(((n) + 127) / 128), dim3(128), 0, (hipStream_t)stream
+#define CHECK_IDE() do { if (init_ide_tables() != 0) return nero_fail(NERO_ERR_LAUNCH, "IDE table upload failed"); } while (0)
+
+extern "C" {
+
+int nero_sdf_alpha_fwd(const float* sdf4, const float* grad, const float* x4, const int* idx, const float* d, int T,
+                       const float* variance, float anneal, int n, float* alpha, float* geo, float* gerr, void* stream) {
+    if (n == 0) return NERO_OK;
+    hipLaunchKernelGGL(sdf_alpha_fwd_kernel, GRID1D(n), sdf4, grad, x4, idx, d, T, variance, anneal, n, alpha, geo, gerr);
+    return nero_check_launch("nero_sdf_alpha_fwd");
+}
+
+int nero_sdf_alpha_bwd(const float* sdf4, const float* grad, const float* x4, const int* idx, const float* d, int T,
+                       const float* variance, float anneal, int n, const float* d_alpha, const float* d_gerr, const float* d_geo,
+                       float* d_sdf4, float* d_grad, float* dinv, void* stream) {
+    const int n_pad = NERO_ROW_PAD(n);
+    if (n_pad == 0) return NERO_OK;
+    hipLaunchKernelGGL(sdf_alpha_bwd_kernel, GRID1D(n_pad), sdf4, grad, x4, idx, d, T, variance, anneal, n, n_pad, d_alpha, d_gerr, d_geo, d_sdf4, d_grad, dinv);
+    return nero_check_launch("nero_sdf_alpha_bwd");
+}
+
+int nero_shade_encode(const float* x4, const float* geo, const float* m_raw, const float* r_raw, const float* a_raw, int n,
+                      float* mat, float* Xd, float* Xs, float* Xi, float* Xo, void* stream) {
+    CHECK_IDE();
+    const int n_pad = NERO_ROW_PAD(n);
+    if (n_pad == 0) return NERO_OK;
+    hipLaunchKernelGGL(shade_encode_kernel, GRID1D(n_pad), x4, geo, m_raw, r_raw, a_raw, n, n_pad, mat, Xd, Xs, Xi, Xo);
+    return nero_check_launch("nero_shade_encode");
+}
+
+int nero_shade_combine_fwd(const float* geo, const float* mat, const float* Ld, const float* Ls, const float* Li, const float* Lo,
+                           const float* lut, float exp_max, int n, float* color, float* occ_prob, void* stream) {
+    if (n == 0) return NERO_OK;
+    hipLaunchKernelGGL(shade_combine_fwd_kernel, GRID1D(n), geo, mat, Ld, Ls, Li, Lo, lut, exp_max, n, color, occ_prob);
+    return nero_check_launch("nero_shade_combine_fwd");
+}
+
+int nero_shade_combine_bwd(const float* geo, const float* mat, const float* Ld, const float* Ls, const float* Li, const float* Lo,
+                           const float* lut, float exp_max, int n, const float* d_color, const float* d_occ, float* dLd, float* dLs,
+                           float* dLi, float* dLo, float* dmat, float* d_geo, void* stream) {
+    const int n_pad = NERO_ROW_PAD(n);
+    if (n_pad == 0) return NERO_OK;
+    hipLaunchKernelGGL(shade_combine_bwd_kernel, GRID1D(n_pad), geo, mat, Ld, Ls, Li, Lo, lut, exp_max, n, n_pad, d_color, d_occ, dLd, dLs, dLi, dLo, dmat, d_geo);
+    return nero_check_launch("nero_shade_combine_bwd");
+}
+
+int nero_shade_encode_bwd(const float* geo, const float* mat, const float* dXd, const float* dXs, const float* dXi, const float* dmat,
+                          int n, float* d_geo, float* dm_raw, float* dr_raw, float* da_raw, void* stream) {
+    CHECK_IDE();
+    const int n_pad = NERO_ROW_PAD(n);
+    if (n_pad == 0) return NERO_OK;
+    hipLaunchKernelGGL(shade_encode_bwd_kernel, GRID1D(n_pad), geo, mat, dXd, dXs, dXi, dmat, n, n_pad, d_geo, dm_raw, dr_raw, da_raw);
+    return nero_check_launch("nero_shade_encode_bwd");
+}
+
+int nero_nerf_head_fwd(const float* sig4, const float* rgb4, const float* dist, int n, float* alpha, float* color, void* stream) {
+    if (n == 0) return NERO_OK;
+    hipLaunchKernelGGL(nerf_head_fwd_kernel, GRID1D(n), sig4, rgb4, dist, n, alpha, color);
+    return nero_check_launch("nero_nerf_head_fwd");
+}
+
+int nero_nerf_head_bwd(const float* sig4, const float* rgb4, const float* dist, int n, const float* d_alpha, const float* d_color,
+                       float* d_sig4, float* d_rgb4, void* stream) {
+    const int n_pad = NERO_ROW_PAD(n);
+    if (n_pad == 0) return NERO_OK;
+    hipLaunchKernelGGL(nerf_head_bwd_kernel, GRID1D(n_pad), sig4, rgb4, dist, n, n_pad, d_alpha, d_color, d_sig4, d_rgb4);
+    return nero_check_launch("nero_nerf_head_bwd");
+}
+
+int nero_scatter_samples(const float* a, const float* c, const int* idx, int n, float* alphaRT, float* colorRT, void* stream) {
+    if (n == 0) return NERO_OK;
+    hipLaunchKernelGGL(scatter_samples_kernel, GRID1D(n), a, c, idx, n, alphaRT, colorRT);
+    return nero_check_launch("nero_scatter_samples");
+}
+
+int nero_composite_fwd(const float* alphaRT, const float* colorRT, int R, int T, float* weights, float* rgb, void* stream) {
+    if (R == 0) return NERO_OK;
+    hipLaunchKernelGGL(composite_fwd_kernel, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, alphaRT, colorRT, R, T, weights, rgb);
+    return nero_check_launch("nero_composite_fwd");
+}
+
+int nero_composite_bwd(const float* alphaRT, const float* colorRT, const float* weights, const float* d_rgb, int R, int T,
+                       float* d_alphaRT, float* d_colorRT, void* stream) {
+    if (R == 0) return NERO_OK;
+    hipLaunchKernelGGL(composite_bwd_kernel, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, alphaRT, colorRT, weights, d_rgb, R, T, d_alphaRT, d_colorRT);
+    return nero_check_launch("nero_composite_bwd");
+}
+
+int nero_gather_sample_grads(const float* d_alphaRT, const float* d_colorRT, const int* idx, int n, float* d_a, float* d_c, void* stream) {
+    if (n == 0) return NERO_OK;
+    hipLaunchKernelGGL(gather_sample_grads_kernel, GRID1D(n), d_alphaRT, d_colorRT, idx, n, d_a, d_c);
+    return nero_check_launch("nero_gather_sample_grads");
+}
+
+}  // extern "C"

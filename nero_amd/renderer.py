@@ -49,5 +49,78 @@ class NeROShapeRenderer(nn.Module):
         mid = 0.5 * (-b) / a
         return torch.clamp(mid - 1.0, min=1e-3), mid + 1.0
 
+    # ------------------------------------------------------------------------------------------------------------
+    def _kernels(self):
+        """effective weights (autograd tensors) + packed HIP chains for the current parameter values"""
+        from .shape_step import ShapeKernels, flatten_effective, unflatten_effective
+        names, eff = flatten_effective(self)
+        K = ShapeKernels(unflatten_effective(names, [t.detach() for t in eff]), self.color_network.cfg, eff[0].device).pack()
+        return names, eff, K
+
+    def sample_ray(self, rays_o, rays_d, near, far, perturb, rand1=None, rand_bg=None, K=None, trace=None):
+        """network/renderer.py:403-443 on the HIP sampler.  rand1 [R,1] / rand_bg [R,n_bg]: optional explicit uniform draws
+        (default: torch.rand on the device when perturb > 0, like the reference)."""
+        from .shape_step import sample_ray
+        if K is None:
+            _, _, K = self._kernels()
+        R = rays_o.shape[0]
+        if perturb > 0:
+            if rand1 is None:
+                rand1 = torch.rand([R, 1], device=rays_o.device)
+            if rand_bg is None:
+                rand_bg = torch.rand([R, self.cfg['n_bg_samples']], device=rays_o.device)
+        else:
+            rand1 = rand_bg = None
+        with torch.no_grad():
+            return sample_ray(K, self.cfg, rays_o.contiguous(), rays_d.contiguous(), near.contiguous(), far.contiguous(),
+                              self.deviation_network.variance.detach(), rand1, rand_bg, trace)
+
+    def render(self, rays_o, rays_d, near, far, human_poses, perturb_overwrite=-1, cos_anneal_ratio=0.0, is_train=True,
+               step=None, rand1=None, rand_bg=None, z_vals=None):
+        """same contract as the reference (network/renderer.py:445-463); extra keyword-only style arguments rand1 / rand_bg /
+        z_vals allow tests to inject the random draws or teacher-force the sample positions."""
+        perturb = self.cfg['perturb']
+        if perturb_overwrite >= 0:
+            perturb = perturb_overwrite
+        names, eff, K = self._kernels()
+        if z_vals is None:
+            z_vals = self.sample_ray(rays_o, rays_d, near, far, perturb, rand1, rand_bg, K)
+        return self.render_core(rays_o, rays_d, z_vals, human_poses, cos_anneal_ratio=cos_anneal_ratio, step=step,
+                                is_train=is_train, _kern=(names, eff))
+
+    def render_core(self, rays_o, rays_d, z_vals, human_poses, cos_anneal_ratio=0.0, step=None, is_train=True, _kern=None):
+        from .shape_step import RenderCore
+        names, eff = _kern if _kern is not None else self._kernels()[:2]
+        c = self.cfg
+        meta = {'names': names, 'shapes': [tuple(t.shape) for t in eff], 'shader_cfg': self.color_network.cfg,
+                'anneal': float(cos_anneal_ratio), 'exp_max': float(self.color_network.cfg['light_exp_max']),
+                'freeze_inv_s': c['freeze_inv_s_step'] is not None and step < c['freeze_inv_s_step']}
+        var = self.deviation_network.variance
+        rgb, gerr, occ_prob = RenderCore.apply(meta, rays_o.contiguous(), rays_d.contiguous(), z_vals.contiguous(), var,
+                                               self.color_network.FG_LUT, *eff)
+        n_in = gerr.shape[0]
+        outputs = {'ray_rgb': rgb, 'gradient_error': gerr if n_in > 0 else torch.zeros(1, device=rgb.device)}
+        inv_s = torch.exp(var * 10.0).clip(1e-6, 1e6)
+        if meta['freeze_inv_s']:
+            inv_s = inv_s.detach()
+        outputs['std'] = torch.mean(1.0 / inv_s) if n_in > 0 else torch.zeros(1, device=rgb.device)
+        if c['apply_occ_loss']:
+            outputs['loss_occ'] = torch.zeros(1, device=rgb.device)
+        outputs['_occ_prob'] = occ_prob
+        outputs['_state'] = meta.get('_state')
+        return outputs
+
+    def compute_rgb_loss(self, rgb_pr, rgb_gt):
+        kind = self.cfg['rgb_loss']
+        if kind == 'l2':
+            return torch.sum((rgb_pr - rgb_gt) ** 2, -1)
+        if kind == 'l1':
+            return torch.sum(torch.abs(rgb_pr - rgb_gt), -1)
+        if kind == 'smooth_l1':
+            return torch.sum(torch.nn.functional.smooth_l1_loss(rgb_pr, rgb_gt, reduction='none', beta=0.25), -1)
+        if kind == 'charbonier':
+            return torch.sqrt(torch.sum((rgb_gt - rgb_pr) ** 2, dim=-1) + 0.001)
+        raise NotImplementedError
+
 
 name2renderer = {'shape': NeROShapeRenderer}

@@ -1,0 +1,319 @@
+"""Stage-I render step on the HIP library: host-side orchestration only (buffer allocation through torch's caching
+allocator, kernel sequencing, autograd glue).  Mirrors NeROShapeRenderer.sample_ray / render_core
+(network/renderer.py:403-443, 550-606) and AppShadingNetwork.forward (network/field.py:591-651); every arithmetic step
+is a call into libnero_hip.so (include/nero_hip.h).  See DESIGN.md §2 for the kernel sequence."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from .chain import Chain, Dense, Head, row_pad
+from .sdf import SDFField
+
+P = C.c_void_p
+
+
+def _p(t):
+    return P(None if t is None else t.data_ptr())
+
+
+def _st():
+    return L.stream_ptr()
+
+
+def predictor_entries(eff, k_main0, k_aux0=0):
+    """eff: 4 (W,b).  Layer 0 may take [main(k_main0) | aux(k_aux0)] columns."""
+    (W0, b0), (W1, b1), (W2, b2), (W3, b3) = eff
+    return [(Dense(W0, b0, L.ACT_RELU, k_main0, 0, k_aux0, k_main0), None), (Dense(W1, b1, L.ACT_RELU, 256), None),
+            (Dense(W2, b2, L.ACT_RELU, 256), None), (None, Head(W3, b3))]
+
+
+class ShapeKernels:
+    """all chains of one NeROShapeRenderer; rebuilt (cheap: descriptors only) whenever the effective weights change."""
+
+    def __init__(self, eff, shader_cfg, device='cuda'):
+        self.device = device
+        self.human = bool(shader_cfg.get('human_light', False))
+        if self.human:
+            raise NotImplementedError('shader_config.human_light is not wired into the HIP path yet')
+        self.sdf = SDFField(eff['sdf'], device)
+        nf = eff['nerf']
+        ent = []
+        for i, (W, b) in enumerate(nf['pts']):
+            if i == 0:
+                ent.append((Dense(W, b, L.ACT_RELU, 84), None))
+            elif i == 5:
+                ent.append((Dense(W, b, L.ACT_RELU, 256, 84, 84, 0), None))
+            else:
+                ent.append((Dense(W, b, L.ACT_RELU, 256), None))
+        ent.append((None, Head(*nf['alpha'])))
+        self.nerf_trunk = Chain(ent, k_init=88, k_aux=88, aux_wide=True, device=device)
+        self.nerf_head = Chain([(Dense(*nf['feature'], L.ACT_NONE, 256), None),
+                                (Dense(*nf['views'], L.ACT_RELU, 256, 0, 27, 256), None),
+                                (None, Head(*nf['rgb']))], k_init=256, k_aux=32, device=device)
+        self.mat = [Chain(predictor_entries(eff[k], 256, 3), k_init=256, k_aux=8, device=device)
+                    for k in ('metallic', 'roughness', 'albedo')]
+        self.outer_light = Chain(predictor_entries(eff['outer_light'], 72), k_init=72, device=device)
+        self.inner_light = Chain(predictor_entries(eff['inner_light'], 123), k_init=128, device=device)
+        self.inner_weight = Chain(predictor_entries(eff['inner_weight'], 90), k_init=96, device=device)
+
+    def pack(self):
+        self.sdf.pack()
+        for c in [self.nerf_trunk, self.nerf_head, self.outer_light, self.inner_light, self.inner_weight] + self.mat:
+            c.pack()
+        return self
+
+
+def flatten_effective(net):
+    """-> (names, tensors): effective weights of a NeROShapeRenderer as a flat list of autograd tensors."""
+    names, ts = [], []
+
+    def add(prefix, wb):
+        names.extend([prefix + '.weight', prefix + '.bias'])
+        ts.extend(wb)
+    for l, wb in enumerate(net.sdf_network.effective()):
+        add(f'sdf.{l}', wb)
+    nf = net.outer_nerf.effective()
+    for i, wb in enumerate(nf['pts']):
+        add(f'nerf.pts.{i}', wb)
+    for k in ('views', 'feature', 'alpha', 'rgb'):
+        add(f'nerf.{k}', nf[k])
+    cn = net.color_network
+    preds = ['metallic_predictor', 'roughness_predictor', 'albedo_predictor', 'outer_light', 'inner_light', 'inner_weight']
+    if cn.cfg['human_light']:
+        preds.append('human_light_predictor')
+    for pn in preds:
+        for i, wb in enumerate(getattr(cn, pn).effective()):
+            add(f'{pn}.{i}', wb)
+    return names, ts
+
+
+def unflatten_effective(names, ts):
+    d = dict(zip(names, ts))
+
+    def wb(prefix):
+        return d[prefix + '.weight'], d[prefix + '.bias']
+    eff = {'sdf': [wb(f'sdf.{l}') for l in range(9)],
+           'nerf': {'pts': [wb(f'nerf.pts.{i}') for i in range(8)], 'views': wb('nerf.views'), 'feature': wb('nerf.feature'),
+                    'alpha': wb('nerf.alpha'), 'rgb': wb('nerf.rgb')}}
+    for short, pn in (('metallic', 'metallic_predictor'), ('roughness', 'roughness_predictor'), ('albedo', 'albedo_predictor'),
+                      ('outer_light', 'outer_light'), ('inner_light', 'inner_light'), ('inner_weight', 'inner_weight'),
+                      ('human', 'human_light_predictor')):
+        if f'{pn}.0.weight' in d:
+            eff[short] = [wb(f'{pn}.{i}') for i in range(4)]
+    return eff
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# sampling (no grad)
+# ----------------------------------------------------------------------------------------------------------------------
+def sample_ray(K, cfg, o, d, near, far, variance, rand1=None, rand_bg=None, trace=None):
+    """network/renderer.py:403-443.  o,d [R,3]; near,far [R,1]; variance: 0-dim device tensor; rand1 [R,1] / rand_bg
+    [R,n_bg] uniform draws (None = no perturbation).  -> z_vals [R, n_samples+n_importance+n_bg]"""
+    dev = o.device
+    R = o.shape[0]
+    ns, nb, up = cfg['n_samples'], cfg['n_bg_samples'], cfg['up_sample_steps']
+    m = cfg['n_importance'] // up
+    n_in = ns + m * up
+    T = n_in + nb
+    z = torch.empty((R, T), dtype=torch.float32, device=dev)
+    tab = torch.empty((R, n_in), dtype=torch.float32, device=dev)
+    st = _st()
+    lib = L.lib
+    L.check(lib.nero_coarse_z(_p(near), _p(far), _p(rand1), R, ns, _p(z), T, st))
+    pe = torch.empty((row_pad(R * ns), 40), dtype=torch.float32, device=dev)
+    L.check(lib.nero_ray_points_pe(_p(o), _p(d), _p(z), T, 0, ns, R, _p(pe), st))
+    s4 = K.sdf.sdf_from_pe(pe, R * ns)
+    L.check(lib.nero_scatter_sdf(_p(s4), 4, R, ns, _p(tab), n_in, st))
+    n = ns
+    z_new = torch.empty((R, m), dtype=torch.float32, device=dev)
+    pe_new = torch.empty((row_pad(R * m), 40), dtype=torch.float32, device=dev)
+    var_ptr = variance if cfg['clip_sample_variance'] else None
+    for i in range(up):
+        w_out = inds = index = None
+        if trace is not None:
+            w_out = torch.empty((R, n - 1), dtype=torch.float32, device=dev)
+            inds = torch.empty((R, m), dtype=torch.int32, device=dev)
+            index = torch.empty((R, n + m), dtype=torch.int32, device=dev)
+            z_before = z[:, :n].clone()
+            sdf_before = tab[:, :n].clone()
+        L.check(lib.nero_upsample(_p(o), _p(d), _p(z), T, _p(tab), n_in, n, _p(var_ptr), C.c_float(64.0 * 2 ** i), m, R,
+                                  _p(z_new), _p(w_out), _p(inds), st))
+        last = (i + 1 == up)
+        if not last:
+            L.check(lib.nero_ray_points_pe(_p(o), _p(d), _p(z_new), m, 0, m, R, _p(pe_new), st))
+            s4 = K.sdf.sdf_from_pe(pe_new, R * m)
+            L.check(lib.nero_merge_sorted(_p(z), T, n, _p(tab), n_in, _p(z_new), m, _p(s4), 4, R, _p(index), st))
+        else:
+            L.check(lib.nero_merge_sorted(_p(z), T, n, _p(None), 0, _p(z_new), m, _p(None), 0, R, _p(index), st))
+        if trace is not None:
+            trace.append(dict(z=z_before, sdf=sdf_before, weights=w_out, z_new=z_new.clone(), inds=inds, index=index,
+                              z_out=z[:, :n + m].clone()))
+        n += m
+    L.check(lib.nero_background_z(_p(far), _p(rand_bg), R, nb, _p(z), T, n_in, st))
+    return z
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# render_core as one autograd node
+# ----------------------------------------------------------------------------------------------------------------------
+class RenderCore(torch.autograd.Function):
+    """inputs: (meta dict, o, d, z_vals, variance, FG_LUT, *effective weights).  outputs: ray_rgb [R,3],
+    gradient_error [N_in], occ_prob [N_in] (unclamped)."""
+
+    @staticmethod
+    def forward(ctx, meta, o, d, z_vals, variance, lut, *params):
+        dev = o.device
+        lib = L.lib
+        st = _st()
+        K = ShapeKernels(unflatten_effective(meta['names'], [p.detach() for p in params]), meta['shader_cfg'], dev).pack()
+        R, T = z_vals.shape
+        f32 = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        pts4 = torch.empty((R * T, 4), **f32)
+        ray_counts, ray_off, counts = torch.empty(R, **i32), torch.empty(R, **i32), torch.empty(2, **i32)
+        L.check(lib.nero_render_prep(_p(o), _p(d), _p(z_vals), R, T, _p(pts4), _p(ray_counts), _p(ray_off), _p(counts), st))
+        n_in, n_out = (int(v) for v in counts.cpu())                 # the one host sync of the step
+        rpi, rpo = row_pad(n_in), row_pad(n_out)
+        inner_idx, outer_idx = torch.empty(max(n_in, 1), **i32), torch.empty(max(n_out, 1), **i32)
+        L.check(lib.nero_compact(_p(pts4), _p(ray_off), R, T, _p(inner_idx), _p(outer_idx), st))
+        alphaRT = torch.zeros(R * T, **f32)
+        colorRT = torch.zeros((R * T, 3), **f32)
+        S = {'K': K, 'R': R, 'T': T, 'n_in': n_in, 'n_out': n_out, 'inner_idx': inner_idx, 'outer_idx': outer_idx,
+             'meta': meta, 'o': o, 'd': d, 'variance': variance, 'lut': lut}
+
+        # ---- outer samples: NeRF++ -------------------------------------------------------------------------------
+        if n_out > 0:
+            pe88, pev32, dist_o = torch.empty((rpo, 88), **f32), torch.empty((rpo, 32), **f32), torch.empty(rpo, **f32)
+            L.check(lib.nero_gather_outer(_p(pts4), _p(d), _p(outer_idx), T, n_out, _p(pe88), _p(pev32), _p(dist_o), st))
+            trunk = K.nerf_trunk.forward(pe88, pe88, n_out)
+            head = K.nerf_head.forward(trunk['saves'][7], pev32, n_out)
+            alpha_o, color_o = torch.empty(rpo, **f32), torch.empty((rpo, 3), **f32)
+            L.check(lib.nero_nerf_head_fwd(_p(trunk['heads'][8]), _p(head['heads'][2]), _p(dist_o), n_out, _p(alpha_o), _p(color_o), st))
+            L.check(lib.nero_scatter_samples(_p(alpha_o), _p(color_o), _p(outer_idx), n_out, _p(alphaRT), _p(colorRT), st))
+            S.update(pe88=pe88, pev32=pev32, dist_o=dist_o, trunk=trunk, head=head)
+
+        # ---- inner samples: SDF + split-sum shader ---------------------------------------------------------------
+        gerr = torch.zeros(max(n_in, 1), **f32)
+        occ_prob = torch.zeros(max(n_in, 1), **f32)
+        if n_in > 0:
+            x4, pe40 = torch.empty((rpi, 4), **f32), torch.empty((rpi, 40), **f32)
+            L.check(lib.nero_gather_inner(_p(pts4), _p(inner_idx), n_in, _p(x4), _p(pe40), st))
+            sctx = K.sdf.forward_normal(x4, n_in, pe40)
+            alpha_i, geo = torch.empty(rpi, **f32), torch.empty((rpi, 8), **f32)
+            L.check(lib.nero_sdf_alpha_fwd(_p(sctx['sdf4']), _p(sctx['normal']), _p(x4), _p(inner_idx), _p(d), T, _p(variance),
+                                           C.c_float(meta['anneal']), n_in, _p(alpha_i), _p(geo), _p(gerr), st))
+            x8 = torch.zeros((rpi, 8), **f32)
+            x8[:, :3] = x4[:, :3]
+            feat = sctx['feat']
+            mats = [c.forward(feat, x8, n_in) for c in K.mat]
+            mat = torch.empty((rpi, 8), **f32)
+            Xo2 = torch.empty((2 * rpi, 72), **f32)           # rows [0,rpi): IDE(n,1) ; rows [rpi,2rpi): IDE(refl, rough)
+            Xi, Xo = torch.empty((rpi, 128), **f32), torch.empty((rpi, 96), **f32)
+            L.check(lib.nero_shade_encode(_p(x4), _p(geo), _p(mats[0]['heads'][3]), _p(mats[1]['heads'][3]), _p(mats[2]['heads'][3]),
+                                          n_in, _p(mat), _p(Xo2[:rpi]), _p(Xo2[rpi:]), _p(Xi), _p(Xo), st))
+            f_out = K.outer_light.forward(Xo2, None, rpi + n_in)
+            f_in = K.inner_light.forward(Xi, None, n_in)
+            f_w = K.inner_weight.forward(Xo, None, n_in)
+            Lh = f_out['heads'][3]
+            color_i = torch.empty((rpi, 3), **f32)
+            L.check(lib.nero_shade_combine_fwd(_p(geo), _p(mat), _p(Lh[:rpi]), _p(Lh[rpi:]), _p(f_in['heads'][3]), _p(f_w['heads'][3]),
+                                               _p(lut), C.c_float(meta['exp_max']), n_in, _p(color_i), _p(occ_prob), st))
+            L.check(lib.nero_scatter_samples(_p(alpha_i), _p(color_i), _p(inner_idx), n_in, _p(alphaRT), _p(colorRT), st))
+            S.update(x4=x4, x8=x8, sctx=sctx, geo=geo, mats=mats, mat=mat, Xo2=Xo2, Xi=Xi, Xo=Xo, f_out=f_out, f_in=f_in,
+                     f_w=f_w)
+        weights, rgb = torch.empty((R, T), **f32), torch.empty((R, 3), **f32)
+        L.check(lib.nero_composite_fwd(_p(alphaRT), _p(colorRT), R, T, _p(weights), _p(rgb), st))
+        S.update(alphaRT=alphaRT, colorRT=colorRT, weights=weights)
+        ctx.S = S
+        ctx.n_params = len(params)
+        meta['_state'] = S                       # lets the caller reach intermediates (occ loss, validation extras)
+        return rgb, gerr[:max(n_in, 0)] if n_in > 0 else gerr[:0], occ_prob[:n_in] if n_in > 0 else occ_prob[:0]
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_gerr, d_occ):
+        S = ctx.S
+        K, R, T, n_in, n_out, meta = S['K'], S['R'], S['T'], S['n_in'], S['n_out'], S['meta']
+        dev = S['o'].device
+        lib = L.lib
+        st = _st()
+        f32 = dict(dtype=torch.float32, device=dev)
+        d_rgb = d_rgb.contiguous()
+        d_aRT, d_cRT = torch.empty(R * T, **f32), torch.empty((R * T, 3), **f32)
+        L.check(lib.nero_composite_bwd(_p(S['alphaRT']), _p(S['colorRT']), _p(S['weights']), _p(d_rgb), R, T, _p(d_aRT), _p(d_cRT), st))
+        ws = torch.empty(L.lib.nero_dw_workspace_floats(max(n_in + row_pad(n_in), n_out, 1)), **f32)
+        G = {}                                   # name -> gradient
+
+        def put_pred(prefix, gr):
+            for i in range(3):
+                G[f'{prefix}.{i}.weight'], G[f'{prefix}.{i}.bias'] = gr[i]['dW'], gr[i]['db']
+            G[f'{prefix}.3.weight'], G[f'{prefix}.3.bias'] = gr[3]['dWh'], gr[3]['dbh']
+
+        if n_out > 0:
+            rpo = row_pad(n_out)
+            d_ao, d_co = torch.empty(rpo, **f32), torch.empty((rpo, 3), **f32)
+            L.check(lib.nero_gather_sample_grads(_p(d_aRT), _p(d_cRT), _p(S['outer_idx']), n_out, _p(d_ao), _p(d_co), st))
+            trunk, head = S['trunk'], S['head']
+            d_sig4, d_rgb4 = torch.empty((rpo, 4), **f32), torch.empty((rpo, 4), **f32)
+            L.check(lib.nero_nerf_head_bwd(_p(trunk['heads'][8]), _p(head['heads'][2]), _p(S['dist_o']), n_out, _p(d_ao), _p(d_co),
+                                           _p(d_sig4), _p(d_rgb4), st))
+            hb = K.nerf_head.backward(head, n_out, head_dys={2: d_rgb4}, need_dinit=True)
+            hg = K.nerf_head.weight_grads(head, hb, n_out, trunk['saves'][7], S['pev32'], head_dys={2: d_rgb4}, workspace=ws)
+            G['nerf.feature.weight'], G['nerf.feature.bias'] = hg[0]['dW'], hg[0]['db']
+            G['nerf.views.weight'], G['nerf.views.bias'] = hg[1]['dW'], hg[1]['db']
+            G['nerf.rgb.weight'], G['nerf.rgb.bias'] = hg[2]['dWh'], hg[2]['dbh']
+            tb = K.nerf_trunk.backward(trunk, n_out, dy=hb['d_init'], head_dys={8: d_sig4})
+            tg = K.nerf_trunk.weight_grads(trunk, tb, n_out, S['pe88'], S['pe88'], head_dys={8: d_sig4}, workspace=ws)
+            for i in range(8):
+                G[f'nerf.pts.{i}.weight'], G[f'nerf.pts.{i}.bias'] = tg[i]['dW'], tg[i]['db']
+            G['nerf.alpha.weight'], G['nerf.alpha.bias'] = tg[8]['dWh'], tg[8]['dbh']
+
+        d_var = None
+        if n_in > 0:
+            rpi = row_pad(n_in)
+            d_ai, d_ci = torch.empty(rpi, **f32), torch.empty((rpi, 3), **f32)
+            L.check(lib.nero_gather_sample_grads(_p(d_aRT), _p(d_cRT), _p(S['inner_idx']), n_in, _p(d_ai), _p(d_ci), st))
+            geo, mat, f_out, f_in, f_w = S['geo'], S['mat'], S['f_out'], S['f_in'], S['f_w']
+            Lh = f_out['heads'][3]
+            dLh = torch.empty((2 * rpi, 4), **f32)
+            dLi, dLo = torch.empty((rpi, 4), **f32), torch.empty((rpi, 4), **f32)
+            dmat, d_geo = torch.empty((rpi, 8), **f32), torch.zeros((rpi, 8), **f32)
+            d_occ_c = d_occ.contiguous() if d_occ is not None else None
+            L.check(lib.nero_shade_combine_bwd(_p(geo), _p(mat), _p(Lh[:rpi]), _p(Lh[rpi:]), _p(f_in['heads'][3]), _p(f_w['heads'][3]),
+                                               _p(S['lut']), C.c_float(meta['exp_max']), n_in, _p(d_ci), _p(d_occ_c),
+                                               _p(dLh[:rpi]), _p(dLh[rpi:]), _p(dLi), _p(dLo), _p(dmat), _p(d_geo), st))
+            n2 = rpi + n_in
+            ob = K.outer_light.backward(f_out, n2, head_dys={3: dLh}, need_dinit=True)
+            put_pred('outer_light', K.outer_light.weight_grads(f_out, ob, n2, S['Xo2'], None, head_dys={3: dLh}, workspace=ws))
+            ib = K.inner_light.backward(f_in, n_in, head_dys={3: dLi}, need_dinit=True)
+            put_pred('inner_light', K.inner_light.weight_grads(f_in, ib, n_in, S['Xi'], None, head_dys={3: dLi}, workspace=ws))
+            wb = K.inner_weight.backward(f_w, n_in, head_dys={3: dLo})
+            put_pred('inner_weight', K.inner_weight.weight_grads(f_w, wb, n_in, S['Xo'], None, head_dys={3: dLo}, workspace=ws))
+            dmr, drr, dar = (torch.empty((rpi, 4), **f32) for _ in range(3))
+            dX = ob['d_init']
+            L.check(lib.nero_shade_encode_bwd(_p(geo), _p(mat), _p(dX[:rpi]), _p(dX[rpi:]), _p(ib['d_init']), _p(dmat), n_in,
+                                              _p(d_geo), _p(dmr), _p(drr), _p(dar), st))
+            d_feat = torch.empty((rpi, 256), **f32)
+            feat = S['sctx']['feat']
+            for j, (c, name, dh) in enumerate(zip(K.mat, ('metallic_predictor', 'roughness_predictor', 'albedo_predictor'), (dmr, drr, dar))):
+                mb = c.backward(S['mats'][j], n_in, head_dys={3: dh}, need_dinit=True, dinit_out=d_feat, accumulate_dinit=(j > 0))
+                put_pred(name, c.weight_grads(S['mats'][j], mb, n_in, feat, S['x8'], head_dys={3: dh}, workspace=ws))
+            d_sdf4, d_grad, dinv = torch.empty((rpi, 4), **f32), torch.empty((rpi, 3), **f32), torch.empty(rpi, **f32)
+            d_gerr_c = d_gerr.contiguous() if d_gerr is not None else None
+            L.check(lib.nero_sdf_alpha_bwd(_p(S['sctx']['sdf4']), _p(S['sctx']['normal']), _p(S['x4']), _p(S['inner_idx']), _p(S['d']), T,
+                                           _p(S['variance']), C.c_float(meta['anneal']), n_in, _p(d_ai), _p(d_gerr_c), _p(d_geo),
+                                           _p(d_sdf4), _p(d_grad), _p(dinv), st))
+            sg = K.sdf.backward(S['sctx'], d_sdf4, d_feat, d_grad, workspace=ws)
+            for l in range(9):
+                G[f'sdf.{l}.weight'], G[f'sdf.{l}.bias'] = sg[l]
+            if not meta['freeze_inv_s']:
+                v = S['variance'].detach()
+                inv_s = torch.exp(v * 10.0)
+                live = ((inv_s >= 1e-6) & (inv_s <= 1e6)).to(torch.float32)
+                d_var = dinv[:n_in].sum() * 10.0 * inv_s * live
+        grads = []
+        for name, shape in zip(meta['names'], meta['shapes']):
+            g = G.get(name)
+            grads.append(g if g is not None else torch.zeros(shape, **f32))
+        ctx.S = None
+        return (None, None, None, None, d_var, None) + tuple(grads)

@@ -1,0 +1,111 @@
+"""GPU tier: the Stage-I render step on the HIP library vs the CPU oracle (oracle/nero_oracle.py), which is itself pinned to
+the unmodified reference by tests/test_oracle_golden.py.  Tolerance: 1e-4 rel fp32 on outputs (BASELINE.json north_star),
+bit-exact on sample indices under teacher forcing."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nero_oracle as O
+from tests.helpers import T, build_case_model, load_golden
+
+pytestmark = pytest.mark.gpu
+
+CASES = ['bell_s25000', 'bell_s5000_sharp', 'bell_c1']
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def _oracle_P(net):
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    return O.effective_params(sd)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_sampler_stagewise_teacher_forced(name):
+    """each up-sampling round is fed the ORACLE's (z, sdf) of that round: searchsorted indices and the merge permutation
+    must be identical; weights / new z within fp32 tolerance."""
+    from nero_amd import _lib as L
+    import ctypes as C
+    z, meta = load_golden(name)
+    net = build_case_model(meta).cuda()
+    cfg = {**O.DEFAULT_CFG, **meta['cfg']}
+    trace = []
+    O.sample_ray(_oracle_P(net), cfg, T(z, 'o'), T(z, 'd'), T(z, 'near'), T(z, 'far'), T(z, 'rand1'), T(z, 'rand_bg'), trace)
+    o, d = T(z, 'o', 'cuda'), T(z, 'd', 'cuda')
+    R = o.shape[0]
+    st = L.stream_ptr()
+    P = C.c_void_p
+    for t in trace:
+        n, m = t['z'].shape[1], t['z_new'].shape[1]
+        zc, sc = t['z'].cuda().contiguous(), t['sdf'].cuda().contiguous()
+        z_new = torch.empty(R, m, device='cuda'); w = torch.empty(R, n - 1, device='cuda')
+        inds = torch.empty(R, m, dtype=torch.int32, device='cuda')
+        L.check(L.lib.nero_upsample(P(o.data_ptr()), P(d.data_ptr()), P(zc.data_ptr()), n, P(sc.data_ptr()), n, n, P(None),
+                                    C.c_float(t['inv_s']), m, R, P(z_new.data_ptr()), P(w.data_ptr()), P(inds.data_ptr()), st))
+        assert rel(w, t['weights']) < 2e-5
+        # indices from the kernel's own weights: identical except where a 1-ulp weight difference crosses a cdf edge
+        assert (inds.cpu() != t['inds'].int()).float().mean() < 2e-3
+        # exact contract: sample_pdf on the oracle's weights
+        wt = t['weights'].cuda().contiguous()
+        out = torch.empty(R, m, device='cuda'); inds2 = torch.empty(R, m, dtype=torch.int32, device='cuda')
+        L.check(L.lib.nero_sample_pdf(P(zc.data_ptr()), n, P(wt.data_ptr()), n - 1, n, m, R, P(out.data_ptr()), P(inds2.data_ptr()), st))
+        assert torch.equal(inds2.cpu(), t['inds'].int())
+        assert (out.cpu() - t['z_new']).abs().max() < 2e-6
+        # exact contract: merge permutation on the oracle's z_new
+        zt = torch.empty(R, n + m, device='cuda'); zt[:, :n] = zc
+        index = torch.empty(R, n + m, dtype=torch.int32, device='cuda')
+        zn = t['z_new'].cuda().contiguous()
+        L.check(L.lib.nero_merge_sorted(P(zt.data_ptr()), n + m, n, P(None), 0, P(zn.data_ptr()), m, P(None), 0, R, P(index.data_ptr()), st))
+        assert torch.equal(index.cpu(), t['index'].int())
+        assert torch.equal(zt.cpu(), t['z_out'])
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_sampler_end_to_end(name):
+    z, meta = load_golden(name)
+    net = build_case_model(meta).cuda()
+    cfg = {**O.DEFAULT_CFG, **meta['cfg']}
+    zo = O.sample_ray(_oracle_P(net), cfg, T(z, 'o'), T(z, 'd'), T(z, 'near'), T(z, 'far'), T(z, 'rand1'), T(z, 'rand_bg'))
+    zg = net.sample_ray(T(z, 'o', 'cuda'), T(z, 'd', 'cuda'), T(z, 'near', 'cuda'), T(z, 'far', 'cuda'), 1.0,
+                        T(z, 'rand1', 'cuda'), T(z, 'rand_bg', 'cuda')).cpu()
+    nb = cfg['n_bg_samples']
+    dz = (zg[:, :-nb] - zo[:, :-nb]).abs()
+    assert dz.max() < 2e-3 and (dz < 1e-5).float().mean() > 0.95, (dz.max(), (dz < 1e-5).float().mean())
+    assert (zg[:, -nb:] / zo[:, -nb:] - 1).abs().max() < 1e-6
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_render_core_outputs_and_grads(name):
+    """teacher-forced on the golden z_vals: ray_rgb / gradient_error / occ_prob and every parameter gradient vs the oracle"""
+    z, meta = load_golden(name)
+    net = build_case_model(meta).cuda()
+    ref = build_case_model(meta)                       # CPU copy for the oracle
+    sd = {k: v for k, v in ref.named_parameters()}
+    sd.update({k: v for k, v in ref.named_buffers()})
+    P = O.effective_params(sd)
+    cfg = {**O.DEFAULT_CFG, **meta['cfg'], 'apply_occ_loss': False}
+    oo = O.render_core(P, cfg, T(z, 'o'), T(z, 'd'), T(z, 'z_vals'), T(z, 'human_poses'), meta['anneal'], meta['step'])
+    loss_o = O.rgb_loss(cfg, oo['ray_rgb'], T(z, 'gt')).mean() + (oo['gradient_error'] * 0.1).mean()
+    loss_o.backward()
+    out = net.render(T(z, 'o', 'cuda'), T(z, 'd', 'cuda'), T(z, 'near', 'cuda'), T(z, 'far', 'cuda'), T(z, 'human_poses', 'cuda'),
+                     -1, meta['anneal'], is_train=True, step=meta['step'], z_vals=T(z, 'z_vals', 'cuda'))
+    assert out['gradient_error'].shape == oo['gradient_error'].shape
+    assert rel(out['ray_rgb'], oo['ray_rgb']) < 1e-4
+    assert rel(out['gradient_error'], oo['gradient_error']) < 1e-4
+    loss = net.compute_rgb_loss(out['ray_rgb'], T(z, 'gt', 'cuda')).mean() + (out['gradient_error'] * 0.1).mean()
+    assert abs(float(loss) - float(loss_o)) < 1e-5
+    loss.backward()
+    worst = {}
+    for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        gq = q.grad if q.grad is not None else torch.zeros_like(q)
+        gp = p.grad if p.grad is not None else torch.zeros_like(p)
+        if gq.abs().max() < 1e-12 and gp.abs().max() < 1e-12:
+            continue
+        worst[k] = rel(gp, gq)
+    # inner_weight only sees the tiny, clamp-gated occlusion-blend gradient (|g| ~ 1e-7): looser; measured elsewhere ~1e-6
+    bad = {k: v for k, v in worst.items() if v > (5e-3 if 'inner_weight' in k else 2e-4)}
+    assert not bad, bad
+    assert np.median(list(worst.values())) < 2e-5
