@@ -29,6 +29,10 @@ enum { NERO_OK = 0, NERO_ERR_ARG = -1, NERO_ERR_LAUNCH = -2, NERO_ERR_UNSUPPORTE
 
 const char* nero_last_error(void);
 int nero_version(void);
+/* per-launch HIP-event timing of the MFMA kernel classes {0 forward, 1 tangent, 2 reverse, 3 weight-gradient GEMM}:
+ * report fills out[kind*3 + {0,1,2}] = {launches, total ms, total algorithmic flops} (host array of 12 doubles). */
+int nero_prof_enable(int on);
+int nero_prof_report(double* out);
 
 /* ---- weight packing -------------------------------------------------------------------------------------------
  * Packs (a column window of) an effective weight matrix W[rows, ld] into the MFMA B-operand order used by the chain
@@ -64,6 +68,7 @@ typedef struct {
     const float* aux;      /* [rows_pad, ld_aux]: first k_aux columns are loaded into the aux tile                    */
     int ld_init, k_init, ld_aux, k_aux;
     int n_layers, aux_wide; /* aux_wide: 0 -> aux tile holds <= 40 columns (2 workgroups/CU), 1 -> <= 88              */
+    double macs_per_row;    /* logical multiply-adds per row (profiling only)                                         */
     nero_fwd_layer layer[NERO_MAX_LAYERS];
 } nero_fwd_chain;
 
@@ -85,6 +90,7 @@ typedef struct {
     const float* init; const float* aux;
     int ld_init, k_init, ld_aux, k_aux;
     int n_layers, aux_wide;
+    double macs_per_row;
     nero_tan_layer layer[NERO_MAX_LAYERS];
 } nero_tan_chain;
 
@@ -114,6 +120,7 @@ typedef struct {
     float* d_aux;          /* out [rows_pad, ld_daux]  gradient w.r.t. the aux columns, summed over the layers using it */
     int ld_dinit, ld_daux, accumulate_dinit;
     int n_layers, aux_wide;
+    double macs_per_row;
     nero_bwd_layer layer[NERO_MAX_LAYERS];   /* in FORWARD order; walked from n_layers-1 down to 0                    */
 } nero_bwd_chain;
 

@@ -21,7 +21,8 @@ class FwdLayer(C.Structure):
 
 class FwdChain(C.Structure):
     _fields_ = [('init', _fp), ('aux', _fp), ('ld_init', C.c_int), ('k_init', C.c_int), ('ld_aux', C.c_int),
-                ('k_aux', C.c_int), ('n_layers', C.c_int), ('aux_wide', C.c_int), ('layer', FwdLayer * MAX_LAYERS)]
+                ('k_aux', C.c_int), ('n_layers', C.c_int), ('aux_wide', C.c_int), ('macs_per_row', C.c_double),
+                ('layer', FwdLayer * MAX_LAYERS)]
 
 
 class TanLayer(C.Structure):
@@ -31,7 +32,8 @@ class TanLayer(C.Structure):
 
 class TanChain(C.Structure):
     _fields_ = [('init', _fp), ('aux', _fp), ('ld_init', C.c_int), ('k_init', C.c_int), ('ld_aux', C.c_int),
-                ('k_aux', C.c_int), ('n_layers', C.c_int), ('aux_wide', C.c_int), ('layer', TanLayer * MAX_LAYERS)]
+                ('k_aux', C.c_int), ('n_layers', C.c_int), ('aux_wide', C.c_int), ('macs_per_row', C.c_double),
+                ('layer', TanLayer * MAX_LAYERS)]
 
 
 class BwdLayer(C.Structure):
@@ -43,7 +45,7 @@ class BwdLayer(C.Structure):
 class BwdChain(C.Structure):
     _fields_ = [('dy', _fp), ('ld_dy', C.c_int), ('k_dy', C.c_int), ('d_init', _fp), ('d_aux', _fp),
                 ('ld_dinit', C.c_int), ('ld_daux', C.c_int), ('accumulate_dinit', C.c_int), ('n_layers', C.c_int),
-                ('aux_wide', C.c_int), ('layer', BwdLayer * MAX_LAYERS)]
+                ('aux_wide', C.c_int), ('macs_per_row', C.c_double), ('layer', BwdLayer * MAX_LAYERS)]
 
 
 class DwJob(C.Structure):

@@ -109,6 +109,7 @@ class Chain:
         ch.init, ch.ld_init, ch.k_init = L.ptr(init), (init.stride(0) if init is not None else 0), self.k_init
         ch.aux, ch.ld_aux, ch.k_aux = L.ptr(aux), (aux.stride(0) if aux is not None else 0), self.k_aux
         ch.n_layers, ch.aux_wide = len(self.entries), int(self.aux_wide)
+        ch.macs_per_row = float(sum(d.n_out * (d.k_main + d.k_aux) for d, _ in self.entries if d is not None))
         if init is not None:
             assert init.shape[0] >= rp and init.shape[1] >= self.k_init
         if aux is not None:
@@ -199,6 +200,16 @@ class Chain:
         if self.entries[last][0] is not None and not skip_last_dense:
             assert dy is not None and self.entries[last][0].act == L.ACT_NONE
             deltas[last] = dy
+        macs = 0.0
+        for i, (d, h) in enumerate(self.entries):
+            if d is None or (skip_last_dense and i == last):
+                continue
+            first = prev_dense[i] is None
+            if first and not need_dinit:
+                macs += d.n_out * d.k_aux if (need_daux and d.k_aux) else 0
+            else:
+                macs += d.n_out * (d.k_main + (d.k_aux if need_daux else 0))
+        ch.macs_per_row = float(macs)
         L.check(L.lib.nero_mlp_backward(C.byref(ch), n_rows, L.stream_ptr()))
         return {'deltas': deltas, 'd_init': d_init, 'd_aux': d_aux}
 

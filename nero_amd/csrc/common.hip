@@ -20,3 +20,41 @@ int nero_check_launch(const char* what) {
 
 extern "C" const char* nero_last_error(void) { return g_err; }
 extern "C" int nero_version(void) { return 100; }
+
+// ---- per-launch kernel timing (disabled by default) ----------------------------------------------------------------
+#include <vector>
+namespace {
+struct ProfRec { hipEvent_t a, b; int kind; double flops; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_recs;
+hipEvent_t g_cur_a;
+}
+void nero_prof_begin(int kind, double flops, hipStream_t s) {
+    if (!g_prof_on) return;
+    ProfRec r; r.kind = kind; r.flops = flops;
+    (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b);
+    (void)hipEventRecord(r.a, s);
+    g_recs.push_back(r);
+}
+void nero_prof_end(int kind, hipStream_t s) {
+    if (!g_prof_on || g_recs.empty()) return;
+    (void)kind;
+    (void)hipEventRecord(g_recs.back().b, s);
+}
+extern "C" int nero_prof_enable(int on) {
+    g_prof_on = on != 0;
+    return 0;
+}
+// out[kind*3 + {0,1,2}] = {launches, total milliseconds, total algorithmic flops}; clears the records
+extern "C" int nero_prof_report(double* out /*host, 12 doubles*/) {
+    for (int i = 0; i < NERO_K_COUNT * 3; ++i) out[i] = 0.0;
+    for (auto& r : g_recs) {
+        (void)hipEventSynchronize(r.b);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, r.a, r.b);
+        out[r.kind * 3 + 0] += 1.0; out[r.kind * 3 + 1] += ms; out[r.kind * 3 + 2] += r.flops;
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    }
+    g_recs.clear();
+    return 0;
+}

@@ -37,6 +37,61 @@ __device__ __forceinline__ WaveTiles wave_tiles(int nt, int wave) {
 }
 
 // acc[rt][ct] += A[64 x 8*nchunks] (LDS, stride lds) * B (packed), for this wave's column tiles.
+// Software pipeline: operands of chunk c+2 (B from the L2-resident packed image, A from LDS) are requested before the
+// 16 MFMAs of chunk c are issued, so neither the ~500-cycle L2 latency nor the LDS latency sits on the MFMA stream
+// (three rotating register buffers, static indexing by a 3x unrolled body).
+struct OpBuf { float4 a0, a1, b0, b1; };
+
+#define NERO_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A, B, ACC, 0, 0, 0)
+
+template <int NCT>
+__device__ __forceinline__ void op_load(OpBuf& o, const float* a0p, const float* a1p, const float4* bp, size_t bstride, int c) {
+    o.b0 = bp[c * bstride];
+    if (NCT == 2) o.b1 = bp[c * bstride + 64];
+    o.a0 = *reinterpret_cast<const float4*>(a0p + 8 * c);
+    o.a1 = *reinterpret_cast<const float4*>(a1p + 8 * c);
+}
+
+template <int NCT>
+__device__ __forceinline__ void op_compute(f32x16 (&acc)[2][2], const OpBuf& o) {
+    NERO_MFMA(acc[0][0], o.a0.x, o.b0.x); if (NCT == 2) NERO_MFMA(acc[0][1], o.a0.x, o.b1.x);
+    NERO_MFMA(acc[1][0], o.a1.x, o.b0.x); if (NCT == 2) NERO_MFMA(acc[1][1], o.a1.x, o.b1.x);
+    NERO_MFMA(acc[0][0], o.a0.y, o.b0.y); if (NCT == 2) NERO_MFMA(acc[0][1], o.a0.y, o.b1.y);
+    NERO_MFMA(acc[1][0], o.a1.y, o.b0.y); if (NCT == 2) NERO_MFMA(acc[1][1], o.a1.y, o.b1.y);
+    NERO_MFMA(acc[0][0], o.a0.z, o.b0.z); if (NCT == 2) NERO_MFMA(acc[0][1], o.a0.z, o.b1.z);
+    NERO_MFMA(acc[1][0], o.a1.z, o.b0.z); if (NCT == 2) NERO_MFMA(acc[1][1], o.a1.z, o.b1.z);
+    NERO_MFMA(acc[0][0], o.a0.w, o.b0.w); if (NCT == 2) NERO_MFMA(acc[0][1], o.a0.w, o.b1.w);
+    NERO_MFMA(acc[1][0], o.a1.w, o.b0.w); if (NCT == 2) NERO_MFMA(acc[1][1], o.a1.w, o.b1.w);
+}
+
+template <int NCT>
+__device__ __forceinline__ void gemm_pipe(f32x16 (&acc)[2][2], const float* a0p, const float* a1p, const float4* bp,
+                                          size_t bstride, int n) {
+    OpBuf u, v, w;
+    const int last = n - 1;
+    op_load<NCT>(u, a0p, a1p, bp, bstride, 0);
+    op_load<NCT>(v, a0p, a1p, bp, bstride, 1 < last ? 1 : last);
+    int c = 0;
+    // sched_barrier(0): hipcc otherwise sinks each prefetch down to its first use and re-serialises the loop
+    __builtin_amdgcn_sched_barrier(0);
+    for (; c + 3 <= n; c += 3) {
+        op_load<NCT>(w, a0p, a1p, bp, bstride, c + 2 < last ? c + 2 : last);
+        __builtin_amdgcn_sched_barrier(0);
+        op_compute<NCT>(acc, u);
+        __builtin_amdgcn_sched_barrier(0);
+        op_load<NCT>(u, a0p, a1p, bp, bstride, c + 3 < last ? c + 3 : last);
+        __builtin_amdgcn_sched_barrier(0);
+        op_compute<NCT>(acc, v);
+        __builtin_amdgcn_sched_barrier(0);
+        op_load<NCT>(v, a0p, a1p, bp, bstride, c + 4 < last ? c + 4 : last);
+        __builtin_amdgcn_sched_barrier(0);
+        op_compute<NCT>(acc, w);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (c < n) op_compute<NCT>(acc, u);
+    if (c + 1 < n) op_compute<NCT>(acc, v);
+}
+
 __device__ __forceinline__ void gemm_part(f32x16 (&acc)[2][2], const float* tile, int lds, int nchunks,
                                           const float* __restrict__ wpack, int nt, WaveTiles wt, int lane) {
     if (nchunks <= 0 || wt.n == 0) return;
@@ -45,45 +100,8 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[2][2], const float* tile
     const float* a1p = a0p + 32 * lds;
     const float4* bp = reinterpret_cast<const float4*>(wpack) + (size_t)wt.ct0 * 64 + lane;
     const size_t bstride = (size_t)nt * 64;          // float4 per chunk
-    if (wt.n == 2) {
-#pragma unroll 2
-        for (int c = 0; c < nchunks; ++c) {
-            float4 b0 = bp[c * bstride], b1 = bp[c * bstride + 64];
-            float4 a0 = *reinterpret_cast<const float4*>(a0p + 8 * c);
-            float4 a1 = *reinterpret_cast<const float4*>(a1p + 8 * c);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b1.x, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc[1][1], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b1.y, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc[1][1], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b1.z, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b0.z, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc[1][1], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b1.w, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc[1][1], 0, 0, 0);
-        }
-    } else {
-#pragma unroll 2
-        for (int c = 0; c < nchunks; ++c) {
-            float4 b0 = bp[c * bstride];
-            float4 a0 = *reinterpret_cast<const float4*>(a0p + 8 * c);
-            float4 a1 = *reinterpret_cast<const float4*>(a1p + 8 * c);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[0][0], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, acc[1][0], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc[0][0], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, acc[1][0], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc[0][0], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b0.z, acc[1][0], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc[0][0], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, acc[1][0], 0, 0, 0);
-        }
-    }
+    if (wt.n == 2) gemm_pipe<2>(acc, a0p, a1p, bp, bstride, nchunks);
+    else gemm_pipe<1>(acc, a0p, a1p, bp, bstride, nchunks);
 }
 
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
@@ -157,6 +175,27 @@ __device__ __forceinline__ void eval_head(const float* tile, const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Epilogue scheme shared by the three chain kernels: (1) every wave drops its raw accumulators into the LDS tile (C
+// layout, immediate-offset ds_write_b32), (2) barrier, (3) a ROLLED row-major pass -- thread t owns columns 4(t&63)..+3 of
+// rows it*4 + (t>>6) -- applies the elementwise math with 16-byte LDS accesses and fully coalesced 16-byte global loads /
+// stores (one 1 KiB row per wave instruction).  Keeps the epilogue at ~40 VGPRs instead of unrolling 64 scalar
+// load/compute/store strands per lane.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dump_acc(f32x16 (&acc)[2][2], float* tile, WaveTiles wt, int lane, const float* __restrict__ bias) {
+    _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) {
+        if (ct < wt.n) {
+            const int col = 32 * (wt.ct0 + ct) + (lane & 31);
+            const float b = bias ? bias[col] : 0.f;
+            _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)
+                _Pragma("unroll") for (int v = 0; v < 16; ++v) {
+                    const int row = 32 * rt + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+                    tile[row * LDA + col] = acc[rt][ct][v] + b;
+                }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // forward chain
 // ---------------------------------------------------------------------------------------------------------------------
 template <bool WIDE>
@@ -174,22 +213,30 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(nero_fwd_chain ch, int 
         const nero_fwd_layer& L = ch.layer[l];
         if (L.n_head > 0) eval_head(act, L.head_w, L.head_b, L.head_out, L.n_head, L.head_k, row0, tid);
         if (L.n_tiles == 0) continue;
-        f32x16 acc[2][2];
-        zero_acc(acc);
-        const WaveTiles wt = wave_tiles(L.n_tiles, wave);
-        gemm_part(acc, act, LDA, L.k_main >> 3, L.w_main, L.n_tiles, wt, lane);
-        gemm_part(acc, aux, LDX, L.k_aux >> 3, L.w_aux, L.n_tiles, wt, lane);
-        __syncthreads();                               // every wave is done reading the input tile
-        const float* __restrict__ bias = L.bias;
+        {
+            f32x16 acc[2][2];
+            zero_acc(acc);
+            const WaveTiles wt = wave_tiles(L.n_tiles, wave);
+            gemm_part(acc, act, LDA, L.k_main >> 3, L.w_main, L.n_tiles, wt, lane);
+            gemm_part(acc, aux, LDX, L.k_aux >> 3, L.w_aux, L.n_tiles, wt, lane);
+            __syncthreads();                               // every wave is done reading the input tile
+            dump_acc(acc, act, wt, lane, L.bias);
+        }
+        __syncthreads();
+        const int ncols = 32 * L.n_tiles, c4 = 4 * lane;
         float* __restrict__ save = L.save;
         const int actk = L.act;
-        FOR_EACH_ACC(wt, {
-            float y = x + (bias ? bias[col] : 0.f);
-            if (actk == NERO_ACT_RELU) y = fmaxf(y, 0.f);
-            else if (actk == NERO_ACT_SOFTPLUS100) y = softplus100(y);
-            act[row * LDA + col] = y;
-            if (save) save[(size_t)(row0 + row) * NERO_HID + col] = y;
-        })
+        if (c4 < ncols && (actk != NERO_ACT_NONE || save)) {
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int row = 4 * it + wave;
+                float4 y = *reinterpret_cast<float4*>(act + row * LDA + c4);
+                if (actk == NERO_ACT_RELU) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+                else if (actk == NERO_ACT_SOFTPLUS100) { y.x = softplus100(y.x); y.y = softplus100(y.y); y.z = softplus100(y.z); y.w = softplus100(y.w); }
+                if (actk != NERO_ACT_NONE) *reinterpret_cast<float4*>(act + row * LDA + c4) = y;
+                if (save) *reinterpret_cast<float4*>(save + (size_t)(row0 + row) * NERO_HID + c4) = y;
+            }
+        }
         __syncthreads();
     }
 }
@@ -197,6 +244,14 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(nero_fwd_chain ch, int 
 // ---------------------------------------------------------------------------------------------------------------------
 // tangent chain (softplus networks):  adot_l = s_l * (W_l adot_{l-1}),  inj_l = gbar_l * beta (1-s_l) * zdot_l
 // ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tan_elem(float a, float zd, float gb, bool live, float& ad, float& ij) {
+    const float s = softplus100_grad_from_out(a);
+    ad = s * zd;
+    // sigma''/sigma' = beta (1 - s); zero in the linear region (torch: softplus double-backward is 0 there)
+    const float r2 = (BETA * a > 20.f) ? 0.f : BETA * (1.f - s);
+    ij = live ? gb * r2 * zd : 0.f;
+}
+
 template <bool WIDE>
 __global__ __launch_bounds__(256, 2) void mlp_tan_kernel(nero_tan_chain ch, int n_rows) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -210,28 +265,40 @@ __global__ __launch_bounds__(256, 2) void mlp_tan_kernel(nero_tan_chain ch, int 
     __syncthreads();
     for (int l = 0; l < ch.n_layers; ++l) {
         const nero_tan_layer& L = ch.layer[l];
-        f32x16 acc[2][2];
-        zero_acc(acc);
-        const WaveTiles wt = wave_tiles(L.n_tiles, wave);
-        gemm_part(acc, act, LDA, L.k_main >> 3, L.w_main, L.n_tiles, wt, lane);
-        gemm_part(acc, aux, LDX, L.k_aux >> 3, L.w_aux, L.n_tiles, wt, lane);
+        {
+            f32x16 acc[2][2];
+            zero_acc(acc);
+            const WaveTiles wt = wave_tiles(L.n_tiles, wave);
+            gemm_part(acc, act, LDA, L.k_main >> 3, L.w_main, L.n_tiles, wt, lane);
+            gemm_part(acc, aux, LDX, L.k_aux >> 3, L.w_aux, L.n_tiles, wt, lane);
+            __syncthreads();
+            dump_acc(acc, act, wt, lane, nullptr);
+        }
         __syncthreads();
+        const int ncols = 32 * L.n_tiles, c4 = 4 * lane;
         const float* __restrict__ asv = L.a_saved;
-        const float* __restrict__ gb = L.gbar;
+        const float* __restrict__ gbp = L.gbar;
         float* __restrict__ adot = L.adot;
         float* __restrict__ inj = L.inj;
-        FOR_EACH_ACC(wt, {
-            const size_t g = (size_t)(row0 + row) * NERO_HID + col;
-            const float a = asv[g];
-            const float s = softplus100_grad_from_out(a);
-            const float ad = s * x;
-            act[row * LDA + col] = ad;
-            const bool live = (row0 + row) < n_rows;
-            adot[g] = live ? ad : 0.f;
-            // sigma''/sigma' = beta (1 - s); zero in the linear region (torch: softplus double-backward is 0 there)
-            const float r2 = (BETA * a > 20.f) ? 0.f : BETA * (1.f - s);
-            inj[g] = live ? gb[g] * r2 * x : 0.f;
-        })
+        if (c4 < ncols) {
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int row = 4 * it + wave;
+                const size_t g = (size_t)(row0 + row) * NERO_HID + c4;
+                const float4 a = *reinterpret_cast<const float4*>(asv + g);
+                const float4 gb = *reinterpret_cast<const float4*>(gbp + g);
+                const float4 zd = *reinterpret_cast<const float4*>(act + row * LDA + c4);
+                const bool live = (row0 + row) < n_rows;
+                float4 ad, ij;
+                tan_elem(a.x, zd.x, gb.x, live, ad.x, ij.x);
+                tan_elem(a.y, zd.y, gb.y, live, ad.y, ij.y);
+                tan_elem(a.z, zd.z, gb.z, live, ad.z, ij.z);
+                tan_elem(a.w, zd.w, gb.w, live, ad.w, ij.w);
+                *reinterpret_cast<float4*>(act + row * LDA + c4) = ad;
+                *reinterpret_cast<float4*>(adot + g) = live ? ad : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(inj + g) = ij;
+            }
+        }
         __syncthreads();
     }
 }
@@ -239,6 +306,12 @@ __global__ __launch_bounds__(256, 2) void mlp_tan_kernel(nero_tan_chain ch, int 
 // ---------------------------------------------------------------------------------------------------------------------
 // reverse chain
 // ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float act_grad(float a, float g, int actp) {
+    if (actp == NERO_ACT_RELU) return a > 0.f ? g : 0.f;
+    if (actp == NERO_ACT_SOFTPLUS100) return g * softplus100_grad_from_out(a);
+    return g;
+}
+
 template <bool WIDE>
 __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(nero_bwd_chain ch, int n_rows) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -251,70 +324,93 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(nero_bwd_chain ch, int 
         const nero_bwd_layer& L = ch.layer[l];
         const bool first = (L.a_prev == nullptr);
         if (first && ch.d_init == nullptr && !(ch.d_aux && L.w_aux_t)) break;
-        f32x16 acc[2][2];
-        zero_acc(acc);
         const int nt = L.k_main_tiles;
-        const WaveTiles wt = wave_tiles(nt, wave);
         if (L.n_out > 0) {
+            f32x16 acc[2][2];
+            // gradient w.r.t. the aux columns of this layer (skip connections), written straight out; done first so that
+            // only one accumulator set is ever live
+            if (ch.d_aux && L.w_aux_t) {
+                zero_acc(acc);
+                const WaveTiles wx = wave_tiles(L.k_aux_tiles, wave);
+                gemm_part(acc, act, LDA, L.n_out >> 3, L.w_aux_t, L.k_aux_tiles, wx, lane);
+                // through the (otherwise unused) aux LDS region, then coalesced rows to d_aux
+                float* auxr = smem + 64 * LDA;
+                FOR_EACH_ACC(wx, { if (col < LDX_NARROW) auxr[row * LDX_NARROW + col] = x; })
+                __syncthreads();
+                const int l4 = ch.ld_daux >> 2;
+                for (int idx = tid; idx < 64 * l4; idx += 256) {
+                    const int r = idx / l4, c4 = (idx - r * l4) * 4;
+                    *reinterpret_cast<float4*>(ch.d_aux + (size_t)(row0 + r) * ch.ld_daux + c4) = *reinterpret_cast<const float4*>(auxr + r * LDX_NARROW + c4);
+                }
+            }
+            zero_acc(acc);
+            const WaveTiles wt = wave_tiles(nt, wave);
             gemm_part(acc, act, LDA, L.n_out >> 3, L.w_main_t, nt, wt, lane);
-        } else if (ch.dy) {
-            // head-only pseudo layer: the tile already is the gradient w.r.t. this layer's input
-            FOR_EACH_ACC(wt, { x = act[row * LDA + col]; })
-        }
-        // gradient w.r.t. the aux columns of this layer (skip connections), written straight out
-        if (ch.d_aux && L.w_aux_t && L.n_out > 0) {
-            f32x16 acx[2][2];
-            zero_acc(acx);
-            const WaveTiles wx = wave_tiles(L.k_aux_tiles, wave);
-            gemm_part(acx, act, LDA, L.n_out >> 3, L.w_aux_t, L.k_aux_tiles, wx, lane);
-            float* __restrict__ dax = ch.d_aux;
-            const int ldx = ch.ld_daux;
-            {
-                f32x16 (&acc)[2][2] = acx;
-                FOR_EACH_ACC(wx, { if (col < ldx) dax[(size_t)(row0 + row) * ldx + col] = x; })
-            }
-        }
-        __syncthreads();
-        if (first) {
-            if (ch.d_init) {
-                float* __restrict__ di = ch.d_init;
-                const int ldi = ch.ld_dinit;
-                const bool accum = ch.accumulate_dinit != 0;
-                FOR_EACH_ACC(wt, {
-                    if (col < ldi) {
-                        const size_t g = (size_t)(row0 + row) * ldi + col;
-                        di[g] = accum ? di[g] + x : x;
+            __syncthreads();
+            dump_acc(acc, act, wt, lane, nullptr);
+            __syncthreads();
+            if (first) {
+                if (ch.d_init) {
+                    const int ldi = ch.ld_dinit, l4 = ldi >> 2;
+                    const bool accum = ch.accumulate_dinit != 0;
+                    for (int idx = tid; idx < 64 * l4; idx += 256) {
+                        const int r = idx / l4, c4 = (idx - r * l4) * 4;
+                        if (c4 < 32 * nt) {
+                            float4 v = *reinterpret_cast<const float4*>(act + r * LDA + c4);
+                            float4* dst = reinterpret_cast<float4*>(ch.d_init + (size_t)(row0 + r) * ldi + c4);
+                            if (accum) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                            *dst = v;
+                        }
                     }
-                })
+                }
+                break;
             }
-            break;
+        } else if (!ch.dy) {
+            // head-only pseudo layer without an upstream tile: start from zero
+            for (int idx = tid; idx < 64 * 64; idx += 256) {
+                const int r = idx >> 6, c4 = (idx & 63) * 4;
+                *reinterpret_cast<float4*>(act + r * LDA + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            __syncthreads();
         }
+        if (first) break;
+        // row-major pass: delta_prev = (g [+ dy_head W_head]) * act'(a_prev) [+ inj], rows >= n_rows zeroed
+        const int ncols = 32 * nt, c4 = 4 * lane;
         const float* __restrict__ ap = L.a_prev;
         const float* __restrict__ inj = L.inj;
         float* __restrict__ dprev = L.delta_prev;
-        const float* __restrict__ hw = L.head_w;
-        const float* __restrict__ hdy = L.head_dy;
         const int nh = L.n_head, actp = L.act_prev;
-        FOR_EACH_ACC(wt, {
-            const size_t g = (size_t)(row0 + row) * NERO_HID + col;
-            float gsum = x;
-            if (nh > 0) {
-                const float4 dyh = *reinterpret_cast<const float4*>(hdy + (size_t)(row0 + row) * 4);
-                gsum = fmaf(dyh.x, hw[col], gsum);
-                if (nh > 1) gsum = fmaf(dyh.y, hw[NERO_HID + col], gsum);
-                if (nh > 2) gsum = fmaf(dyh.z, hw[2 * NERO_HID + col], gsum);
-                if (nh > 3) gsum = fmaf(dyh.w, hw[3 * NERO_HID + col], gsum);
+        if (c4 < ncols) {
+            float4 hw[4];
+            for (int j = 0; j < 4; ++j) hw[j] = (j < nh) ? *reinterpret_cast<const float4*>(L.head_w + j * NERO_HID + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int row = 4 * it + wave;
+                const size_t g = (size_t)(row0 + row) * NERO_HID + c4;
+                const float4 a = *reinterpret_cast<const float4*>(ap + g);
+                float4 gs = *reinterpret_cast<const float4*>(act + row * LDA + c4);
+                if (nh > 0) {
+                    const float4 dyh = *reinterpret_cast<const float4*>(L.head_dy + (size_t)(row0 + row) * 4);
+                    const float dj[4] = {dyh.x, dyh.y, dyh.z, dyh.w};
+                    for (int j = 0; j < 4; ++j) {
+                        if (j < nh) {
+                            gs.x = fmaf(dj[j], hw[j].x, gs.x); gs.y = fmaf(dj[j], hw[j].y, gs.y);
+                            gs.z = fmaf(dj[j], hw[j].z, gs.z); gs.w = fmaf(dj[j], hw[j].w, gs.w);
+                        }
+                    }
+                }
+                float4 d;
+                d.x = act_grad(a.x, gs.x, actp); d.y = act_grad(a.y, gs.y, actp);
+                d.z = act_grad(a.z, gs.z, actp); d.w = act_grad(a.w, gs.w, actp);
+                if (inj) {
+                    const float4 ij = *reinterpret_cast<const float4*>(inj + g);
+                    d.x += ij.x; d.y += ij.y; d.z += ij.z; d.w += ij.w;
+                }
+                if (row0 + row >= n_rows) d = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(act + row * LDA + c4) = d;
+                if (dprev) *reinterpret_cast<float4*>(dprev + g) = d;
             }
-            const float a = ap[g];
-            float d;
-            if (actp == NERO_ACT_RELU) d = a > 0.f ? gsum : 0.f;
-            else if (actp == NERO_ACT_SOFTPLUS100) d = gsum * softplus100_grad_from_out(a);
-            else d = gsum;
-            if (inj) d += inj[g];
-            if (row0 + row >= n_rows) d = 0.f;
-            act[row * LDA + col] = d;
-            if (dprev) dprev[g] = d;
-        })
+        }
         __syncthreads();
     }
 }
@@ -518,6 +614,7 @@ int nero_mlp_forward(const nero_fwd_chain* ch, int n_rows, void* stream) {
     if (ch->k_aux > (ch->aux_wide ? 88 : 40) || ch->k_init > 256 || (ch->k_init & 3) || (ch->k_aux & 3))
         return nero_fail(NERO_ERR_ARG, "nero_mlp_forward: init/aux width out of range");
     const dim3 grid((n_rows + 63) / 64), block(256);
+    nero_prof_begin(NERO_K_FWD, 2.0 * ch->macs_per_row * n_rows, (hipStream_t)stream);
     if (ch->aux_wide) {
         NERO_ONCE(hipFuncSetAttribute((const void*)mlp_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(1)));
         hipLaunchKernelGGL(mlp_fwd_kernel<true>, grid, block, lds_bytes(1), (hipStream_t)stream, *ch, n_rows);
@@ -525,6 +622,7 @@ int nero_mlp_forward(const nero_fwd_chain* ch, int n_rows, void* stream) {
         NERO_ONCE(hipFuncSetAttribute((const void*)mlp_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(0)));
         hipLaunchKernelGGL(mlp_fwd_kernel<false>, grid, block, lds_bytes(0), (hipStream_t)stream, *ch, n_rows);
     }
+    nero_prof_end(NERO_K_FWD, (hipStream_t)stream);
     return nero_check_launch("nero_mlp_forward");
 }
 
@@ -532,6 +630,7 @@ int nero_mlp_tangent(const nero_tan_chain* ch, int n_rows, void* stream) {
     if (!ch || n_rows < 0 || ch->n_layers > NERO_MAX_LAYERS) return nero_fail(NERO_ERR_ARG, "nero_mlp_tangent: bad argument");
     if (n_rows == 0) return NERO_OK;
     const dim3 grid((n_rows + 63) / 64), block(256);
+    nero_prof_begin(NERO_K_TAN, 2.0 * ch->macs_per_row * n_rows, (hipStream_t)stream);
     if (ch->aux_wide) {
         NERO_ONCE(hipFuncSetAttribute((const void*)mlp_tan_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(1)));
         hipLaunchKernelGGL(mlp_tan_kernel<true>, grid, block, lds_bytes(1), (hipStream_t)stream, *ch, n_rows);
@@ -539,6 +638,7 @@ int nero_mlp_tangent(const nero_tan_chain* ch, int n_rows, void* stream) {
         NERO_ONCE(hipFuncSetAttribute((const void*)mlp_tan_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(0)));
         hipLaunchKernelGGL(mlp_tan_kernel<false>, grid, block, lds_bytes(0), (hipStream_t)stream, *ch, n_rows);
     }
+    nero_prof_end(NERO_K_TAN, (hipStream_t)stream);
     return nero_check_launch("nero_mlp_tangent");
 }
 
@@ -547,7 +647,9 @@ int nero_mlp_backward(const nero_bwd_chain* ch, int n_rows, void* stream) {
     if (n_rows == 0) return NERO_OK;
     const dim3 grid((n_rows + 63) / 64), block(256);
     NERO_ONCE(hipFuncSetAttribute((const void*)mlp_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(0)));
+    nero_prof_begin(NERO_K_BWD, 2.0 * ch->macs_per_row * n_rows, (hipStream_t)stream);
     hipLaunchKernelGGL(mlp_bwd_kernel<false>, grid, block, lds_bytes(0), (hipStream_t)stream, *ch, n_rows);
+    nero_prof_end(NERO_K_BWD, (hipStream_t)stream);
     return nero_check_launch("nero_mlp_backward");
 }
 
@@ -565,7 +667,9 @@ int nero_dw_gemm(const nero_dw_job* job, int n_rows, float* partials, void* stre
     const int rps = dw_rows_per_slice(rows);
     const int slices = (rows + rps - 1) / rps;
     const int lds = 2 * DW_RC * DW_LD * (int)sizeof(float);
+    nero_prof_begin(NERO_K_DW, 2.0 * job->n_out * job->k_cols * (job->d1 ? 2.0 : 1.0) * n_rows, (hipStream_t)stream);
     hipLaunchKernelGGL(dw_gemm_kernel, dim3(slices), dim3(512), lds, (hipStream_t)stream, *job, n_rows, rps, partials, n_pad, k_pad);
+    nero_prof_end(NERO_K_DW, (hipStream_t)stream);
     const int total = job->n_out * job->k_cols + job->n_out;
     hipLaunchKernelGGL(dw_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, *job, partials, slices, n_pad, k_pad);
     return nero_check_launch("nero_dw_gemm");

@@ -98,6 +98,7 @@ class SDFField:
             tc.init, tc.ld_init, tc.k_init = ehat.data_ptr(), LD_PE, LD_PE
             tc.aux, tc.ld_aux, tc.k_aux = ehat.data_ptr(), LD_PE, LD_PE
             tc.n_layers, tc.aux_wide = 8, 0
+            tc.macs_per_row = float(sum(ch.entries[l][0].n_out * (ch.entries[l][0].k_main + ch.entries[l][0].k_aux) for l in range(8)))
             tbuf = torch.empty((2, 8, rp, L.HID), dtype=torch.float32, device=self.device)
             for l in range(8):
                 d, p = ch.entries[l][0], ch._packed[l]

@@ -1,0 +1,76 @@
+"""Stage-I training step driver: ray pool resident in HBM, render + loss + backward on the HIP path, data-parallel gradient
+all-reduce over RCCL, Adam.  Mirrors Trainer.run's inner loop (train/trainer.py:109-140), NeROShapeRenderer.train_step
+(network/renderer.py:319-330), the loss assembly (network/loss.py) and the warm-up/cosine LR rule
+(train/lr_common_manager.py:20-43)."""
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .renderer import NeROShapeRenderer
+from .synthetic import perturb_state, synthetic_rays
+
+
+def warm_up_cos_lr(step, total_step=300000, warm_up_end=5000, learning_rate=5e-4, learning_rate_alpha=0.05):
+    if step < warm_up_end:
+        f = step / warm_up_end
+    else:
+        prog = (step - warm_up_end) / (total_step - warm_up_end)
+        f = (math.cos(math.pi * prog) + 1.0) * 0.5 * (1 - learning_rate_alpha) + learning_rate_alpha
+    return f * learning_rate
+
+
+class ShapeTrainStep:
+    """one process = one GPU.  Every rank holds the same weights and a disjoint slice of each global ray batch
+    (rank-strided); gradients are summed with ONE flat all-reduce per step and divided by world size."""
+
+    def __init__(self, cfg, rays_per_rank=4096, pool_rays=262144, device='cuda', seed=6033, variance=None, eikonal_weight=0.1,
+                 rank=0, world=1):
+        self.device, self.rank, self.world, self.R = device, rank, world, rays_per_rank
+        torch.manual_seed(seed)
+        self.net = NeROShapeRenderer(cfg, training=False)
+        if variance is not None:
+            perturb_state(self.net, variance)
+        self.net = self.net.to(device)
+        self.params = [p for p in self.net.parameters()]
+        self.opt = torch.optim.Adam(self.params, lr=1e-3, fused=(device != 'cpu'))
+        self.eik_w = eikonal_weight
+        o, d, poses, gt = synthetic_rays(pool_rays, seed=1)
+        self.pool = {'o': o.to(device), 'd': d.to(device), 'gt': gt.to(device)}
+        self.pool_n = pool_rays
+        self.cursor = 0
+        self.flat = None
+
+    def _batch(self):
+        G = self.R * self.world
+        if self.cursor + G > self.pool_n:
+            self.cursor = 0
+        lo = self.cursor + self.rank * self.R
+        self.cursor += G
+        s = slice(lo, lo + self.R)
+        return self.pool['o'][s], self.pool['d'][s], self.pool['gt'][s]
+
+    def step(self, step):
+        net = self.net
+        lr = warm_up_cos_lr(step)
+        for g in self.opt.param_groups:
+            g['lr'] = lr
+        self.opt.zero_grad(set_to_none=True)
+        o, d, gt = self._batch()
+        near, far = net.near_far_from_sphere(o, d)
+        out = net.render(o, d, near, far, None, -1, net.get_anneal_val(step), is_train=True, step=step)
+        loss = net.compute_rgb_loss(out['ray_rgb'], gt).mean() + (out['gradient_error'] * self.eik_w).mean()
+        if 'loss_occ' in out:
+            loss = loss + out['loss_occ'].mean()
+        loss.backward()
+        if self.world > 1:
+            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
+            flat = torch._utils._flatten_dense_tensors(grads)
+            dist.all_reduce(flat)
+            flat.div_(self.world)
+            for p, g in zip(self.params, torch._utils._unflatten_dense_tensors(flat, grads)):
+                p.grad = g
+        self.opt.step()
+        st = out['_state']
+        return {'loss': loss.detach(), 'n_in': st['n_in'], 'n_out': st['n_out']}
