@@ -3,6 +3,8 @@ the product path -- if it is missing or fails to load, importing this module rai
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- must come first: libnero_hip.so has to bind to the HIP runtime torch already loaded
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libnero_hip.so')
 

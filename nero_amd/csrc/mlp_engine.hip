@@ -707,7 +707,9 @@ int nero_mlp_backward(const nero_bwd_chain* ch, int n_rows, void* stream) {
 int nero_dw_workspace_floats(int n_rows) {
     const int rps = dw_rows_per_slice(n_rows < 1 ? 1 : n_rows);
     const int slices = ((n_rows < 1 ? 1 : n_rows) + rps - 1) / rps;
-    return slices * (256 * 256 + 256);
+    const int head_blocks = ((n_rows < 1 ? 1 : n_rows) + 255) / 256;
+    const int a = slices * (256 * 256 + 256), b = head_blocks * (4 * NERO_HID + 4);
+    return a > b ? a : b;                       // one buffer serves nero_dw_gemm and nero_head_dw
 }
 
 int nero_dw_gemm(const nero_dw_job* job, int n_rows, float* partials, void* stream) {
@@ -731,8 +733,7 @@ int nero_head_dw(const float* dy, const float* a, const float* extra, int n_head
                  float* partials, int accumulate, void* stream) {
     if (!dy || !a || !dWh || !partials || n_head < 1 || n_head > 4) return nero_fail(NERO_ERR_ARG, "nero_head_dw: bad argument");
     const int rows = n_rows < 1 ? 1 : n_rows;
-    int rps = (rows + 255) / 256;
-    rps = rps < 64 ? 64 : rps;
+    int rps = 256;                                     // rows per block; partials reduced by 8-strand sums
     const int slices = (rows + rps - 1) / rps;
     hipLaunchKernelGGL(head_dw_kernel, dim3(slices), dim3(256), 0, (hipStream_t)stream, dy, a, extra, n_head, n_rows, rps, partials);
     const int total = n_head * NERO_HID + n_head;

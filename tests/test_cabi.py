@@ -1,0 +1,35 @@
+"""CPU tier: the C-ABI library loads and exports every symbol include/nero_hip.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    ge.build()
+    hdr = open(os.path.join(ROOT, 'include', 'nero_hip.h')).read()
+    names = sorted(set(re.findall(r'\b(nero_[a-z0-9_]+)\s*\(', hdr)))
+    assert len(names) >= 30
+    lib = ctypes.CDLL(os.path.join(ROOT, 'nero_amd', 'libnero_hip.so'))
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    lib.nero_last_error.restype = ctypes.c_char_p
+    assert lib.nero_version() >= 100
+    assert isinstance(lib.nero_last_error(), bytes)
+
+
+def test_struct_layouts_match_header():
+    """ctypes mirrors of the descriptor structs must have the sizes the C compiler gives them."""
+    import subprocess, tempfile
+    from nero_amd import _lib as L
+    src = '#include <stdio.h>\n#include "nero_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(nero_fwd_layer), sizeof(nero_fwd_chain), sizeof(nero_tan_layer), sizeof(nero_tan_chain), sizeof(nero_bwd_layer), sizeof(nero_bwd_chain), sizeof(nero_dw_job));}'
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, 's.c')
+        open(c, 'w').write(src)
+        exe = os.path.join(td, 's')
+        subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), c, '-o', exe])
+        sizes = [int(x) for x in subprocess.check_output([exe]).split()]
+    mine = [ctypes.sizeof(t) for t in (L.FwdLayer, L.FwdChain, L.TanLayer, L.TanChain, L.BwdLayer, L.BwdChain, L.DwJob)]
+    assert sizes == mine, (sizes, mine)
