@@ -178,6 +178,15 @@ int nero_merge_sorted(float* z, int ldz, int n, float* sdf, int lds, const float
                       int R, int* index_out, void* stream);
 int nero_scatter_sdf(const float* src, int ld_src, int R, int n, float* sdf, int lds, void* stream);
 
+/* ---- occlusion-loss march along the reflected rays (compute_occ_loss, network/renderer.py:522-548; get_intersection /
+ *      get_weights / get_sphere_intersection, network/field.py:390-396, 432-484) ----------------------------------------- */
+int nero_occ_candidates(const float* x4, const float* sdf4, const float* grad, const int* idx, const float* d, int T, float thresh,
+                        int n, unsigned char* flag, void* stream);
+int nero_occ_z(const float* o, const float* d, int P, int n, float* z /*[P,n]*/, void* stream);
+/* sdf is read as sdf[(p*n+i)*lds] (column 0 of a head output [rows,4] -> lds = 4); w_out [P,n-1] and/or wsum [P] */
+int nero_section_weights(const float* z, const float* sdf, int lds, int n, const float* variance, int P, float* w_out, float* wsum,
+                         void* stream);
+
 /* ---- render preparation (render_core, network/renderer.py:550-565): mid points, section lengths, inner/outer split ---- */
 /* pts4 [R*T,4] = (x,y,z,dist); ray_counts/ray_off int32 [R]; counts int32 [2] = (#inner, #outer) */
 int nero_render_prep(const float* o, const float* d, const float* z, int R, int T, float* pts4, int* ray_counts, int* ray_off,

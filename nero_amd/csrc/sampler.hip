@@ -420,3 +420,86 @@ int nero_gather_outer(const float* pts4, const float* d, const int* idx, int T, 
 }
 
 }  // extern "C"
+
+// ---- secondary-ray occlusion march (compute_occ_loss / get_intersection / get_weights, network/renderer.py:522-548,
+//      network/field.py:432-484) -------------------------------------------------------------------------------------
+namespace {
+
+// surface candidates: |p| < 0.999 & |sdf| < thresh & grad . d < 0        (renderer.py:530-533)
+__global__ void occ_candidates_kernel(const float* __restrict__ x4, const float* __restrict__ sdf4, const float* __restrict__ grad,
+                                      const int* __restrict__ idx, const float* __restrict__ d, int T, float thresh, int n,
+                                      unsigned char* __restrict__ flag) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float x = x4[(size_t)k * 4], y = x4[(size_t)k * 4 + 1], z = x4[(size_t)k * 4 + 2];
+    const int r = idx[k] / T;
+    const float dx = d[r * 3], dy = d[r * 3 + 1], dz = d[r * 3 + 2];
+    const float dn = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
+    const float dot = (grad[k * 3] * (dx / dn) + grad[k * 3 + 1] * (dy / dn)) + grad[k * 3 + 2] * (dz / dn);
+    const bool ok = (sqrtf(x * x + y * y + z * z) < 0.999f) && (fabsf(sdf4[(size_t)k * 4]) < thresh) && (dot < 0.f);
+    flag[k] = ok ? 1 : 0;
+}
+
+// z[p, i] = maxd_p * lin(0,1,n)[i],  maxd = -<p,d> + sqrt(<p,d>^2 - |p|^2 + 1 + 1e-6)      (field.py:390-396, 474-475)
+__global__ void occ_z_kernel(const float* __restrict__ o, const float* __restrict__ d, int P_, int n, float* __restrict__ z) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P_ * n) return;
+    const int p = idx / n, i = idx - p * n;
+    const float ox = o[p * 3], oy = o[p * 3 + 1], oz = o[p * 3 + 2], dx = d[p * 3], dy = d[p * 3 + 1], dz = d[p * 3 + 2];
+    const float dtx = (ox * dx + oy * dy) + oz * dz, xtx = (ox * ox + oy * oy) + oz * oz;
+    const float maxd = -dtx + sqrtf(dtx * dtx - xtx + 1.0f + 1e-6f);
+    z[idx] = maxd * linspace_f32(0.f, 1.f, n, i);
+}
+
+// get_weights (field.py:432-452): weights [P, n-1] (or only their sum when w_out == NULL)
+__global__ void section_weights_kernel(const float* __restrict__ z, const float* __restrict__ sdf, int lds, int n,
+                                       const float* __restrict__ variance, int P_, float* __restrict__ w_out, float* __restrict__ wsum) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P_) return;
+    const float inv_s = expf(variance[0] * 10.0f);
+    double T = 1.0;
+    float sum = 0.f;
+    float zp = z[(size_t)p * n], sp = sdf[(size_t)p * n * lds];
+    for (int i = 0; i < n - 1; ++i) {
+        const float zn = z[(size_t)p * n + i + 1], sn = sdf[((size_t)p * n + i + 1) * lds];
+        const float dist = zn - zp;
+        const float mid = (sp + sn) * 0.5f;
+        float c = (sn - sp) / (dist + 1e-5f);
+        const float mask = c < 0.f ? 1.f : 0.f;
+        c = fminf(c, 0.f);
+        const float pc = sigmoid_f((mid - c * dist * 0.5f) * inv_s), nc = sigmoid_f((mid + c * dist * 0.5f) * inv_s);
+        const float alpha = (pc - nc + 1e-5f) / (pc + 1e-5f) * mask;
+        const float w = alpha * (float)T;
+        T *= (double)(1.0f - alpha + 1e-7f);
+        if (w_out) w_out[(size_t)p * (n - 1) + i] = w;
+        sum += w;
+        zp = zn; sp = sn;
+    }
+    if (wsum) wsum[p] = sum;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nero_occ_candidates(const float* x4, const float* sdf4, const float* grad, const int* idx, const float* d, int T, float thresh,
+                        int n, unsigned char* flag, void* stream) {
+    if (n == 0) return NERO_OK;
+    hipLaunchKernelGGL(occ_candidates_kernel, GRID1D(n), x4, sdf4, grad, idx, d, T, thresh, n, flag);
+    return nero_check_launch("nero_occ_candidates");
+}
+
+int nero_occ_z(const float* o, const float* d, int P_, int n, float* z, void* stream) {
+    if (P_ * n == 0) return NERO_OK;
+    hipLaunchKernelGGL(occ_z_kernel, GRID1D(P_ * n), o, d, P_, n, z);
+    return nero_check_launch("nero_occ_z");
+}
+
+int nero_section_weights(const float* z, const float* sdf, int lds, int n, const float* variance, int P_, float* w_out, float* wsum,
+                         void* stream) {
+    if (P_ == 0) return NERO_OK;
+    hipLaunchKernelGGL(section_weights_kernel, dim3((P_ + 63) / 64), dim3(64), 0, (hipStream_t)stream, z, sdf, lds, n, variance, P_, w_out, wsum);
+    return nero_check_launch("nero_section_weights");
+}
+
+}  // extern "C"

@@ -76,7 +76,7 @@ class NeROShapeRenderer(nn.Module):
                               self.deviation_network.variance.detach(), rand1, rand_bg, trace)
 
     def render(self, rays_o, rays_d, near, far, human_poses, perturb_overwrite=-1, cos_anneal_ratio=0.0, is_train=True,
-               step=None, rand1=None, rand_bg=None, z_vals=None):
+               step=None, rand1=None, rand_bg=None, z_vals=None, occ_keys=None):
         """same contract as the reference (network/renderer.py:445-463); extra keyword-only style arguments rand1 / rand_bg /
         z_vals allow tests to inject the random draws or teacher-force the sample positions."""
         perturb = self.cfg['perturb']
@@ -86,11 +86,14 @@ class NeROShapeRenderer(nn.Module):
         if z_vals is None:
             z_vals = self.sample_ray(rays_o, rays_d, near, far, perturb, rand1, rand_bg, K)
         return self.render_core(rays_o, rays_d, z_vals, human_poses, cos_anneal_ratio=cos_anneal_ratio, step=step,
-                                is_train=is_train, _kern=(names, eff))
+                                is_train=is_train, _kern=(names, eff, K), occ_keys=occ_keys)
 
-    def render_core(self, rays_o, rays_d, z_vals, human_poses, cos_anneal_ratio=0.0, step=None, is_train=True, _kern=None):
-        from .shape_step import RenderCore
-        names, eff = _kern if _kern is not None else self._kernels()[:2]
+    def render_core(self, rays_o, rays_d, z_vals, human_poses, cos_anneal_ratio=0.0, step=None, is_train=True, _kern=None,
+                    occ_keys=None):
+        from .shape_step import RenderCore, SDFValue, occ_loss
+        if not is_train:
+            raise NotImplementedError('validation extras (compute_validation_info) are not on the HIP path yet')
+        names, eff, Kpre = _kern if _kern is not None else self._kernels()
         c = self.cfg
         meta = {'names': names, 'shapes': [tuple(t.shape) for t in eff], 'shader_cfg': self.color_network.cfg,
                 'anneal': float(cos_anneal_ratio), 'exp_max': float(self.color_network.cfg['light_exp_max']),
@@ -104,8 +107,16 @@ class NeROShapeRenderer(nn.Module):
         if meta['freeze_inv_s']:
             inv_s = inv_s.detach()
         outputs['std'] = torch.mean(1.0 / inv_s) if n_in > 0 else torch.zeros(1, device=rgb.device)
+        S = meta.get('_state')
+        if step is not None and step < 1000:                               # inputs of InitSDFRegLoss (renderer.py:591-594)
+            pts = S['pts4'][:, :3]
+            m = torch.norm(pts, dim=-1) < 1.2
+            outputs['sdf_pts'] = pts[m]
+            outputs['sdf_vals'] = SDFValue.apply(Kpre, outputs['sdf_pts'], *eff[:18])
         if c['apply_occ_loss']:
             outputs['loss_occ'] = torch.zeros(1, device=rgb.device)
+            if n_in > 0 and step is not None and step >= c['occ_loss_step']:
+                outputs['loss_occ'], outputs['_occ_count'] = occ_loss(S, occ_prob, c, var.detach(), occ_keys)
         outputs['_occ_prob'] = occ_prob
         outputs['_state'] = meta.get('_state')
         return outputs

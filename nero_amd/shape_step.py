@@ -179,7 +179,7 @@ class RenderCore(torch.autograd.Function):
         L.check(lib.nero_compact(_p(pts4), _p(ray_off), R, T, _p(inner_idx), _p(outer_idx), st))
         alphaRT = torch.zeros(R * T, **f32)
         colorRT = torch.zeros((R * T, 3), **f32)
-        S = {'K': K, 'R': R, 'T': T, 'n_in': n_in, 'n_out': n_out, 'inner_idx': inner_idx, 'outer_idx': outer_idx,
+        S = {'K': K, 'R': R, 'T': T, 'pts4': pts4, 'n_in': n_in, 'n_out': n_out, 'inner_idx': inner_idx, 'outer_idx': outer_idx,
              'meta': meta, 'o': o, 'd': d, 'variance': variance, 'lut': lut}
 
         # ---- outer samples: NeRF++ -------------------------------------------------------------------------------
@@ -317,3 +317,79 @@ class RenderCore(torch.autograd.Function):
             grads.append(g if g is not None else torch.zeros(shape, **f32))
         ctx.S = None
         return (None, None, None, None, d_var, None) + tuple(grads)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# plain SDF value with first-order weight gradients (InitSDFRegLoss inputs, network/renderer.py:591-594)
+# ----------------------------------------------------------------------------------------------------------------------
+class SDFValue(torch.autograd.Function):
+    """sdf(x) for x [n,3] as an autograd node w.r.t. the 18 effective SDF weights (no gradient w.r.t. x)."""
+
+    @staticmethod
+    def forward(ctx, K, x, *params):
+        from .sdf import encode_pe, N_FREQ, LD_PE
+        n = x.shape[0]
+        pe = encode_pe(x.contiguous(), n, 3, N_FREQ, LD_PE)
+        fwd = K.sdf.value_only.forward(pe, pe, n, save=True)
+        ctx.K, ctx.pe, ctx.fwd, ctx.n = K, pe, fwd, n
+        ctx.shapes = [tuple(p.shape) for p in params]
+        return fwd['heads'][8][:n, 0].clone()
+
+    @staticmethod
+    def backward(ctx, d_sdf):
+        K, pe, fwd, n = ctx.K, ctx.pe, ctx.fwd, ctx.n
+        ch = K.sdf.value_only
+        rp = row_pad(n)
+        dy = torch.zeros((rp, 4), dtype=torch.float32, device=d_sdf.device)
+        dy[:n, 0] = d_sdf
+        bwd = ch.backward(fwd, n, head_dys={8: dy})
+        gr = ch.weight_grads(fwd, bwd, n, pe, pe, head_dys={8: dy})
+        out = []
+        for l in range(8):
+            out += [gr[l]['dW'], gr[l]['db']]
+        dW8 = torch.zeros(ctx.shapes[16], dtype=torch.float32, device=d_sdf.device)
+        db8 = torch.zeros(ctx.shapes[17], dtype=torch.float32, device=d_sdf.device)
+        dW8[0:1] = gr[8]['dWh']
+        db8[0:1] = gr[8]['dbh']
+        out += [dW8, db8]
+        return (None, None) + tuple(out)
+
+
+def occ_loss(S, occ_prob, cfg, variance, occ_keys=None):
+    """compute_occ_loss (network/renderer.py:522-548): surface subset -> march the reflected ray to the unit sphere
+    (64 uniform + 16 importance z, no grad) -> L1(occ_prob, sum of section weights)."""
+    K, n_in, T = S['K'], S['n_in'], S['T']
+    dev = occ_prob.device
+    lib, st = L.lib, _st()
+    f32 = dict(dtype=torch.float32, device=dev)
+    flag = torch.empty(n_in, dtype=torch.uint8, device=dev)
+    sctx = S['sctx']
+    L.check(lib.nero_occ_candidates(_p(S['x4']), _p(sctx['sdf4']), _p(sctx['normal']), _p(S['inner_idx']), _p(S['d']), T,
+                                    C.c_float(cfg['occ_sdf_thresh']), n_in, _p(flag), st))
+    cand = torch.nonzero(flag)[:, 0]
+    Pn = cand.numel()
+    if Pn > cfg['occ_loss_max_pn']:
+        keys = occ_keys[:Pn].to(dev) if occ_keys is not None else torch.rand(Pn, device=dev)
+        keep = torch.sort(torch.argsort(keys, stable=True)[:cfg['occ_loss_max_pn']])[0]
+        cand = cand[keep]
+        Pn = cand.numel()
+    if Pn == 0:
+        return torch.zeros(1, device=dev), 0
+    o = S['x4'][cand, :3].contiguous()
+    dr = S['geo'][cand, 4:7].contiguous()
+    sn0, sn1 = 64, 16
+    z = torch.empty((Pn, sn0), **f32)
+    L.check(lib.nero_occ_z(_p(o), _p(dr), Pn, sn0, _p(z), st))
+    pe = torch.empty((row_pad(Pn * sn0), 40), **f32)
+    L.check(lib.nero_ray_points_pe(_p(o), _p(dr), _p(z), sn0, 0, sn0, Pn, _p(pe), st))
+    s4 = K.sdf.sdf_from_pe(pe, Pn * sn0)
+    w = torch.empty((Pn, sn0 - 1), **f32)
+    L.check(lib.nero_section_weights(_p(z), _p(s4), 4, sn0, _p(variance), Pn, _p(w), _p(None), st))
+    z_new = torch.empty((Pn, sn1), **f32)
+    L.check(lib.nero_sample_pdf(_p(z), sn0, _p(w), sn0 - 1, sn0, sn1, Pn, _p(z_new), _p(None), st))
+    pe2 = torch.empty((row_pad(Pn * sn1), 40), **f32)
+    L.check(lib.nero_ray_points_pe(_p(o), _p(dr), _p(z_new), sn1, 0, sn1, Pn, _p(pe2), st))
+    s4b = K.sdf.sdf_from_pe(pe2, Pn * sn1)
+    gt = torch.empty(Pn, **f32)
+    L.check(lib.nero_section_weights(_p(z_new), _p(s4b), 4, sn1, _p(variance), Pn, _p(None), _p(gt), st))
+    return torch.nn.functional.l1_loss(occ_prob[cand], gt), Pn

@@ -21,6 +21,27 @@ def warm_up_cos_lr(step, total_step=300000, warm_up_end=5000, learning_rate=5e-4
     return f * learning_rate
 
 
+def shape_training_loss(net, out, gt, step, eikonal_weight=0.1):
+    """sum of the means of every `loss*` entry the reference's loss objects produce for the shape stage
+    (train/trainer.py:127-137; network/loss.py: NeRFRenderLoss, EikonalLoss, OccLoss, InitSDFRegLoss)."""
+    loss = net.compute_rgb_loss(out['ray_rgb'], gt).mean() + (out['gradient_error'] * eikonal_weight).mean()
+    if 'loss_occ' in out:
+        loss = loss + out['loss_occ'].mean()
+    if step < 1000 and 'sdf_vals' in out:
+        norm = torch.norm(out['sdf_pts'], dim=-1)
+        sdf = out['sdf_vals']
+        w = (math.cos(step / 1000 * math.pi) + 1) / 2
+        sm = norm < 0.1
+        if int(sm.sum()) > 0:
+            sl = torch.mean(torch.clamp(sdf[sm] - (norm[sm] - 0.1), min=0.0))
+            loss = loss + sl / ((sl > 1e-5).float() + 1e-3) * w
+        lm = norm > 1.05
+        if int(lm.sum()) > 0:
+            ll = torch.clamp((norm[lm] - 1.05) - sdf[lm], min=0.0)
+            loss = loss + torch.sum(ll) / (torch.sum(ll > 1e-5) + 1e-3) * w
+    return loss
+
+
 class ShapeTrainStep:
     """one process = one GPU.  Every rank holds the same weights and a disjoint slice of each global ray batch
     (rank-strided); gradients are summed with ONE flat all-reduce per step and divided by world size."""
@@ -70,9 +91,7 @@ class ShapeTrainStep:
         o, d, gt = self._batch()
         near, far = net.near_far_from_sphere(o, d)
         out = net.render(o, d, near, far, None, -1, net.get_anneal_val(step), is_train=True, step=step)
-        loss = net.compute_rgb_loss(out['ray_rgb'], gt).mean() + (out['gradient_error'] * self.eik_w).mean()
-        if 'loss_occ' in out:
-            loss = loss + out['loss_occ'].mean()
+        loss = shape_training_loss(net, out, gt, step, self.eik_w)
         loss.backward()
         if self.world > 1:
             grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]

@@ -86,6 +86,10 @@ def run_case(name, cfg, R, step, variance, seed=6033, occ_keys_seed=None):
     out['loss_rgb'] = net.compute_rgb_loss(out['ray_rgb'], gt)
     # trainer loss assembly (train/trainer.py:127-137, network/loss.py): eikonal 0.1, occ, (init_sdf_reg for step<1000)
     loss = out['loss_rgb'].mean() + (out['gradient_error'] * 0.1).mean() + out['loss_occ'].mean()
+    if step < 1000:                                                       # InitSDFRegLoss, network/loss.py:90-122
+        from network.loss import InitSDFRegLoss
+        for k, v in InitSDFRegLoss(cfg)(out, None, step).items():
+            loss = loss + torch.mean(v)
     loss.backward()
     grads = {k: p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)
              for k, p in net.named_parameters()}
@@ -164,3 +168,4 @@ if __name__ == '__main__':
     run_case('bear_s25000', dict(small, shader_config={'human_light': True}), R=48, step=25000, variance=0.4)
     run_case('bell_occcap', dict(small, occ_loss_max_pn=24), R=48, step=25000, variance=0.5, occ_keys_seed=5)
     run_case('bell_c1', dict(n_samples=32, n_importance=32, n_bg_samples=32), R=32, step=25000, variance=0.3)
+    run_case('bell_s500', dict(small, freeze_inv_s_step=15000), R=48, step=500, variance=0.3)

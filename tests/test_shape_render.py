@@ -114,3 +114,44 @@ def test_render_core_outputs_and_grads(name):
     assert not bad, bad
     assert np.quantile(vals, 0.9) < 2e-4, np.quantile(vals, 0.9)
     assert np.median(vals) < 2e-5
+
+
+@pytest.mark.parametrize('name', ['bell_s25000', 'bell_occcap', 'bell_s500'])
+def test_full_training_loss_with_occ_and_init_reg(name):
+    """trainer loss incl. the occlusion loss (step >= 20000, with and without the random cap) and the InitSDFRegLoss inputs
+    (step < 1000), teacher-forced on the golden z_vals; loss, loss_occ and gradients vs the oracle"""
+    from nero_amd.train import shape_training_loss
+    z, meta = load_golden(name)
+    net = build_case_model(meta).cuda()
+    ref = build_case_model(meta)
+    sd = {k: v for k, v in ref.named_parameters()}
+    sd.update({k: v for k, v in ref.named_buffers()})
+    P = O.effective_params(sd)
+    cfg = {**O.DEFAULT_CFG, **meta['cfg']}
+    keys = T(z, 'occ_keys') if 'occ_keys' in z.files else None
+    oo = O.render_core(P, cfg, T(z, 'o'), T(z, 'd'), T(z, 'z_vals'), T(z, 'human_poses'), meta['anneal'], meta['step'], keys)
+    loss_o = O.training_loss(cfg, oo, T(z, 'gt'), meta['step'])
+    loss_o.backward()
+    out = net.render(T(z, 'o', 'cuda'), T(z, 'd', 'cuda'), T(z, 'near', 'cuda'), T(z, 'far', 'cuda'), T(z, 'human_poses', 'cuda'),
+                     -1, meta['anneal'], is_train=True, step=meta['step'], z_vals=T(z, 'z_vals', 'cuda'), occ_keys=keys)
+    if meta['step'] >= 20000:
+        assert out['_occ_count'] == oo['occ_count'] > 0
+        assert abs(float(out['loss_occ']) - float(oo['loss_occ'])) < 1e-5
+    if meta['step'] < 1000:
+        assert out['sdf_vals'].shape == oo['sdf_vals'].shape
+        assert rel(out['sdf_vals'], oo['sdf_vals']) < 2e-5
+    loss = shape_training_loss(net, out, T(z, 'gt', 'cuda'), meta['step'])
+    assert abs(float(loss) - float(loss_o)) < 2e-5
+    assert abs(float(loss) - float(z['loss'])) < 5e-5            # and the unmodified reference's own loss value
+    loss.backward()
+    worst = {}
+    for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        gq = q.grad if q.grad is not None else torch.zeros_like(q)
+        gp = p.grad if p.grad is not None else torch.zeros_like(p)
+        if gq.abs().max() < 1e-12 and gp.abs().max() < 1e-12:
+            continue
+        worst[k] = rel(gp, gq)
+    vals = np.array(list(worst.values()))
+    bad = {k: v for k, v in worst.items() if v > (5e-2 if 'inner_weight' in k else 5e-3)}
+    assert not bad, bad
+    assert np.quantile(vals, 0.9) < 2e-4 and np.median(vals) < 2e-5
