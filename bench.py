@@ -62,7 +62,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--rays', type=int, default=4096)
-    ap.add_argument('--train-step', type=int, default=5000, help='training-schedule step the batch is evaluated at')
+    ap.add_argument('--train-step', type=int, default=25000, help='training-schedule step the batch is evaluated at')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 

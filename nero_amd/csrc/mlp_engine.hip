@@ -585,6 +585,7 @@ __global__ __launch_bounds__(256) void head_dw_kernel(const float* __restrict__ 
     int r_end = r_begin + rows_per_slice;
     r_end = r_end < n_rows ? r_end : n_rows;
     float s[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
     for (int r = r_begin; r < r_end; ++r) {
         const float4 d = *reinterpret_cast<const float4*>(dy + (size_t)r * 4);
         const float av = a[(size_t)r * NERO_HID + k];
@@ -707,7 +708,7 @@ int nero_mlp_backward(const nero_bwd_chain* ch, int n_rows, void* stream) {
 int nero_dw_workspace_floats(int n_rows) {
     const int rps = dw_rows_per_slice(n_rows < 1 ? 1 : n_rows);
     const int slices = ((n_rows < 1 ? 1 : n_rows) + rps - 1) / rps;
-    const int head_blocks = ((n_rows < 1 ? 1 : n_rows) + 255) / 256;
+    const int head_blocks = ((n_rows < 1 ? 1 : n_rows) + 127) / 128;
     const int a = slices * (256 * 256 + 256), b = head_blocks * (4 * NERO_HID + 4);
     return a > b ? a : b;                       // one buffer serves nero_dw_gemm and nero_head_dw
 }
@@ -733,7 +734,7 @@ int nero_head_dw(const float* dy, const float* a, const float* extra, int n_head
                  float* partials, int accumulate, void* stream) {
     if (!dy || !a || !dWh || !partials || n_head < 1 || n_head > 4) return nero_fail(NERO_ERR_ARG, "nero_head_dw: bad argument");
     const int rows = n_rows < 1 ? 1 : n_rows;
-    int rps = 256;                                     // rows per block; partials reduced by 8-strand sums
+    int rps = 128;                                     // rows per block; partials reduced by 8-strand sums
     const int slices = (rows + rps - 1) / rps;
     hipLaunchKernelGGL(head_dw_kernel, dim3(slices), dim3(256), 0, (hipStream_t)stream, dy, a, extra, n_head, n_rows, rps, partials);
     const int total = n_head * NERO_HID + n_head;

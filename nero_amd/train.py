@@ -6,7 +6,9 @@ import math
 
 import numpy as np
 import torch
-import torch.distributed as dist
+import torch.distributed as dist  # noqa: F401
+
+from .parallel import allreduce_mean_grads, rank_slice
 
 from .renderer import NeROShapeRenderer
 from .synthetic import perturb_state, synthetic_rays
@@ -77,9 +79,8 @@ class ShapeTrainStep:
         G = self.R * self.world
         if self.cursor + G > self.pool_n:
             self.cursor = 0
-        lo = self.cursor + self.rank * self.R
+        s = rank_slice(self.cursor, self.R, self.rank)
         self.cursor += G
-        s = slice(lo, lo + self.R)
         return self.pool['o'][s], self.pool['d'][s], self.pool['gt'][s]
 
     def step(self, step):
@@ -93,13 +94,7 @@ class ShapeTrainStep:
         out = net.render(o, d, near, far, None, -1, net.get_anneal_val(step), is_train=True, step=step)
         loss = shape_training_loss(net, out, gt, step, self.eik_w)
         loss.backward()
-        if self.world > 1:
-            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
-            flat = torch._utils._flatten_dense_tensors(grads)
-            dist.all_reduce(flat)
-            flat.div_(self.world)
-            for p, g in zip(self.params, torch._utils._unflatten_dense_tensors(flat, grads)):
-                p.grad = g
+        allreduce_mean_grads(self.params, self.world)
         self.opt.step()
         st = out['_state']
         return {'loss': loss.detach(), 'n_in': st['n_in'], 'n_out': st['n_out']}

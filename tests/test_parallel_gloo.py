@@ -1,0 +1,76 @@
+"""CPU tier, world_size 2 over gloo: the N>1 path (rank-strided ray shards + one flat gradient all-reduce) reproduces the
+single-process big-batch gradient.  The local compute is the CPU oracle (tests may use it); the product's GPU step uses the
+same two helpers from nero_amd/parallel.py."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _small_net():
+    from nero_amd.renderer import NeROShapeRenderer
+    from nero_amd.synthetic import perturb_state
+    torch.manual_seed(6033)
+    net = NeROShapeRenderer(dict(n_samples=8, n_importance=8, n_bg_samples=4, up_sample_steps=2, apply_occ_loss=False), training=False)
+    perturb_state(net, 0.4)
+    return net
+
+
+def _grads(net, o, d, gt):
+    from oracle import nero_oracle as O
+    sd = {k: v for k, v in net.named_parameters()}
+    sd.update({k: v for k, v in net.named_buffers()})
+    P = O.effective_params(sd)
+    cfg = {**O.DEFAULT_CFG, **net.cfg}
+    near, far = O.near_far_from_sphere(o, d)
+    out = O.render(P, cfg, o, d, near, far, torch.zeros(o.shape[0], 3, 4), 5000, 0.1)
+    loss = O.rgb_loss(cfg, out['ray_rgb'], gt).mean()          # ray-level mean: exact under equal shards
+    for p in net.parameters():
+        p.grad = None
+    loss.backward()
+    return [p for p in net.parameters()]
+
+
+def _worker(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from nero_amd.parallel import allreduce_mean_grads, rank_slice
+    from nero_amd.synthetic import synthetic_rays
+    R = 6
+    o, d, _, gt = synthetic_rays(world * R, seed=1, window=200)
+    s = rank_slice(0, R, rank)
+    net = _small_net()
+    params = _grads(net, o[s], d[s], gt[s])
+    allreduce_mean_grads(params, world)
+    if rank == 0:
+        ret['dp'] = [p.grad.clone() if p.grad is not None else None for p in params]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_allreduce_matches_big_batch():
+    from nero_amd.parallel import rank_slice
+    from nero_amd.synthetic import synthetic_rays
+    assert rank_slice(12, 6, 1) == slice(18, 24)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    o, d, _, gt = synthetic_rays(12, seed=1, window=200)
+    torch.set_num_threads(4)
+    net = _small_net()
+    params = _grads(net, o, d, gt)
+    n = 0
+    for p, g in zip(params, ret['dp']):
+        ref = p.grad if p.grad is not None else torch.zeros_like(p)
+        g = g if g is not None else torch.zeros_like(p)
+        scale = float(ref.abs().max())
+        if scale < 1e-12:
+            continue
+        assert float((g - ref).abs().max()) / scale < 2e-4
+        n += 1
+    assert n > 50
