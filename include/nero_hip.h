@@ -208,13 +208,23 @@ int nero_sdf_alpha_bwd(const float* sdf4, const float* grad, const float* x4, co
 int nero_shade_encode(const float* x4, const float* geo, const float* m_raw, const float* r_raw, const float* a_raw, int n,
                       float* mat /*[rows,8]*/, float* Xd /*[rows,72]*/, float* Xs /*[rows,72]*/, float* Xi /*[rows,128]*/,
                       float* Xo /*[rows,96]*/, void* stream);
+/* Lh [rows,4] raw human-light head + hmask [rows] (from nero_human_encode), or NULL/NULL when shader_config.human_light is off */
 int nero_shade_combine_fwd(const float* geo, const float* mat, const float* Ld, const float* Ls, const float* Li, const float* Lo,
-                           const float* lut /*[256,256,2]*/, float exp_max, int n, float* color /*[n,3]*/, float* occ_prob, void* stream);
+                           const float* lut /*[256,256,2]*/, float exp_max, int n, float* color /*[n,3]*/, float* occ_prob,
+                           const float* Lh, const float* hmask, void* stream);
 int nero_shade_combine_bwd(const float* geo, const float* mat, const float* Ld, const float* Ls, const float* Li, const float* Lo,
                            const float* lut, float exp_max, int n, const float* d_color, const float* d_occ /*or NULL*/, float* dLd,
-                           float* dLs, float* dLi, float* dLo, float* dmat /*[rows,8]*/, float* d_geo /*[rows,8]*/, void* stream);
+                           float* dLs, float* dLi, float* dLo, float* dmat /*[rows,8]*/, float* d_geo /*[rows,8]*/,
+                           const float* Lh, const float* hmask, float* dLh, void* stream);
+/* extra [rows,4] = { d_refl(3), d_rough } from nero_human_encode_bwd, or NULL */
 int nero_shade_encode_bwd(const float* geo, const float* mat, const float* dXd, const float* dXs, const float* dXi, const float* dmat,
-                          int n, float* d_geo, float* dm_raw, float* dr_raw, float* da_raw, void* stream);
+                          int n, float* d_geo, float* dm_raw, float* dr_raw, float* da_raw, const float* extra, void* stream);
+/* human ("photo capturer") light input (predict_human_light, network/field.py:536-552; get_camera_plane_intersection :348-367;
+ * IPE :369-378): Xh [rows,24], hmask [rows]; poses [R,3,4] human-frame poses per RAY, sample k belongs to ray idx[k]/T */
+int nero_human_encode(const float* x4, const float* geo, const float* mat, const int* idx, int T, const float* poses, int n,
+                      float* Xh, float* hmask, void* stream);
+int nero_human_encode_bwd(const float* x4, const float* geo, const float* mat, const int* idx, int T, const float* poses, int n,
+                          const float* dXh, float* extra, void* stream);
 
 /* ---- NeRF++ head (compute_density_alpha, network/renderer.py:514-520) and compositing (renderer.py:578-579) ----------- */
 int nero_nerf_head_fwd(const float* sig4, const float* rgb4, const float* dist, int n, float* alpha, float* color, void* stream);

@@ -283,15 +283,116 @@ __global__ void shade_encode_kernel(const float* __restrict__ x4, const float* _
     for (int c = 90; c < 96; ++c) xo[c] = 0.f;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// human ("photo capturer") light input: intersection of the reflected ray with the z=0 plane of the per-image human
+// frame, IPE of the hit position (predict_human_light / get_camera_plane_intersection / IPE, field.py:348-378, 536-552)
+// Xh [rows,24]; hmask[k] = hit flag (1/0)
+// ------------------------------------------------------------------------------------------------------------------
+struct HumanGeom { float px, py, pz, dx, dy, dz, dzp, dist, ix, iy, h; bool hits0; };
+
+__device__ __forceinline__ HumanGeom human_geom(const float* __restrict__ pose, const float* p, const float* rf) {
+    HumanGeom g;
+    g.px = pose[0] * p[0] + pose[1] * p[1] + pose[2] * p[2] + pose[3];
+    g.py = pose[4] * p[0] + pose[5] * p[1] + pose[6] * p[2] + pose[7];
+    g.pz = pose[8] * p[0] + pose[9] * p[1] + pose[10] * p[2] + pose[11];
+    g.dx = pose[0] * rf[0] + pose[1] * rf[1] + pose[2] * rf[2];
+    g.dy = pose[4] * rf[0] + pose[5] * rf[1] + pose[6] * rf[2];
+    g.dz = pose[8] * rf[0] + pose[9] * rf[1] + pose[10] * rf[2];
+    g.hits0 = fabsf(g.dz) > 1e-4f;
+    g.dzp = g.hits0 ? g.dz : 1e-4f;
+    g.dist = -g.pz / g.dzp;
+    g.ix = g.px + g.dist * g.dx;
+    g.iy = g.py + g.dist * g.dy;
+    const float mx = g.ix * 0.3f, my = g.iy * 0.3f;
+    g.h = (g.hits0 && sqrtf(mx * mx + my * my) < 1.5f && g.dist > 0.f) ? 1.f : 0.f;
+    return g;
+}
+
+__global__ void human_encode_kernel(const float* __restrict__ x4, const float* __restrict__ geo, const float* __restrict__ mat,
+                                    const int* __restrict__ idx, int T, const float* __restrict__ poses, int n, int n_pad,
+                                    float* __restrict__ Xh, float* __restrict__ hmask) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_pad) return;
+    float* o = Xh + (size_t)k * 24;
+    if (k >= n) { for (int c = 0; c < 24; ++c) o[c] = 0.f; hmask[k] = 0.f; return; }
+    const float p[3] = {x4[(size_t)k * 4], x4[(size_t)k * 4 + 1], x4[(size_t)k * 4 + 2]};
+    const float* q = geo + (size_t)k * 8;
+    const float rf[3] = {q[4], q[5], q[6]};
+    const HumanGeom g = human_geom(poses + (size_t)(idx[k] / T) * 12, p, rf);
+    const float r = mat[(size_t)k * 8 + 1];
+    const float mean[2] = {g.ix * 0.3f * g.h, g.iy * 0.3f * g.h};
+    const float sd = g.dist * 0.3f;
+    const float var = r * sd * sd * g.h;
+    float sc = 1.f;
+    for (int s = 0; s < 6; ++s) {
+        for (int c = 0; c < 2; ++c) {
+            const float sm = mean[c] * sc, sv = var * sc * sc;
+            const float e = expf(-0.5f * sv);
+            o[2 * s + c] = e * sinf(sm);
+            o[12 + 2 * s + c] = e * sinf(sm + 1.5707963267948966f);
+        }
+        sc *= 2.f;
+    }
+    hmask[k] = g.h;
+}
+
+// dXh [rows,24] -> extra[k] = { d_refl(3), d_rough }
+__global__ void human_encode_bwd_kernel(const float* __restrict__ x4, const float* __restrict__ geo, const float* __restrict__ mat,
+                                        const int* __restrict__ idx, int T, const float* __restrict__ poses, int n,
+                                        const float* __restrict__ dXh, float* __restrict__ extra) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float p[3] = {x4[(size_t)k * 4], x4[(size_t)k * 4 + 1], x4[(size_t)k * 4 + 2]};
+    const float* q = geo + (size_t)k * 8;
+    const float rf[3] = {q[4], q[5], q[6]};
+    const float* pose = poses + (size_t)(idx[k] / T) * 12;
+    const HumanGeom g = human_geom(pose, p, rf);
+    const float r = mat[(size_t)k * 8 + 1];
+    const float mean[2] = {g.ix * 0.3f * g.h, g.iy * 0.3f * g.h};
+    const float sd = g.dist * 0.3f;
+    const float var = r * sd * sd * g.h;
+    const float* gx = dXh + (size_t)k * 24;
+    float dmean[2] = {0.f, 0.f}, dvar = 0.f;
+    float sc = 1.f;
+    for (int s = 0; s < 6; ++s) {
+        for (int c = 0; c < 2; ++c) {
+            const float sm = mean[c] * sc, sv = var * sc * sc;
+            const float e = expf(-0.5f * sv);
+            const float sn = sinf(sm), cs = sinf(sm + 1.5707963267948966f), ms = cosf(sm + 1.5707963267948966f);
+            const float ga = gx[2 * s + c], gb = gx[12 + 2 * s + c];
+            dmean[c] += sc * (ga * e * cosf(sm) + gb * e * ms);
+            dvar += sc * sc * (-0.5f) * (ga * e * sn + gb * e * cs);
+        }
+        sc *= 2.f;
+    }
+    const float dix = 0.3f * g.h * dmean[0], diy = 0.3f * g.h * dmean[1];
+    const float d_rough = dvar * sd * sd * g.h;
+    float d_dist = dvar * r * 2.f * 0.09f * g.dist * g.h + dix * g.dx + diy * g.dy;
+    const float ddx = g.dist * dix, ddy = g.dist * diy;
+    const float ddz = g.hits0 ? d_dist * g.pz / (g.dzp * g.dzp) : 0.f;
+    float* o = extra + (size_t)k * 4;
+    o[0] = pose[0] * ddx + pose[4] * ddy + pose[8] * ddz;
+    o[1] = pose[1] * ddx + pose[5] * ddy + pose[9] * ddz;
+    o[2] = pose[2] * ddx + pose[6] * ddy + pose[10] * ddz;
+    o[3] = d_rough;
+}
+
 // combine (field.py:601-623).  light heads are RAW outputs [rows,4]: diff(3), direct(3), indirect(3), occ(1).
 // color[k*3..], occ_prob[k] (unclamped, for the occ loss)
 __global__ void shade_combine_fwd_kernel(const float* __restrict__ geo, const float* __restrict__ mat, const float* __restrict__ Ld,
                                          const float* __restrict__ Ls, const float* __restrict__ Li, const float* __restrict__ Lo,
                                          const float* __restrict__ lut, float exp_max, int n, float* __restrict__ color,
-                                         float* __restrict__ occ_prob) {
+                                         float* __restrict__ occ_prob, const float* __restrict__ Lh, const float* __restrict__ hmask) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const float* mo = mat + (size_t)k * 8;
+    // human light: exp(min(raw,0)) * hit; channel 3 is the blend weight clamped to [0,1]   (field.py:548-551, 575)
+    float hl[3] = {0.f, 0.f, 0.f}, hw = 0.f;
+    if (Lh) {
+        const float hm = hmask[k];
+        for (int c = 0; c < 3; ++c) hl[c] = expf(fminf(Lh[(size_t)k * 4 + c], 0.f)) * hm;
+        hw = fminf(fmaxf(expf(fminf(Lh[(size_t)k * 4 + 3], 0.f)) * hm, 0.f), 1.f);
+    }
     const float m = mo[0], r = mo[1];
     const float nov = geo[(size_t)k * 8 + 3];
     float f0, f1, a0, a1, a2, a3;
@@ -304,7 +405,7 @@ __global__ void shade_combine_fwd_kernel(const float* __restrict__ geo, const fl
         const float dl = expf(fminf(Ld[(size_t)k * 4 + c], exp_max));
         const float direct = expf(fminf(Ls[(size_t)k * 4 + c], exp_max));
         const float indirect = expf(fminf(Li[(size_t)k * 4 + c], exp_max));
-        const float sl = indirect * oc + direct * (1.f - oc);
+        const float sl = indirect * oc + (hl[c] * hw + direct * (1.f - hw)) * (1.f - oc);
         const float da = (1.f - m) * a, sa = 0.04f * (1.f - m) + m * a;
         const float lin = da * dl + (sa * f0 + f1) * sl;
         color[(size_t)k * 3 + c] = fminf(fmaxf(srgb_f(lin), 0.f), 1.f);
@@ -318,15 +419,25 @@ __global__ void shade_combine_bwd_kernel(const float* __restrict__ geo, const fl
                                          const float* __restrict__ lut, float exp_max, int n, int n_pad,
                                          const float* __restrict__ d_color, const float* __restrict__ d_occ,
                                          float* __restrict__ dLd, float* __restrict__ dLs, float* __restrict__ dLi, float* __restrict__ dLo,
-                                         float* __restrict__ dmat, float* __restrict__ d_geo) {
+                                         float* __restrict__ dmat, float* __restrict__ d_geo, const float* __restrict__ Lh,
+                                         const float* __restrict__ hmask, float* __restrict__ dLh) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_pad) return;
     float4 z4 = make_float4(0, 0, 0, 0);
     if (k >= n) {
         reinterpret_cast<float4*>(dLd)[k] = z4; reinterpret_cast<float4*>(dLs)[k] = z4;
         reinterpret_cast<float4*>(dLi)[k] = z4; reinterpret_cast<float4*>(dLo)[k] = z4;
+        if (dLh) reinterpret_cast<float4*>(dLh)[k] = z4;
         return;
     }
+    float hl[3] = {0.f, 0.f, 0.f}, hw = 0.f, hw_raw = 0.f, hm = 0.f;
+    if (Lh) {
+        hm = hmask[k];
+        for (int c = 0; c < 3; ++c) hl[c] = expf(fminf(Lh[(size_t)k * 4 + c], 0.f)) * hm;
+        hw_raw = expf(fminf(Lh[(size_t)k * 4 + 3], 0.f)) * hm;
+        hw = fminf(fmaxf(hw_raw, 0.f), 1.f);
+    }
+    float d_hl[3] = {0.f, 0.f, 0.f}, d_hw = 0.f;
     const float* mo = mat + (size_t)k * 8;
     const float m = mo[0], r = mo[1];
     const float nov = geo[(size_t)k * 8 + 3];
@@ -341,7 +452,8 @@ __global__ void shade_combine_bwd_kernel(const float* __restrict__ geo, const fl
         const float a = mo[2 + c];
         const float rd = Ld[(size_t)k * 4 + c], rs = Ls[(size_t)k * 4 + c], ri = Li[(size_t)k * 4 + c];
         const float dl = expf(fminf(rd, exp_max)), direct = expf(fminf(rs, exp_max)), indirect = expf(fminf(ri, exp_max));
-        const float sl = indirect * oc + direct * (1.f - oc);
+        const float bl = hl[c] * hw + direct * (1.f - hw);
+        const float sl = indirect * oc + bl * (1.f - oc);
         const float dalb = (1.f - m) * a, salb = 0.04f * (1.f - m) + m * a;
         const float sref = salb * f0 + f1;
         const float lin = dalb * dl + sref * sl;
@@ -355,8 +467,18 @@ __global__ void shade_combine_bwd_kernel(const float* __restrict__ geo, const fl
         da_out[c] = (1.f - m) * d_dalb + m * d_salb;
         ld[c] = rd <= exp_max ? d_dl * dl : 0.f;
         li[c] = ri <= exp_max ? d_sl * oc * indirect : 0.f;
-        ls[c] = rs <= exp_max ? d_sl * (1.f - oc) * direct : 0.f;
-        d_oc += d_sl * (indirect - direct);
+        const float d_bl = d_sl * (1.f - oc);
+        ls[c] = rs <= exp_max ? d_bl * (1.f - hw) * direct : 0.f;
+        d_hl[c] = d_bl * hw;
+        d_hw += d_bl * (hl[c] - direct);
+        d_oc += d_sl * (indirect - bl);
+    }
+    if (dLh) {
+        float o4[4];
+        for (int c = 0; c < 3; ++c) o4[c] = Lh[(size_t)k * 4 + c] <= 0.f ? d_hl[c] * hl[c] : 0.f;        // hl = exp(raw)*hm
+        const float dhw_raw = (hw_raw >= 0.f && hw_raw <= 1.f) ? d_hw : 0.f;
+        o4[3] = Lh[(size_t)k * 4 + 3] <= 0.f ? dhw_raw * hw_raw : 0.f;
+        reinterpret_cast<float4*>(dLh)[k] = make_float4(o4[0], o4[1], o4[2], o4[3]);
     }
     float d_occ_tot = (occ >= 0.f && occ <= 1.f) ? d_oc : 0.f;
     if (d_occ) d_occ_tot += d_occ[k];
@@ -376,7 +498,7 @@ __global__ void shade_combine_bwd_kernel(const float* __restrict__ geo, const fl
 __global__ void shade_encode_bwd_kernel(const float* __restrict__ geo, const float* __restrict__ mat, const float* __restrict__ dXd,
                                         const float* __restrict__ dXs, const float* __restrict__ dXi, const float* __restrict__ dmat,
                                         int n, int n_pad, float* __restrict__ d_geo, float* __restrict__ dm_raw,
-                                        float* __restrict__ dr_raw, float* __restrict__ da_raw) {
+                                        float* __restrict__ dr_raw, float* __restrict__ da_raw, const float* __restrict__ extra) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_pad) return;
     float4 z4 = make_float4(0, 0, 0, 0);
@@ -395,10 +517,14 @@ __global__ void shade_encode_bwd_kernel(const float* __restrict__ geo, const flo
     float drx = 0.f, dry = 0.f, drz = 0.f, dkr = 0.f;
     for (int c = 0; c < 72; ++c) g[c] = dXs[(size_t)k * 72 + c] + dXi[(size_t)k * 128 + 51 + c];
     ide_backward(q[4], q[5], q[6], r, g, drx, dry, drz, dkr);
+    float d_r = dm[1] + dkr;
+    if (extra) {                                   // human-light branch: d_refl(3), d_rough
+        const float* ex = extra + (size_t)k * 4;
+        drx += ex[0]; dry += ex[1]; drz += ex[2]; d_r += ex[3];
+    }
     float* o = d_geo + (size_t)k * 8;
     o[0] = dnx; o[1] = dny; o[2] = dnz;
     o[4] = drx; o[5] = dry; o[6] = drz; o[7] = 0.f;
-    const float d_r = dm[1] + dkr;
     reinterpret_cast<float4*>(dm_raw)[k] = make_float4(dm[0] * m * (1.f - m), 0.f, 0.f, 0.f);
     reinterpret_cast<float4*>(dr_raw)[k] = make_float4(d_r * r * (1.f - r), 0.f, 0.f, 0.f);
     reinterpret_cast<float4*>(da_raw)[k] = make_float4(dm[2] * mo[2] * (1.f - mo[2]), dm[3] * mo[3] * (1.f - mo[3]), dm[4] * mo[4] * (1.f - mo[4]), 0.f);
@@ -536,28 +662,45 @@ int nero_shade_encode(const float* x4, const float* geo, const float* m_raw, con
 }
 
 int nero_shade_combine_fwd(const float* geo, const float* mat, const float* Ld, const float* Ls, const float* Li, const float* Lo,
-                           const float* lut, float exp_max, int n, float* color, float* occ_prob, void* stream) {
+                           const float* lut, float exp_max, int n, float* color, float* occ_prob, const float* Lh, const float* hmask,
+                           void* stream) {
     if (n == 0) return NERO_OK;
-    hipLaunchKernelGGL(shade_combine_fwd_kernel, GRID1D(n), geo, mat, Ld, Ls, Li, Lo, lut, exp_max, n, color, occ_prob);
+    hipLaunchKernelGGL(shade_combine_fwd_kernel, GRID1D(n), geo, mat, Ld, Ls, Li, Lo, lut, exp_max, n, color, occ_prob, Lh, hmask);
     return nero_check_launch("nero_shade_combine_fwd");
 }
 
 int nero_shade_combine_bwd(const float* geo, const float* mat, const float* Ld, const float* Ls, const float* Li, const float* Lo,
                            const float* lut, float exp_max, int n, const float* d_color, const float* d_occ, float* dLd, float* dLs,
-                           float* dLi, float* dLo, float* dmat, float* d_geo, void* stream) {
+                           float* dLi, float* dLo, float* dmat, float* d_geo, const float* Lh, const float* hmask, float* dLh,
+                           void* stream) {
     const int n_pad = NERO_ROW_PAD(n);
     if (n_pad == 0) return NERO_OK;
-    hipLaunchKernelGGL(shade_combine_bwd_kernel, GRID1D(n_pad), geo, mat, Ld, Ls, Li, Lo, lut, exp_max, n, n_pad, d_color, d_occ, dLd, dLs, dLi, dLo, dmat, d_geo);
+    hipLaunchKernelGGL(shade_combine_bwd_kernel, GRID1D(n_pad), geo, mat, Ld, Ls, Li, Lo, lut, exp_max, n, n_pad, d_color, d_occ, dLd, dLs, dLi, dLo, dmat, d_geo, Lh, hmask, dLh);
     return nero_check_launch("nero_shade_combine_bwd");
 }
 
 int nero_shade_encode_bwd(const float* geo, const float* mat, const float* dXd, const float* dXs, const float* dXi, const float* dmat,
-                          int n, float* d_geo, float* dm_raw, float* dr_raw, float* da_raw, void* stream) {
+                          int n, float* d_geo, float* dm_raw, float* dr_raw, float* da_raw, const float* extra, void* stream) {
     CHECK_IDE();
     const int n_pad = NERO_ROW_PAD(n);
     if (n_pad == 0) return NERO_OK;
-    hipLaunchKernelGGL(shade_encode_bwd_kernel, GRID1D(n_pad), geo, mat, dXd, dXs, dXi, dmat, n, n_pad, d_geo, dm_raw, dr_raw, da_raw);
+    hipLaunchKernelGGL(shade_encode_bwd_kernel, GRID1D(n_pad), geo, mat, dXd, dXs, dXi, dmat, n, n_pad, d_geo, dm_raw, dr_raw, da_raw, extra);
     return nero_check_launch("nero_shade_encode_bwd");
+}
+
+int nero_human_encode(const float* x4, const float* geo, const float* mat, const int* idx, int T, const float* poses, int n,
+                      float* Xh, float* hmask, void* stream) {
+    const int n_pad = NERO_ROW_PAD(n);
+    if (n_pad == 0) return NERO_OK;
+    hipLaunchKernelGGL(human_encode_kernel, GRID1D(n_pad), x4, geo, mat, idx, T, poses, n, n_pad, Xh, hmask);
+    return nero_check_launch("nero_human_encode");
+}
+
+int nero_human_encode_bwd(const float* x4, const float* geo, const float* mat, const int* idx, int T, const float* poses, int n,
+                          const float* dXh, float* extra, void* stream) {
+    if (n == 0) return NERO_OK;
+    hipLaunchKernelGGL(human_encode_bwd_kernel, GRID1D(n), x4, geo, mat, idx, T, poses, n, dXh, extra);
+    return nero_check_launch("nero_human_encode_bwd");
 }
 
 int nero_nerf_head_fwd(const float* sig4, const float* rgb4, const float* dist, int n, float* alpha, float* color, void* stream) {

@@ -38,6 +38,23 @@ class NeROShapeRenderer(nn.Module):
     def _init_dataset(self):
         raise NotImplementedError('dataset-backed training pool: see nero_amd.raypool (synthetic pools only in this round)')
 
+    def get_human_coordinate_poses(self, poses):
+        """per-image "human" frame [R|t]: z = horizontal viewing direction, y = -world z, origin at the camera centre projected
+        to z=0 unless fixed_camera (network/renderer.py:240-256)."""
+        pn = poses.shape[0]
+        cam_cen = (-poses[:, :, :3].permute(0, 2, 1) @ poses[:, :, 3:])[..., 0].clone()
+        if not self.cfg['fixed_camera']:
+            cam_cen[..., 2] = 0
+        Y = torch.zeros([pn, 3], device=poses.device, dtype=poses.dtype)
+        Y[:, 2] = -1.0
+        Z = torch.clone(poses[:, 2, :3])
+        Z[:, 2] = 0
+        Z = torch.nn.functional.normalize(Z, dim=-1)
+        X = torch.cross(Y, Z, dim=-1)
+        Rm = torch.stack([X, Y, Z], 1)
+        t = -Rm @ cam_cen[:, :, None]
+        return torch.cat([Rm, t], -1)
+
     def get_anneal_val(self, step):
         e = self.cfg['anneal_end']
         return 1.0 if e < 0 else float(np.min([1.0, step / e]))
@@ -99,8 +116,13 @@ class NeROShapeRenderer(nn.Module):
                 'anneal': float(cos_anneal_ratio), 'exp_max': float(self.color_network.cfg['light_exp_max']),
                 'freeze_inv_s': c['freeze_inv_s_step'] is not None and step < c['freeze_inv_s_step']}
         var = self.deviation_network.variance
+        poses = None
+        if self.color_network.cfg['human_light']:
+            if human_poses is None:
+                raise ValueError('shader_config.human_light needs human_poses [R,3,4]')
+            poses = human_poses.to(torch.float32).contiguous()
         rgb, gerr, occ_prob = RenderCore.apply(meta, rays_o.contiguous(), rays_d.contiguous(), z_vals.contiguous(), var,
-                                               self.color_network.FG_LUT, *eff)
+                                               self.color_network.FG_LUT, poses, *eff)
         n_in = gerr.shape[0]
         outputs = {'ray_rgb': rgb, 'gradient_error': gerr if n_in > 0 else torch.zeros(1, device=rgb.device)}
         inv_s = torch.exp(var * 10.0).clip(1e-6, 1e6)

@@ -34,8 +34,6 @@ class ShapeKernels:
     def __init__(self, eff, shader_cfg, device='cuda'):
         self.device = device
         self.human = bool(shader_cfg.get('human_light', False))
-        if self.human:
-            raise NotImplementedError('shader_config.human_light is not wired into the HIP path yet')
         self.sdf = SDFField(eff['sdf'], device)
         nf = eff['nerf']
         ent = []
@@ -56,11 +54,13 @@ class ShapeKernels:
         self.outer_light = Chain(predictor_entries(eff['outer_light'], 72), k_init=72, device=device)
         self.inner_light = Chain(predictor_entries(eff['inner_light'], 123), k_init=128, device=device)
         self.inner_weight = Chain(predictor_entries(eff['inner_weight'], 90), k_init=96, device=device)
+        self.human_light = Chain(predictor_entries(eff['human'], 24), k_init=24, device=device) if self.human else None
 
     def pack(self):
         self.sdf.pack()
-        for c in [self.nerf_trunk, self.nerf_head, self.outer_light, self.inner_light, self.inner_weight] + self.mat:
-            c.pack()
+        for c in [self.nerf_trunk, self.nerf_head, self.outer_light, self.inner_light, self.inner_weight, self.human_light] + self.mat:
+            if c is not None:
+                c.pack()
         return self
 
 
@@ -162,7 +162,7 @@ class RenderCore(torch.autograd.Function):
     gradient_error [N_in], occ_prob [N_in] (unclamped)."""
 
     @staticmethod
-    def forward(ctx, meta, o, d, z_vals, variance, lut, *params):
+    def forward(ctx, meta, o, d, z_vals, variance, lut, poses, *params):
         dev = o.device
         lib = L.lib
         st = _st()
@@ -215,13 +215,19 @@ class RenderCore(torch.autograd.Function):
             f_out = K.outer_light.forward(Xo2, None, rpi + n_in)
             f_in = K.inner_light.forward(Xi, None, n_in)
             f_w = K.inner_weight.forward(Xo, None, n_in)
+            f_h = Xh = hmask = None
+            if K.human:
+                Xh, hmask = torch.empty((rpi, 24), **f32), torch.empty(rpi, **f32)
+                L.check(lib.nero_human_encode(_p(x4), _p(geo), _p(mat), _p(inner_idx), T, _p(poses), n_in, _p(Xh), _p(hmask), st))
+                f_h = K.human_light.forward(Xh, None, n_in)
             Lh = f_out['heads'][3]
             color_i = torch.empty((rpi, 3), **f32)
             L.check(lib.nero_shade_combine_fwd(_p(geo), _p(mat), _p(Lh[:rpi]), _p(Lh[rpi:]), _p(f_in['heads'][3]), _p(f_w['heads'][3]),
-                                               _p(lut), C.c_float(meta['exp_max']), n_in, _p(color_i), _p(occ_prob), st))
+                                               _p(lut), C.c_float(meta['exp_max']), n_in, _p(color_i), _p(occ_prob),
+                                               _p(f_h['heads'][3] if f_h else None), _p(hmask), st))
             L.check(lib.nero_scatter_samples(_p(alpha_i), _p(color_i), _p(inner_idx), n_in, _p(alphaRT), _p(colorRT), st))
             S.update(x4=x4, x8=x8, sctx=sctx, geo=geo, mats=mats, mat=mat, Xo2=Xo2, Xi=Xi, Xo=Xo, f_out=f_out, f_in=f_in,
-                     f_w=f_w)
+                     f_w=f_w, f_h=f_h, Xh=Xh, hmask=hmask, poses=poses)
         weights, rgb = torch.empty((R, T), **f32), torch.empty((R, 3), **f32)
         L.check(lib.nero_composite_fwd(_p(alphaRT), _p(colorRT), R, T, _p(weights), _p(rgb), st))
         S.update(alphaRT=alphaRT, colorRT=colorRT, weights=weights)
@@ -279,9 +285,12 @@ class RenderCore(torch.autograd.Function):
             dLi, dLo = torch.empty((rpi, 4), **f32), torch.empty((rpi, 4), **f32)
             dmat, d_geo = torch.empty((rpi, 8), **f32), torch.zeros((rpi, 8), **f32)
             d_occ_c = d_occ.contiguous() if d_occ is not None else None
+            f_h = S['f_h']
+            dLhum = torch.empty((rpi, 4), **f32) if f_h else None
             L.check(lib.nero_shade_combine_bwd(_p(geo), _p(mat), _p(Lh[:rpi]), _p(Lh[rpi:]), _p(f_in['heads'][3]), _p(f_w['heads'][3]),
                                                _p(S['lut']), C.c_float(meta['exp_max']), n_in, _p(d_ci), _p(d_occ_c),
-                                               _p(dLh[:rpi]), _p(dLh[rpi:]), _p(dLi), _p(dLo), _p(dmat), _p(d_geo), st))
+                                               _p(dLh[:rpi]), _p(dLh[rpi:]), _p(dLi), _p(dLo), _p(dmat), _p(d_geo),
+                                               _p(f_h['heads'][3] if f_h else None), _p(S['hmask']), _p(dLhum), st))
             n2 = rpi + n_in
             ob = K.outer_light.backward(f_out, n2, head_dys={3: dLh}, need_dinit=True)
             put_pred('outer_light', K.outer_light.weight_grads(f_out, ob, n2, S['Xo2'], None, head_dys={3: dLh}, workspace=ws))
@@ -289,10 +298,17 @@ class RenderCore(torch.autograd.Function):
             put_pred('inner_light', K.inner_light.weight_grads(f_in, ib, n_in, S['Xi'], None, head_dys={3: dLi}, workspace=ws))
             wb = K.inner_weight.backward(f_w, n_in, head_dys={3: dLo})
             put_pred('inner_weight', K.inner_weight.weight_grads(f_w, wb, n_in, S['Xo'], None, head_dys={3: dLo}, workspace=ws))
+            extra = None
+            if f_h:
+                hb = K.human_light.backward(f_h, n_in, head_dys={3: dLhum}, need_dinit=True)
+                put_pred('human_light_predictor', K.human_light.weight_grads(f_h, hb, n_in, S['Xh'], None, head_dys={3: dLhum}, workspace=ws))
+                extra = torch.empty((rpi, 4), **f32)
+                L.check(lib.nero_human_encode_bwd(_p(S['x4']), _p(geo), _p(mat), _p(S['inner_idx']), T, _p(S['poses']), n_in,
+                                                  _p(hb['d_init']), _p(extra), st))
             dmr, drr, dar = (torch.empty((rpi, 4), **f32) for _ in range(3))
             dX = ob['d_init']
             L.check(lib.nero_shade_encode_bwd(_p(geo), _p(mat), _p(dX[:rpi]), _p(dX[rpi:]), _p(ib['d_init']), _p(dmat), n_in,
-                                              _p(d_geo), _p(dmr), _p(drr), _p(dar), st))
+                                              _p(d_geo), _p(dmr), _p(drr), _p(dar), _p(extra), st))
             d_feat = torch.empty((rpi, 256), **f32)
             feat = S['sctx']['feat']
             for j, (c, name, dh) in enumerate(zip(K.mat, ('metallic_predictor', 'roughness_predictor', 'albedo_predictor'), (dmr, drr, dar))):
@@ -316,7 +332,7 @@ class RenderCore(torch.autograd.Function):
             g = G.get(name)
             grads.append(g if g is not None else torch.zeros(shape, **f32))
         ctx.S = None
-        return (None, None, None, None, d_var, None) + tuple(grads)
+        return (None, None, None, None, d_var, None, None) + tuple(grads)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
