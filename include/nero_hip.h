@@ -9,7 +9,8 @@
  * row-major with an explicit leading dimension; every row count `n` may be any value >= 0 but all row buffers must be
  * allocated for NERO_ROW_PAD(n) rows; every call is asynchronous on `stream` (a hipStream_t passed as void*); every
  * function returns 0 on success or a negative error code, with a message available from nero_last_error().
- * Nothing here allocates device memory or synchronises.
+ * Nothing here allocates device memory or synchronises, except nero_bvh_create / nero_bvh_destroy (the library owns BVH
+ * handles) and the one-time upload of the IDE coefficient table.
  */
 #ifndef NERO_HIP_H
 #define NERO_HIP_H
@@ -235,6 +236,16 @@ int nero_composite_fwd(const float* alphaRT, const float* colorRT, int R, int T,
 int nero_composite_bwd(const float* alphaRT, const float* colorRT, const float* weights, const float* d_rgb, int R, int T,
                        float* d_alphaRT, float* d_colorRT, void* stream);
 int nero_gather_sample_grads(const float* d_alphaRT, const float* d_colorRT, const int* idx, int n, float* d_a, float* d_c, void* stream);
+
+/* ---- mesh ray tracer (Stage II).  Replaces the third-party CUDA extension `_raytracing` behind raytracing/raytracer.py:
+ *      create_raytracer(vertices, triangles) (:19) and impl.trace(rays_o, rays_d, positions, face_normals, depth) (:49).
+ *      verts [nV,3] float32 / tris [nT,3] int32 are HOST arrays; rays and outputs are device arrays.  Closest hit with t > 0;
+ *      face normal = normalize(cross(v1-v0, v2-v0)); a miss reports depth = 10, position = o + 10 d, normal = 0
+ *      (NeROMaterialRenderer.trace treats depth >= 10 as a miss, network/renderer.py:727). */
+int nero_bvh_create(const float* verts, int nV, const int* tris, int nT, void** handle);
+int nero_bvh_trace(void* handle, const float* rays_o, const float* rays_d, int n, float* positions, float* face_normals, float* depth,
+                   void* stream);
+int nero_bvh_destroy(void* handle);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,51 @@
+"""Drop-in for the reference's `raytracing.RayTracer` (raytracing/raytracer.py:8-54): same constructor and trace() contract,
+backed by the HIP BVH in libnero_hip.so instead of the un-vendored `_raytracing` CUDA extension."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+class RayTracer:
+    def __init__(self, vertices, triangles):
+        if torch.is_tensor(vertices):
+            vertices = vertices.detach().cpu().numpy()
+        if torch.is_tensor(triangles):
+            triangles = triangles.detach().cpu().numpy()
+        assert triangles.shape[0] > 8, "BVH needs at least 8 triangles."          # same guard as the reference wrapper (:16)
+        self._v = np.ascontiguousarray(vertices, dtype=np.float32)
+        self._f = np.ascontiguousarray(triangles, dtype=np.int32)
+        self._h = C.c_void_p()
+        L.check(L.lib.nero_bvh_create(self._v.ctypes.data_as(C.c_void_p), self._v.shape[0], self._f.ctypes.data_as(C.c_void_p),
+                                      self._f.shape[0], C.byref(self._h)))
+
+    def __del__(self):
+        try:
+            if getattr(self, '_h', None):
+                L.lib.nero_bvh_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def trace(self, rays_o, rays_d, inplace=False):
+        rays_o = rays_o.float().contiguous()
+        rays_d = rays_d.float().contiguous()
+        if not rays_o.is_cuda:
+            rays_o = rays_o.cuda()
+        if not rays_d.is_cuda:
+            rays_d = rays_d.cuda()
+        prefix = rays_o.shape[:-1]
+        rays_o = rays_o.view(-1, 3)
+        rays_d = rays_d.view(-1, 3)
+        n = rays_o.shape[0]
+        positions = rays_o if inplace else torch.empty_like(rays_o)
+        face_normals = rays_d if inplace else torch.empty_like(rays_d)
+        depth = torch.empty(n, dtype=torch.float32, device=rays_o.device)
+        if inplace:                      # the kernel reads o/d before it writes: each thread owns its ray
+            pass
+        L.check(L.lib.nero_bvh_trace(self._h, C.c_void_p(rays_o.data_ptr()), C.c_void_p(rays_d.data_ptr()), n,
+                                     C.c_void_p(positions.data_ptr()), C.c_void_p(face_normals.data_ptr()),
+                                     C.c_void_p(depth.data_ptr()), L.stream_ptr()))
+        return positions.view(*prefix, 3), face_normals.view(*prefix, 3), depth.view(*prefix)

@@ -35,8 +35,79 @@ class NeROShapeRenderer(nn.Module):
         if training:
             self._init_dataset()
 
-    def _init_dataset(self):
-        raise NotImplementedError('dataset-backed training pool: see nero_amd.raypool (synthetic pools only in this round)')
+    # ---- dataset-backed ray pool, resident in HBM (network/renderer.py:136-187, 319-326) ---------
+    def _init_dataset(self, database=None):
+        """`database` is any object with the reference's BaseDatabase interface (get_image / get_K / get_pose / get_img_ids,
+        dataset/database.py:20-42).  When omitted it is resolved through the reference's own `dataset.database` module, which
+        must then be importable (the renderer is meant to be dropped into the reference tree; dataset IO is out of scope here)."""
+        if database is None:
+            try:
+                from dataset.database import get_database_split, parse_database_name
+            except ImportError as e:
+                raise ImportError('no database object given and the reference `dataset.database` module is not importable') from e
+            database = parse_database_name(self.cfg['database_name'])
+            train_ids, test_ids = get_database_split(database)
+        else:
+            ids = list(database.get_img_ids())
+            train_ids, test_ids = ids, ids[:1]
+        self.database, self.train_ids, self.test_ids = database, np.asarray(train_ids), test_ids
+        imgs = np.stack([np.asarray(database.get_image(i)) for i in train_ids], 0).astype(np.float32)
+        if imgs.max() > 1.5:
+            imgs = imgs / 255.0                                   # color_map_forward (utils/base_utils.py)
+        Ks = np.stack([database.get_K(i) for i in train_ids], 0).astype(np.float32)
+        poses = np.stack([database.get_pose(i) for i in train_ids], 0).astype(np.float32)
+        self.set_ray_pool(torch.from_numpy(imgs), torch.from_numpy(Ks), torch.from_numpy(poses))
+
+    def set_ray_pool(self, imgs, Ks, poses, device=None):
+        """imgs [imn,h,w,3] in [0,1], Ks [imn,3,3], poses [imn,3,4] (world->camera).  Builds the pool of every training pixel
+        (dirs = K^-1 [u+.5, v+.5, 1], network/renderer.py:167-187) ON THE DEVICE and shuffles it there; train_step slices it
+        without any host->device traffic."""
+        device = device or next(self.parameters()).device
+        imn, h, w, _ = imgs.shape
+        ys, xs = torch.meshgrid(torch.arange(h, device=device), torch.arange(w, device=device), indexing='ij')
+        coords = torch.stack([xs + 0.5, ys + 0.5, torch.ones_like(xs, dtype=torch.float32)], -1).reshape(1, h * w, 3).float()
+        dirs = coords @ torch.inverse(Ks.to(device)).permute(0, 2, 1)                      # imn, h*w, 3
+        self.train_poses = poses.to(device).float()
+        self._human_poses_img = self.get_human_coordinate_poses(self.train_poses)
+        self.train_batch = {'dirs': dirs.reshape(-1, 3).contiguous(), 'rgbs': imgs.to(device).reshape(-1, 3).float().contiguous(),
+                            'idxs': torch.arange(imn, device=device).repeat_interleave(h * w)}
+        self.tbn = imn * h * w
+        self._shuffle_train_batch()
+
+    def _shuffle_train_batch(self):
+        self.train_batch_i = 0
+        perm = torch.randperm(self.tbn, device=self.train_batch['dirs'].device)
+        self.train_batch = {k: v[perm] for k, v in self.train_batch.items()}
+
+    def _process_ray_batch(self, ray_batch, poses):
+        """world-space rays of a pool slice (network/renderer.py:258-272)"""
+        idxs = ray_batch['idxs']
+        Rm, t = poses[:, :, :3], poses[:, :, 3:]
+        rays_o = (Rm.permute(0, 2, 1) @ -t)[idxs, :, 0]
+        rays_d = (Rm[idxs].permute(0, 2, 1) @ ray_batch['dirs'].unsqueeze(-1))[..., 0]
+        rays_d = torch.nn.functional.normalize(rays_d, dim=-1)
+        near, far = self.near_far_from_sphere(rays_o, rays_d)
+        return rays_o, rays_d, near, far, self._human_poses_img[idxs]
+
+    def train_step(self, step):
+        rn = self.cfg['train_ray_num']
+        s = slice(self.train_batch_i, self.train_batch_i + rn)
+        batch = {k: v[s] for k, v in self.train_batch.items()}
+        self.train_batch_i += rn
+        if self.train_batch_i + rn >= self.tbn:
+            self._shuffle_train_batch()
+        rays_o, rays_d, near, far, human_poses = self._process_ray_batch(batch, self.train_poses)
+        outputs = self.render(rays_o, rays_d, near, far, human_poses, -1, self.get_anneal_val(step), is_train=True, step=step)
+        outputs['loss_rgb'] = self.compute_rgb_loss(outputs['ray_rgb'], batch['rgbs'])
+        return outputs
+
+    def forward(self, data):
+        """Trainer entry point (network/renderer.py:608-627).  No process-global default-tensor-type switch: every tensor is
+        created on the parameters' device explicitly."""
+        if 'eval' in data:
+            raise NotImplementedError('validation (test_step / compute_validation_info) is not on the HIP path yet')
+        outputs = self.train_step(data['step'])
+        return {k: v for k, v in outputs.items() if not k.startswith('_')}
 
     def get_human_coordinate_poses(self, poses):
         """per-image "human" frame [R|t]: z = horizontal viewing direction, y = -world z, origin at the camera centre projected

@@ -63,3 +63,37 @@ def perturb_state(module, variance, seed=77):
             a, b = (0.05, 0.001) if name.startswith('sdf_network') else (0.1, 0.003)
             p.add_((noise * (a * s + b)).to(p.device, p.dtype))
         module.deviation_network.variance.fill_(variance)
+
+
+def icosphere(subdiv=3, radius=0.5, bumps=0.0, seed=0):
+    """-> (vertices [nV,3] float32, triangles [nT,3] int32), outward winding; `bumps` > 0 adds a smooth radial perturbation with
+    concavities so that secondary rays from the surface hit the mesh (Stage-II stand-in for the extracted shape mesh)."""
+    t = (1.0 + np.sqrt(5.0)) / 2.0
+    v = np.array([[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t],
+                  [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]], np.float64)
+    f = np.array([[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9], [5, 11, 4], [11, 10, 2], [10, 7, 6],
+                  [7, 1, 8], [3, 9, 4], [3, 4, 2], [3, 2, 6], [3, 6, 8], [3, 8, 9], [4, 9, 5], [2, 4, 11], [6, 2, 10], [8, 6, 7],
+                  [9, 8, 1]], np.int64)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    for _ in range(subdiv):
+        cache, nf = {}, []
+        vl = list(v)
+
+        def mid(a, b):
+            k = (min(a, b), max(a, b))
+            if k not in cache:
+                m = (vl[a] + vl[b]) / 2
+                vl.append(m / np.linalg.norm(m))
+                cache[k] = len(vl) - 1
+            return cache[k]
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [[a, ab, ca], [b, bc, ab], [c, ca, bc], [ab, bc, ca]]
+        v, f = np.array(vl), np.array(nf, np.int64)
+    r = np.full(len(v), radius)
+    if bumps > 0:
+        rg = np.random.default_rng(seed)
+        for _ in range(6):
+            k = rg.normal(size=3) * 3.0
+            r = r + bumps * radius * np.sin(v @ k + rg.uniform(0, 6.28))
+    return (v * r[:, None]).astype(np.float32), f.astype(np.int32)

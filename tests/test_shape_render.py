@@ -155,3 +155,33 @@ def test_full_training_loss_with_occ_and_init_reg(name):
     bad = {k: v for k, v in worst.items() if v > (5e-2 if 'inner_weight' in k else 5e-3)}
     assert not bad, bad
     assert np.quantile(vals, 0.9) < 2e-4 and np.median(vals) < 2e-5
+
+
+def test_trainer_entry_point_with_database_object():
+    """forward({'step': ...}) over an HBM-resident ray pool built from a database-like object: output keys of the reference's
+    train_step and a finite backward."""
+    from nero_amd.renderer import NeROShapeRenderer
+    from nero_amd.synthetic import look_at_pose
+
+    class FakeDB:
+        def __init__(self):
+            rg = np.random.default_rng(0)
+            self.imgs = rg.uniform(0, 1, (3, 32, 32, 3)).astype(np.float32)
+            self.K = np.array([[40., 0, 16], [0, 40., 16], [0, 0, 1]], np.float32)
+            self.poses = [look_at_pose(np.array(c, dtype=np.float64)) for c in ([3, 0, 0.5], [0, 3, 1.0], [-2, -2, 1.5])]
+        def get_img_ids(self): return [0, 1, 2]
+        def get_image(self, i): return self.imgs[i]
+        def get_K(self, i): return self.K
+        def get_pose(self, i): return self.poses[i]
+
+    torch.manual_seed(1)
+    net = NeROShapeRenderer({'train_ray_num': 256, 'n_samples': 16, 'n_importance': 16, 'n_bg_samples': 8,
+                             'shader_config': {'human_light': True}}, training=False).cuda()
+    net._init_dataset(FakeDB())
+    out = net({'step': 25000})
+    for k in ('ray_rgb', 'gradient_error', 'std', 'loss_occ', 'loss_rgb'):
+        assert k in out, k
+    assert out['ray_rgb'].shape == (256, 3) and out['loss_rgb'].shape == (256,)
+    loss = out['loss_rgb'].mean() + (out['gradient_error'] * 0.1).mean() + out['loss_occ'].mean()
+    loss.backward()
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
