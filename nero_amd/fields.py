@@ -144,3 +144,72 @@ def build_shape_fields(cfg):
     nn.init.constant_(nerf.rgb_linear.bias, math.log(0.5))
     color = AppShadingNetwork(cfg['shader_config'])
     return sdf, dev, nerf, color
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Stage II (material) parameter containers: MaterialFeatsNetwork / MCShadingNetwork (network/field.py:660-689, 694-754)
+# ----------------------------------------------------------------------------------------------------------------------
+def _relu_stack(dims, last_relu):
+    mods = []
+    for i in range(len(dims) - 1):
+        mods.append(_wn_linear(dims[i], dims[i + 1]))
+        if i < len(dims) - 2 or last_relu:
+            mods.append(nn.ReLU())
+    return nn.Sequential(*mods)
+
+
+class MaterialFeatsNetwork(nn.Module):
+    """PE-8(p) -> 4x256 ReLU -> cat[h, pe] -> 3x256 ReLU + Linear 256 (weight-normed; Sequential indices 0,2,4,6)"""
+
+    def __init__(self):
+        super().__init__()
+        d = 3 + 3 * 2 * 8
+        self.module0 = _relu_stack([d, 256, 256, 256, 256], True)
+        self.module1 = _relu_stack([d + 256, 256, 256, 256, 256], False)
+
+    def effective(self):
+        return [_eff(self.module0[i]) for i in (0, 2, 4, 6)] + [_eff(self.module1[i]) for i in (0, 2, 4, 6)]
+
+
+def fibonacci_az_el(n):
+    """sample_sphere(n, 0) scaled to [0,1] (utils/base_utils.py:800-813; network/field.py:741-749)"""
+    num = int(n // 0.5)
+    phi = (np.sqrt(5) - 1.0) / 2.0
+    idx = np.arange(num - n, num)
+    z = 2.0 * idx / num - 1.0
+    az = (2 * np.pi * idx * phi) % (2 * np.pi)
+    el = np.arcsin(z)
+    return az, el
+
+
+class MCShadingNetwork(nn.Module):
+    default_cfg = {
+        'diffuse_sample_num': 512, 'specular_sample_num': 256, 'human_lights': True, 'light_exp_max': 5.0,
+        'inner_light_exp_max': 5.0, 'outer_light_version': 'direction', 'geometry_type': 'schlick', 'reg_change': True,
+        'change_eps': 0.05, 'change_type': 'gaussian', 'reg_lambda1': 0.005, 'reg_min_max': True, 'random_azimuth': True,
+        'is_real': False,
+    }
+
+    def __init__(self, cfg, ray_trace_fun=None):
+        self.cfg = {**self.default_cfg, **cfg}
+        super().__init__()
+        self.feats_network = MaterialFeatsNetwork()
+        self.metallic_predictor = Predictor(256 + 3, 1)
+        self.roughness_predictor = Predictor(256 + 3, 1)
+        self.albedo_predictor = Predictor(256 + 3, 3)
+        if self.cfg['outer_light_version'] == 'direction':
+            self.outer_light = Predictor(72, 3)
+        elif self.cfg['outer_light_version'] == 'sphere_direction':
+            self.outer_light = Predictor(72 * 2, 3)
+        else:
+            raise NotImplementedError
+        nn.init.constant_(self.outer_light[-2].bias, np.log(0.5))
+        if self.cfg['human_lights']:
+            self.human_light = Predictor(2 * 2 * 6, 4)
+            nn.init.constant_(self.human_light[-2].bias, np.log(0.02))
+        self.inner_light = Predictor(51 + 72, 3)
+        nn.init.constant_(self.inner_light[-2].bias, np.log(0.5))
+        az, el = fibonacci_az_el(8192)
+        pts = np.stack([np.cos(az) * np.cos(el), np.sin(az) * np.cos(el), np.sin(el)], -1)
+        self.register_buffer('light_pts', torch.from_numpy(pts.astype(np.float32)))
+        self.ray_trace_fun = ray_trace_fun

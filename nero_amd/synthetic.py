@@ -62,7 +62,8 @@ def perturb_state(module, variance, seed=77):
             noise = torch.randn(p.shape, generator=g)
             a, b = (0.05, 0.001) if name.startswith('sdf_network') else (0.1, 0.003)
             p.add_((noise * (a * s + b)).to(p.device, p.dtype))
-        module.deviation_network.variance.fill_(variance)
+        if variance is not None and hasattr(module, 'deviation_network'):
+            module.deviation_network.variance.fill_(variance)
 
 
 def icosphere(subdiv=3, radius=0.5, bumps=0.0, seed=0):

@@ -115,6 +115,65 @@ def run_case(name, cfg, R, step, variance, seed=6033, occ_keys_seed=None):
     print(name, 'loss', loss.item(), 'N_in', out['gradient_error'].shape[0], 'loss_occ', float(out['loss_occ']))
 
 
+def run_material_case(name, shader_cfg, P_, step, seed=6033):
+    """MCShadingNetwork.forward + material_regularization + diffuse-light regulariser of the unmodified reference on surface points
+    of a bumpy icosphere, traced by the brute-force oracle tracer behind NeROMaterialRenderer.trace's contract."""
+    import torch.nn as nn
+    from nero_amd.synthetic import icosphere
+    from oracle.tracer_oracle import trace_bruteforce
+    renderer, field = ref_shim.load_reference()
+    verts, tris = icosphere(3, 0.5, 0.15)
+
+    def trace(o, d):                                                     # network/renderer.py:719-729
+        pos, nrm, depth, _ = trace_bruteforce(verts, tris, o.detach().numpy(), d.detach().numpy())
+        nrm = torch.from_numpy(-nrm).float()
+        nrm = torch.nn.functional.normalize(nrm, dim=-1)
+        depth = torch.from_numpy(depth).float().reshape(-1, 1)
+        return torch.from_numpy(pos).float(), nrm, depth, (depth < 10)[:, 0]
+
+    class Holder(nn.Module):
+        pass
+    torch.manual_seed(seed)
+    net = Holder()
+    net.shader_network = field.MCShadingNetwork(shader_cfg, trace)
+    perturb_state(net, None)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    # surface points: camera rays that hit the mesh
+    o, d, poses_img, gt = synthetic_rays(4 * P_, seed=5, window=120)
+    pos, nrm, depth, hit = trace(o, d)
+    sel = torch.nonzero(hit)[:P_, 0]
+    assert sel.numel() == P_
+    pts, view, normals, gt = pos[sel], -d[sel], nrm[sel], gt[sel]
+    rr = renderer.NeROShapeRenderer.__new__(renderer.NeROShapeRenderer)   # only for get_human_coordinate_poses (same code in both renderers)
+    rr.cfg = {'fixed_camera': False}
+    hp = torch.cat([renderer.NeROShapeRenderer.get_human_coordinate_poses(rr, poses_img[sel][i:i + 1].clone()) for i in range(P_)], 0)
+    torch.manual_seed(3)
+    rand_d, rand_s = torch.rand(P_, 1, 1), torch.rand(P_, 1, 1)
+    reg_ang = torch.rand(P_, 1)
+    reg_eps = torch.normal(mean=0.0, std=0.05, size=[P_, 1])
+    torch.manual_seed(3)
+    rgb, out = net.shader_network(pts, view, normals, hp, step, True)
+    loss_rgb = torch.sqrt(torch.sum((gt - rgb) ** 2, dim=-1) + 1e-3)
+    reg = net.shader_network.material_regularization(pts, normals, out['metallic'], out['roughness'], out['albedo'], step)
+    dl = out['diffuse_light']
+    white = torch.sum(torch.abs(dl - torch.mean(dl, dim=-1, keepdim=True)), dim=-1) * 0.1
+    loss = loss_rgb.mean() + reg.mean() + white.mean()
+    loss.backward()
+    grads = {k: p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p) for k, p in net.named_parameters()}
+    rec = dict(meta=json.dumps(dict(name=name, shader_cfg=shader_cfg, P=P_, step=step, seed=seed)),
+               pts=pts.numpy(), view=view.numpy(), normals=normals.numpy(), human_poses=hp.numpy(), gt=gt.numpy(),
+               rand_d=rand_d.numpy(), rand_s=rand_s.numpy(), reg_ang=reg_ang.numpy(), reg_eps=reg_eps.numpy(),
+               rgb=rgb.detach().numpy(), loss=np.float32(loss.item()), loss_mat_reg=reg.detach().numpy(), loss_white=white.detach().numpy())
+    for k in ('albedo', 'roughness', 'metallic', 'diffuse_light', 'specular_light', 'diffuse_color', 'specular_color', 'approximate_light'):
+        rec['out/' + k] = out[k].detach().numpy()
+    for k, v in state_checksums(sd).items():
+        rec['ck/' + k] = v
+    for k, v in grad_digest(grads).items():
+        rec['gd/' + k] = v
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **rec)
+    print(name, 'loss', loss.item(), 'reg', float(reg.mean()), 'white', float(white.mean()))
+
+
 def unit_vectors():
     """Small per-function vectors from the reference's own encoders / helpers."""
     renderer, field = ref_shim.load_reference()
@@ -169,3 +228,7 @@ if __name__ == '__main__':
     run_case('bell_occcap', dict(small, occ_loss_max_pn=24), R=48, step=25000, variance=0.5, occ_keys_seed=5)
     run_case('bell_c1', dict(n_samples=32, n_importance=32, n_bg_samples=32), R=32, step=25000, variance=0.3)
     run_case('bell_s500', dict(small, freeze_inv_s_step=15000), R=48, step=500, variance=0.3)
+    msmall = dict(diffuse_sample_num=16, specular_sample_num=8)
+    run_material_case('mat_bell', dict(msmall, human_lights=False, outer_light_version='direction'), P_=24, step=5000)
+    run_material_case('mat_bell_early', dict(msmall, human_lights=False, outer_light_version='direction'), P_=24, step=500)
+    run_material_case('mat_bear', dict(msmall, human_lights=True, outer_light_version='sphere_direction'), P_=24, step=5000)

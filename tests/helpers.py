@@ -33,3 +33,37 @@ def build_case_model(meta, device='cpu'):
 
 def T(z, k, device='cpu'):
     return torch.from_numpy(np.asarray(z[k])).to(device)
+
+
+class MatHolder(torch.nn.Module):
+    """state_dict prefix `shader_network.` like NeROMaterialRenderer (network/renderer.py:699-701)"""
+
+    def __init__(self, shader_cfg):
+        super().__init__()
+        from nero_amd.fields import MCShadingNetwork
+        self.shader_network = MCShadingNetwork(shader_cfg)
+
+
+def build_material_case(meta, device='cpu'):
+    torch.manual_seed(meta['seed'])
+    net = MatHolder(meta['shader_cfg'])
+    perturb_state(net, None)
+    return net.to(device)
+
+
+def golden_mesh():
+    from nero_amd.synthetic import icosphere
+    return icosphere(3, 0.5, 0.15)
+
+
+def oracle_trace_fn():
+    """NeROMaterialRenderer.trace contract (network/renderer.py:719-729) over the brute-force tracer oracle"""
+    from oracle.tracer_oracle import trace_bruteforce
+    verts, tris = golden_mesh()
+
+    def trace(o, d):
+        pos, nrm, depth, _ = trace_bruteforce(verts, tris, o.detach().cpu().numpy(), d.detach().cpu().numpy())
+        nrm = torch.nn.functional.normalize(torch.from_numpy(-nrm).float(), dim=-1)
+        depth = torch.from_numpy(depth).float().reshape(-1, 1)
+        return torch.from_numpy(pos).float(), nrm, depth, (depth < 10)[:, 0]
+    return trace
