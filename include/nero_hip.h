@@ -247,6 +247,26 @@ int nero_bvh_trace(void* handle, const float* rays_o, const float* rays_d, int n
                    void* stream);
 int nero_bvh_destroy(void* handle);
 
+/* ---- Stage-II Monte-Carlo shading glue (MCShadingNetwork.shade_mixed and helpers, network/field.py:756-1012).
+ *      Row r = p*D + j, D = Dd + Ds (j < Dd cosine-weighted diffuse samples, then GGX specular samples).
+ *      pt [P,32] per-point record (layout in mc_shade.hip); mat5 [P,5] = metallic, roughness, albedo(3);
+ *      tab_d [Dd,2] / tab_s [Ds,2] = fixed (azimuth, elevation) tables in [0,1] (field.py:741-749);
+ *      slot[r] >= 0 -> miss row index, < 0 -> hit row index -(slot)-1. ---------------------------------------------------- */
+int nero_mc_point_setup(const float* pts, const float* view, const float* normals, const float* mat5, const float* rand_d,
+                        const float* rand_s, int P, float* pt, void* stream);
+int nero_mc_dirs(const float* pt, const float* tab_d, const float* tab_s, int P, int Dd, int Ds, float* dirs, float* origins, void* stream);
+int nero_mc_encode_miss(const float* dirs, const int* idx, int n, float* X /*[rows,72]*/, void* stream);
+int nero_mc_encode_hit(const float* dirs, const float* pos, const float* face_normals, const int* idx, int n, float* X /*[rows,128]*/,
+                       void* stream);
+int nero_mc_combine_fwd(const float* pt, const float* dirs, const float* depth, const int* slot, const float* outer_raw,
+                        const float* inner_raw, float exp_max, float inner_exp_max, int P, int Dd, int Ds, float* rgb_lin,
+                        float* dl_mean, float* sl_mean, float* spec_lin /*or NULL*/, void* stream);
+int nero_mc_combine_bwd(const float* pt, const float* dirs, const float* depth, const int* slot, const float* outer_raw,
+                        const float* inner_raw, float exp_max, float inner_exp_max, int P, int Dd, int Ds, const float* d_rgb,
+                        const float* d_dl, float* d_outer_raw, float* d_inner_raw, float* d_mat5, float* d_wspec, void* stream);
+int nero_mc_dir_bwd(const float* pt, const float* dirs, const float* face_normals, const int* slot, const float* tab_s,
+                    const float* dX_miss, const float* dX_hit, const float* d_wspec, int P, int Dd, int Ds, float* d_mat5, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,508 @@
+// mc_shade.hip -- Stage-II Monte-Carlo shading on gfx950: direction sampling (cosine-weighted + GGX importance), light-MLP
+// input encodings for hit / miss secondary rays, the microfacet estimator and its hand-derived backward.
+// Replaces MCShadingNetwork.shade_mixed / sample_*_directions / get_lights / fresnel / geometry / distribution
+// (network/field.py:756-1012) and what autograd derives from them.  The light MLPs themselves run on the MLP-chain engine and
+// the secondary rays on the BVH tracer (bvh.hip); this file is the per-direction glue.  'direction' outer light, no human
+// lights (the bell material config); the bear variants are rejected by the host driver for now.
+//
+// Row r = p*D + j  (p = surface point, j = direction; j < Dd diffuse, j >= Dd specular).
+// Point record pt[p][32]:  0-2 v, 3-5 n, 6-8 refl, 9 metallic, 10 roughness, 11-13 albedo, 14 NoV, 15-17 x_d, 18-20 y_d,
+//                          21-23 x_s, 24-26 y_s, 27 az offset diffuse (rad), 28 az offset specular (rad), 29-31 p
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "../../include/nero_hip.h"
+#include "common.h"
+
+// IDE helpers live in shade.hip's translation unit; re-declare the small pieces needed here (same formulas, own TU).
+namespace {
+
+constexpr int IDE_N = 36;
+__constant__ float m_ide_mat[17 * IDE_N];
+__constant__ int m_ide_m[IDE_N];
+__constant__ int m_ide_l[IDE_N];
+
+double fact(int n) { double r = 1.0; for (int i = 2; i <= n; ++i) r *= i; return r; }
+double gen_binom(double a, int k) { double p = 1.0; for (int i = 0; i < k; ++i) p *= (a - i); return p / fact(k); }
+double sph_coeff(int l, int m, int k) {
+    const double al = ((m & 1) ? -1.0 : 1.0) * pow(2.0, l) * fact(l) / fact(k) / fact(l - k - m) * gen_binom(0.5 * (l + k + m - 1.0), l);
+    return sqrt((2.0 * l + 1.0) * fact(l - m) / (4.0 * M_PI * fact(l + m))) * al;
+}
+int init_tables() {
+    static bool done = false;
+    if (done) return 0;
+    float mat[17 * IDE_N];
+    int ms[IDE_N], ls[IDE_N];
+    for (int i = 0; i < 17 * IDE_N; ++i) mat[i] = 0.f;
+    int i = 0;
+    for (int e = 0; e < 5; ++e) {
+        const int l = 1 << e;
+        for (int m = 0; m <= l; ++m, ++i) {
+            ms[i] = m; ls[i] = l;
+            for (int k = 0; k <= l - m; ++k) mat[k * IDE_N + i] = (float)sph_coeff(l, m, k);
+        }
+    }
+    if (hipMemcpyToSymbol(HIP_SYMBOL(m_ide_mat), mat, sizeof(mat)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(m_ide_m), ms, sizeof(ms)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(m_ide_l), ls, sizeof(ls)) != hipSuccess) return -1;
+    done = true;
+    return 0;
+}
+
+// IDE with kappa_inv = 0 (no attenuation): out[0..36) Re, [36..72) Im
+__device__ void ide0_forward(float x, float y, float z, float* __restrict__ out) {
+    float zp[17], re[17], im[17];
+    zp[0] = 1.f; re[0] = 1.f; im[0] = 0.f;
+    for (int k = 1; k <= 16; ++k) { zp[k] = zp[k - 1] * z; re[k] = re[k - 1] * x - im[k - 1] * y; im[k] = re[k - 1] * y + im[k - 1] * x; }
+    for (int i = 0; i < IDE_N; ++i) {
+        const int m = m_ide_m[i], l = m_ide_l[i];
+        float poly = 0.f;
+        for (int k = 0; k <= l - m; ++k) poly = fmaf(zp[k], m_ide_mat[k * IDE_N + i], poly);
+        out[i] = re[m] * poly;
+        out[IDE_N + i] = im[m] * poly;
+    }
+}
+__device__ void ide0_backward(float x, float y, float z, const float* __restrict__ g, float& dx, float& dy, float& dz) {
+    float zp[17], re[17], im[17], dre[17], dim_[17];
+    zp[0] = 1.f; re[0] = 1.f; im[0] = 0.f;
+    for (int k = 1; k <= 16; ++k) { zp[k] = zp[k - 1] * z; re[k] = re[k - 1] * x - im[k - 1] * y; im[k] = re[k - 1] * y + im[k - 1] * x; }
+    for (int k = 0; k <= 16; ++k) { dre[k] = 0.f; dim_[k] = 0.f; }
+    float gz = 0.f;
+    for (int i = 0; i < IDE_N; ++i) {
+        const int m = m_ide_m[i], l = m_ide_l[i];
+        float poly = 0.f, dpoly = 0.f;
+        for (int k = 0; k <= l - m; ++k) {
+            const float c = m_ide_mat[k * IDE_N + i];
+            poly = fmaf(zp[k], c, poly);
+            if (k > 0) dpoly = fmaf((float)k * zp[k - 1], c, dpoly);
+        }
+        gz += (g[i] * re[m] + g[IDE_N + i] * im[m]) * dpoly;
+        dre[m] += g[i] * poly;
+        dim_[m] += g[IDE_N + i] * poly;
+    }
+    float gx = 0.f, gy = 0.f;
+    for (int m = 1; m <= 16; ++m) {
+        gx += (float)m * (dre[m] * re[m - 1] + dim_[m] * im[m - 1]);
+        gy += (float)m * (-dre[m] * im[m - 1] + dim_[m] * re[m - 1]);
+    }
+    dx += gx; dy += gy; dz += gz;
+}
+
+__device__ __forceinline__ float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ void norm3(const float* a, float* o) {
+    const float n = fmaxf(sqrtf(dot3(a, a)), 1e-12f);
+    o[0] = a[0] / n; o[1] = a[1] / n; o[2] = a[2] / n;
+}
+__device__ __forceinline__ void ortho3(const float* d, float* o) {            // get_orthogonal_directions, field.py:756-766
+    const float o0[3] = {d[1], -d[0], 0.f}, o1[3] = {-d[2], 0.f, d[0]};
+    const bool m0 = sqrtf(dot3(o0, o0)) > sqrtf(dot3(o1, o1));
+    norm3(m0 ? o0 : o1, o);
+}
+__device__ __forceinline__ void cross3(const float* a, const float* b, float* o) {
+    o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ __forceinline__ float sat(float x) { return fminf(fmaxf(x, 0.f), 1.f); }
+__device__ __forceinline__ float satg(float x) { return (x >= 0.f && x <= 1.f) ? 1.f : 0.f; }   // gradient gate of clamp(x,0,1)
+
+constexpr float TWO_PI = 6.283185307179586f;
+
+// per-point record (field.py:1014-1017, 951-957)
+__global__ void mc_point_setup_kernel(const float* __restrict__ pts, const float* __restrict__ view, const float* __restrict__ normals,
+                                      const float* __restrict__ mat5, const float* __restrict__ rand_d, const float* __restrict__ rand_s,
+                                      int P_, float* __restrict__ pt) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P_) return;
+    float v[3], n[3];
+    norm3(view + p * 3, v);
+    norm3(normals + p * 3, n);
+    const float nv = dot3(v, n);
+    float* o = pt + (size_t)p * 32;
+    float refl[3];
+    for (int c = 0; c < 3; ++c) { o[c] = v[c]; o[3 + c] = n[c]; refl[c] = nv * n[c] * 2.f - v[c]; o[6 + c] = refl[c]; }
+    for (int c = 0; c < 5; ++c) o[9 + c] = mat5[p * 5 + c];
+    o[14] = sat(nv);
+    float x[3], y[3];
+    ortho3(n, x); cross3(n, x, y);
+    for (int c = 0; c < 3; ++c) { o[15 + c] = x[c]; o[18 + c] = y[c]; }
+    ortho3(refl, x); cross3(refl, x, y);
+    for (int c = 0; c < 3; ++c) { o[21 + c] = x[c]; o[24 + c] = y[c]; }
+    o[27] = rand_d ? rand_d[p] * TWO_PI : -1.f;       // < 0: no random azimuth (inference)
+    o[28] = rand_s ? rand_s[p] * TWO_PI : -1.f;
+    for (int c = 0; c < 3; ++c) o[29 + c] = pts[p * 3 + c];
+}
+
+struct SpecSample { float cphi, sphi, cost, sint; };
+
+__device__ __forceinline__ void diffuse_dir(const float* q, float az_t, float el, float* w) {      // field.py:768-787
+    float az = az_t * TWO_PI;
+    if (q[27] >= 0.f) az = fmodf(az + q[27], TWO_PI);
+    const float es = sqrtf(el + 1e-7f), cz = sqrtf(1.f - el + 1e-7f);
+    const float cx = es * cosf(az), cy = es * sinf(az);
+    for (int c = 0; c < 3; ++c) w[c] = cx * q[15 + c] + cy * q[18 + c] + cz * q[3 + c];
+}
+__device__ __forceinline__ SpecSample specular_dir(const float* q, float az_t, float el, float* w) { // field.py:789-810
+    const float a = q[10];
+    SpecSample s;
+    s.cost = sqrtf((1.0f - el + 1e-6f) / (1.0f + (a * a - 1.0f) * el + 1e-6f) + 1e-6f);
+    s.sint = sqrtf(1.f - s.cost * s.cost + 1e-6f);
+    float phi = TWO_PI * az_t;
+    if (q[28] >= 0.f) phi = fmodf(phi + q[28], TWO_PI);
+    s.cphi = cosf(phi); s.sphi = sinf(phi);
+    for (int c = 0; c < 3; ++c) w[c] = s.cphi * s.sint * q[21 + c] + s.sphi * s.sint * q[24 + c] + s.cost * q[6 + c];
+    return s;
+}
+
+// directions + ray origins for the tracer (field.py:859-860: origin = p + 1e-5 w)
+__global__ void mc_dirs_kernel(const float* __restrict__ pt, const float* __restrict__ tab_d, const float* __restrict__ tab_s,
+                               int P_, int Dd, int Ds, float* __restrict__ dirs, float* __restrict__ orig) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    const int D = Dd + Ds;
+    if (row >= P_ * D) return;
+    const int p = row / D, j = row - p * D;
+    const float* q = pt + (size_t)p * 32;
+    float w[3];
+    if (j < Dd) diffuse_dir(q, tab_d[2 * j], tab_d[2 * j + 1], w);
+    else specular_dir(q, tab_s[2 * (j - Dd)], tab_s[2 * (j - Dd) + 1], w);
+    for (int c = 0; c < 3; ++c) { dirs[(size_t)row * 3 + c] = w[c]; orig[(size_t)row * 3 + c] = q[29 + c] + w[c] * 1e-5f; }
+}
+
+// miss rows: X[k] = IDE(w, 0) (72)        (predict_outer_lights 'direction', field.py:837-839)
+__global__ void mc_encode_miss_kernel(const float* __restrict__ dirs, const int* __restrict__ idx, int n, int n_pad, float* __restrict__ X) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_pad) return;
+    float* o = X + (size_t)k * 72;
+    if (k >= n) { for (int c = 0; c < 72; ++c) o[c] = 0.f; return; }
+    const float* w = dirs + (size_t)idx[k] * 3;
+    float e[72];
+    ide0_forward(w[0], w[1], w[2], e);
+    for (int c = 0; c < 72; ++c) o[c] = e[c];
+}
+
+// hit rows: X[k] = [PE8(x_hit) (51), IDE(reflect(-w about n_hit), 0) (72), pad]  ld 128; n_hit = -normalize(face normal)
+// (get_inner_lights, field.py:812-818; NeROMaterialRenderer.trace flips the normal, renderer.py:722-723)
+__device__ __forceinline__ void hit_reflection(const float* w, const float* fn, float* nh, float* vv, float* refl) {
+    const float neg[3] = {-fn[0], -fn[1], -fn[2]};
+    norm3(neg, nh);                      // trace(): -normal, normalised
+    norm3(nh, nh);                       // get_inner_lights normalises again (idempotent)
+    const float mv[3] = {-w[0], -w[1], -w[2]};
+    norm3(mv, vv);
+    const float d = dot3(vv, nh);
+    for (int c = 0; c < 3; ++c) refl[c] = d * nh[c] * 2.f - vv[c];
+}
+__global__ void mc_encode_hit_kernel(const float* __restrict__ dirs, const float* __restrict__ pos, const float* __restrict__ fnrm,
+                                     const int* __restrict__ idx, int n, int n_pad, float* __restrict__ X) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_pad) return;
+    float* o = X + (size_t)k * 128;
+    if (k >= n) { for (int c = 0; c < 128; ++c) o[c] = 0.f; return; }
+    const int row = idx[k];
+    const float* x = pos + (size_t)row * 3;
+    for (int c = 0; c < 3; ++c) o[c] = x[c];
+    float f = 1.f;
+    int q = 3;
+    for (int i = 0; i < 8; ++i) {
+        for (int c = 0; c < 3; ++c) o[q + c] = sinf(x[c] * f);
+        for (int c = 0; c < 3; ++c) o[q + 3 + c] = cosf(x[c] * f);
+        q += 6; f *= 2.f;
+    }
+    float nh[3], vv[3], refl[3], e[72];
+    hit_reflection(dirs + (size_t)row * 3, fnrm + (size_t)row * 3, nh, vv, refl);
+    ide0_forward(refl[0], refl[1], refl[2], e);
+    for (int c = 0; c < 72; ++c) o[51 + c] = e[c];
+    for (int c = 123; c < 128; ++c) o[c] = 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// estimator (shade_mixed, field.py:950-998).  One wave per point; lane handles directions lane, lane+64, ...
+// slot[row] >= 0: miss row index into outer_raw; < 0: hit row index -(slot)-1 into inner_raw.
+// ---------------------------------------------------------------------------------------------------------------------
+struct Brdf { float H[3], hlen, hov, nol, noh, fc, gv, gl, denv, denl, dg, t, dden, prob, W, N, Q; };
+
+__device__ __forceinline__ void brdf_terms(const float* q, const float* w, bool diffuse, float wd, float ws, Brdf& b) {
+    const float* v = q; const float* n = q + 3;
+    const float r = q[10], nov = q[14];
+    float h[3] = {v[0] + w[0], v[1] + w[1], v[2] + w[2]};
+    b.hlen = fmaxf(sqrtf(dot3(h, h)), 1e-12f);
+    for (int c = 0; c < 3; ++c) b.H[c] = h[c] / b.hlen;
+    b.hov = sat(dot3(b.H, v));
+    b.nol = sat(dot3(n, w));
+    b.noh = sat(dot3(n, b.H));
+    const float cc = sat(1.f - b.hov);
+    b.fc = cc * cc * cc * cc * cc;
+    const float k = r * 0.5f;
+    b.denv = nov * (1.f - k) + k + 1e-5f; b.denl = b.nol * (1.f - k) + k + 1e-5f;
+    b.gv = nov / b.denv; b.gl = b.nol / b.denl;
+    const float a2 = r * r;
+    b.t = b.noh * b.noh * (a2 - 1.f) + 1.f;
+    b.dden = 3.14159265358979f * b.t * b.t + 1e-4f;
+    b.dg = a2 / b.dden;
+    b.prob = diffuse ? b.nol / 3.14159265358979f * wd : b.dg * b.noh / (4.f * b.hov + 1e-5f) * ws;
+    b.N = b.dg * b.gv * b.gl;
+    b.Q = 4.f * nov * b.prob + 1e-5f;
+    b.W = b.N / b.Q;
+}
+
+__device__ __forceinline__ void light_value(int s, const float* __restrict__ outer_raw, const float* __restrict__ inner_raw,
+                                            float emax, float imax, float near, float* L) {
+    if (s >= 0) { for (int c = 0; c < 3; ++c) L[c] = expf(fminf(outer_raw[(size_t)s * 4 + c], emax)) * near; }
+    else { const int k = -s - 1; for (int c = 0; c < 3; ++c) L[c] = expf(fminf(inner_raw[(size_t)k * 4 + c], imax)) * near; }
+}
+
+__global__ __launch_bounds__(64) void mc_combine_fwd_kernel(const float* __restrict__ pt, const float* __restrict__ dirs,
+                                                            const float* __restrict__ depth, const int* __restrict__ slot,
+                                                            const float* __restrict__ outer_raw, const float* __restrict__ inner_raw,
+                                                            float emax, float imax, int P_, int Dd, int Ds,
+                                                            float* __restrict__ rgb_lin, float* __restrict__ dl_mean, float* __restrict__ sl_mean, float* __restrict__ spec_lin) {
+    const int p = blockIdx.x, lane = threadIdx.x;
+    if (p >= P_) return;
+    const int D = Dd + Ds;
+    const float* q = pt + (size_t)p * 32;
+    const float wd = (float)Dd / (float)D, ws = (float)Ds / (float)D;
+    const float m = q[9];
+    float spec[3] = {0, 0, 0}, diff[3] = {0, 0, 0}, dl[3] = {0, 0, 0}, sl[3] = {0, 0, 0};
+    for (int j = lane; j < D; j += 64) {
+        const size_t row = (size_t)p * D + j;
+        const float w[3] = {dirs[row * 3], dirs[row * 3 + 1], dirs[row * 3 + 2]};
+        Brdf b;
+        brdf_terms(q, w, j < Dd, wd, ws, b);
+        float L[3];
+        light_value(slot[row], outer_raw, inner_raw, emax, imax, depth[row] > 1e-5f ? 1.f : 0.f, L);
+        for (int c = 0; c < 3; ++c) {
+            const float F0 = 0.04f * (1.f - m) + m * q[11 + c];
+            const float Fr = F0 + (1.f - F0) * b.fc;
+            spec[c] += Fr * L[c] * b.W;
+            sl[c] += L[c] * b.W;
+            if (j < Dd) { diff[c] += q[11 + c] * (1.f - m) * L[c]; dl[c] += L[c]; }
+        }
+    }
+    for (int c = 0; c < 3; ++c) {
+        for (int off = 32; off > 0; off >>= 1) {
+            spec[c] += __shfl_xor(spec[c], off); diff[c] += __shfl_xor(diff[c], off);
+            dl[c] += __shfl_xor(dl[c], off); sl[c] += __shfl_xor(sl[c], off);
+        }
+    }
+    if (lane == 0) {
+        for (int c = 0; c < 3; ++c) {
+            rgb_lin[p * 3 + c] = diff[c] / (float)Dd + spec[c] / (float)D;
+            dl_mean[p * 3 + c] = dl[c] / (float)Dd;
+            sl_mean[p * 3 + c] = sl[c] / (float)D;
+            if (spec_lin) spec_lin[p * 3 + c] = spec[c] / (float)D;
+        }
+    }
+}
+
+// backward of the estimator: d_rgb_lin [P,3], d_dl_mean [P,3] ->
+//   d_outer_raw [n_miss_pad,4], d_inner_raw [n_hit_pad,4] (raw head gradients), d_mat5 [P,5] (metallic, roughness, albedo),
+//   d_wspec [P*Ds,3] (gradient w.r.t. the specular directions through the BRDF terms)
+__global__ __launch_bounds__(64) void mc_combine_bwd_kernel(const float* __restrict__ pt, const float* __restrict__ dirs,
+                                                            const float* __restrict__ depth, const int* __restrict__ slot,
+                                                            const float* __restrict__ outer_raw, const float* __restrict__ inner_raw,
+                                                            float emax, float imax, int P_, int Dd, int Ds,
+                                                            const float* __restrict__ d_rgb, const float* __restrict__ d_dl,
+                                                            float* __restrict__ d_outer_raw, float* __restrict__ d_inner_raw,
+                                                            float* __restrict__ d_mat5, float* __restrict__ d_wspec) {
+    const int p = blockIdx.x, lane = threadIdx.x;
+    if (p >= P_) return;
+    const int D = Dd + Ds;
+    const float* q = pt + (size_t)p * 32;
+    const float* v = q; const float* n = q + 3;
+    const float wd = (float)Dd / (float)D, ws = (float)Ds / (float)D;
+    const float m = q[9], r = q[10], nov = q[14];
+    const float k = r * 0.5f;
+    float gs[3], gd[3], gl_[3];
+    for (int c = 0; c < 3; ++c) { gs[c] = d_rgb[p * 3 + c] / (float)D; gd[c] = d_rgb[p * 3 + c] / (float)Dd; gl_[c] = d_dl ? d_dl[p * 3 + c] / (float)Dd : 0.f; }
+    float dm = 0.f, dr = 0.f, da[3] = {0, 0, 0};
+    for (int j = lane; j < D; j += 64) {
+        const size_t row = (size_t)p * D + j;
+        const bool diffuse = j < Dd;
+        const float w[3] = {dirs[row * 3], dirs[row * 3 + 1], dirs[row * 3 + 2]};
+        Brdf b;
+        brdf_terms(q, w, diffuse, wd, ws, b);
+        const float near = depth[row] > 1e-5f ? 1.f : 0.f;
+        const int s = slot[row];
+        float L[3];
+        light_value(s, outer_raw, inner_raw, emax, imax, near, L);
+        float dL[3], dW = 0.f, dFc = 0.f;
+        for (int c = 0; c < 3; ++c) {
+            const float a = q[11 + c];
+            const float F0 = 0.04f * (1.f - m) + m * a;
+            const float Fr = F0 + (1.f - F0) * b.fc;
+            dL[c] = gs[c] * Fr * b.W + (diffuse ? gd[c] * a * (1.f - m) + gl_[c] : 0.f);
+            const float dF = gs[c] * L[c] * b.W;
+            const float dF0 = dF * (1.f - b.fc);
+            dFc += dF * (1.f - F0);
+            dW += gs[c] * Fr * L[c];
+            dm += dF0 * (a - 0.04f);
+            da[c] += dF0 * m;
+            if (diffuse) { da[c] += gd[c] * (1.f - m) * L[c]; dm -= gd[c] * a * L[c]; }
+        }
+        // raw head gradients: L = exp(min(raw, cap)) * near
+        if (s >= 0) {
+            float o4[3];
+            for (int c = 0; c < 3; ++c) o4[c] = outer_raw[(size_t)s * 4 + c] <= emax ? dL[c] * L[c] : 0.f;
+            reinterpret_cast<float4*>(d_outer_raw)[s] = make_float4(o4[0], o4[1], o4[2], 0.f);
+        } else {
+            const int kk = -s - 1;
+            float o4[3];
+            for (int c = 0; c < 3; ++c) o4[c] = inner_raw[(size_t)kk * 4 + c] <= imax ? dL[c] * L[c] : 0.f;
+            reinterpret_cast<float4*>(d_inner_raw)[kk] = make_float4(o4[0], o4[1], o4[2], 0.f);
+        }
+        // W = N / Q
+        float dDg = dW * b.gv * b.gl / b.Q;
+        const float dG = dW * b.dg / b.Q;
+        const float dprob = -dW * b.N / (b.Q * b.Q) * 4.f * nov;
+        const float dgl = dG * b.gv, dgv = dG * b.gl;
+        // g(x) = x / (x(1-k)+k+eps): dg/dk = -x(1-x)/den^2 ; dg/dx = (k+eps)/den^2
+        dr += 0.5f * (dgv * (-nov * (1.f - nov) / (b.denv * b.denv)) + dgl * (-b.nol * (1.f - b.nol) / (b.denl * b.denl)));
+        float dnol = dgl * (k + 1e-5f) / (b.denl * b.denl);
+        float dnoh = 0.f, dhov = 0.f;
+        if (!diffuse) {
+            const float e = 4.f * b.hov + 1e-5f;
+            dDg += dprob * b.noh / e * ws;
+            dnoh += dprob * b.dg / e * ws;
+            dhov += -dprob * b.dg * b.noh * 4.f / (e * e) * ws;
+        }
+        // Dg(noh, r)
+        const float a2 = r * r;
+        const float dDg_da2 = 1.f / b.dden - a2 * (2.f * 3.14159265358979f * b.t * b.noh * b.noh) / (b.dden * b.dden);
+        dr += dDg * dDg_da2 * 2.f * r;
+        dnoh += dDg * (-a2 * (2.f * 3.14159265358979f * b.t * 2.f * b.noh * (a2 - 1.f)) / (b.dden * b.dden));
+        // Fc = clamp(1-hov,0,1)^5
+        const float cc = sat(1.f - b.hov);
+        dhov += -5.f * cc * cc * cc * cc * dFc;
+        if (!diffuse) {
+            // through H = normalize(v + w), hov = sat(H.v), noh = sat(n.H), nol = sat(n.w)
+            const float rh = dot3(b.H, v), rn = dot3(n, b.H), rl = dot3(n, w);
+            float dH[3], dw[3];
+            for (int c = 0; c < 3; ++c) dH[c] = dhov * satg(rh) * v[c] + dnoh * satg(rn) * n[c];
+            const float hd = dot3(b.H, dH);
+            for (int c = 0; c < 3; ++c) dw[c] = (dH[c] - b.H[c] * hd) / b.hlen + dnol * satg(rl) * n[c];
+            const size_t sr = (size_t)p * Ds + (j - Dd);
+            for (int c = 0; c < 3; ++c) d_wspec[sr * 3 + c] = dw[c];
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        dm += __shfl_xor(dm, off); dr += __shfl_xor(dr, off);
+        for (int c = 0; c < 3; ++c) da[c] += __shfl_xor(da[c], off);
+    }
+    if (lane == 0) {
+        float* o = d_mat5 + (size_t)p * 5;
+        o[0] = dm; o[1] = dr; o[2] = da[0]; o[3] = da[1]; o[4] = da[2];
+    }
+}
+
+// specular directions depend on the roughness: add the light-input gradients (IDE backward of the MLP input gradients) to
+// d_wspec and fold everything into d_roughness (field.py:794-809).  One wave per point.
+__global__ __launch_bounds__(64) void mc_dir_bwd_kernel(const float* __restrict__ pt, const float* __restrict__ dirs,
+                                                        const float* __restrict__ fnrm, const int* __restrict__ slot,
+                                                        const float* __restrict__ tab_s, const float* __restrict__ dX_miss,
+                                                        const float* __restrict__ dX_hit, const float* __restrict__ d_wspec,
+                                                        int P_, int Dd, int Ds, float* __restrict__ d_mat5) {
+    const int p = blockIdx.x, lane = threadIdx.x;
+    if (p >= P_) return;
+    const int D = Dd + Ds;
+    const float* q = pt + (size_t)p * 32;
+    const float a = q[10];
+    float dr = 0.f;
+    for (int js = lane; js < Ds; js += 64) {
+        const size_t row = (size_t)p * D + Dd + js;
+        const float w[3] = {dirs[row * 3], dirs[row * 3 + 1], dirs[row * 3 + 2]};
+        float dw[3] = {d_wspec[((size_t)p * Ds + js) * 3], d_wspec[((size_t)p * Ds + js) * 3 + 1], d_wspec[((size_t)p * Ds + js) * 3 + 2]};
+        const int s = slot[row];
+        float g[72];
+        if (s >= 0) {
+            for (int c = 0; c < 72; ++c) g[c] = dX_miss[(size_t)s * 72 + c];
+            ide0_backward(w[0], w[1], w[2], g, dw[0], dw[1], dw[2]);
+        } else {
+            const int kk = -s - 1;
+            for (int c = 0; c < 72; ++c) g[c] = dX_hit[(size_t)kk * 128 + 51 + c];
+            float nh[3], vv[3], refl[3];
+            hit_reflection(w, fnrm + row * 3, nh, vv, refl);
+            float drf[3] = {0.f, 0.f, 0.f};
+            ide0_backward(refl[0], refl[1], refl[2], g, drf[0], drf[1], drf[2]);
+            // refl = 2 (vv.n) n - vv ; vv = normalize(-w)
+            const float dn = dot3(drf, nh);
+            float dvv[3];
+            for (int c = 0; c < 3; ++c) dvv[c] = 2.f * nh[c] * dn - drf[c];
+            const float wl = fmaxf(sqrtf(dot3(w, w)), 1e-12f);
+            const float pv = dot3(vv, dvv);
+            for (int c = 0; c < 3; ++c) dw[c] += -(dvv[c] - vv[c] * pv) / wl;
+        }
+        // w = sint (cphi x + sphi y) + cost z,  cost(a) = sqrt(A/B + 1e-6), sint = sqrt(1 - cost^2 + 1e-6)
+        const float el = tab_s[2 * js + 1];
+        float wtmp[3];
+        const SpecSample sp = specular_dir(q, tab_s[2 * js], el, wtmp);
+        const float A = 1.0f - el + 1e-6f, B = 1.0f + (a * a - 1.0f) * el + 1e-6f;
+        const float dcost = (1.f / (2.f * sp.cost)) * (-A / (B * B)) * (2.f * a * el);
+        const float dsint = -(sp.cost / sp.sint) * dcost;
+        float txy[3];
+        for (int c = 0; c < 3; ++c) txy[c] = sp.cphi * q[21 + c] + sp.sphi * q[24 + c];
+        dr += dot3(dw, txy) * dsint + dot3(dw, q + 6) * dcost;
+    }
+    for (int off = 32; off > 0; off >>= 1) dr += __shfl_xor(dr, off);
+    if (lane == 0) d_mat5[(size_t)p * 5 + 1] += dr;
+}
+
+}  // namespace
+
+#define GRID1D(n) dim3(((n) + 127) / 128), dim3(128), 0, (hipStream_t)stream
+#define CHECK_T() do { if (init_tables() != 0) return nero_fail(NERO_ERR_LAUNCH, "IDE table upload failed"); } while (0)
+
+extern "C" {
+
+int nero_mc_point_setup(const float* pts, const float* view, const float* normals, const float* mat5, const float* rand_d,
+                        const float* rand_s, int P, float* pt, void* stream) {
+    if (P == 0) return NERO_OK;
+    hipLaunchKernelGGL(mc_point_setup_kernel, GRID1D(P), pts, view, normals, mat5, rand_d, rand_s, P, pt);
+    return nero_check_launch("nero_mc_point_setup");
+}
+
+int nero_mc_dirs(const float* pt, const float* tab_d, const float* tab_s, int P, int Dd, int Ds, float* dirs, float* origins, void* stream) {
+    if (P * (Dd + Ds) == 0) return NERO_OK;
+    hipLaunchKernelGGL(mc_dirs_kernel, GRID1D(P * (Dd + Ds)), pt, tab_d, tab_s, P, Dd, Ds, dirs, origins);
+    return nero_check_launch("nero_mc_dirs");
+}
+
+int nero_mc_encode_miss(const float* dirs, const int* idx, int n, float* X, void* stream) {
+    CHECK_T();
+    const int n_pad = NERO_ROW_PAD(n);
+    if (n_pad == 0) return NERO_OK;
+    hipLaunchKernelGGL(mc_encode_miss_kernel, GRID1D(n_pad), dirs, idx, n, n_pad, X);
+    return nero_check_launch("nero_mc_encode_miss");
+}
+
+int nero_mc_encode_hit(const float* dirs, const float* pos, const float* face_normals, const int* idx, int n, float* X, void* stream) {
+    CHECK_T();
+    const int n_pad = NERO_ROW_PAD(n);
+    if (n_pad == 0) return NERO_OK;
+    hipLaunchKernelGGL(mc_encode_hit_kernel, GRID1D(n_pad), dirs, pos, face_normals, idx, n, n_pad, X);
+    return nero_check_launch("nero_mc_encode_hit");
+}
+
+int nero_mc_combine_fwd(const float* pt, const float* dirs, const float* depth, const int* slot, const float* outer_raw,
+                        const float* inner_raw, float exp_max, float inner_exp_max, int P, int Dd, int Ds, float* rgb_lin,
+                        float* dl_mean, float* sl_mean, float* spec_lin, void* stream) {
+    if (P == 0) return NERO_OK;
+    hipLaunchKernelGGL(mc_combine_fwd_kernel, dim3(P), dim3(64), 0, (hipStream_t)stream, pt, dirs, depth, slot, outer_raw, inner_raw,
+                       exp_max, inner_exp_max, P, Dd, Ds, rgb_lin, dl_mean, sl_mean, spec_lin);
+    return nero_check_launch("nero_mc_combine_fwd");
+}
+
+int nero_mc_combine_bwd(const float* pt, const float* dirs, const float* depth, const int* slot, const float* outer_raw,
+                        const float* inner_raw, float exp_max, float inner_exp_max, int P, int Dd, int Ds, const float* d_rgb,
+                        const float* d_dl, float* d_outer_raw, float* d_inner_raw, float* d_mat5, float* d_wspec, void* stream) {
+    if (P == 0) return NERO_OK;
+    hipLaunchKernelGGL(mc_combine_bwd_kernel, dim3(P), dim3(64), 0, (hipStream_t)stream, pt, dirs, depth, slot, outer_raw, inner_raw,
+                       exp_max, inner_exp_max, P, Dd, Ds, d_rgb, d_dl, d_outer_raw, d_inner_raw, d_mat5, d_wspec);
+    return nero_check_launch("nero_mc_combine_bwd");
+}
+
+int nero_mc_dir_bwd(const float* pt, const float* dirs, const float* face_normals, const int* slot, const float* tab_s,
+                    const float* dX_miss, const float* dX_hit, const float* d_wspec, int P, int Dd, int Ds, float* d_mat5, void* stream) {
+    CHECK_T();
+    if (P == 0) return NERO_OK;
+    hipLaunchKernelGGL(mc_dir_bwd_kernel, dim3(P), dim3(64), 0, (hipStream_t)stream, pt, dirs, face_normals, slot, tab_s, dX_miss, dX_hit,
+                       d_wspec, P, Dd, Ds, d_mat5);
+    return nero_check_launch("nero_mc_dir_bwd");
+}
+
+}  // extern "C"

@@ -227,4 +227,137 @@ class NeROShapeRenderer(nn.Module):
         raise NotImplementedError
 
 
-name2renderer = {'shape': NeROShapeRenderer}
+def linear_to_srgb(x):
+    """utils/raw_utils.py:4-10 (on [P,3] outputs of the HIP shader; loss glue)"""
+    eps = torch.finfo(torch.float32).eps
+    return torch.where(x <= 0.0031308, 323 / 25 * x, (211 * torch.clamp(x, min=eps) ** (5 / 12) - 11) / 200)
+
+
+class NeROMaterialRenderer(nn.Module):
+    """Stage II: fixed mesh, Monte-Carlo microfacet shading of surface points (network/renderer.py:649-915).  `mesh` may be given
+    as (vertices [nV,3], triangles [nT,3]); otherwise cfg['mesh'] is read with trimesh (not a dependency of the hot path)."""
+    default_cfg = {
+        'train_ray_num': 512, 'test_ray_num': 1024, 'database_name': 'real/bear/raw_1024', 'rgb_loss': 'charbonier',
+        'mesh': 'data/meshes/bear_shape-300000.ply', 'shader_cfg': {}, 'reg_mat': True, 'reg_diffuse_light': True,
+        'reg_diffuse_light_lambda': 0.1, 'fixed_camera': False,
+    }
+
+    def __init__(self, cfg, is_train=True, mesh=None):
+        self.cfg = {**self.default_cfg, **cfg}
+        super().__init__()
+        from .fields import MCShadingNetwork
+        from .raytracing import RayTracer
+        if mesh is None:
+            try:
+                import trimesh
+            except ImportError as e:
+                raise ImportError('pass mesh=(vertices, triangles) or install trimesh to read cfg["mesh"]') from e
+            tm = trimesh.load(self.cfg['mesh'], force='mesh', skip_material=True, process=False)
+            mesh = (np.asarray(tm.vertices), np.asarray(tm.faces))
+        self.ray_tracer = RayTracer(mesh[0], mesh[1])
+        self.cfg['shader_cfg'] = dict(self.cfg['shader_cfg'])
+        self.cfg['shader_cfg']['is_real'] = self.cfg['database_name'].startswith('real')
+        self.shader_network = MCShadingNetwork(self.cfg['shader_cfg'], lambda o, d: self.trace(o, d))
+
+    def trace(self, rays_o, rays_d):
+        """network/renderer.py:719-729: flipped + normalised face normals, hit <=> depth < 10"""
+        inters, normals, depth = self.ray_tracer.trace(rays_o, rays_d)
+        depth = depth.reshape(*depth.shape, 1)
+        normals = torch.nn.functional.normalize(-normals, dim=-1)
+        return inters, normals, depth, ~(depth >= 10)[..., 0]
+
+    def _kernels(self):
+        from .material_step import MaterialKernels, flatten_material_effective, unflatten_material_effective
+        names, eff = flatten_material_effective(self.shader_network)
+        K = MaterialKernels(unflatten_material_effective(names, [t.detach() for t in eff]), self.shader_network.cfg, eff[0].device).pack()
+        return names, eff, K
+
+    def predict_materials(self, pts, _kern=None):
+        """-> metallic [n,1], roughness [n,1] (affine to [0.04^2, 1]), albedo [n,3]   (network/field.py:915-922)"""
+        from .material_step import PredictMaterials
+        names, eff, K = _kern if _kern is not None else self._kernels()
+        raw = PredictMaterials.apply(K, names[:40], pts, *eff[:40])
+        rmin = 0.04 ** 2
+        return torch.sigmoid(raw[:, 0:1]), torch.sigmoid(raw[:, 1:2]) * (1.0 - rmin) + rmin, torch.sigmoid(raw[:, 2:5])
+
+    def shade(self, pts, view_dirs, normals, human_poses, is_train, step=None, rand_d=None, rand_s=None, _reg_pts=None):
+        from .material_step import MCShade
+        kern = self._kernels()
+        names, eff, K = kern
+        scfg = self.shader_network.cfg
+        Pn = pts.shape[0]
+        x = pts if _reg_pts is None else torch.cat([pts, _reg_pts], 0)
+        metallic, rough, albedo = self.predict_materials(x, kern)
+        m2 = (metallic[Pn:], rough[Pn:], albedo[Pn:]) if _reg_pts is not None else None
+        metallic, rough, albedo = metallic[:Pn], rough[:Pn], albedo[:Pn]
+        if is_train and scfg['random_azimuth']:
+            rand_d = torch.rand(Pn, 1, 1, device=pts.device) if rand_d is None else rand_d
+            rand_s = torch.rand(Pn, 1, 1, device=pts.device) if rand_s is None else rand_s
+        else:
+            rand_d = rand_s = None
+        mat5 = torch.cat([metallic, rough, albedo], -1)
+        rgb_lin, dl, sl, sp = MCShade.apply(K, self.ray_tracer, names[40:], pts, view_dirs, normals, mat5, rand_d, rand_s, *eff[40:])
+        kd = 1 - metallic
+        outputs = {
+            'rgb_pr': linear_to_srgb(rgb_lin), 'albedo': albedo, 'roughness': rough, 'metallic': metallic,
+            'human_lights': torch.zeros(1, 3, device=pts.device),
+            'diffuse_light': torch.clamp(linear_to_srgb(dl), 0, 1), 'specular_light': torch.clamp(linear_to_srgb(sl), 0, 1),
+            'diffuse_color': torch.clamp(linear_to_srgb(rgb_lin - sp), 0, 1).detach(), 'specular_color': torch.clamp(linear_to_srgb(sp), 0, 1),
+            # reference quirk (field.py:1007-1011): uses the already clamped sRGB specular colour
+            'approximate_light': torch.clamp(linear_to_srgb(kd * dl + torch.clamp(linear_to_srgb(sp), 0, 1)), 0, 1).detach(),
+        }
+        if m2 is not None:
+            outputs['_reg_materials'] = m2
+        return outputs
+
+    def material_regularization(self, pts, normals, metallic, rough, albedo, step, m2):
+        """network/field.py:1061-1087 given the materials m2 at the perturbed points"""
+        scfg = self.shader_network.cfg
+        reg = 0
+        if scfg['reg_change']:
+            reg = reg + torch.mean((torch.abs(m2[0] - metallic) + torch.abs(m2[1] - rough) + torch.abs(m2[2] - albedo)) * scfg['reg_lambda1'], dim=1)
+        if scfg['reg_min_max'] and step is not None and step < 2000:
+            reg = reg + torch.sum(torch.clamp(rough - 0.98 ** 2, min=0)) + torch.sum(torch.clamp(0.02 ** 2 - rough, min=0))
+            reg = reg + torch.sum(torch.clamp(metallic - 0.98, min=0)) + torch.sum(torch.clamp(0.02 - metallic, min=0))
+        return reg
+
+    def regularization_points(self, pts, normals, reg_ang=None, reg_eps=None):
+        """tangent-plane perturbation of the surface points (network/field.py:1066-1076)"""
+        scfg = self.shader_network.cfg
+        n = torch.nn.functional.normalize(normals, dim=-1)
+        o0 = torch.stack([n[:, 1], -n[:, 0], torch.zeros_like(n[:, 0])], -1)
+        o1 = torch.stack([-n[:, 2], torch.zeros_like(n[:, 0]), n[:, 0]], -1)
+        x = torch.nn.functional.normalize(torch.where((o0.norm(dim=-1) > o1.norm(dim=-1)).unsqueeze(-1), o0, o1), dim=-1)
+        y = torch.cross(n, x, dim=-1)
+        ang = (torch.rand(pts.shape[0], 1, device=pts.device) if reg_ang is None else reg_ang) * np.pi * 2
+        if scfg['change_type'] == 'constant':
+            eps = scfg['change_eps']
+        elif scfg['change_type'] == 'gaussian':
+            eps = torch.normal(mean=0.0, std=scfg['change_eps'], size=[pts.shape[0], 1], device=pts.device) if reg_eps is None else reg_eps
+        else:
+            raise NotImplementedError
+        return pts + (torch.cos(ang) * x + torch.sin(ang) * y) * eps
+
+    def compute_rgb_loss(self, rgb_pr, rgb_gt):
+        if self.cfg['rgb_loss'] == 'l1':
+            return torch.sum(torch.abs(rgb_pr - rgb_gt), -1)
+        if self.cfg['rgb_loss'] == 'charbonier':
+            return torch.sqrt(torch.sum((rgb_gt - rgb_pr) ** 2, dim=-1) + 0.001)
+        raise NotImplementedError
+
+    def shade_train(self, pts, view_dirs, normals, human_poses, rgb_gt, step, rand_d=None, rand_s=None, reg_ang=None, reg_eps=None):
+        """the arithmetic of train_step (network/renderer.py:837-844) for an explicit batch"""
+        reg_pts = self.regularization_points(pts, normals, reg_ang, reg_eps) if (self.cfg['reg_mat'] and self.shader_network.cfg['reg_change']) else None
+        out = self.shade(pts, view_dirs, normals, human_poses, True, step, rand_d, rand_s, _reg_pts=reg_pts)
+        out['rgb_gt'] = rgb_gt
+        out['loss_rgb'] = self.compute_rgb_loss(out['rgb_pr'], rgb_gt)
+        if self.cfg['reg_mat']:
+            out['loss_mat_reg'] = self.material_regularization(pts, normals, out['metallic'], out['roughness'], out['albedo'], step,
+                                                               out.pop('_reg_materials', None))
+        if self.cfg['reg_diffuse_light']:
+            dl = out['diffuse_light']
+            out['loss_diffuse_light'] = torch.sum(torch.abs(dl - torch.mean(dl, dim=-1, keepdim=True)), dim=-1) * self.cfg['reg_diffuse_light_lambda']
+        return out
+
+
+name2renderer = {'shape': NeROShapeRenderer, 'material': NeROMaterialRenderer}

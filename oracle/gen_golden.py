@@ -123,6 +123,7 @@ def run_material_case(name, shader_cfg, P_, step, seed=6033):
     from oracle.tracer_oracle import trace_bruteforce
     renderer, field = ref_shim.load_reference()
     verts, tris = icosphere(3, 0.5, 0.15)
+    tris = np.ascontiguousarray(tris[:, ::-1])      # inward winding like a NeuS-extracted mesh: NeRO flips the tracer's normals (renderer.py:722)
 
     def trace(o, d):                                                     # network/renderer.py:719-729
         pos, nrm, depth, _ = trace_bruteforce(verts, tris, o.detach().numpy(), d.detach().numpy())

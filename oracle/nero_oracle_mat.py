@@ -224,7 +224,8 @@ def mc_shade(P, cfg, trace_fn, pts, view_dirs, normals, poses, rand_d=None, rand
         'diffuse_light': torch.clamp(linear_to_srgb(torch.mean(diff_l, dim=1)), 0, 1),
         'specular_light': torch.clamp(linear_to_srgb(torch.mean(spec_l, dim=1)), 0, 1),
         'diffuse_color': torch.clamp(linear_to_srgb(diff_c), 0, 1), 'specular_color': torch.clamp(linear_to_srgb(spec_c), 0, 1),
-        'approximate_light': torch.clamp(linear_to_srgb(torch.mean(kd * diff_l, dim=1) + spec_c), 0, 1),
+        # reference quirk (field.py:1007-1011): `specular_colors` has already been re-assigned to its clamped sRGB value here
+        'approximate_light': torch.clamp(linear_to_srgb(torch.mean(kd * diff_l, dim=1) + torch.clamp(linear_to_srgb(spec_c), 0, 1)), 0, 1),
         'hit_fraction': hit.float().mean(),
     }
     return colors, out

@@ -53,7 +53,8 @@ def build_material_case(meta, device='cpu'):
 
 def golden_mesh():
     from nero_amd.synthetic import icosphere
-    return icosphere(3, 0.5, 0.15)
+    v, f = icosphere(3, 0.5, 0.15)
+    return v, np.ascontiguousarray(f[:, ::-1])       # inward winding (see oracle/gen_golden.py::run_material_case)
 
 
 def oracle_trace_fn():
