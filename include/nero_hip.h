@@ -255,17 +255,24 @@ int nero_bvh_destroy(void* handle);
 int nero_mc_point_setup(const float* pts, const float* view, const float* normals, const float* mat5, const float* rand_d,
                         const float* rand_s, int P, float* pt, void* stream);
 int nero_mc_dirs(const float* pt, const float* tab_d, const float* tab_s, int P, int Dd, int Ds, float* dirs, float* origins, void* stream);
-int nero_mc_encode_miss(const float* dirs, const int* idx, int n, float* X /*[rows,72]*/, void* stream);
+/* sphere != 0 ('sphere_direction'): X [rows,144] = [IDE(w,0) | IDE(unit-sphere exit point,0)], else X [rows,72] */
+int nero_mc_encode_miss(const float* dirs, const int* idx, const float* pt, int D, int sphere, int n, float* X, void* stream);
+/* human-light input of the miss rows (get_human_light, network/field.py:820-834): Xh [rows,24], hmask [rows]; poses [P,3,4] */
+int nero_mc_human_encode(const float* dirs, const int* idx, const float* pt, int D, const float* poses, int n, float* Xh, float* hmask,
+                         void* stream);
 int nero_mc_encode_hit(const float* dirs, const float* pos, const float* face_normals, const int* idx, int n, float* X /*[rows,128]*/,
                        void* stream);
+/* human_raw [miss rows,4] / hmask [miss rows] may be NULL (shader_cfg.human_lights false) */
 int nero_mc_combine_fwd(const float* pt, const float* dirs, const float* depth, const int* slot, const float* outer_raw,
-                        const float* inner_raw, float exp_max, float inner_exp_max, int P, int Dd, int Ds, float* rgb_lin,
-                        float* dl_mean, float* sl_mean, float* spec_lin /*or NULL*/, void* stream);
+                        const float* inner_raw, const float* human_raw, const float* hmask, float exp_max, float inner_exp_max, int P,
+                        int Dd, int Ds, float* rgb_lin, float* dl_mean, float* sl_mean, float* spec_lin /*or NULL*/, void* stream);
 int nero_mc_combine_bwd(const float* pt, const float* dirs, const float* depth, const int* slot, const float* outer_raw,
-                        const float* inner_raw, float exp_max, float inner_exp_max, int P, int Dd, int Ds, const float* d_rgb,
-                        const float* d_dl, float* d_outer_raw, float* d_inner_raw, float* d_mat5, float* d_wspec, void* stream);
+                        const float* inner_raw, const float* human_raw, const float* hmask, float exp_max, float inner_exp_max, int P,
+                        int Dd, int Ds, const float* d_rgb, const float* d_dl, float* d_outer_raw, float* d_inner_raw, float* d_human_raw,
+                        float* d_mat5, float* d_wspec, void* stream);
 int nero_mc_dir_bwd(const float* pt, const float* dirs, const float* face_normals, const int* slot, const float* tab_s,
-                    const float* dX_miss, const float* dX_hit, const float* d_wspec, int P, int Dd, int Ds, float* d_mat5, void* stream);
+                    const float* dX_miss, const float* dX_hit, const float* d_wspec, int P, int Dd, int Ds, float* d_mat5, int sphere,
+                    const float* dXh /*or NULL*/, const float* poses /*[P,3,4] or NULL*/, void* stream);
 
 #ifdef __cplusplus
 }

@@ -165,16 +165,75 @@ __global__ void mc_dirs_kernel(const float* __restrict__ pt, const float* __rest
     for (int c = 0; c < 3; ++c) { dirs[(size_t)row * 3 + c] = w[c]; orig[(size_t)row * 3 + c] = q[29 + c] + w[c] * 1e-5f; }
 }
 
-// miss rows: X[k] = IDE(w, 0) (72)        (predict_outer_lights 'direction', field.py:837-839)
-__global__ void mc_encode_miss_kernel(const float* __restrict__ dirs, const int* __restrict__ idx, int n, int n_pad, float* __restrict__ X) {
+// exit point of the ray (p', w) on the unit sphere, p' = 0.999 p when |p| > 0.999   (field.py:843-849, 390-396)
+struct SphereExit { float pp[3], dtx, s, dist, sph[3]; };
+__device__ __forceinline__ SphereExit sphere_exit(const float* p, const float* w) {
+    SphereExit e;
+    const float n = sqrtf(dot3(p, p));
+    const float sc = n > 0.999f ? 0.999f : 1.f;
+    for (int c = 0; c < 3; ++c) e.pp[c] = p[c] * sc;
+    e.dtx = dot3(e.pp, w);
+    e.s = sqrtf(e.dtx * e.dtx - dot3(e.pp, e.pp) + 1.f + 1e-6f);
+    e.dist = -e.dtx + e.s;
+    for (int c = 0; c < 3; ++c) e.sph[c] = e.pp[c] + w[c] * e.dist;
+    return e;
+}
+
+// miss rows: X[k] = IDE(w, 0) (72) [ | IDE(sphere exit point, 0) (72) when sphere != 0 ]   (predict_outer_lights, field.py:836-854)
+__global__ void mc_encode_miss_kernel(const float* __restrict__ dirs, const int* __restrict__ idx, const float* __restrict__ pt, int D,
+                                      int sphere, int n, int n_pad, float* __restrict__ X) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_pad) return;
-    float* o = X + (size_t)k * 72;
-    if (k >= n) { for (int c = 0; c < 72; ++c) o[c] = 0.f; return; }
-    const float* w = dirs + (size_t)idx[k] * 3;
+    const int ld = sphere ? 144 : 72;
+    float* o = X + (size_t)k * ld;
+    if (k >= n) { for (int c = 0; c < ld; ++c) o[c] = 0.f; return; }
+    const int row = idx[k];
+    const float* w = dirs + (size_t)row * 3;
     float e[72];
     ide0_forward(w[0], w[1], w[2], e);
     for (int c = 0; c < 72; ++c) o[c] = e[c];
+    if (sphere) {
+        const SphereExit se = sphere_exit(pt + (size_t)(row / D) * 32 + 29, w);
+        ide0_forward(se.sph[0], se.sph[1], se.sph[2], e);
+        for (int c = 0; c < 72; ++c) o[72 + c] = e[c];
+    }
+}
+
+// human light input for miss rows (get_human_light, field.py:820-834): zero-variance IPE of the hit on the z=0 plane of the
+// per-point human frame.  Xh [rows,24], hmask[rows]
+struct HumanGeom { float px, py, pz, dx, dy, dz, dzp, dist, ix, iy, h; bool hits0; };
+__device__ __forceinline__ HumanGeom human_geom(const float* __restrict__ pose, const float* p, const float* rf) {
+    HumanGeom g;
+    g.px = pose[0] * p[0] + pose[1] * p[1] + pose[2] * p[2] + pose[3];
+    g.py = pose[4] * p[0] + pose[5] * p[1] + pose[6] * p[2] + pose[7];
+    g.pz = pose[8] * p[0] + pose[9] * p[1] + pose[10] * p[2] + pose[11];
+    g.dx = pose[0] * rf[0] + pose[1] * rf[1] + pose[2] * rf[2];
+    g.dy = pose[4] * rf[0] + pose[5] * rf[1] + pose[6] * rf[2];
+    g.dz = pose[8] * rf[0] + pose[9] * rf[1] + pose[10] * rf[2];
+    g.hits0 = fabsf(g.dz) > 1e-4f;
+    g.dzp = g.hits0 ? g.dz : 1e-4f;
+    g.dist = -g.pz / g.dzp;
+    g.ix = g.px + g.dist * g.dx;
+    g.iy = g.py + g.dist * g.dy;
+    const float mx = g.ix * 0.3f, my = g.iy * 0.3f;
+    g.h = (g.hits0 && sqrtf(mx * mx + my * my) < 1.5f && g.dist > 0.f) ? 1.f : 0.f;
+    return g;
+}
+__global__ void mc_human_encode_kernel(const float* __restrict__ dirs, const int* __restrict__ idx, const float* __restrict__ pt, int D,
+                                       const float* __restrict__ poses, int n, int n_pad, float* __restrict__ Xh, float* __restrict__ hmask) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_pad) return;
+    float* o = Xh + (size_t)k * 24;
+    if (k >= n) { for (int c = 0; c < 24; ++c) o[c] = 0.f; hmask[k] = 0.f; return; }
+    const int row = idx[k], p = row / D;
+    const HumanGeom g = human_geom(poses + (size_t)p * 12, pt + (size_t)p * 32 + 29, dirs + (size_t)row * 3);
+    const float mean[2] = {g.ix * 0.3f * g.h, g.iy * 0.3f * g.h};
+    float sc = 1.f;
+    for (int s = 0; s < 6; ++s) {
+        for (int c = 0; c < 2; ++c) { o[2 * s + c] = sinf(mean[c] * sc); o[12 + 2 * s + c] = sinf(mean[c] * sc + 1.5707963267948966f); }
+        sc *= 2.f;
+    }
+    hmask[k] = g.h;
 }
 
 // hit rows: X[k] = [PE8(x_hit) (51), IDE(reflect(-w about n_hit), 0) (72), pad]  ld 128; n_hit = -normalize(face normal)
@@ -241,16 +300,30 @@ __device__ __forceinline__ void brdf_terms(const float* q, const float* w, bool 
     b.W = b.N / b.Q;
 }
 
-__device__ __forceinline__ void light_value(int s, const float* __restrict__ outer_raw, const float* __restrict__ inner_raw,
-                                            float emax, float imax, float near, float* L) {
-    if (s >= 0) { for (int c = 0; c < 3; ++c) L[c] = expf(fminf(outer_raw[(size_t)s * 4 + c], emax)) * near; }
-    else { const int k = -s - 1; for (int c = 0; c < 3; ++c) L[c] = expf(fminf(inner_raw[(size_t)k * 4 + c], imax)) * near; }
+struct Lights { const float* outer_raw; const float* inner_raw; const float* human_raw; const float* hmask; float emax, imax; };
+
+// L = near * ( miss: outer (1-hw) + hl hw ; hit: inner )      (get_lights, field.py:866-879)
+__device__ __forceinline__ void light_value(int s, const Lights& P_, float near, float* L, float* outer, float* hl, float& hw, float& hw_raw) {
+    hw = 0.f; hw_raw = 0.f;
+    for (int c = 0; c < 3; ++c) { outer[c] = 0.f; hl[c] = 0.f; }
+    if (s >= 0) {
+        for (int c = 0; c < 3; ++c) outer[c] = expf(fminf(P_.outer_raw[(size_t)s * 4 + c], P_.emax));
+        if (P_.human_raw) {
+            const float hm = P_.hmask[s];
+            for (int c = 0; c < 3; ++c) hl[c] = expf(fminf(P_.human_raw[(size_t)s * 4 + c], 0.f)) * hm;
+            hw_raw = expf(fminf(P_.human_raw[(size_t)s * 4 + 3], 0.f)) * hm;
+            hw = sat(hw_raw);
+        }
+        for (int c = 0; c < 3; ++c) L[c] = (outer[c] * (1.f - hw) + hl[c] * hw) * near;
+    } else {
+        const int k = -s - 1;
+        for (int c = 0; c < 3; ++c) L[c] = expf(fminf(P_.inner_raw[(size_t)k * 4 + c], P_.imax)) * near;
+    }
 }
 
 __global__ __launch_bounds__(64) void mc_combine_fwd_kernel(const float* __restrict__ pt, const float* __restrict__ dirs,
                                                             const float* __restrict__ depth, const int* __restrict__ slot,
-                                                            const float* __restrict__ outer_raw, const float* __restrict__ inner_raw,
-                                                            float emax, float imax, int P_, int Dd, int Ds,
+                                                            Lights LP, int P_, int Dd, int Ds,
                                                             float* __restrict__ rgb_lin, float* __restrict__ dl_mean, float* __restrict__ sl_mean, float* __restrict__ spec_lin) {
     const int p = blockIdx.x, lane = threadIdx.x;
     if (p >= P_) return;
@@ -264,8 +337,8 @@ __global__ __launch_bounds__(64) void mc_combine_fwd_kernel(const float* __restr
         const float w[3] = {dirs[row * 3], dirs[row * 3 + 1], dirs[row * 3 + 2]};
         Brdf b;
         brdf_terms(q, w, j < Dd, wd, ws, b);
-        float L[3];
-        light_value(slot[row], outer_raw, inner_raw, emax, imax, depth[row] > 1e-5f ? 1.f : 0.f, L);
+        float L[3], ou[3], hl[3], hw, hwr;
+        light_value(slot[row], LP, depth[row] > 1e-5f ? 1.f : 0.f, L, ou, hl, hw, hwr);
         for (int c = 0; c < 3; ++c) {
             const float F0 = 0.04f * (1.f - m) + m * q[11 + c];
             const float Fr = F0 + (1.f - F0) * b.fc;
@@ -295,11 +368,10 @@ __global__ __launch_bounds__(64) void mc_combine_fwd_kernel(const float* __restr
 //   d_wspec [P*Ds,3] (gradient w.r.t. the specular directions through the BRDF terms)
 __global__ __launch_bounds__(64) void mc_combine_bwd_kernel(const float* __restrict__ pt, const float* __restrict__ dirs,
                                                             const float* __restrict__ depth, const int* __restrict__ slot,
-                                                            const float* __restrict__ outer_raw, const float* __restrict__ inner_raw,
-                                                            float emax, float imax, int P_, int Dd, int Ds,
+                                                            Lights LP, int P_, int Dd, int Ds,
                                                             const float* __restrict__ d_rgb, const float* __restrict__ d_dl,
                                                             float* __restrict__ d_outer_raw, float* __restrict__ d_inner_raw,
-                                                            float* __restrict__ d_mat5, float* __restrict__ d_wspec) {
+                                                            float* __restrict__ d_human_raw, float* __restrict__ d_mat5, float* __restrict__ d_wspec) {
     const int p = blockIdx.x, lane = threadIdx.x;
     if (p >= P_) return;
     const int D = Dd + Ds;
@@ -319,8 +391,8 @@ __global__ __launch_bounds__(64) void mc_combine_bwd_kernel(const float* __restr
         brdf_terms(q, w, diffuse, wd, ws, b);
         const float near = depth[row] > 1e-5f ? 1.f : 0.f;
         const int s = slot[row];
-        float L[3];
-        light_value(s, outer_raw, inner_raw, emax, imax, near, L);
+        float L[3], ou[3], hl[3], hw, hwr;
+        light_value(s, LP, near, L, ou, hl, hw, hwr);
         float dL[3], dW = 0.f, dFc = 0.f;
         for (int c = 0; c < 3; ++c) {
             const float a = q[11 + c];
@@ -335,15 +407,28 @@ __global__ __launch_bounds__(64) void mc_combine_bwd_kernel(const float* __restr
             da[c] += dF0 * m;
             if (diffuse) { da[c] += gd[c] * (1.f - m) * L[c]; dm -= gd[c] * a * L[c]; }
         }
-        // raw head gradients: L = exp(min(raw, cap)) * near
+        // raw head gradients: L = near * (outer (1-hw) + hl hw) with outer = exp(min(raw, cap)), or near * inner
         if (s >= 0) {
-            float o4[3];
-            for (int c = 0; c < 3; ++c) o4[c] = outer_raw[(size_t)s * 4 + c] <= emax ? dL[c] * L[c] : 0.f;
+            float o4[3], h4[4] = {0.f, 0.f, 0.f, 0.f};
+            float dhw = 0.f;
+            for (int c = 0; c < 3; ++c) {
+                const float dl_ = dL[c] * near;
+                o4[c] = LP.outer_raw[(size_t)s * 4 + c] <= LP.emax ? dl_ * (1.f - hw) * ou[c] : 0.f;
+                if (LP.human_raw) {
+                    h4[c] = LP.human_raw[(size_t)s * 4 + c] <= 0.f ? dl_ * hw * hl[c] : 0.f;
+                    dhw += dl_ * (hl[c] - ou[c]);
+                }
+            }
             reinterpret_cast<float4*>(d_outer_raw)[s] = make_float4(o4[0], o4[1], o4[2], 0.f);
+            if (LP.human_raw) {
+                const float g = (hwr >= 0.f && hwr <= 1.f) ? dhw : 0.f;
+                h4[3] = LP.human_raw[(size_t)s * 4 + 3] <= 0.f ? g * hwr : 0.f;
+                reinterpret_cast<float4*>(d_human_raw)[s] = make_float4(h4[0], h4[1], h4[2], h4[3]);
+            }
         } else {
             const int kk = -s - 1;
             float o4[3];
-            for (int c = 0; c < 3; ++c) o4[c] = inner_raw[(size_t)kk * 4 + c] <= imax ? dL[c] * L[c] : 0.f;
+            for (int c = 0; c < 3; ++c) o4[c] = LP.inner_raw[(size_t)kk * 4 + c] <= LP.imax ? dL[c] * L[c] : 0.f;
             reinterpret_cast<float4*>(d_inner_raw)[kk] = make_float4(o4[0], o4[1], o4[2], 0.f);
         }
         // W = N / Q
@@ -396,7 +481,8 @@ __global__ __launch_bounds__(64) void mc_dir_bwd_kernel(const float* __restrict_
                                                         const float* __restrict__ fnrm, const int* __restrict__ slot,
                                                         const float* __restrict__ tab_s, const float* __restrict__ dX_miss,
                                                         const float* __restrict__ dX_hit, const float* __restrict__ d_wspec,
-                                                        int P_, int Dd, int Ds, float* __restrict__ d_mat5) {
+                                                        int P_, int Dd, int Ds, float* __restrict__ d_mat5, int sphere,
+                                                        const float* __restrict__ dXh, const float* __restrict__ poses) {
     const int p = blockIdx.x, lane = threadIdx.x;
     if (p >= P_) return;
     const int D = Dd + Ds;
@@ -410,8 +496,39 @@ __global__ __launch_bounds__(64) void mc_dir_bwd_kernel(const float* __restrict_
         const int s = slot[row];
         float g[72];
         if (s >= 0) {
-            for (int c = 0; c < 72; ++c) g[c] = dX_miss[(size_t)s * 72 + c];
+            const int ldm = sphere ? 144 : 72;
+            for (int c = 0; c < 72; ++c) g[c] = dX_miss[(size_t)s * ldm + c];
             ide0_backward(w[0], w[1], w[2], g, dw[0], dw[1], dw[2]);
+            if (sphere) {
+                // sph = p' + w dist(w), dist = -<p',w> + sqrt(<p',w>^2 - |p'|^2 + 1 + 1e-6)
+                const SphereExit se = sphere_exit(q + 29, w);
+                for (int c = 0; c < 72; ++c) g[c] = dX_miss[(size_t)s * ldm + 72 + c];
+                float ds[3] = {0.f, 0.f, 0.f};
+                ide0_backward(se.sph[0], se.sph[1], se.sph[2], g, ds[0], ds[1], ds[2]);
+                const float dd = dot3(ds, w) * (se.dtx / se.s - 1.f);
+                for (int c = 0; c < 3; ++c) dw[c] += se.dist * ds[c] + dd * se.pp[c];
+            }
+            if (dXh) {
+                // IPE(mean, 0) of the human-plane hit: mean = 0.3 h inter_xy
+                const float* pose = poses + (size_t)p * 12;
+                const HumanGeom hg = human_geom(pose, q + 29, w);
+                const float* gx = dXh + (size_t)s * 24;
+                const float mean[2] = {hg.ix * 0.3f * hg.h, hg.iy * 0.3f * hg.h};
+                float dmean[2] = {0.f, 0.f};
+                float sc = 1.f;
+                for (int t = 0; t < 6; ++t) {
+                    for (int c = 0; c < 2; ++c)
+                        dmean[c] += sc * (gx[2 * t + c] * cosf(mean[c] * sc) + gx[12 + 2 * t + c] * cosf(mean[c] * sc + 1.5707963267948966f));
+                    sc *= 2.f;
+                }
+                const float dix = 0.3f * hg.h * dmean[0], diy = 0.3f * hg.h * dmean[1];
+                const float d_dist = dix * hg.dx + diy * hg.dy;
+                const float ddx = hg.dist * dix, ddy = hg.dist * diy;
+                const float ddz = hg.hits0 ? d_dist * hg.pz / (hg.dzp * hg.dzp) : 0.f;
+                dw[0] += pose[0] * ddx + pose[4] * ddy + pose[8] * ddz;
+                dw[1] += pose[1] * ddx + pose[5] * ddy + pose[9] * ddz;
+                dw[2] += pose[2] * ddx + pose[6] * ddy + pose[10] * ddz;
+            }
         } else {
             const int kk = -s - 1;
             for (int c = 0; c < 72; ++c) g[c] = dX_hit[(size_t)kk * 128 + 51 + c];
@@ -462,12 +579,20 @@ int nero_mc_dirs(const float* pt, const float* tab_d, const float* tab_s, int P,
     return nero_check_launch("nero_mc_dirs");
 }
 
-int nero_mc_encode_miss(const float* dirs, const int* idx, int n, float* X, void* stream) {
+int nero_mc_encode_miss(const float* dirs, const int* idx, const float* pt, int D, int sphere, int n, float* X, void* stream) {
     CHECK_T();
     const int n_pad = NERO_ROW_PAD(n);
     if (n_pad == 0) return NERO_OK;
-    hipLaunchKernelGGL(mc_encode_miss_kernel, GRID1D(n_pad), dirs, idx, n, n_pad, X);
+    hipLaunchKernelGGL(mc_encode_miss_kernel, GRID1D(n_pad), dirs, idx, pt, D, sphere, n, n_pad, X);
     return nero_check_launch("nero_mc_encode_miss");
+}
+
+int nero_mc_human_encode(const float* dirs, const int* idx, const float* pt, int D, const float* poses, int n, float* Xh, float* hmask,
+                         void* stream) {
+    const int n_pad = NERO_ROW_PAD(n);
+    if (n_pad == 0) return NERO_OK;
+    hipLaunchKernelGGL(mc_human_encode_kernel, GRID1D(n_pad), dirs, idx, pt, D, poses, n, n_pad, Xh, hmask);
+    return nero_check_launch("nero_mc_human_encode");
 }
 
 int nero_mc_encode_hit(const float* dirs, const float* pos, const float* face_normals, const int* idx, int n, float* X, void* stream) {
@@ -479,29 +604,33 @@ int nero_mc_encode_hit(const float* dirs, const float* pos, const float* face_no
 }
 
 int nero_mc_combine_fwd(const float* pt, const float* dirs, const float* depth, const int* slot, const float* outer_raw,
-                        const float* inner_raw, float exp_max, float inner_exp_max, int P, int Dd, int Ds, float* rgb_lin,
-                        float* dl_mean, float* sl_mean, float* spec_lin, void* stream) {
+                        const float* inner_raw, const float* human_raw, const float* hmask, float exp_max, float inner_exp_max, int P,
+                        int Dd, int Ds, float* rgb_lin, float* dl_mean, float* sl_mean, float* spec_lin, void* stream) {
     if (P == 0) return NERO_OK;
-    hipLaunchKernelGGL(mc_combine_fwd_kernel, dim3(P), dim3(64), 0, (hipStream_t)stream, pt, dirs, depth, slot, outer_raw, inner_raw,
-                       exp_max, inner_exp_max, P, Dd, Ds, rgb_lin, dl_mean, sl_mean, spec_lin);
+    Lights LP{outer_raw, inner_raw, human_raw, hmask, exp_max, inner_exp_max};
+    hipLaunchKernelGGL(mc_combine_fwd_kernel, dim3(P), dim3(64), 0, (hipStream_t)stream, pt, dirs, depth, slot, LP, P, Dd, Ds, rgb_lin,
+                       dl_mean, sl_mean, spec_lin);
     return nero_check_launch("nero_mc_combine_fwd");
 }
 
 int nero_mc_combine_bwd(const float* pt, const float* dirs, const float* depth, const int* slot, const float* outer_raw,
-                        const float* inner_raw, float exp_max, float inner_exp_max, int P, int Dd, int Ds, const float* d_rgb,
-                        const float* d_dl, float* d_outer_raw, float* d_inner_raw, float* d_mat5, float* d_wspec, void* stream) {
+                        const float* inner_raw, const float* human_raw, const float* hmask, float exp_max, float inner_exp_max, int P,
+                        int Dd, int Ds, const float* d_rgb, const float* d_dl, float* d_outer_raw, float* d_inner_raw, float* d_human_raw,
+                        float* d_mat5, float* d_wspec, void* stream) {
     if (P == 0) return NERO_OK;
-    hipLaunchKernelGGL(mc_combine_bwd_kernel, dim3(P), dim3(64), 0, (hipStream_t)stream, pt, dirs, depth, slot, outer_raw, inner_raw,
-                       exp_max, inner_exp_max, P, Dd, Ds, d_rgb, d_dl, d_outer_raw, d_inner_raw, d_mat5, d_wspec);
+    Lights LP{outer_raw, inner_raw, human_raw, hmask, exp_max, inner_exp_max};
+    hipLaunchKernelGGL(mc_combine_bwd_kernel, dim3(P), dim3(64), 0, (hipStream_t)stream, pt, dirs, depth, slot, LP, P, Dd, Ds, d_rgb,
+                       d_dl, d_outer_raw, d_inner_raw, d_human_raw, d_mat5, d_wspec);
     return nero_check_launch("nero_mc_combine_bwd");
 }
 
 int nero_mc_dir_bwd(const float* pt, const float* dirs, const float* face_normals, const int* slot, const float* tab_s,
-                    const float* dX_miss, const float* dX_hit, const float* d_wspec, int P, int Dd, int Ds, float* d_mat5, void* stream) {
+                    const float* dX_miss, const float* dX_hit, const float* d_wspec, int P, int Dd, int Ds, float* d_mat5, int sphere,
+                    const float* dXh, const float* poses, void* stream) {
     CHECK_T();
     if (P == 0) return NERO_OK;
     hipLaunchKernelGGL(mc_dir_bwd_kernel, dim3(P), dim3(64), 0, (hipStream_t)stream, pt, dirs, face_normals, slot, tab_s, dX_miss, dX_hit,
-                       d_wspec, P, Dd, Ds, d_mat5);
+                       d_wspec, P, Dd, Ds, d_mat5, sphere, dXh, poses);
     return nero_check_launch("nero_mc_dir_bwd");
 }
 

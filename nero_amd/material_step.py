@@ -15,8 +15,8 @@ from .shape_step import _p, _st, predictor_entries
 
 class MaterialKernels:
     def __init__(self, eff, cfg, device='cuda'):
-        if cfg['outer_light_version'] != 'direction' or cfg['human_lights']:
-            raise NotImplementedError("HIP MC shader: only outer_light_version='direction' without human_lights so far")
+        if cfg['outer_light_version'] not in ('direction', 'sphere_direction'):
+            raise NotImplementedError(cfg['outer_light_version'])
         if cfg['geometry_type'] != 'schlick':
             raise NotImplementedError("HIP MC shader: geometry_type 'schlick' only")
         self.device, self.cfg = device, cfg
@@ -28,8 +28,11 @@ class MaterialKernels:
         self.feats = Chain(ent, k_init=56, k_aux=56, aux_wide=True, device=device)
         self.mat = [Chain(predictor_entries(eff[k], 256, 3), k_init=256, k_aux=8, device=device)
                     for k in ('metallic', 'roughness', 'albedo')]
-        self.outer_light = Chain(predictor_entries(eff['outer_light'], 72), k_init=72, device=device)
+        self.sphere = int(cfg['outer_light_version'] == 'sphere_direction')
+        kout = 144 if self.sphere else 72
+        self.outer_light = Chain(predictor_entries(eff['outer_light'], kout), k_init=kout, device=device)
         self.inner_light = Chain(predictor_entries(eff['inner_light'], 123), k_init=128, device=device)
+        self.human_light = Chain(predictor_entries(eff['human'], 24), k_init=24, device=device) if cfg['human_lights'] else None
         dn, sn = cfg['diffuse_sample_num'], cfg['specular_sample_num']
 
         def table(n):
@@ -38,8 +41,9 @@ class MaterialKernels:
         self.tab_d, self.tab_s = table(dn), table(sn)
 
     def pack(self):
-        for c in [self.feats, self.outer_light, self.inner_light] + self.mat:
-            c.pack()
+        for c in [self.feats, self.outer_light, self.inner_light, self.human_light] + self.mat:
+            if c is not None:
+                c.pack()
         return self
 
 
@@ -130,7 +134,7 @@ class MCShade(torch.autograd.Function):
     weighted specular light [P,3] (no grad).  Gradients: mat5 and the outer / inner light MLP weights."""
 
     @staticmethod
-    def forward(ctx, K, tracer, names, pts, view, normals, mat5, rand_d, rand_s, *params):
+    def forward(ctx, K, tracer, names, pts, view, normals, mat5, rand_d, rand_s, poses, *params):
         dev = pts.device
         lib, st = L.lib, _st()
         f32 = dict(dtype=torch.float32, device=dev)
@@ -154,22 +158,31 @@ class MCShade(torch.autograd.Function):
         slot[miss_idx.long()] = torch.arange(n_miss, dtype=torch.int32, device=dev)
         slot[hit_idx.long()] = -torch.arange(n_hit, dtype=torch.int32, device=dev) - 1
         rpm, rph = row_pad(n_miss), row_pad(n_hit)
-        Xm, Xh = torch.empty((max(rpm, 64), 72), **f32), torch.empty((max(rph, 64), 128), **f32)
-        fo = fi = None
-        outer_raw = inner_raw = None
+        Xm, Xh = torch.empty((max(rpm, 64), 144 if K.sphere else 72), **f32), torch.empty((max(rph, 64), 128), **f32)
+        fo = fi = fh = None
+        outer_raw = inner_raw = human_raw = hmask = Xhum = None
+        poses = poses.detach().contiguous().float() if (poses is not None and K.human_light is not None) else None
+        if K.human_light is not None and poses is None:
+            raise ValueError('shader_cfg.human_lights needs human_poses [P,3,4]')
         if n_miss > 0:
-            L.check(lib.nero_mc_encode_miss(_p(dirs), _p(miss_idx), n_miss, _p(Xm), st))
+            L.check(lib.nero_mc_encode_miss(_p(dirs), _p(miss_idx), _p(pt), D, K.sphere, n_miss, _p(Xm), st))
             fo = K.outer_light.forward(Xm, None, n_miss)
             outer_raw = fo['heads'][3]
+            if K.human_light is not None:
+                Xhum, hmask = torch.empty((rpm, 24), **f32), torch.empty(rpm, **f32)
+                L.check(lib.nero_mc_human_encode(_p(dirs), _p(miss_idx), _p(pt), D, _p(poses), n_miss, _p(Xhum), _p(hmask), st))
+                fh = K.human_light.forward(Xhum, None, n_miss)
+                human_raw = fh['heads'][3]
         if n_hit > 0:
             L.check(lib.nero_mc_encode_hit(_p(dirs), _p(pos), _p(fnrm), _p(hit_idx), n_hit, _p(Xh), st))
             fi = K.inner_light.forward(Xh, None, n_hit)
             inner_raw = fi['heads'][3]
         rgb, dl, sl, sp = (torch.empty((Pn, 3), **f32) for _ in range(4))
-        L.check(lib.nero_mc_combine_fwd(_p(pt), _p(dirs), _p(depth), _p(slot), _p(outer_raw), _p(inner_raw),
+        L.check(lib.nero_mc_combine_fwd(_p(pt), _p(dirs), _p(depth), _p(slot), _p(outer_raw), _p(inner_raw), _p(human_raw), _p(hmask),
                                         C.c_float(cfg['light_exp_max']), C.c_float(cfg['inner_light_exp_max']), Pn, Dd, Ds,
                                         _p(rgb), _p(dl), _p(sl), _p(sp), st))
         ctx.S = dict(K=K, names=names, P=Pn, pt=pt, dirs=dirs, depth=depth, fnrm=fnrm, slot=slot, Xm=Xm, Xh=Xh, fo=fo, fi=fi,
+                     fh=fh, Xhum=Xhum, hmask=hmask, poses=poses,
                      n_miss=n_miss, n_hit=n_hit, shapes=[tuple(p.shape) for p in params])
         ctx.mark_non_differentiable(sl, sp)
         return rgb, dl, sl, sp
@@ -184,16 +197,18 @@ class MCShade(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         Dd, Ds = cfg['diffuse_sample_num'], cfg['specular_sample_num']
         n_miss, n_hit = S['n_miss'], S['n_hit']
-        fo, fi = S['fo'], S['fi']
+        fo, fi, fh = S['fo'], S['fi'], S['fh']
+        d_hr = torch.zeros((max(row_pad(n_miss), 64), 4), **f32) if fh else None
         d_or = torch.zeros((max(row_pad(n_miss), 64), 4), **f32)
         d_ir = torch.zeros((max(row_pad(n_hit), 64), 4), **f32)
         d_mat5 = torch.empty((Pn, 5), **f32)
         d_w = torch.zeros((Pn * Ds, 3), **f32)
         L.check(lib.nero_mc_combine_bwd(_p(S['pt']), _p(S['dirs']), _p(S['depth']), _p(S['slot']),
                                         _p(fo['heads'][3] if fo else None), _p(fi['heads'][3] if fi else None),
+                                        _p(fh['heads'][3] if fh else None), _p(S['hmask']),
                                         C.c_float(cfg['light_exp_max']), C.c_float(cfg['inner_light_exp_max']), Pn, Dd, Ds,
                                         _p(d_rgb.contiguous()), _p(d_dl.contiguous() if d_dl is not None else None),
-                                        _p(d_or), _p(d_ir), _p(d_mat5), _p(d_w), st))
+                                        _p(d_or), _p(d_ir), _p(d_hr), _p(d_mat5), _p(d_w), st))
         ws = torch.empty(L.lib.nero_dw_workspace_floats(max(n_miss, n_hit, 1)), **f32)
         G = {}
 
@@ -201,20 +216,24 @@ class MCShade(torch.autograd.Function):
             for i in range(3):
                 G[f'{prefix}.{i}.weight'], G[f'{prefix}.{i}.bias'] = gr[i]['dW'], gr[i]['db']
             G[f'{prefix}.3.weight'], G[f'{prefix}.3.bias'] = gr[3]['dWh'], gr[3]['dbh']
-        dXm = dXh = None
+        dXm = dXh = dXhum = None
         if n_miss > 0:
             ob = K.outer_light.backward(fo, n_miss, head_dys={3: d_or}, need_dinit=True)
             put('outer_light', K.outer_light.weight_grads(fo, ob, n_miss, S['Xm'], None, head_dys={3: d_or}, workspace=ws))
             dXm = ob['d_init']
+            if fh:
+                hb = K.human_light.backward(fh, n_miss, head_dys={3: d_hr}, need_dinit=True)
+                put('human_light', K.human_light.weight_grads(fh, hb, n_miss, S['Xhum'], None, head_dys={3: d_hr}, workspace=ws))
+                dXhum = hb['d_init']
         if n_hit > 0:
             ib = K.inner_light.backward(fi, n_hit, head_dys={3: d_ir}, need_dinit=True)
             put('inner_light', K.inner_light.weight_grads(fi, ib, n_hit, S['Xh'], None, head_dys={3: d_ir}, workspace=ws))
             dXh = ib['d_init']
         L.check(lib.nero_mc_dir_bwd(_p(S['pt']), _p(S['dirs']), _p(S['fnrm']), _p(S['slot']), _p(K.tab_s), _p(dXm), _p(dXh), _p(d_w),
-                                    Pn, Dd, Ds, _p(d_mat5), st))
+                                    Pn, Dd, Ds, _p(d_mat5), K.sphere, _p(dXhum), _p(S['poses']), st))
         grads = []
         for nm, shape in zip(S['names'], S['shapes']):
             g = G.get(nm)
             grads.append(g if g is not None else torch.zeros(shape, **f32))
         ctx.S = None
-        return (None, None, None, None, None, None, d_mat5, None, None) + tuple(grads)
+        return (None, None, None, None, None, None, d_mat5, None, None, None) + tuple(grads)

@@ -296,7 +296,8 @@ class NeROMaterialRenderer(nn.Module):
         else:
             rand_d = rand_s = None
         mat5 = torch.cat([metallic, rough, albedo], -1)
-        rgb_lin, dl, sl, sp = MCShade.apply(K, self.ray_tracer, names[40:], pts, view_dirs, normals, mat5, rand_d, rand_s, *eff[40:])
+        rgb_lin, dl, sl, sp = MCShade.apply(K, self.ray_tracer, names[40:], pts, view_dirs, normals, mat5, rand_d, rand_s, human_poses,
+                                            *eff[40:])
         kd = 1 - metallic
         outputs = {
             'rgb_pr': linear_to_srgb(rgb_lin), 'albedo': albedo, 'roughness': rough, 'metallic': metallic,
