@@ -346,6 +346,71 @@ class NeROMaterialRenderer(nn.Module):
             return torch.sqrt(torch.sum((rgb_gt - rgb_pr) ** 2, dim=-1) + 0.001)
         raise NotImplementedError
 
+    # ---- dataset pre-trace: every training pixel -> surface sample, resident in HBM (network/renderer.py:756-808)
+    def get_human_coordinate_poses(self, poses):
+        return NeROShapeRenderer.get_human_coordinate_poses(self, poses)
+
+    def trace_in_batch(self, rays_o, rays_d, batch_size=1024 ** 2):
+        outs = [self.trace(rays_o[i:i + batch_size], rays_d[i:i + batch_size]) for i in range(0, rays_o.shape[0], batch_size)]
+        return tuple(torch.cat(x, 0) for x in zip(*outs))
+
+    def set_ray_pool(self, imgs, Ks, poses, device=None):
+        """imgs [imn,h,w,3] in [0,1], Ks [imn,3,3], poses [imn,3,4].  Traces all imn*h*w camera rays through the mesh on the device
+        (chunks of 2^20 like the reference) and keeps the hits as the training pool -- no host round trip, and one human-frame
+        pose per IMAGE (indexed per sample) instead of the reference's per-pixel [N,3,4] copy."""
+        device = device or next(self.parameters()).device
+        imn, h, w, _ = imgs.shape
+        ys, xs = torch.meshgrid(torch.arange(h, device=device), torch.arange(w, device=device), indexing='ij')
+        coords = torch.stack([xs + 0.5, ys + 0.5, torch.ones_like(xs, dtype=torch.float32)], -1).reshape(1, h * w, 3).float()
+        poses = poses.to(device).float()
+        Rm, t = poses[:, :, :3], poses[:, :, 3:]
+        rays_d = torch.nn.functional.normalize((coords @ torch.inverse(Ks.to(device)).permute(0, 2, 1)) @ Rm, dim=-1)
+        rays_o = (-Rm.permute(0, 2, 1) @ t).permute(0, 2, 1).repeat(1, h * w, 1)
+        if float(torch.max(torch.norm(rays_o.reshape(-1, 3), dim=-1) + 1.0)) > 10.0:
+            print('warning!!! a camera is farther than 10 from the origin: beyond the ray tracer miss distance')
+        inters, normals, depth, hit = self.trace_in_batch(rays_o.reshape(-1, 3).contiguous(), rays_d.reshape(-1, 3).contiguous())
+        idx = torch.arange(imn, device=device).repeat_interleave(h * w)
+        rgb = imgs.to(device).reshape(-1, 3).float()
+        self._human_poses_img = self.get_human_coordinate_poses(poses)
+        keep = torch.nonzero(hit)[:, 0]
+        self.train_batch = {'rays_o': rays_o.reshape(-1, 3)[keep], 'rays_d': rays_d.reshape(-1, 3)[keep], 'inters': inters[keep],
+                            'normals': normals[keep], 'depth': depth[keep], 'img_idx': idx[keep], 'rgb': rgb[keep]}
+        self.tbn = keep.numel()
+        self._shuffle_train_batch()
+
+    def _shuffle_train_batch(self):
+        self.train_batch_i = 0
+        perm = torch.randperm(self.tbn, device=self.train_batch['rgb'].device)
+        self.train_batch = {k: v[perm] for k, v in self.train_batch.items()}
+
+    def train_step(self, step):
+        rn = self.cfg['train_ray_num']
+        s = slice(self.train_batch_i, self.train_batch_i + rn)
+        b = {k: v[s] for k, v in self.train_batch.items()}
+        out = self.shade_train(b['inters'], -b['rays_d'], b['normals'], self._human_poses_img[b['img_idx']], b['rgb'], step)
+        self.train_batch_i += rn
+        if self.train_batch_i + rn >= self.tbn:
+            self._shuffle_train_batch()
+        return out
+
+    def forward(self, data):
+        if 'eval' in data:
+            raise NotImplementedError('validation (test_step) is not on the HIP path yet')
+        return {k: v for k, v in self.train_step(data['step']).items() if not k.startswith('_')}
+
+    def predict_materials_of_vertices(self, vertices, batch_size=8192):
+        """extract_materials.py / NeROMaterialRenderer.predict_materials (network/renderer.py:903-915): per-vertex metallic,
+        roughness (square-rooted: the network predicts alpha = roughness^2), albedo as numpy arrays"""
+        kern = self._kernels()
+        out = {'metallic': [], 'roughness': [], 'albedo': []}
+        with torch.no_grad():
+            for i in range(0, vertices.shape[0], batch_size):
+                m, r, a = self.predict_materials(vertices[i:i + batch_size].float().contiguous(), kern)
+                out['metallic'].append(m.cpu().numpy())
+                out['roughness'].append(torch.sqrt(torch.clamp(r, min=1e-7)).cpu().numpy())
+                out['albedo'].append(a.cpu().numpy())
+        return {k: np.concatenate(v, 0) for k, v in out.items()}
+
     def shade_train(self, pts, view_dirs, normals, human_poses, rgb_gt, step, rand_d=None, rand_s=None, reg_ang=None, reg_eps=None):
         """the arithmetic of train_step (network/renderer.py:837-844) for an explicit batch"""
         reg_pts = self.regularization_points(pts, normals, reg_ang, reg_eps) if (self.cfg['reg_mat'] and self.shader_network.cfg['reg_change']) else None

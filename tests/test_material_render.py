@@ -89,3 +89,29 @@ def test_mc_shading_with_hip_tracer_close_to_oracle():
         out = net.shade(c('pts'), c('view'), c('normals'), c('human_poses'), True, meta['step'], c('rand_d'), c('rand_s'))
     err = (out['rgb_pr'].cpu() - torch.from_numpy(z['rgb'])).abs().max(-1)[0]
     assert (err < 1e-4).float().mean() > 0.7 and err.max() < 0.1
+
+
+def test_material_trainer_entry_point_and_pretrace():
+    """forward({'step':...}) over the device-side pre-traced pixel pool (camera rays through the HIP BVH) + per-vertex materials"""
+    from nero_amd.renderer import NeROMaterialRenderer
+    from nero_amd.synthetic import icosphere, look_at_pose
+    v, f = icosphere(4, 0.5, 0.15)
+    f = np.ascontiguousarray(f[:, ::-1])
+    torch.manual_seed(0)
+    net = NeROMaterialRenderer({'shader_cfg': dict(diffuse_sample_num=32, specular_sample_num=16, human_lights=True,
+                                                   outer_light_version='sphere_direction'),
+                                'database_name': 'real/x', 'train_ray_num': 128}, mesh=(v, f)).cuda()
+    rg = np.random.default_rng(0)
+    imgs = torch.from_numpy(rg.uniform(0, 1, (2, 48, 48, 3)).astype(np.float32))
+    K = torch.tensor([[60., 0, 24], [0, 60., 24], [0, 0, 1]]).repeat(2, 1, 1)
+    poses = torch.from_numpy(np.stack([look_at_pose(np.array(c, dtype=np.float64)) for c in ([2.5, 0, 0.5], [0, 2.5, 1.0])], 0))
+    net.set_ray_pool(imgs, K, poses)
+    assert 0.15 * 2 * 48 * 48 < net.tbn < 0.9 * 2 * 48 * 48
+    out = net({'step': 100})
+    for k in ('rgb_pr', 'rgb_gt', 'loss_rgb', 'loss_mat_reg', 'loss_diffuse_light', 'albedo', 'roughness', 'metallic', 'diffuse_light',
+              'specular_light', 'diffuse_color', 'specular_color', 'approximate_light', 'human_lights'):
+        assert k in out, k
+    (out['loss_rgb'].mean() + out['loss_mat_reg'].mean() + out['loss_diffuse_light'].mean()).backward()
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+    mats = net.predict_materials_of_vertices(torch.from_numpy(v).cuda())
+    assert mats['albedo'].shape == (v.shape[0], 3) and np.isfinite(mats['roughness']).all()
