@@ -217,6 +217,9 @@ int nero_shade_combine_bwd(const float* geo, const float* mat, const float* Ld, 
                            const float* lut, float exp_max, int n, const float* d_color, const float* d_occ /*or NULL*/, float* dLd,
                            float* dLs, float* dLi, float* dLo, float* dmat /*[rows,8]*/, float* d_geo /*[rows,8]*/,
                            const float* Lh, const float* hmask, float* dLh, void* stream);
+/* validation-only shader intermediates (inter_results=True, network/field.py:630-649): rec [n,32], layout in shade.hip */
+int nero_shade_inter_results(const float* geo, const float* mat, const float* Ld, const float* Ls, const float* Li, const float* Lo,
+                             const float* lut, float exp_max, int n, const float* Lh, const float* hmask, float* rec, void* stream);
 /* extra [rows,4] = { d_refl(3), d_rough } from nero_human_encode_bwd, or NULL */
 int nero_shade_encode_bwd(const float* geo, const float* mat, const float* dXd, const float* dXs, const float* dXi, const float* dmat,
                           int n, float* d_geo, float* dm_raw, float* dr_raw, float* da_raw, const float* extra, void* stream);

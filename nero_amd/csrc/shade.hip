@@ -412,6 +412,50 @@ __global__ void shade_combine_fwd_kernel(const float* __restrict__ geo, const fl
     }
 }
 
+// validation-only intermediates of the shader (inter_results=True, field.py:630-649): rec[k][32] =
+//  0-2 specular_albedo, 3-5 clamp(specular_ref), 6-8 clamp(sRGB(specular_light)), 9-11 clamp(sRGB(specular_color)),
+//  12-14 diffuse_albedo, 15-17 clamp(sRGB(diffuse_light)), 18-20 clamp(sRGB(diffuse_color)), 21 metallic, 22 roughness,
+//  23 clamp(occ_prob), 24-26 indirect_light*occ, 27-29 sRGB(human_light*weight), 30-31 unused
+__global__ void shade_inter_kernel(const float* __restrict__ geo, const float* __restrict__ mat, const float* __restrict__ Ld,
+                                   const float* __restrict__ Ls, const float* __restrict__ Li, const float* __restrict__ Lo,
+                                   const float* __restrict__ lut, float exp_max, int n, const float* __restrict__ Lh,
+                                   const float* __restrict__ hmask, float* __restrict__ rec) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float* mo = mat + (size_t)k * 8;
+    const float m = mo[0], r = mo[1];
+    const float nov = geo[(size_t)k * 8 + 3];
+    float f0, f1, a0, a1, a2, a3;
+    fg_fetch(lut, fminf(fmaxf(nov, 0.f), 1.f), fminf(fmaxf(r, 0.f), 1.f), f0, f1, a0, a1, a2, a3);
+    float hl[3] = {0.f, 0.f, 0.f}, hw = 0.f;
+    if (Lh) {
+        const float hm = hmask[k];
+        for (int c = 0; c < 3; ++c) hl[c] = expf(fminf(Lh[(size_t)k * 4 + c], 0.f)) * hm;
+        hw = fminf(fmaxf(expf(fminf(Lh[(size_t)k * 4 + 3], 0.f)) * hm, 0.f), 1.f);
+    }
+    const float oc = fminf(fmaxf(Lo[(size_t)k * 4] * 0.5f + 0.5f, 0.f), 1.f);
+    float* o = rec + (size_t)k * 32;
+    for (int c = 0; c < 3; ++c) {
+        const float a = mo[2 + c];
+        const float dl = expf(fminf(Ld[(size_t)k * 4 + c], exp_max));
+        const float direct = expf(fminf(Ls[(size_t)k * 4 + c], exp_max));
+        const float indirect = expf(fminf(Li[(size_t)k * 4 + c], exp_max));
+        const float sl = indirect * oc + (hl[c] * hw + direct * (1.f - hw)) * (1.f - oc);
+        const float da = (1.f - m) * a, sa = 0.04f * (1.f - m) + m * a;
+        const float sref = sa * f0 + f1;
+        o[c] = sa;
+        o[3 + c] = fminf(fmaxf(sref, 0.f), 1.f);
+        o[6 + c] = fminf(fmaxf(srgb_f(sl), 0.f), 1.f);
+        o[9 + c] = fminf(fmaxf(srgb_f(sref * sl), 0.f), 1.f);
+        o[12 + c] = da;
+        o[15 + c] = fminf(fmaxf(srgb_f(dl), 0.f), 1.f);
+        o[18 + c] = fminf(fmaxf(srgb_f(da * dl), 0.f), 1.f);
+        o[24 + c] = indirect * oc;
+        o[27 + c] = srgb_f(hl[c] * hw);
+    }
+    o[21] = m; o[22] = r; o[23] = oc; o[30] = 0.f; o[31] = 0.f;
+}
+
 // backward of combine: writes the gradients of the RAW head outputs (dLd, dLs, dLi, dLo [rows,4]), the partial
 // material grads dmat[k] = { d_metallic, d_rough(LUT part), d_albedo(3) } and d_geo[k][3] = d_NoV (LUT part)
 __global__ void shade_combine_bwd_kernel(const float* __restrict__ geo, const float* __restrict__ mat, const float* __restrict__ Ld,
@@ -667,6 +711,13 @@ int nero_shade_combine_fwd(const float* geo, const float* mat, const float* Ld, 
     if (n == 0) return NERO_OK;
     hipLaunchKernelGGL(shade_combine_fwd_kernel, GRID1D(n), geo, mat, Ld, Ls, Li, Lo, lut, exp_max, n, color, occ_prob, Lh, hmask);
     return nero_check_launch("nero_shade_combine_fwd");
+}
+
+int nero_shade_inter_results(const float* geo, const float* mat, const float* Ld, const float* Ls, const float* Li, const float* Lo,
+                             const float* lut, float exp_max, int n, const float* Lh, const float* hmask, float* rec, void* stream) {
+    if (n == 0) return NERO_OK;
+    hipLaunchKernelGGL(shade_inter_kernel, GRID1D(n), geo, mat, Ld, Ls, Li, Lo, lut, exp_max, n, Lh, hmask, rec);
+    return nero_check_launch("nero_shade_inter_results");
 }
 
 int nero_shade_combine_bwd(const float* geo, const float* mat, const float* Ld, const float* Ls, const float* Li, const float* Lo,

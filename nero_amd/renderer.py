@@ -72,6 +72,7 @@ class NeROShapeRenderer(nn.Module):
         self.train_batch = {'dirs': dirs.reshape(-1, 3).contiguous(), 'rgbs': imgs.to(device).reshape(-1, 3).float().contiguous(),
                             'idxs': torch.arange(imn, device=device).repeat_interleave(h * w)}
         self.tbn = imn * h * w
+        self._test_views = [(poses[i].cpu().numpy(), Ks[i].cpu().numpy(), (h, w)) for i in range(imn)]
         self._shuffle_train_batch()
 
     def _shuffle_train_batch(self):
@@ -101,11 +102,62 @@ class NeROShapeRenderer(nn.Module):
         outputs['loss_rgb'] = self.compute_rgb_loss(outputs['ray_rgb'], batch['rgbs'])
         return outputs
 
+    def render_image(self, pose, K, h, w, step=300000, chunk=None, extras=False):
+        """nvs / test_step inner loop (network/renderer.py:189-222, 301-307): render one h x w view in chunks of test_ray_num rays,
+        perturb 0, no grad.  -> dict of [h*w, C] tensors (ray_rgb; with extras=True also the validation intermediates)"""
+        dev = next(self.parameters()).device
+        chunk = chunk or self.cfg['test_ray_num']
+        K = torch.as_tensor(np.asarray(K, np.float32), device=dev).reshape(1, 3, 3)
+        pose = torch.as_tensor(np.asarray(pose, np.float32), device=dev).reshape(1, 3, 4)
+        ys, xs = torch.meshgrid(torch.arange(h, device=dev), torch.arange(w, device=dev), indexing='ij')
+        coords = torch.stack([xs + 0.5, ys + 0.5, torch.ones_like(xs, dtype=torch.float32)], -1).reshape(h * w, 3).float()
+        dirs = coords @ torch.inverse(K)[0].T
+        hp_img = self.get_human_coordinate_poses(pose)
+        outs = {}
+        with torch.no_grad():
+            for i in range(0, h * w, chunk):
+                batch = {'dirs': dirs[i:i + chunk], 'idxs': torch.zeros(min(chunk, h * w - i), dtype=torch.long, device=dev)}
+                self._human_poses_img = hp_img
+                ro, rd, near, far, hp = self._process_ray_batch(batch, pose)
+                o = self.render(ro, rd, near, far, hp, 0, 0, is_train=not extras, step=step)
+                for k, v in o.items():
+                    if not k.startswith('_') and torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == ro.shape[0]:
+                        outs.setdefault(k, []).append(v)
+        return {k: torch.cat(v, 0) for k, v in outs.items()}
+
+    def extract_fields(self, bound_min=(-1., -1., -1.), bound_max=(1., 1., 1.), resolution=512, chunk=2 ** 21, outside_val=1.0):
+        """SDF on a resolution^3 grid for marching cubes (extract_fields, network/field.py:1090-1108; used by extract_mesh.py:24-27):
+        value-only SDF chain, points outside the unit sphere set to `outside_val`.  -> float32 numpy [res,res,res] (x,y,z order)"""
+        dev = next(self.parameters()).device
+        _, _, K = self._kernels()
+        axes = [torch.linspace(bound_min[a], bound_max[a], resolution, device=dev) for a in range(3)]
+        u = torch.empty(resolution ** 3, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for i in range(0, resolution ** 3, chunk):
+                idx = torch.arange(i, min(i + chunk, resolution ** 3), device=dev)
+                ix, iy, iz = idx // (resolution * resolution), (idx // resolution) % resolution, idx % resolution
+                pts = torch.stack([axes[0][ix], axes[1][iy], axes[2][iz]], -1).contiguous()
+                val = K.sdf.sdf(pts)[:, 0]
+                u[i:i + idx.numel()] = torch.where(torch.norm(pts, dim=-1) >= 1.0, torch.full_like(val, outside_val), val)
+        return u.reshape(resolution, resolution, resolution).cpu().numpy()
+
+    def nvs(self, pose, K, h, w):
+        """network/renderer.py:189-222 -> [h,w,3] numpy image"""
+        return self.render_image(pose, K, h, w)['ray_rgb'].reshape(h, w, 3).cpu().numpy()
+
+    def test_step(self, index, step):
+        """network/renderer.py:274-317 without the database-specific depth/mask lookup and the cv2 down-sampling (dataset IO is out
+        of scope): renders test view `index` of the pool's poses at full resolution with all validation outputs."""
+        pose, K, (h, w) = self._test_views[index]
+        out = self.render_image(pose, K, h, w, step=step, extras=True)
+        out['ray_rgb'] = out['ray_rgb'].reshape(h, w, 3)
+        return out
+
     def forward(self, data):
         """Trainer entry point (network/renderer.py:608-627).  No process-global default-tensor-type switch: every tensor is
         created on the parameters' device explicitly."""
         if 'eval' in data:
-            raise NotImplementedError('validation (test_step / compute_validation_info) is not on the HIP path yet')
+            return self.test_step(data['index'], step=data['step'])
         outputs = self.train_step(data['step'])
         return {k: v for k, v in outputs.items() if not k.startswith('_')}
 
@@ -178,9 +230,7 @@ class NeROShapeRenderer(nn.Module):
 
     def render_core(self, rays_o, rays_d, z_vals, human_poses, cos_anneal_ratio=0.0, step=None, is_train=True, _kern=None,
                     occ_keys=None):
-        from .shape_step import RenderCore, SDFValue, occ_loss
-        if not is_train:
-            raise NotImplementedError('validation extras (compute_validation_info) are not on the HIP path yet')
+        from .shape_step import RenderCore, SDFValue, occ_loss, validation_info
         names, eff, Kpre = _kern if _kern is not None else self._kernels()
         c = self.cfg
         meta = {'names': names, 'shapes': [tuple(t.shape) for t in eff], 'shader_cfg': self.color_network.cfg,
@@ -210,6 +260,10 @@ class NeROShapeRenderer(nn.Module):
             outputs['loss_occ'] = torch.zeros(1, device=rgb.device)
             if n_in > 0 and step is not None and step >= c['occ_loss_step']:
                 outputs['loss_occ'], outputs['_occ_count'] = occ_loss(S, occ_prob, c, var.detach(), occ_keys)
+        if not is_train:                                                    # renderer.py:603-604
+            with torch.no_grad():
+                outputs.update(validation_info(Kpre, c, self.color_network.cfg, self.color_network.FG_LUT, var.detach(),
+                                               rays_o.contiguous(), rays_d.contiguous(), z_vals, S['weights'], poses))
         outputs['_occ_prob'] = occ_prob
         outputs['_state'] = meta.get('_state')
         return outputs

@@ -371,6 +371,87 @@ class SDFValue(torch.autograd.Function):
         return (None, None) + tuple(out)
 
 
+def secondary_occlusion(K, o, dr, variance, sn0, sn1):
+    """get_intersection (network/field.py:454-484) for points o [P,3] inside the unit sphere and unit directions dr [P,3]:
+    sum of the sn1-1 section weights of the importance-resampled march = occlusion probability [P]"""
+    dev = o.device
+    lib, st = L.lib, _st()
+    f32 = dict(dtype=torch.float32, device=dev)
+    Pn = o.shape[0]
+    z = torch.empty((Pn, sn0), **f32)
+    L.check(lib.nero_occ_z(_p(o), _p(dr), Pn, sn0, _p(z), st))
+    pe = torch.empty((row_pad(Pn * sn0), 40), **f32)
+    L.check(lib.nero_ray_points_pe(_p(o), _p(dr), _p(z), sn0, 0, sn0, Pn, _p(pe), st))
+    s4 = K.sdf.sdf_from_pe(pe, Pn * sn0)
+    w = torch.empty((Pn, sn0 - 1), **f32)
+    L.check(lib.nero_section_weights(_p(z), _p(s4), 4, sn0, _p(variance), Pn, _p(w), _p(None), st))
+    z_new = torch.empty((Pn, sn1), **f32)
+    L.check(lib.nero_sample_pdf(_p(z), sn0, _p(w), sn0 - 1, sn0, sn1, Pn, _p(z_new), _p(None), st))
+    pe2 = torch.empty((row_pad(Pn * sn1), 40), **f32)
+    L.check(lib.nero_ray_points_pe(_p(o), _p(dr), _p(z_new), sn1, 0, sn1, Pn, _p(pe2), st))
+    s4b = K.sdf.sdf_from_pe(pe2, Pn * sn1)
+    gt = torch.empty(Pn, **f32)
+    L.check(lib.nero_section_weights(_p(z_new), _p(s4b), 4, sn1, _p(variance), Pn, _p(None), _p(gt), st))
+    return gt
+
+
+INTER_KEYS = (('specular_albedo', 0, 3), ('specular_ref', 3, 6), ('specular_light', 6, 9), ('specular_color', 9, 12),
+              ('diffuse_albedo', 12, 15), ('diffuse_light', 15, 18), ('diffuse_color', 18, 21), ('metallic', 21, 22),
+              ('roughness', 22, 23), ('occ_prob', 23, 24), ('indirect_light', 24, 27))
+
+
+def validation_info(K, cfg, shader_cfg, lut, variance, o, d, z_vals, weights, poses):
+    """compute_validation_info (network/renderer.py:465-482): expected depth, normal map, shader intermediates at the depth point
+    and the marched occlusion probability (sn0=128, sn1=9).  No grad."""
+    dev = o.device
+    lib, st = L.lib, _st()
+    f32 = dict(dtype=torch.float32, device=dev)
+    R = o.shape[0]
+    depth = torch.sum(weights * z_vals, -1, keepdim=True)
+    pts = (depth * d + o).contiguous()
+    inner = (torch.norm(pts, dim=-1, keepdim=True) <= 1.0).float()
+    rp = row_pad(R)
+    x4 = torch.zeros((rp, 4), **f32)
+    x4[:R, :3] = pts
+    sctx = K.sdf.forward_normal(x4, R)
+    grad = sctx['normal']
+    out = {'depth': depth, 'normal': ((torch.nn.functional.normalize(grad, dim=-1) + 1.0) * 0.5) * inner}
+    idx = torch.arange(R, dtype=torch.int32, device=dev)            # sample k belongs to ray k (T = 1)
+    alpha, geo, gerr = torch.empty(rp, **f32), torch.empty((rp, 8), **f32), torch.empty(rp, **f32)
+    L.check(lib.nero_sdf_alpha_fwd(_p(sctx['sdf4']), _p(grad), _p(x4), _p(idx), _p(d), 1, _p(variance), C.c_float(0.0), R,
+                                   _p(alpha), _p(geo), _p(gerr), st))
+    x8 = torch.zeros((rp, 8), **f32)
+    x8[:, :3] = x4[:, :3]
+    mats = [c.forward(sctx['feat'], x8, R, save=False) for c in K.mat]
+    mat = torch.empty((rp, 8), **f32)
+    Xo2, Xi, Xo = torch.empty((2 * rp, 72), **f32), torch.empty((rp, 128), **f32), torch.empty((rp, 96), **f32)
+    L.check(lib.nero_shade_encode(_p(x4), _p(geo), _p(mats[0]['heads'][3]), _p(mats[1]['heads'][3]), _p(mats[2]['heads'][3]), R,
+                                  _p(mat), _p(Xo2[:rp]), _p(Xo2[rp:]), _p(Xi), _p(Xo), st))
+    Lh2 = K.outer_light.forward(Xo2, None, rp + R, save=False)['heads'][3]
+    Li = K.inner_light.forward(Xi, None, R, save=False)['heads'][3]
+    Lo = K.inner_weight.forward(Xo, None, R, save=False)['heads'][3]
+    Lhum = hmask = None
+    if K.human:
+        Xh, hmask = torch.empty((rp, 24), **f32), torch.empty(rp, **f32)
+        L.check(lib.nero_human_encode(_p(x4), _p(geo), _p(mat), _p(idx), 1, _p(poses), R, _p(Xh), _p(hmask), st))
+        Lhum = K.human_light.forward(Xh, None, R, save=False)['heads'][3]
+    rec = torch.empty((R, 32), **f32)
+    L.check(lib.nero_shade_inter_results(_p(geo), _p(mat), _p(Lh2[:rp]), _p(Lh2[rp:]), _p(Li), _p(Lo), _p(lut),
+                                         C.c_float(shader_cfg['light_exp_max']), R, _p(Lhum), _p(hmask), _p(rec), st))
+    for k, a, b in INTER_KEYS:
+        out[k] = rec[:, a:b] * inner
+    if K.human:
+        out['human_light'] = rec[:, 27:30] * inner
+    # marched occlusion along the reflected ray; points at |p| >= 0.999 report 0 (field.py:464-470)
+    inside = torch.norm(pts, dim=-1) < 0.999
+    gt = torch.zeros((R, 1), **f32)
+    sel = torch.nonzero(inside)[:, 0]
+    if sel.numel() > 0:
+        gt[sel, 0] = secondary_occlusion(K, pts[sel].contiguous(), geo[sel, 4:7].contiguous(), variance, 128, 9)
+    out['occ_prob_gt'] = gt
+    return out
+
+
 def occ_loss(S, occ_prob, cfg, variance, occ_keys=None):
     """compute_occ_loss (network/renderer.py:522-548): surface subset -> march the reflected ray to the unit sphere
     (64 uniform + 16 importance z, no grad) -> L1(occ_prob, sum of section weights)."""
@@ -391,21 +472,5 @@ def occ_loss(S, occ_prob, cfg, variance, occ_keys=None):
         Pn = cand.numel()
     if Pn == 0:
         return torch.zeros(1, device=dev), 0
-    o = S['x4'][cand, :3].contiguous()
-    dr = S['geo'][cand, 4:7].contiguous()
-    sn0, sn1 = 64, 16
-    z = torch.empty((Pn, sn0), **f32)
-    L.check(lib.nero_occ_z(_p(o), _p(dr), Pn, sn0, _p(z), st))
-    pe = torch.empty((row_pad(Pn * sn0), 40), **f32)
-    L.check(lib.nero_ray_points_pe(_p(o), _p(dr), _p(z), sn0, 0, sn0, Pn, _p(pe), st))
-    s4 = K.sdf.sdf_from_pe(pe, Pn * sn0)
-    w = torch.empty((Pn, sn0 - 1), **f32)
-    L.check(lib.nero_section_weights(_p(z), _p(s4), 4, sn0, _p(variance), Pn, _p(w), _p(None), st))
-    z_new = torch.empty((Pn, sn1), **f32)
-    L.check(lib.nero_sample_pdf(_p(z), sn0, _p(w), sn0 - 1, sn0, sn1, Pn, _p(z_new), _p(None), st))
-    pe2 = torch.empty((row_pad(Pn * sn1), 40), **f32)
-    L.check(lib.nero_ray_points_pe(_p(o), _p(dr), _p(z_new), sn1, 0, sn1, Pn, _p(pe2), st))
-    s4b = K.sdf.sdf_from_pe(pe2, Pn * sn1)
-    gt = torch.empty(Pn, **f32)
-    L.check(lib.nero_section_weights(_p(z_new), _p(s4b), 4, sn1, _p(variance), Pn, _p(None), _p(gt), st))
+    gt = secondary_occlusion(K, S['x4'][cand, :3].contiguous(), S['geo'][cand, 4:7].contiguous(), variance, 64, 16)
     return torch.nn.functional.l1_loss(occ_prob[cand], gt), Pn

@@ -115,6 +115,26 @@ def run_case(name, cfg, R, step, variance, seed=6033, occ_keys_seed=None):
     print(name, 'loss', loss.item(), 'N_in', out['gradient_error'].shape[0], 'loss_occ', float(out['loss_occ']))
 
 
+def run_validation_case(name, cfg, R, step, variance, seed=6033):
+    """is_train=False render of the unmodified reference (test_step's inner call, renderer.py:304): all validation outputs"""
+    renderer, field = ref_shim.load_reference()
+    torch.manual_seed(seed)
+    net = renderer.NeROShapeRenderer(cfg, training=False)
+    perturb_state(net, variance)
+    o, d, poses_img, gt = synthetic_rays(R, seed=1, window=200)
+    near, far = net.near_far_from_sphere(o, d)
+    hp = torch.cat([net.get_human_coordinate_poses(poses_img[i:i + 1].clone()) for i in range(R)], 0)
+    with torch.no_grad():
+        out = net.render(o, d, near, far, hp, 0, 0, is_train=False, step=step)
+    rec = dict(meta=json.dumps(dict(name=name, cfg=cfg, R=R, step=step, variance=variance, seed=seed, anneal=0.0)),
+               o=o.numpy(), d=d.numpy(), near=near.numpy(), far=far.numpy(), human_poses=hp.numpy())
+    for k, v in out.items():
+        if torch.is_tensor(v):
+            rec['out/' + k] = v.detach().numpy()
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **rec)
+    print(name, sorted(k for k in out.keys()))
+
+
 def run_material_case(name, shader_cfg, P_, step, seed=6033):
     """MCShadingNetwork.forward + material_regularization + diffuse-light regulariser of the unmodified reference on surface points
     of a bumpy icosphere, traced by the brute-force oracle tracer behind NeROMaterialRenderer.trace's contract."""
@@ -229,6 +249,8 @@ if __name__ == '__main__':
     run_case('bell_occcap', dict(small, occ_loss_max_pn=24), R=48, step=25000, variance=0.5, occ_keys_seed=5)
     run_case('bell_c1', dict(n_samples=32, n_importance=32, n_bg_samples=32), R=32, step=25000, variance=0.3)
     run_case('bell_s500', dict(small, freeze_inv_s_step=15000), R=48, step=500, variance=0.3)
+    run_validation_case('bell_val', dict(small), R=48, step=25000, variance=0.5)
+    run_validation_case('bear_val', dict(small, shader_config={'human_light': True}), R=48, step=25000, variance=0.5)
     msmall = dict(diffuse_sample_num=16, specular_sample_num=8)
     run_material_case('mat_bell', dict(msmall, human_lights=False, outer_light_version='direction'), P_=24, step=5000)
     run_material_case('mat_bell_early', dict(msmall, human_lights=False, outer_light_version='direction'), P_=24, step=500)

@@ -553,6 +553,21 @@ def render_core(P, cfg, o, d, z_vals, poses, cos_anneal, step, occ_keys=None):
     return out
 
 
+def validation_info(P, cfg, o, d, z_vals, weights, poses):
+    """compute_validation_info (network/renderer.py:465-482), inference only"""
+    cfg = {**DEFAULT_CFG, **cfg}
+    depth = torch.sum(weights * z_vals, -1, keepdim=True)
+    pts = depth * d + o
+    y, grad = sdf_value_and_normal(P, pts)
+    inner = (torch.norm(pts, dim=-1, keepdim=True) <= 1.0).float()
+    out = {'depth': depth, 'normal': ((F.normalize(grad, dim=-1) + 1.0) * 0.5) * inner}
+    _, occ_info, inter = app_shading(P, cfg['shader_config'], pts, grad, -F.normalize(d, dim=-1), y[:, 1:], poses, want_inter=True)
+    out['occ_prob_gt'] = secondary_ray_occlusion(P, pts.detach(), occ_info['reflective'].detach(), 128, 9)
+    for k, v in inter.items():
+        out[k] = v * inner
+    return {k: v.detach() for k, v in out.items()}
+
+
 def rgb_loss(cfg, pr, gt):
     """network/renderer.py:332-344."""
     kind = {**DEFAULT_CFG, **cfg}['rgb_loss']

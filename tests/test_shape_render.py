@@ -185,3 +185,50 @@ def test_trainer_entry_point_with_database_object():
     loss = out['loss_rgb'].mean() + (out['gradient_error'] * 0.1).mean() + out['loss_occ'].mean()
     loss.backward()
     assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+
+
+@pytest.mark.parametrize('name', ['bell_val', 'bear_val'])
+def test_validation_path(name):
+    """is_train=False: ray_rgb + compute_validation_info outputs (depth, normal, shader intermediates, marched occlusion)
+    vs the oracle on the same z_vals, and render_image / nvs plumbing"""
+    from tests.test_oracle_golden import VAL_KEYS
+    z, meta = load_golden(name)
+    net = build_case_model(meta).cuda()
+    P = _oracle_P(net)
+    cfg = {**O.DEFAULT_CFG, **meta['cfg']}
+    with torch.no_grad():
+        zv = O.sample_ray(P, cfg, T(z, 'o'), T(z, 'd'), T(z, 'near'), T(z, 'far'))
+        oo = O.render_core(P, cfg, T(z, 'o'), T(z, 'd'), zv, T(z, 'human_poses'), 0.0, meta['step'])
+        val = O.validation_info(P, cfg, T(z, 'o'), T(z, 'd'), zv, oo['weights'], T(z, 'human_poses'))
+        out = net.render(T(z, 'o', 'cuda'), T(z, 'd', 'cuda'), T(z, 'near', 'cuda'), T(z, 'far', 'cuda'), T(z, 'human_poses', 'cuda'),
+                         0, 0, is_train=False, step=meta['step'], z_vals=zv.cuda())
+    assert rel(out['ray_rgb'], oo['ray_rgb']) < 1e-4
+    keys = VAL_KEYS + (['human_light'] if name.startswith('bear') else [])
+    for k in keys:
+        assert out[k].shape == val[k].shape, k
+        assert rel(out[k], val[k]) < (2e-3 if k == 'occ_prob_gt' else 2e-4), (k, rel(out[k], val[k]))
+
+
+def test_nvs_renders_an_image():
+    from nero_amd.renderer import NeROShapeRenderer
+    from nero_amd.synthetic import look_at_pose
+    torch.manual_seed(2)
+    net = NeROShapeRenderer({'n_samples': 16, 'n_importance': 16, 'n_bg_samples': 8, 'test_ray_num': 500}, training=False).cuda()
+    K = np.array([[30., 0, 12], [0, 30., 12], [0, 0, 1]], np.float32)
+    img = net.nvs(look_at_pose(np.array([0., -3., 1.])), K, 24, 24)
+    assert img.shape == (24, 24, 3) and np.isfinite(img).all() and img.std() > 1e-3
+
+
+def test_extract_fields_grid():
+    """SDF grid for mesh extraction (field.py:1090-1108) vs the oracle's SDF on the same grid points"""
+    z, meta = load_golden('bell_s25000')
+    net = build_case_model(meta).cuda()
+    u = net.extract_fields(resolution=24, chunk=5000)
+    P = _oracle_P(net)
+    ax = torch.linspace(-1, 1, 24)
+    g = torch.stack(torch.meshgrid(ax, ax, ax, indexing='ij'), -1).reshape(-1, 3)
+    with torch.no_grad():
+        ref = O.sdf_network(P, g)[:, 0]
+    ref = torch.where(torch.norm(g, dim=-1) >= 1.0, torch.ones_like(ref), ref).reshape(24, 24, 24)
+    assert np.abs(u - ref.numpy()).max() < 2e-5
+    assert (u < 0).sum() > 10
