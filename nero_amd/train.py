@@ -65,6 +65,17 @@ class ShapeTrainStep:
         self.cursor = 0
         if device != 'cpu':
             self.prime_allocator()
+            self._lazy_init()
+
+    def _lazy_init(self):
+        """one 64-ray render so that one-time costs (library load, hipFuncSetAttribute, IDE table upload, kernel code objects)
+        are paid at construction, not inside the first training step"""
+        o, d = self.pool['o'][:64], self.pool['d'][:64]
+        near, far = self.net.near_far_from_sphere(o, d)
+        out = self.net.render(o, d, near, far, None, -1, 0.5, is_train=True, step=25000)
+        shape_training_loss(self.net, out, self.pool['gt'][:64], 25000).backward()
+        self.opt.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
 
     def prime_allocator(self, fraction=0.35):
         """Reserve one large HBM segment up front (default 35 % of the free memory, ~100 GB of the 288 GB) and hand it to

@@ -232,3 +232,21 @@ def test_extract_fields_grid():
     ref = torch.where(torch.norm(g, dim=-1) >= 1.0, torch.ones_like(ref), ref).reshape(24, 24, 24)
     assert np.abs(u - ref.numpy()).max() < 2e-5
     assert (u < 0).sum() > 10
+
+
+def test_training_reduces_the_loss():
+    """functional check of the whole loop (render -> loss -> backward -> all-reduce(no-op) -> Adam): the rgb loss on a fixed small
+    batch drops when the same batch is fitted for a few dozen steps"""
+    from nero_amd.train import ShapeTrainStep
+    ts = ShapeTrainStep({'n_samples': 16, 'n_importance': 16, 'n_bg_samples': 8, 'freeze_inv_s_step': 15000}, rays_per_rank=256,
+                        pool_rays=256, device='cuda:0', variance=0.3)
+    ts.pool['gt'] = (0.5 + 0.5 * torch.sin(ts.pool['d'] * 3.0)).contiguous()       # a smooth, learnable target
+    first = last = None
+    for i in range(40):
+        ts.cursor = 0
+        info = ts.step(6000 + i)
+        v = float(info['loss'])
+        first = v if first is None else first
+        last = v
+        assert np.isfinite(v)
+    assert last < 0.8 * first, (first, last)
