@@ -17,9 +17,15 @@ class RayTracer:
         assert triangles.shape[0] > 8, "BVH needs at least 8 triangles."          # same guard as the reference wrapper (:16)
         self._v = np.ascontiguousarray(vertices, dtype=np.float32)
         self._f = np.ascontiguousarray(triangles, dtype=np.int32)
-        self._h = C.c_void_p()
-        L.check(L.lib.nero_bvh_create(self._v.ctypes.data_as(C.c_void_p), self._v.shape[0], self._f.ctypes.data_as(C.c_void_p),
-                                      self._f.shape[0], C.byref(self._h)))
+        self._h = None                       # the device BVH is built on first use (construction works without a GPU)
+
+    def _handle(self):
+        if self._h is None:
+            h = C.c_void_p()
+            L.check(L.lib.nero_bvh_create(self._v.ctypes.data_as(C.c_void_p), self._v.shape[0], self._f.ctypes.data_as(C.c_void_p),
+                                          self._f.shape[0], C.byref(h)))
+            self._h = h
+        return self._h
 
     def __del__(self):
         try:
@@ -45,7 +51,7 @@ class RayTracer:
         depth = torch.empty(n, dtype=torch.float32, device=rays_o.device)
         if inplace:                      # the kernel reads o/d before it writes: each thread owns its ray
             pass
-        L.check(L.lib.nero_bvh_trace(self._h, C.c_void_p(rays_o.data_ptr()), C.c_void_p(rays_d.data_ptr()), n,
+        L.check(L.lib.nero_bvh_trace(self._handle(), C.c_void_p(rays_o.data_ptr()), C.c_void_p(rays_d.data_ptr()), n,
                                      C.c_void_p(positions.data_ptr()), C.c_void_p(face_normals.data_ptr()),
                                      C.c_void_p(depth.data_ptr()), L.stream_ptr()))
         return positions.view(*prefix, 3), face_normals.view(*prefix, 3), depth.view(*prefix)
