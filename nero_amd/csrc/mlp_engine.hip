@@ -706,11 +706,13 @@ int nero_mlp_backward(const nero_bwd_chain* ch, int n_rows, void* stream) {
 }
 
 int nero_dw_workspace_floats(int n_rows) {
-    const int rps = dw_rows_per_slice(n_rows < 1 ? 1 : n_rows);
-    const int slices = ((n_rows < 1 ? 1 : n_rows) + rps - 1) / rps;
-    const int head_blocks = ((n_rows < 1 ? 1 : n_rows) + 127) / 128;
-    const int a = slices * (256 * 256 + 256), b = head_blocks * (4 * NERO_HID + 4);
-    return a > b ? a : b;                       // one buffer serves nero_dw_gemm and nero_head_dw
+    // The slice count ceil(n / rows_per_slice(n)) is NOT monotonic in n (rows_per_slice rounds up to a multiple of 32), so a
+    // buffer sized for the largest job of a step could be too small for a smaller one.  Always size for the worst case:
+    // DW_MAX_SLICES partial matrices for nero_dw_gemm, one 4x256(+4) partial per 128-row block for nero_head_dw.
+    const int rows = n_rows < 1 ? 1 : n_rows;
+    const int head_blocks = (rows + 127) / 128;
+    const int a = DW_MAX_SLICES * (256 * 256 + 256), b = head_blocks * (4 * NERO_HID + 4);
+    return a > b ? a : b;
 }
 
 int nero_dw_gemm(const nero_dw_job* job, int n_rows, float* partials, void* stream) {

@@ -233,7 +233,7 @@ class NeROShapeRenderer(nn.Module):
         from .shape_step import RenderCore, SDFValue, occ_loss, validation_info
         names, eff, Kpre = _kern if _kern is not None else self._kernels()
         c = self.cfg
-        meta = {'names': names, 'shapes': [tuple(t.shape) for t in eff], 'shader_cfg': self.color_network.cfg,
+        meta = {'names': names, 'shapes': [tuple(t.shape) for t in eff], 'shader_cfg': self.color_network.cfg, 'K': Kpre,
                 'anneal': float(cos_anneal_ratio), 'exp_max': float(self.color_network.cfg['light_exp_max']),
                 'freeze_inv_s': c['freeze_inv_s_step'] is not None and step < c['freeze_inv_s_step']}
         var = self.deviation_network.variance

@@ -166,7 +166,9 @@ class RenderCore(torch.autograd.Function):
         dev = o.device
         lib = L.lib
         st = _st()
-        K = ShapeKernels(unflatten_effective(meta['names'], [p.detach() for p in params]), meta['shader_cfg'], dev).pack()
+        K = meta.get('K')                   # packed once per step by the caller (sampler and render share it)
+        if K is None:
+            K = ShapeKernels(unflatten_effective(meta['names'], [p.detach() for p in params]), meta['shader_cfg'], dev).pack()
         R, T = z_vals.shape
         f32 = dict(dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)

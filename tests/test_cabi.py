@@ -33,3 +33,12 @@ def test_struct_layouts_match_header():
         sizes = [int(x) for x in subprocess.check_output([exe]).split()]
     mine = [ctypes.sizeof(t) for t in (L.FwdLayer, L.FwdChain, L.TanLayer, L.TanChain, L.BwdLayer, L.BwdChain, L.DwJob)]
     assert sizes == mine, (sizes, mine)
+
+
+def test_dw_workspace_is_worst_case_sized():
+    """regression: the split-K slice count is not monotonic in the row count, so the workspace query must not depend on it"""
+    lib = ctypes.CDLL(os.path.join(ROOT, 'nero_amd', 'libnero_hip.so'))
+    base = 256 * (256 * 256 + 256)
+    for n in (0, 1, 100, 8000, 8192, 8193, 300000, 1 << 22):
+        assert lib.nero_dw_workspace_floats(n) >= base
+    assert lib.nero_dw_workspace_floats(1 << 22) >= ((1 << 22) // 128) * 1028
