@@ -550,75 +550,116 @@ __global__ __launch_bounds__(512, 2) void dw_gemm_kernel(nero_dw_job job, int n_
     if (tid < n_pad) P[(size_t)n_pad * k_pad + tid] = bsum;
 }
 
-__global__ void dw_reduce_kernel(nero_dw_job job, const float* __restrict__ partials, int n_slices, int n_pad, int k_pad) {
+// partial reduction: block = 64 outputs x 4 slice groups (fixed order inside a group, groups combined in fixed order ->
+// deterministic), so ~1000 workgroups keep enough loads in flight to run at HBM speed
+__global__ __launch_bounds__(256) void dw_reduce_kernel(nero_dw_job job, const float* __restrict__ partials, int n_slices, int n_pad, int k_pad) {
+    __shared__ float red[4][64];
     const size_t per = (size_t)n_pad * k_pad + n_pad;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + lane;
     const int total = job.n_out * job.k_cols;
-    if (idx < total) {
-        const int n = idx / job.k_cols, k = idx - n * job.k_cols;
-        // fixed summation order (deterministic), 8 independent strands so the loads of 8 slices are in flight together
-        const float* p0 = partials + (size_t)n * k_pad + k;
-        float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int sl = 0;
-        for (; sl + 8 <= n_slices; sl += 8) {
+    const bool is_w = idx < total, is_b = !is_w && idx < total + job.n_out && job.db != nullptr;
+    float s = 0.f;
+    if (is_w || is_b) {
+        size_t off;
+        if (is_w) { const int n = idx / job.k_cols, k = idx - n * job.k_cols; off = (size_t)n * k_pad + k; }
+        else off = (size_t)n_pad * k_pad + (idx - total);
+        const int per_grp = (n_slices + 3) / 4;
+        const int s0 = grp * per_grp, s1 = min(n_slices, s0 + per_grp);
+        float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+        int sl = s0;
+        for (; sl + 4 <= s1; sl += 4) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc8[u] += p0[(size_t)(sl + u) * per];
+            for (int u = 0; u < 4; ++u) acc4[u] += partials[(size_t)(sl + u) * per + off];
         }
-        for (; sl < n_slices; ++sl) acc8[0] += p0[(size_t)sl * per];
-        const float s = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
-        float* o = job.dW + (size_t)n * job.ldw + job.col0 + k;
-        *o = job.accumulate ? *o + s * job.scale : s * job.scale;
-    } else if (idx < total + job.n_out && job.db) {
-        const int n = idx - total;
-        float s = 0.f;
-        for (int sl = 0; sl < n_slices; ++sl) s += partials[sl * per + (size_t)n_pad * k_pad + n];
-        job.db[n] = job.accumulate ? job.db[n] + s : s;
+        for (; sl < s1; ++sl) acc4[0] += partials[(size_t)sl * per + off];
+        s = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+    }
+    red[grp][lane] = s;
+    __syncthreads();
+    if (grp == 0 && (is_w || is_b)) {
+        const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        if (is_w) {
+            const int n = idx / job.k_cols, k = idx - n * job.k_cols;
+            float* o = job.dW + (size_t)n * job.ldw + job.col0 + k;
+            *o = job.accumulate ? *o + t * job.scale : t * job.scale;
+        } else {
+            const int n = idx - total;
+            job.db[n] = job.accumulate ? job.db[n] + t : t;
+        }
     }
 }
 
-// head weight gradient: thread k (256) accumulates dWh[j][k] over the slice's rows
+// head weight gradient: dWh[j][k] = sum_r dy[r][j] a[r][k] (+ extra[r][k] for j == 0).  Thread t owns columns 4(t&63)..+3 and the
+// rows r = r_begin + (t>>6) + 4i of the block's slice (16-byte loads, 4 independent row strands), strands combined through LDS.
 __global__ __launch_bounds__(256) void head_dw_kernel(const float* __restrict__ dy, const float* __restrict__ a,
                                                       const float* __restrict__ extra, int n_head, int n_rows,
                                                       int rows_per_slice, float* __restrict__ partials) {
-    const int k = threadIdx.x;
+    __shared__ float red[4][4][NERO_HID];
+    __shared__ float redb[4][4];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6, c4 = 4 * lane;
     const int r_begin = blockIdx.x * rows_per_slice;
     int r_end = r_begin + rows_per_slice;
     r_end = r_end < n_rows ? r_end : n_rows;
-    float s[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-    for (int r = r_begin; r < r_end; ++r) {
+    float4 s[4];
+    float sb[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 4; ++j) s[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int r = r_begin + grp; r < r_end; r += 4) {
         const float4 d = *reinterpret_cast<const float4*>(dy + (size_t)r * 4);
-        const float av = a[(size_t)r * NERO_HID + k];
-        s[0] = fmaf(d.x, av, s[0]); s[1] = fmaf(d.y, av, s[1]); s[2] = fmaf(d.z, av, s[2]); s[3] = fmaf(d.w, av, s[3]);
-        if (extra) s[0] += extra[(size_t)r * NERO_HID + k];
-        sb[0] += d.x; sb[1] += d.y; sb[2] += d.z; sb[3] += d.w;
-    }
-    float* P = partials + (size_t)blockIdx.x * (4 * NERO_HID + 4);
+        const float4 av = *reinterpret_cast<const float4*>(a + (size_t)r * NERO_HID + c4);
+        const float dj[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) P[j * NERO_HID + k] = s[j];
-    if (k < 4) P[4 * NERO_HID + k] = sb[k];
+        for (int j = 0; j < 4; ++j) {
+            s[j].x = fmaf(dj[j], av.x, s[j].x); s[j].y = fmaf(dj[j], av.y, s[j].y);
+            s[j].z = fmaf(dj[j], av.z, s[j].z); s[j].w = fmaf(dj[j], av.w, s[j].w);
+            sb[j] += dj[j];
+        }
+        if (extra) {
+            const float4 e = *reinterpret_cast<const float4*>(extra + (size_t)r * NERO_HID + c4);
+            s[0].x += e.x; s[0].y += e.y; s[0].z += e.z; s[0].w += e.w;
+        }
+    }
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(&red[grp][j][c4]) = s[j];
+    if (lane == 0) for (int j = 0; j < 4; ++j) redb[grp][j] = sb[j];
+    __syncthreads();
+    float* P = partials + (size_t)blockIdx.x * (4 * NERO_HID + 4);
+    for (int e = threadIdx.x; e < 4 * NERO_HID; e += 256) {
+        const int j = e >> 8, k = e & 255;
+        P[e] = (red[0][j][k] + red[1][j][k]) + (red[2][j][k] + red[3][j][k]);
+    }
+    if (threadIdx.x < 4) P[4 * NERO_HID + threadIdx.x] = (redb[0][threadIdx.x] + redb[1][threadIdx.x]) + (redb[2][threadIdx.x] + redb[3][threadIdx.x]);
     (void)n_head;
 }
 
-__global__ void head_dw_reduce_kernel(const float* __restrict__ partials, int n_slices, int n_head, float* __restrict__ dWh,
-                                      float* __restrict__ dbh, int accumulate) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void head_dw_reduce_kernel(const float* __restrict__ partials, int n_slices, int n_head, float* __restrict__ dWh,
+                                                             float* __restrict__ dbh, int accumulate) {
+    __shared__ float red[4][64];
     const size_t per = 4 * NERO_HID + 4;
-    if (idx < n_head * NERO_HID) {
-        float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int sl = 0;
-        for (; sl + 8 <= n_slices; sl += 8) {
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + lane;                   // [0, n_head*256) weights, then n_head biases
+    const int nw = n_head * NERO_HID;
+    const bool is_w = idx < nw, is_b = !is_w && idx < nw + n_head && dbh != nullptr;
+    float s = 0.f;
+    if (is_w || is_b) {
+        const size_t off = is_w ? (size_t)idx : (size_t)(4 * NERO_HID + (idx - nw));
+        const int per_grp = (n_slices + 3) / 4;
+        const int s0 = grp * per_grp, s1 = min(n_slices, s0 + per_grp);
+        float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+        int sl = s0;
+        for (; sl + 4 <= s1; sl += 4) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc8[u] += partials[(size_t)(sl + u) * per + idx];
+            for (int u = 0; u < 4; ++u) acc4[u] += partials[(size_t)(sl + u) * per + off];
         }
-        for (; sl < n_slices; ++sl) acc8[0] += partials[(size_t)sl * per + idx];
-        const float s = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
-        dWh[idx] = accumulate ? dWh[idx] + s : s;
-    } else if (idx < n_head * NERO_HID + n_head && dbh) {
-        const int j = idx - n_head * NERO_HID;
-        float s = 0.f;
-        for (int sl = 0; sl < n_slices; ++sl) s += partials[sl * per + 4 * NERO_HID + j];
-        dbh[j] = accumulate ? dbh[j] + s : s;
+        for (; sl < s1; ++sl) acc4[0] += partials[(size_t)sl * per + off];
+        s = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+    }
+    red[grp][lane] = s;
+    __syncthreads();
+    if (grp == 0 && (is_w || is_b)) {
+        const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        if (is_w) dWh[idx] = accumulate ? dWh[idx] + t : t;
+        else dbh[idx - nw] = accumulate ? dbh[idx - nw] + t : t;
     }
 }
 
@@ -728,7 +769,7 @@ int nero_dw_gemm(const nero_dw_job* job, int n_rows, float* partials, void* stre
     hipLaunchKernelGGL(dw_gemm_kernel, dim3(slices), dim3(512), lds, (hipStream_t)stream, *job, n_rows, rps, partials, n_pad, k_pad);
     nero_prof_end(NERO_K_DW, (hipStream_t)stream);
     const int total = job->n_out * job->k_cols + job->n_out;
-    hipLaunchKernelGGL(dw_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, *job, partials, slices, n_pad, k_pad);
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, (hipStream_t)stream, *job, partials, slices, n_pad, k_pad);
     return nero_check_launch("nero_dw_gemm");
 }
 
@@ -736,11 +777,11 @@ int nero_head_dw(const float* dy, const float* a, const float* extra, int n_head
                  float* partials, int accumulate, void* stream) {
     if (!dy || !a || !dWh || !partials || n_head < 1 || n_head > 4) return nero_fail(NERO_ERR_ARG, "nero_head_dw: bad argument");
     const int rows = n_rows < 1 ? 1 : n_rows;
-    int rps = 128;                                     // rows per block; partials reduced by 8-strand sums
+    int rps = 1024;                                    // rows per block (<= a few hundred partials to reduce)
     const int slices = (rows + rps - 1) / rps;
     hipLaunchKernelGGL(head_dw_kernel, dim3(slices), dim3(256), 0, (hipStream_t)stream, dy, a, extra, n_head, n_rows, rps, partials);
     const int total = n_head * NERO_HID + n_head;
-    hipLaunchKernelGGL(head_dw_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials, slices, n_head, dWh, dbh, accumulate);
+    hipLaunchKernelGGL(head_dw_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, (hipStream_t)stream, partials, slices, n_head, dWh, dbh, accumulate);
     return nero_check_launch("nero_head_dw");
 }
 

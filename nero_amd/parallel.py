@@ -22,3 +22,15 @@ def allreduce_mean_grads(params, world, group=None):
     flat.div_(world)
     for p, g in zip(params, torch._utils._unflatten_dense_tensors(flat, grads)):
         p.grad = g.contiguous()
+
+
+def global_count_weight(local_count, world, device, group=None):
+    """factor w such that  mean_over_ranks( w_r * sum_i v_ri / n_r )  ==  sum_ri v_ri / sum_r n_r :  the per-sample loss terms
+    whose sample count differs between ranks (the eikonal term is a mean over each rank's inner samples, network/renderer.py:574,
+    network/loss.py:42) then reproduce the single-process big-batch mean exactly.  One scalar all-reduce."""
+    if world <= 1:
+        return 1.0
+    t = torch.tensor([float(local_count)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, group=group)
+    total = float(t.item())
+    return float(local_count) * world / total if total > 0 else 1.0

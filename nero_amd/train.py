@@ -8,7 +8,7 @@ import numpy as np
 import torch
 import torch.distributed as dist  # noqa: F401
 
-from .parallel import allreduce_mean_grads, rank_slice
+from .parallel import allreduce_mean_grads, global_count_weight, rank_slice
 
 from .renderer import NeROShapeRenderer
 from .synthetic import perturb_state, synthetic_rays
@@ -23,10 +23,10 @@ def warm_up_cos_lr(step, total_step=300000, warm_up_end=5000, learning_rate=5e-4
     return f * learning_rate
 
 
-def shape_training_loss(net, out, gt, step, eikonal_weight=0.1):
+def shape_training_loss(net, out, gt, step, eikonal_weight=0.1, eikonal_rank_weight=1.0):
     """sum of the means of every `loss*` entry the reference's loss objects produce for the shape stage
     (train/trainer.py:127-137; network/loss.py: NeRFRenderLoss, EikonalLoss, OccLoss, InitSDFRegLoss)."""
-    loss = net.compute_rgb_loss(out['ray_rgb'], gt).mean() + (out['gradient_error'] * eikonal_weight).mean()
+    loss = net.compute_rgb_loss(out['ray_rgb'], gt).mean() + (out['gradient_error'] * eikonal_weight).mean() * eikonal_rank_weight
     if 'loss_occ' in out:
         loss = loss + out['loss_occ'].mean()
     if step < 1000 and 'sdf_vals' in out:
@@ -103,7 +103,9 @@ class ShapeTrainStep:
         o, d, gt = self._batch()
         near, far = net.near_far_from_sphere(o, d)
         out = net.render(o, d, near, far, None, -1, net.get_anneal_val(step), is_train=True, step=step)
-        loss = shape_training_loss(net, out, gt, step, self.eik_w)
+        # data parallel: the eikonal mean runs over each rank's own inner samples -> weight it by the global count
+        w = global_count_weight(out['_state']['n_in'], self.world, self.device)
+        loss = shape_training_loss(net, out, gt, step, self.eik_w, w)
         loss.backward()
         allreduce_mean_grads(self.params, self.world)
         self.opt.step()

@@ -18,7 +18,7 @@ def _small_net():
     return net
 
 
-def _grads(net, o, d, gt):
+def _grads(net, o, d, gt, weight_fn=None):
     from oracle import nero_oracle as O
     sd = {k: v for k, v in net.named_parameters()}
     sd.update({k: v for k, v in net.named_buffers()})
@@ -27,6 +27,8 @@ def _grads(net, o, d, gt):
     near, far = O.near_far_from_sphere(o, d)
     out = O.render(P, cfg, o, d, near, far, torch.zeros(o.shape[0], 3, 4), 5000, 0.1)
     loss = O.rgb_loss(cfg, out['ray_rgb'], gt).mean()          # ray-level mean: exact under equal shards
+    if weight_fn is not None:                                  # sample-level mean (eikonal): needs the global-count weight
+        loss = loss + (out['gradient_error'] * 0.1).mean() * weight_fn(out['n_inner'])
     for p in net.parameters():
         p.grad = None
     loss.backward()
@@ -38,13 +40,13 @@ def _worker(rank, world, port, ret):
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.set_num_threads(2)
-    from nero_amd.parallel import allreduce_mean_grads, rank_slice
+    from nero_amd.parallel import allreduce_mean_grads, global_count_weight, rank_slice
     from nero_amd.synthetic import synthetic_rays
     R = 6
     o, d, _, gt = synthetic_rays(world * R, seed=1, window=200)
     s = rank_slice(0, R, rank)
     net = _small_net()
-    params = _grads(net, o[s], d[s], gt[s])
+    params = _grads(net, o[s], d[s], gt[s], lambda n: global_count_weight(n, world, 'cpu'))
     allreduce_mean_grads(params, world)
     if rank == 0:
         ret['dp'] = [p.grad.clone() if p.grad is not None else None for p in params]
@@ -63,7 +65,7 @@ def test_two_rank_allreduce_matches_big_batch():
     o, d, _, gt = synthetic_rays(12, seed=1, window=200)
     torch.set_num_threads(4)
     net = _small_net()
-    params = _grads(net, o, d, gt)
+    params = _grads(net, o, d, gt, lambda n: 1.0)
     n = 0
     for p, g in zip(params, ret['dp']):
         ref = p.grad if p.grad is not None else torch.zeros_like(p)
