@@ -336,6 +336,18 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(nero_bwd_chain ch, int 
         const bool first = (L.a_prev == nullptr);
         if (first && ch.d_init == nullptr && !(ch.d_aux && L.w_aux_t)) break;
         const int nt = L.k_main_tiles;
+        // the saved activations this thread's row-major epilogue needs (16 rows x 16 bytes).  The first half is requested here,
+        // before the GEMM, so that its HBM latency hides behind the MFMA stream; the second half at the top of the epilogue
+        // (once the accumulators are dead) and is consumed after the first half.  Row bases are wave-uniform (SGPR), the
+        // per-thread part is just the column offset.
+        float4 apf[8];
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const size_t rbase = (size_t)(row0 + wv) * NERO_HID;
+        if (!first && 4 * lane < 32 * nt) {
+            const float* __restrict__ ap0 = L.a_prev + rbase;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) apf[it] = *reinterpret_cast<const float4*>(ap0 + it * 4 * NERO_HID + 4 * lane);
+        }
         if (L.n_out > 0) {
             f32x16 acc[2][2];
             // gradient w.r.t. the aux columns of this layer (skip connections), written straight out; done first so that
@@ -387,21 +399,24 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(nero_bwd_chain ch, int 
         if (first) break;
         // row-major pass: delta_prev = (g [+ dy_head W_head]) * act'(a_prev) [+ inj], rows >= n_rows zeroed
         const int ncols = 32 * nt, c4 = 4 * lane;
-        const float* __restrict__ ap = L.a_prev;
-        const float* __restrict__ inj = L.inj;
-        float* __restrict__ dprev = L.delta_prev;
+        const float* __restrict__ apb = L.a_prev + rbase;
+        const float* __restrict__ injb = L.inj ? L.inj + rbase : nullptr;
+        float* __restrict__ dpb = L.delta_prev ? L.delta_prev + rbase : nullptr;
+        const float* __restrict__ hdy = L.head_dy ? L.head_dy + (size_t)(row0 + wv) * 4 : nullptr;
+        float* actw = act + wv * LDA;
         const int nh = L.n_head, actp = L.act_prev;
         if (c4 < ncols) {
             float4 hw[4];
             for (int j = 0; j < 4; ++j) hw[j] = (j < nh) ? *reinterpret_cast<const float4*>(L.head_w + j * NERO_HID + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
+            float4 apg[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) apg[it] = *reinterpret_cast<const float4*>(apb + (it + 8) * 4 * NERO_HID + c4);
+#pragma unroll
             for (int it = 0; it < 16; ++it) {
-                const int row = 4 * it + wave;
-                const size_t g = (size_t)(row0 + row) * NERO_HID + c4;
-                const float4 a = *reinterpret_cast<const float4*>(ap + g);
-                float4 gs = *reinterpret_cast<const float4*>(act + row * LDA + c4);
+                const float4 a = it < 8 ? apf[it & 7] : apg[it & 7];
+                float4 gs = *reinterpret_cast<const float4*>(actw + it * 4 * LDA + c4);
                 if (nh > 0) {
-                    const float4 dyh = *reinterpret_cast<const float4*>(L.head_dy + (size_t)(row0 + row) * 4);
+                    const float4 dyh = *reinterpret_cast<const float4*>(hdy + it * 16);
                     const float dj[4] = {dyh.x, dyh.y, dyh.z, dyh.w};
                     for (int j = 0; j < 4; ++j) {
                         if (j < nh) {
@@ -413,13 +428,14 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(nero_bwd_chain ch, int 
                 float4 d;
                 d.x = act_grad(a.x, gs.x, actp); d.y = act_grad(a.y, gs.y, actp);
                 d.z = act_grad(a.z, gs.z, actp); d.w = act_grad(a.w, gs.w, actp);
-                if (inj) {
-                    const float4 ij = *reinterpret_cast<const float4*>(inj + g);
+                if (injb) {
+                    const float4 ij = *reinterpret_cast<const float4*>(injb + it * 4 * NERO_HID + c4);
                     d.x += ij.x; d.y += ij.y; d.z += ij.z; d.w += ij.w;
                 }
-                if (row0 + row >= n_rows) d = make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4*>(act + row * LDA + c4) = d;
-                if (dprev) *reinterpret_cast<float4*>(dprev + g) = d;
+                if (row0 + wv + 4 * it >= n_rows) d = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(actw + it * 4 * LDA + c4) = d;
+                if (dpb) *reinterpret_cast<float4*>(dpb + it * 4 * NERO_HID + c4) = d;
+                if ((it & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the unrolled pass from hoisting all 16 rows' loads
             }
         }
         __syncthreads();

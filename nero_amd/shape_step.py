@@ -182,7 +182,8 @@ class RenderCore(torch.autograd.Function):
         alphaRT = torch.zeros(R * T, **f32)
         colorRT = torch.zeros((R * T, 3), **f32)
         S = {'K': K, 'R': R, 'T': T, 'pts4': pts4, 'n_in': n_in, 'n_out': n_out, 'inner_idx': inner_idx, 'outer_idx': outer_idx,
-             'meta': meta, 'o': o, 'd': d, 'variance': variance, 'lut': lut}
+             'meta': {k: v for k, v in meta.items() if k != '_state'},   # a copy: meta['_state'] = S below must not close a cycle
+             'o': o, 'd': d, 'variance': variance, 'lut': lut}
 
         # ---- outer samples: NeRF++ -------------------------------------------------------------------------------
         if n_out > 0:

@@ -5,6 +5,8 @@ all-reduce over RCCL, Adam.  Mirrors Trainer.run's inner loop (train/trainer.py:
 import math
 
 import numpy as np
+import gc
+
 import torch
 import torch.distributed as dist  # noqa: F401
 
@@ -49,7 +51,7 @@ class ShapeTrainStep:
     (rank-strided); gradients are summed with ONE flat all-reduce per step and divided by world size."""
 
     def __init__(self, cfg, rays_per_rank=4096, pool_rays=262144, device='cuda', seed=6033, variance=None, eikonal_weight=0.1,
-                 rank=0, world=1):
+                 rank=0, world=1, prime_fraction=0.35):
         self.device, self.rank, self.world, self.R = device, rank, world, rays_per_rank
         torch.manual_seed(seed)
         self.net = NeROShapeRenderer(cfg, training=False)
@@ -64,8 +66,13 @@ class ShapeTrainStep:
         self.pool_n = pool_rays
         self.cursor = 0
         if device != 'cpu':
-            self.prime_allocator()
+            if prime_fraction > 0:
+                self.prime_allocator(prime_fraction)
             self._lazy_init()
+            # everything built so far (modules, packed-weight caches, ray pool) is long-lived: keep it out of the cyclic GC's
+            # generations, so that a periodic full collection does not stall a step walking it
+            gc.collect()
+            gc.freeze()
 
     def _lazy_init(self):
         """one 64-ray render so that one-time costs (library load, hipFuncSetAttribute, IDE table upload, kernel code objects)
@@ -77,12 +84,12 @@ class ShapeTrainStep:
         self.opt.zero_grad(set_to_none=True)
         torch.cuda.synchronize()
 
-    def prime_allocator(self, fraction=0.35):
-        """Reserve one large HBM segment up front (default 35 % of the free memory, ~100 GB of the 288 GB) and hand it to
-        torch's caching allocator: every per-step activation / gradient workspace is then carved out of it instead of
-        triggering hipMalloc (hundreds of ms for multi-GB segments) while the per-step sample counts fluctuate."""
+    def prime_allocator(self, fraction=0.35, cap_bytes=64 << 30):
+        """Reserve one large HBM segment up front (35 % of the free memory, at most 64 GB: a 4096-ray step peaks at ~30 GB)
+        and hand it to torch's caching allocator: every per-step activation / gradient workspace is then carved out of it
+        instead of triggering hipMalloc (hundreds of ms for multi-GB segments) while the per-step sample counts fluctuate."""
         free, _ = torch.cuda.mem_get_info(self.device)
-        n = int(free * fraction) // 4
+        n = min(int(free * fraction), cap_bytes) // 4
         t = torch.empty(n, dtype=torch.float32, device=self.device)
         del t
 

@@ -39,3 +39,6 @@ C_mat, C_outer, C_inner = 1078272, 150272, 163328
 D = Dd + Ds
 flop = 2 * 3 * (2 * C_mat + D * C_outer) * P_
 print(f'P={P_} D={Dd}+{Ds}: {dt*1e3:.1f} ms/step, {P_/dt:.0f} pts/s, {P_*D/dt/1e6:.1f} M light-rays/s, ~{flop/dt/1e12:.1f} TFLOP/s (hit-fraction~0 model)')
+import gc
+gc.collect(); gc.disable(); torch.cuda.synchronize(); m0 = torch.cuda.memory_allocated(); step(0); torch.cuda.synchronize()
+print(f'live memory before / after one more step without cyclic GC: {m0/2**30:.3f} / {torch.cuda.memory_allocated()/2**30:.3f} GB')
