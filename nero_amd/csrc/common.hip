@@ -22,6 +22,8 @@ extern "C" const char* nero_last_error(void) { return g_err; }
 extern "C" int nero_version(void) { return 100; }
 
 // ---- per-launch kernel timing (disabled by default) ----------------------------------------------------------------
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 namespace {
 struct ProfRec { hipEvent_t a, b; int kind; double flops; };
@@ -48,13 +50,18 @@ extern "C" int nero_prof_enable(int on) {
 // out[kind*3 + {0,1,2}] = {launches, total milliseconds, total algorithmic flops}; clears the records
 extern "C" int nero_prof_report(double* out /*host, 12 doubles*/) {
     for (int i = 0; i < NERO_K_COUNT * 3; ++i) out[i] = 0.0;
+    // NERO_PROF_DUMP=<file>: additionally append one "kind ms flops" line per launch (tuning aid)
+    const char* dump = getenv("NERO_PROF_DUMP");
+    FILE* df = dump ? fopen(dump, "a") : nullptr;
     for (auto& r : g_recs) {
         (void)hipEventSynchronize(r.b);
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, r.a, r.b);
         out[r.kind * 3 + 0] += 1.0; out[r.kind * 3 + 1] += ms; out[r.kind * 3 + 2] += r.flops;
+        if (df) fprintf(df, "%d %.4f %.0f\n", r.kind, ms, r.flops);
         (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
     }
+    if (df) fclose(df);
     g_recs.clear();
     return 0;
 }

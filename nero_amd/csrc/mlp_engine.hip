@@ -276,6 +276,21 @@ __global__ __launch_bounds__(256, 2) void mlp_tan_kernel(nero_tan_chain ch, int 
     __syncthreads();
     for (int l = 0; l < ch.n_layers; ++l) {
         const nero_tan_layer& L = ch.layer[l];
+        // saved activations / normal-pass gradients for the row-major epilogue: first halves requested before the GEMM (latency
+        // hidden behind the MFMA stream), second halves at the top of the epilogue; row bases are wave-uniform
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const size_t rbase = (size_t)(row0 + wv) * NERO_HID;
+        const int ncols = 32 * L.n_tiles, c4 = 4 * lane;
+        const float* __restrict__ asv = L.a_saved + rbase + c4;
+        const float* __restrict__ gbp = L.gbar + rbase + c4;
+        float4 pa[8], pg[8];
+        if (c4 < ncols) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                pa[it] = *reinterpret_cast<const float4*>(asv + it * 4 * NERO_HID);
+                pg[it] = *reinterpret_cast<const float4*>(gbp + it * 4 * NERO_HID);
+            }
+        }
         {
             f32x16 acc[2][2];
             zero_acc(acc);
@@ -286,28 +301,31 @@ __global__ __launch_bounds__(256, 2) void mlp_tan_kernel(nero_tan_chain ch, int 
             dump_acc(acc, act, wt, lane, nullptr);
         }
         __syncthreads();
-        const int ncols = 32 * L.n_tiles, c4 = 4 * lane;
-        const float* __restrict__ asv = L.a_saved;
-        const float* __restrict__ gbp = L.gbar;
-        float* __restrict__ adot = L.adot;
-        float* __restrict__ inj = L.inj;
+        float* __restrict__ adot = L.adot + rbase + c4;
+        float* __restrict__ inj = L.inj + rbase + c4;
+        float* actw = act + wv * LDA + c4;
         if (c4 < ncols) {
-#pragma unroll 4
+            float4 qa[8], qg[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                qa[it] = *reinterpret_cast<const float4*>(asv + (it + 8) * 4 * NERO_HID);
+                qg[it] = *reinterpret_cast<const float4*>(gbp + (it + 8) * 4 * NERO_HID);
+            }
+#pragma unroll
             for (int it = 0; it < 16; ++it) {
-                const int row = 4 * it + wave;
-                const size_t g = (size_t)(row0 + row) * NERO_HID + c4;
-                const float4 a = *reinterpret_cast<const float4*>(asv + g);
-                const float4 gb = *reinterpret_cast<const float4*>(gbp + g);
-                const float4 zd = *reinterpret_cast<const float4*>(act + row * LDA + c4);
-                const bool live = (row0 + row) < n_rows;
+                const float4 a = it < 8 ? pa[it & 7] : qa[it & 7];
+                const float4 gb = it < 8 ? pg[it & 7] : qg[it & 7];
+                const float4 zd = *reinterpret_cast<const float4*>(actw + it * 4 * LDA);
+                const bool live = (row0 + wv + 4 * it) < n_rows;
                 float4 ad, ij;
                 tan_elem(a.x, zd.x, gb.x, live, ad.x, ij.x);
                 tan_elem(a.y, zd.y, gb.y, live, ad.y, ij.y);
                 tan_elem(a.z, zd.z, gb.z, live, ad.z, ij.z);
                 tan_elem(a.w, zd.w, gb.w, live, ad.w, ij.w);
-                *reinterpret_cast<float4*>(act + row * LDA + c4) = ad;
-                *reinterpret_cast<float4*>(adot + g) = live ? ad : make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4*>(inj + g) = ij;
+                *reinterpret_cast<float4*>(actw + it * 4 * LDA) = ad;
+                *reinterpret_cast<float4*>(adot + it * 4 * NERO_HID) = live ? ad : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(inj + it * 4 * NERO_HID) = ij;
+                if ((it & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();
@@ -347,6 +365,13 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(nero_bwd_chain ch, int 
             const float* __restrict__ ap0 = L.a_prev + rbase;
 #pragma unroll
             for (int it = 0; it < 8; ++it) apf[it] = *reinterpret_cast<const float4*>(ap0 + it * 4 * NERO_HID + 4 * lane);
+        }
+        float4 ijf[4];
+        const bool has_inj = !first && L.inj != nullptr;
+        if (has_inj && 4 * lane < 32 * nt) {
+            const float* __restrict__ ij0 = L.inj + rbase;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) ijf[it] = *reinterpret_cast<const float4*>(ij0 + it * 4 * NERO_HID + 4 * lane);
         }
         if (L.n_out > 0) {
             f32x16 acc[2][2];
@@ -411,6 +436,11 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(nero_bwd_chain ch, int 
             float4 apg[8];
 #pragma unroll
             for (int it = 0; it < 8; ++it) apg[it] = *reinterpret_cast<const float4*>(apb + (it + 8) * 4 * NERO_HID + c4);
+            float4 ijg[12];
+            if (has_inj) {
+#pragma unroll
+                for (int it = 0; it < 12; ++it) ijg[it] = *reinterpret_cast<const float4*>(injb + (it + 4) * 4 * NERO_HID + c4);
+            }
 #pragma unroll
             for (int it = 0; it < 16; ++it) {
                 const float4 a = it < 8 ? apf[it & 7] : apg[it & 7];
@@ -428,8 +458,8 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(nero_bwd_chain ch, int 
                 float4 d;
                 d.x = act_grad(a.x, gs.x, actp); d.y = act_grad(a.y, gs.y, actp);
                 d.z = act_grad(a.z, gs.z, actp); d.w = act_grad(a.w, gs.w, actp);
-                if (injb) {
-                    const float4 ij = *reinterpret_cast<const float4*>(injb + it * 4 * NERO_HID + c4);
+                if (has_inj) {
+                    const float4 ij = it < 4 ? ijf[it & 3] : ijg[it < 4 ? 0 : it - 4];
                     d.x += ij.x; d.y += ij.y; d.z += ij.z; d.w += ij.w;
                 }
                 if (row0 + wv + 4 * it >= n_rows) d = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -478,11 +508,38 @@ __device__ __forceinline__ void dw_put(float* dst, const float4 (&v)[4], int tid
 // 512 threads = 8 waves in a 4(n) x 2(k) grid, 64x128 block per wave (2x4 tiles, 128 accumulator VGPRs).  Row chunks of 32
 // are double-buffered in LDS: the next chunk's 16-byte global loads are issued before the 128 MFMAs of the current chunk
 // and stored to the other buffer afterwards -- one barrier per chunk, HBM latency hidden behind the MFMA stream.
+// NARROW (k_pad <= 128: first layers, skip/aux column blocks): the 8 waves split n eight ways (one 32-row tile each) and
+// multiply only the k-tiles that exist, and only 128 columns of B are staged -- such jobs are then bound by streaming D, not
+// by MFMAs on zero padding.
+__device__ __forceinline__ void dw_fetch_narrow(float4 (&v)[4], const float* __restrict__ src, int ld, int cols, int r0, int r1, int tid) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int idx = tid + 512 * q;
+        const int r = idx >> 5, c4 = (idx & 31) * 4;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int gr = r0 + r;
+        if (gr < r1 && c4 < cols) {
+            const float* p = src + (size_t)gr * ld + c4;
+            if (c4 + 3 < cols) x = *reinterpret_cast<const float4*>(p);
+            else { x.x = p[0]; if (c4 + 1 < cols) x.y = p[1]; if (c4 + 2 < cols) x.z = p[2]; }
+        }
+        v[q] = x;
+    }
+}
+__device__ __forceinline__ void dw_put_narrow(float* dst, const float4 (&v)[4], int tid) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int idx = tid + 512 * q;
+        *reinterpret_cast<float4*>(dst + (idx >> 5) * DW_LD + (idx & 31) * 4) = v[q];
+    }
+}
+
+template <bool NARROW>
 __global__ __launch_bounds__(512, 2) void dw_gemm_kernel(nero_dw_job job, int n_rows, int rows_per_slice, float* __restrict__ partials,
                                                           int n_pad, int k_pad) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave >> 1, wk = wave & 1;
+    const int wn = NARROW ? wave : wave >> 1, wk = NARROW ? 0 : wave & 1;
     const int i = lane & 31, h = lane >> 5;
     const int r_begin = blockIdx.x * rows_per_slice;
     int r_end = r_begin + rows_per_slice;
@@ -496,15 +553,17 @@ __global__ __launch_bounds__(512, 2) void dw_gemm_kernel(nero_dw_job job, int n_
             for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
     float bsum = 0.f;                    // bias gradient: thread tid < 256 owns column tid of D0
     const int n_tiles = n_pad >> 5, k_tiles = k_pad >> 5;
-    const bool wave_live = (2 * wn < n_tiles) && (4 * wk < k_tiles);
+    const bool wave_live = NARROW ? (wn < n_tiles) : ((2 * wn < n_tiles) && (4 * wk < k_tiles));
     const int nch = r_end > r_begin ? (r_end - r_begin + DW_RC - 1) / DW_RC : 0;
     const int total = nch * (job.d1 ? 2 : 1);
     float4 pd[4], pb[4];
     if (total > 0) {
         dw_fetch(pd, job.d0, job.ldd0, job.n_out, r_begin, r_end, tid);
-        dw_fetch(pb, job.b0, job.ldb0, job.k_cols, r_begin, r_end, tid);
+        if (NARROW) dw_fetch_narrow(pb, job.b0, job.ldb0, job.k_cols, r_begin, r_end, tid);
+        else dw_fetch(pb, job.b0, job.ldb0, job.k_cols, r_begin, r_end, tid);
         dw_put(smem, pd, tid);
-        dw_put(smem + DW_BUF, pb, tid);
+        if (NARROW) dw_put_narrow(smem + DW_BUF, pb, tid);
+        else dw_put(smem + DW_BUF, pb, tid);
     }
     __syncthreads();
     for (int q = 0; q < total; ++q) {
@@ -516,33 +575,48 @@ __global__ __launch_bounds__(512, 2) void dw_gemm_kernel(nero_dw_job job, int n_
             const bool second = q1 >= nch;
             const int r0 = r_begin + (second ? q1 - nch : q1) * DW_RC;
             dw_fetch(pd, second ? job.d1 : job.d0, second ? job.ldd1 : job.ldd0, job.n_out, r0, r_end, tid);
-            dw_fetch(pb, second ? job.b1 : job.b0, second ? job.ldb1 : job.ldb0, job.k_cols, r0, r_end, tid);
+            if (NARROW) dw_fetch_narrow(pb, second ? job.b1 : job.b0, second ? job.ldb1 : job.ldb0, job.k_cols, r0, r_end, tid);
+            else dw_fetch(pb, second ? job.b1 : job.b0, second ? job.ldb1 : job.ldb0, job.k_cols, r0, r_end, tid);
         }
         if (q < nch && tid < 256) {
 #pragma unroll 8
             for (int r = 0; r < DW_RC; ++r) bsum += sD[r * DW_LD + tid];
         }
         if (wave_live) {
+            if (NARROW) {
 #pragma unroll 4
-            for (int j = 0; j < DW_RC / 2; ++j) {
-                const float* dr = sD + (2 * j + h) * DW_LD + 64 * wn + i;
-                const float* br = sB + (2 * j + h) * DW_LD + 128 * wk + i;
-                float a0 = dr[0], a1 = dr[32];
-                float b0 = br[0], b1 = br[32], b2 = br[64], b3 = br[96];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b2, acc[0][2], 0, 0, 0);
-                acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b3, acc[0][3], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-                acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b2, acc[1][2], 0, 0, 0);
-                acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b3, acc[1][3], 0, 0, 0);
+                for (int j = 0; j < DW_RC / 2; ++j) {
+                    const float* dr = sD + (2 * j + h) * DW_LD + 32 * wn + i;
+                    const float* br = sB + (2 * j + h) * DW_LD + i;
+                    const float a0 = dr[0];
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, br[0], acc[0][0], 0, 0, 0);
+                    if (k_tiles > 1) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, br[32], acc[0][1], 0, 0, 0);
+                    if (k_tiles > 2) acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, br[64], acc[0][2], 0, 0, 0);
+                    if (k_tiles > 3) acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, br[96], acc[0][3], 0, 0, 0);
+                }
+            } else {
+#pragma unroll 4
+                for (int j = 0; j < DW_RC / 2; ++j) {
+                    const float* dr = sD + (2 * j + h) * DW_LD + 64 * wn + i;
+                    const float* br = sB + (2 * j + h) * DW_LD + 128 * wk + i;
+                    float a0 = dr[0], a1 = dr[32];
+                    float b0 = br[0], b1 = br[32], b2 = br[64], b3 = br[96];
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b2, acc[0][2], 0, 0, 0);
+                    acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b3, acc[0][3], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                    acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b2, acc[1][2], 0, 0, 0);
+                    acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b3, acc[1][3], 0, 0, 0);
+                }
             }
         }
         if (more) {
             float* nD = smem + ((q + 1) & 1) * 2 * DW_BUF;
             dw_put(nD, pd, tid);
-            dw_put(nD + DW_BUF, pb, tid);
+            if (NARROW) dw_put_narrow(nD + DW_BUF, pb, tid);
+            else dw_put(nD + DW_BUF, pb, tid);
         }
         __syncthreads();
     }
@@ -553,8 +627,8 @@ __global__ __launch_bounds__(512, 2) void dw_gemm_kernel(nero_dw_job job, int n_
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                const int nt = 2 * wn + a, kt = 4 * wk + b;
-                if (nt < n_tiles && kt < k_tiles) {
+                const int nt = NARROW ? wn : 2 * wn + a, kt = 4 * wk + b;
+                if ((!NARROW || a == 0) && nt < n_tiles && kt < k_tiles) {
 #pragma unroll
                     for (int v = 0; v < 16; ++v) {
                         const int row = 32 * nt + (v & 3) + 8 * (v >> 2) + 4 * h;
@@ -780,9 +854,13 @@ int nero_dw_gemm(const nero_dw_job* job, int n_rows, float* partials, void* stre
     const int rps = dw_rows_per_slice(rows);
     const int slices = (rows + rps - 1) / rps;
     const int lds = 4 * DW_BUF * (int)sizeof(float);
-    NERO_ONCE(hipFuncSetAttribute((const void*)dw_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    NERO_ONCE(hipFuncSetAttribute((const void*)dw_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    NERO_ONCE(hipFuncSetAttribute((const void*)dw_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     nero_prof_begin(NERO_K_DW, 2.0 * job->n_out * job->k_cols * (job->d1 ? 2.0 : 1.0) * n_rows, (hipStream_t)stream);
-    hipLaunchKernelGGL(dw_gemm_kernel, dim3(slices), dim3(512), lds, (hipStream_t)stream, *job, n_rows, rps, partials, n_pad, k_pad);
+    if (k_pad <= 128)
+        hipLaunchKernelGGL(dw_gemm_kernel<true>, dim3(slices), dim3(512), lds, (hipStream_t)stream, *job, n_rows, rps, partials, n_pad, k_pad);
+    else
+        hipLaunchKernelGGL(dw_gemm_kernel<false>, dim3(slices), dim3(512), lds, (hipStream_t)stream, *job, n_rows, rps, partials, n_pad, k_pad);
     nero_prof_end(NERO_K_DW, (hipStream_t)stream);
     const int total = job->n_out * job->k_cols + job->n_out;
     hipLaunchKernelGGL(dw_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, (hipStream_t)stream, *job, partials, slices, n_pad, k_pad);
