@@ -26,6 +26,11 @@ extern "C" {
 #define NERO_HID 256              /* leading dimension of every saved hidden activation matrix */
 
 enum { NERO_ACT_NONE = 0, NERO_ACT_RELU = 1, NERO_ACT_SOFTPLUS100 = 2 };
+/* arithmetic of the dense layers.  F32: v_mfma_f32_32x32x2_f32, an exact fp32 fmaf chain (157 TFLOP/s peak).
+ * BF16X6: every fp32 operand is carried as three bf16 planes (exact 3-way split) and each product is the sum of the six
+ * significant plane products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- dropped terms <= 3*2^-27 relative, i.e.
+ * below fp32's own rounding; 417 TFLOP/s fp32-equivalent peak.  Packed operands are mode specific. */
+enum { NERO_GEMM_F32 = 0, NERO_GEMM_BF16X6 = 1 };
 enum { NERO_OK = 0, NERO_ERR_ARG = -1, NERO_ERR_LAUNCH = -2, NERO_ERR_UNSUPPORTED = -3 };
 
 const char* nero_last_error(void);
@@ -44,6 +49,12 @@ int nero_prof_report(double* out);
  * nn.Linear (network/field.py:142, 266, 325-331). */
 int nero_pack_weight(const float* W, int nrows, int ld, int col0, int ncols, int transpose, float scale,
                      int kpad, int nt_count, float* out, void* stream);
+/* NERO_GEMM_BF16X6 operand: same (W, window, transpose, scale) meaning; kpad is a multiple of 16 and the image holds three
+ * bf16 planes in A-fragment order, nt_count * (kpad/16) * 3072 bytes:
+ *   out[(((t*(kpad/16) + c)*3 + p)*64 + lane)*8 + j] = plane_p(A[32t + (lane&31)][16c + 8(lane>>5) + j]),
+ *   transpose == 0: A[m][k] = W[m][col0 + k] (M = nrows, K = ncols);  transpose == 1: A[m][k] = W[k][col0 + m] */
+int nero_pack_weight_split(const float* W, int nrows, int ld, int col0, int ncols, int transpose, float scale,
+                           int kpad, int nt_count, void* out, void* stream);
 
 /* ---- fused MLP chain ------------------------------------------------------------------------------------------
  * One workgroup owns a tile of 64 rows and walks the whole layer list with the activations resident in LDS; every
@@ -69,6 +80,8 @@ typedef struct {
     const float* aux;      /* [rows_pad, ld_aux]: first k_aux columns are loaded into the aux tile                    */
     int ld_init, k_init, ld_aux, k_aux;
     int n_layers, aux_wide; /* aux_wide: 0 -> aux tile holds <= 40 columns (2 workgroups/CU), 1 -> <= 88              */
+    int gemm_mode, pad_;    /* NERO_GEMM_*: the packed operands must have been built for the same mode; BF16X6 wants
+                               k_main / k_aux padded to multiples of 16                                               */
     double macs_per_row;    /* logical multiply-adds per row (profiling only)                                         */
     nero_fwd_layer layer[NERO_MAX_LAYERS];
 } nero_fwd_chain;
@@ -91,6 +104,7 @@ typedef struct {
     const float* init; const float* aux;
     int ld_init, k_init, ld_aux, k_aux;
     int n_layers, aux_wide;
+    int gemm_mode, pad_;
     double macs_per_row;
     nero_tan_layer layer[NERO_MAX_LAYERS];
 } nero_tan_chain;
@@ -121,6 +135,7 @@ typedef struct {
     float* d_aux;          /* out [rows_pad, ld_daux]  gradient w.r.t. the aux columns, summed over the layers using it */
     int ld_dinit, ld_daux, accumulate_dinit;
     int n_layers, aux_wide;
+    int gemm_mode;
     double macs_per_row;
     nero_bwd_layer layer[NERO_MAX_LAYERS];   /* in FORWARD order; walked from n_layers-1 down to 0                    */
 } nero_bwd_chain;

@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, 'libnero_hip.so')
 MAX_LAYERS = 10
 HID = 256
 ACT_NONE, ACT_RELU, ACT_SOFTPLUS100 = 0, 1, 2
+GEMM_F32, GEMM_BF16X6 = 0, 1
 
 _fp = C.c_void_p   # device pointers travel as integers
 
@@ -23,8 +24,8 @@ class FwdLayer(C.Structure):
 
 class FwdChain(C.Structure):
     _fields_ = [('init', _fp), ('aux', _fp), ('ld_init', C.c_int), ('k_init', C.c_int), ('ld_aux', C.c_int),
-                ('k_aux', C.c_int), ('n_layers', C.c_int), ('aux_wide', C.c_int), ('macs_per_row', C.c_double),
-                ('layer', FwdLayer * MAX_LAYERS)]
+                ('k_aux', C.c_int), ('n_layers', C.c_int), ('aux_wide', C.c_int), ('gemm_mode', C.c_int), ('pad_', C.c_int),
+                ('macs_per_row', C.c_double), ('layer', FwdLayer * MAX_LAYERS)]
 
 
 class TanLayer(C.Structure):
@@ -34,8 +35,8 @@ class TanLayer(C.Structure):
 
 class TanChain(C.Structure):
     _fields_ = [('init', _fp), ('aux', _fp), ('ld_init', C.c_int), ('k_init', C.c_int), ('ld_aux', C.c_int),
-                ('k_aux', C.c_int), ('n_layers', C.c_int), ('aux_wide', C.c_int), ('macs_per_row', C.c_double),
-                ('layer', TanLayer * MAX_LAYERS)]
+                ('k_aux', C.c_int), ('n_layers', C.c_int), ('aux_wide', C.c_int), ('gemm_mode', C.c_int), ('pad_', C.c_int),
+                ('macs_per_row', C.c_double), ('layer', TanLayer * MAX_LAYERS)]
 
 
 class BwdLayer(C.Structure):
@@ -47,7 +48,7 @@ class BwdLayer(C.Structure):
 class BwdChain(C.Structure):
     _fields_ = [('dy', _fp), ('ld_dy', C.c_int), ('k_dy', C.c_int), ('d_init', _fp), ('d_aux', _fp),
                 ('ld_dinit', C.c_int), ('ld_daux', C.c_int), ('accumulate_dinit', C.c_int), ('n_layers', C.c_int),
-                ('aux_wide', C.c_int), ('macs_per_row', C.c_double), ('layer', BwdLayer * MAX_LAYERS)]
+                ('aux_wide', C.c_int), ('gemm_mode', C.c_int), ('macs_per_row', C.c_double), ('layer', BwdLayer * MAX_LAYERS)]
 
 
 class DwJob(C.Structure):

@@ -2,6 +2,7 @@
 entries, packs its effective weights into the MFMA operand images once per step, and launches forward / reverse /
 weight-gradient passes through the C ABI (include/nero_hip.h).  No arithmetic happens here."""
 import ctypes as C
+import os
 import math
 
 import torch
@@ -9,8 +10,27 @@ import torch
 from . import _lib as L
 
 
+
+
+# arithmetic of the dense layers (include/nero_hip.h NERO_GEMM_*): 'f32' = exact fp32 MFMA, 'bf16x6' = 3-plane split on the
+# bf16 matrix pipe (fp32-grade, ~2.6x the peak).  Per-pass selection: passes the split engine does not implement yet stay on f32.
+_MODE_NAMES = {'f32': L.GEMM_F32, 'bf16x6': L.GEMM_BF16X6}
+GEMM_MODE = {k: _MODE_NAMES[os.environ.get('NERO_GEMM_' + k.upper(), os.environ.get('NERO_GEMM', 'f32'))]
+             for k in ('fwd', 'tan', 'bwd', 'dw')}
+
+
+def set_gemm_mode(mode, passes=('fwd', 'tan', 'bwd', 'dw')):
+    """select the dense-layer arithmetic ('f32' | 'bf16x6') for the given passes; chains must be (re)packed afterwards"""
+    for k in passes:
+        GEMM_MODE[k] = _MODE_NAMES[mode]
+
+
 def _r8(x):
     return (x + 7) // 8 * 8
+
+
+def _r16(x):
+    return (x + 15) // 16 * 16
 
 
 def _tiles(x):
@@ -63,6 +83,12 @@ class Chain:
                 e['bm'] = (_r8(d.n_out) // 8) * _tiles(d.k_main) * 256 if d.k_main else 0
                 e['ba'] = (_r8(d.n_out) // 8) * _tiles(d.k_aux) * 256 if d.k_aux else 0
                 e['bias'] = 32 * nt
+                if L.GEMM_BF16X6 in (GEMM_MODE['fwd'], GEMM_MODE['tan']):   # three bf16 planes: 768 floats per (tile, 16-k step)
+                    e['sfm'] = (_r16(d.k_main) // 16) * nt * 768 if d.k_main else 0
+                    e['sfa'] = (_r16(d.k_aux) // 16) * nt * 768 if d.k_aux else 0
+                if GEMM_MODE['bwd'] == L.GEMM_BF16X6:
+                    e['sbm'] = (_r16(d.n_out) // 16) * _tiles(d.k_main) * 768 if d.k_main else 0
+                    e['sba'] = (_r16(d.n_out) // 16) * _tiles(d.k_aux) * 768 if d.k_aux else 0
             if h is not None:
                 e['hw'] = 4 * L.HID
                 e['hb'] = 4
@@ -90,6 +116,14 @@ class Chain:
                                                    C.c_float(d.scale), _r8(d.k_aux), nt, C.c_void_p(p['fa'].data_ptr()), st))
                     L.check(L.lib.nero_pack_weight(C.c_void_p(W.data_ptr()), d.n_out, W.stride(0), d.aux_c0, d.k_aux, 1,
                                                    C.c_float(d.scale), _r8(d.n_out), _tiles(d.k_aux), C.c_void_p(p['ba'].data_ptr()), st))
+                for key, c0, kc in (('sfm', d.main_c0, d.k_main), ('sfa', d.aux_c0, d.k_aux)):
+                    if kc and key in p:
+                        L.check(L.lib.nero_pack_weight_split(C.c_void_p(W.data_ptr()), d.n_out, W.stride(0), c0, kc, 0,
+                                                             C.c_float(d.scale), _r16(kc), nt, C.c_void_p(p[key].data_ptr()), st))
+                for key, c0, kc in (('sbm', d.main_c0, d.k_main), ('sba', d.aux_c0, d.k_aux)):
+                    if kc and key in p:
+                        L.check(L.lib.nero_pack_weight_split(C.c_void_p(W.data_ptr()), d.n_out, W.stride(0), c0, kc, 1,
+                                                             C.c_float(d.scale), _r16(d.n_out), _tiles(kc), C.c_void_p(p[key].data_ptr()), st))
                 if d.b is not None:
                     p['bias'][:d.n_out].copy_(d.b.detach())
             if h is not None:
@@ -109,6 +143,9 @@ class Chain:
         ch.init, ch.ld_init, ch.k_init = L.ptr(init), (init.stride(0) if init is not None else 0), self.k_init
         ch.aux, ch.ld_aux, ch.k_aux = L.ptr(aux), (aux.stride(0) if aux is not None else 0), self.k_aux
         ch.n_layers, ch.aux_wide = len(self.entries), int(self.aux_wide)
+        split = GEMM_MODE['fwd'] == L.GEMM_BF16X6
+        ch.gemm_mode = GEMM_MODE['fwd']
+        ch.pad_ = int(os.environ.get('NERO_SPLIT_DEBUG', '0'))
         ch.macs_per_row = float(sum(d.n_out * (d.k_main + d.k_aux) for d, _ in self.entries if d is not None))
         if init is not None:
             assert init.shape[0] >= rp and init.shape[1] >= self.k_init
@@ -128,10 +165,11 @@ class Chain:
                 fl.head_w, fl.head_b, fl.head_out = p['hw'].data_ptr(), p['hb'].data_ptr(), ho.data_ptr()
                 fl.n_head, fl.head_k = h.n_head, (h.k + 3) // 4 * 4
             if d is not None:
-                fl.w_main = L.ptr(p['fm'])
-                fl.w_aux = L.ptr(p['fa'])
+                rk = _r16 if split else _r8
+                fl.w_main = L.ptr(p['sfm' if split else 'fm'])
+                fl.w_aux = L.ptr(p['sfa' if split else 'fa'])
                 fl.bias = p['bias'].data_ptr()
-                fl.k_main, fl.k_aux = (_r8(d.k_main) if d.k_main else 0), (_r8(d.k_aux) if d.k_aux else 0)
+                fl.k_main, fl.k_aux = (rk(d.k_main) if d.k_main else 0), (rk(d.k_aux) if d.k_aux else 0)
                 fl.n_tiles, fl.act = _tiles(d.n_out), d.act
                 if save or i == last_dense:
                     saves[i] = sbuf[si]
@@ -152,6 +190,9 @@ class Chain:
         saves = fwd['saves']
         ch = L.BwdChain()
         ch.n_layers, ch.aux_wide = len(self.entries), 0
+        split = GEMM_MODE['bwd'] == L.GEMM_BF16X6
+        ch.gemm_mode = GEMM_MODE['bwd']
+        rk = _r16 if split else _r8
         last = len(self.entries) - 1
         if dy is not None:
             ch.dy, ch.ld_dy = dy.data_ptr(), dy.stride(0)
@@ -180,9 +221,9 @@ class Chain:
             bl = ch.layer[i]
             j = prev_dense[i]                      # dense entry that produced this entry's input tile
             if d is not None and not (skip_last_dense and i == last):
-                bl.w_main_t = L.ptr(p['bm'])
-                bl.w_aux_t = L.ptr(p['ba']) if need_daux else None
-                bl.n_out = _r8(d.n_out)
+                bl.w_main_t = L.ptr(p['sbm' if split else 'bm'])
+                bl.w_aux_t = L.ptr(p['sba' if split else 'ba']) if need_daux else None
+                bl.n_out = rk(d.n_out)
                 bl.k_main_tiles = _tiles(d.k_main) if d.k_main else 0
                 bl.k_aux_tiles = _tiles(d.k_aux) if d.k_aux else 0
             else:

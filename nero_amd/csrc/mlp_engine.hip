@@ -16,6 +16,7 @@
 #include <string.h>
 #include "../../include/nero_hip.h"
 #include "common.h"
+#include "mlp_split.h"
 
 namespace {
 
@@ -789,6 +790,12 @@ int nero_pack_weight(const float* W, int nrows, int ld, int col0, int ncols, int
     return nero_check_launch("nero_pack_weight");
 }
 
+int nero_pack_weight_split(const float* W, int nrows, int ld, int col0, int ncols, int transpose, float scale, int kpad,
+                           int nt_count, void* out, void* stream) {
+    if (!W || !out || nt_count <= 0) return nero_fail(NERO_ERR_ARG, "nero_pack_weight_split: bad argument");
+    return nero_split_pack(W, nrows, ld, col0, ncols, transpose, scale, kpad, nt_count, out, (hipStream_t)stream);
+}
+
 static int lds_bytes(int wide) { return (64 * LDA + 64 * (wide ? LDX_WIDE : LDX_NARROW)) * (int)sizeof(float); }
 
 int nero_mlp_forward(const nero_fwd_chain* ch, int n_rows, void* stream) {
@@ -798,6 +805,11 @@ int nero_mlp_forward(const nero_fwd_chain* ch, int n_rows, void* stream) {
         return nero_fail(NERO_ERR_ARG, "nero_mlp_forward: init/aux width out of range");
     const dim3 grid((n_rows + 63) / 64), block(256);
     nero_prof_begin(NERO_K_FWD, 2.0 * ch->macs_per_row * n_rows, (hipStream_t)stream);
+    if (ch->gemm_mode == NERO_GEMM_BF16X6) {
+        const int rc = nero_split_forward(ch, n_rows, (hipStream_t)stream);
+        nero_prof_end(NERO_K_FWD, (hipStream_t)stream);
+        return rc != NERO_OK ? rc : nero_check_launch("nero_mlp_forward(bf16x6)");
+    }
     if (ch->aux_wide) {
         NERO_ONCE(hipFuncSetAttribute((const void*)mlp_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(1)));
         hipLaunchKernelGGL(mlp_fwd_kernel<true>, grid, block, lds_bytes(1), (hipStream_t)stream, *ch, n_rows);
@@ -814,6 +826,11 @@ int nero_mlp_tangent(const nero_tan_chain* ch, int n_rows, void* stream) {
     if (n_rows == 0) return NERO_OK;
     const dim3 grid((n_rows + 63) / 64), block(256);
     nero_prof_begin(NERO_K_TAN, 2.0 * ch->macs_per_row * n_rows, (hipStream_t)stream);
+    if (ch->gemm_mode == NERO_GEMM_BF16X6) {
+        const int rc = nero_split_tangent(ch, n_rows, (hipStream_t)stream);
+        nero_prof_end(NERO_K_TAN, (hipStream_t)stream);
+        return rc != NERO_OK ? rc : nero_check_launch("nero_mlp_tangent(bf16x6)");
+    }
     if (ch->aux_wide) {
         NERO_ONCE(hipFuncSetAttribute((const void*)mlp_tan_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(1)));
         hipLaunchKernelGGL(mlp_tan_kernel<true>, grid, block, lds_bytes(1), (hipStream_t)stream, *ch, n_rows);
@@ -831,6 +848,11 @@ int nero_mlp_backward(const nero_bwd_chain* ch, int n_rows, void* stream) {
     const dim3 grid((n_rows + 63) / 64), block(256);
     NERO_ONCE(hipFuncSetAttribute((const void*)mlp_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(0)));
     nero_prof_begin(NERO_K_BWD, 2.0 * ch->macs_per_row * n_rows, (hipStream_t)stream);
+    if (ch->gemm_mode == NERO_GEMM_BF16X6) {
+        const int rc = nero_split_backward(ch, n_rows, (hipStream_t)stream);
+        nero_prof_end(NERO_K_BWD, (hipStream_t)stream);
+        return rc != NERO_OK ? rc : nero_check_launch("nero_mlp_backward(bf16x6)");
+    }
     hipLaunchKernelGGL(mlp_bwd_kernel<false>, grid, block, lds_bytes(0), (hipStream_t)stream, *ch, n_rows);
     nero_prof_end(NERO_K_BWD, (hipStream_t)stream);
     return nero_check_launch("nero_mlp_backward");

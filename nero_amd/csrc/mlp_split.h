@@ -1,0 +1,11 @@
+// mlp_split.h -- internal entry points of the split-bf16 engine (mlp_split.hip), dispatched from the C-ABI functions in
+// mlp_engine.hip when a chain / job asks for gemm_mode NERO_GEMM_BF16X6
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/nero_hip.h"
+
+int nero_split_pack(const float* W, int nrows, int ld, int col0, int ncols, int transpose, float scale, int kpad, int nt_count,
+                    void* out, hipStream_t stream);
+int nero_split_forward(const nero_fwd_chain* ch, int n_rows, hipStream_t stream);
+int nero_split_tangent(const nero_tan_chain* ch, int n_rows, hipStream_t stream);
+int nero_split_backward(const nero_bwd_chain* ch, int n_rows, hipStream_t stream);

@@ -16,7 +16,7 @@ import math
 import torch
 
 from . import _lib as L
-from .chain import Chain, Dense, Head, row_pad, _r8, _tiles
+from .chain import Chain, Dense, Head, row_pad, _r8, _r16, _tiles, GEMM_MODE
 
 N_FREQ, D_PE, LD_PE = 6, 39, 40
 
@@ -98,15 +98,18 @@ class SDFField:
             tc.init, tc.ld_init, tc.k_init = ehat.data_ptr(), LD_PE, LD_PE
             tc.aux, tc.ld_aux, tc.k_aux = ehat.data_ptr(), LD_PE, LD_PE
             tc.n_layers, tc.aux_wide = 8, 0
+            tsplit = GEMM_MODE['tan'] == L.GEMM_BF16X6
+            tc.gemm_mode = GEMM_MODE['tan']
+            rk = _r16 if tsplit else _r8
             tc.macs_per_row = float(sum(ch.entries[l][0].n_out * (ch.entries[l][0].k_main + ch.entries[l][0].k_aux) for l in range(8)))
             tbuf = torch.empty((2, 8, rp, L.HID), dtype=torch.float32, device=self.device)
             for l in range(8):
                 d, p = ch.entries[l][0], ch._packed[l]
                 tl = tc.layer[l]
-                tl.w_main, tl.w_aux = L.ptr(p['fm']), L.ptr(p['fa'])
+                tl.w_main, tl.w_aux = L.ptr(p['sfm' if tsplit else 'fm']), L.ptr(p['sfa' if tsplit else 'fa'])
                 tl.a_saved, tl.gbar = fwd['saves'][l].data_ptr(), gbar[l].data_ptr()
                 tl.adot, tl.inj = tbuf[0, l].data_ptr(), tbuf[1, l].data_ptr()
-                tl.k_main, tl.k_aux, tl.n_tiles = _r8(d.k_main), (_r8(d.k_aux) if d.k_aux else 0), _tiles(d.n_out)
+                tl.k_main, tl.k_aux, tl.n_tiles = rk(d.k_main), (rk(d.k_aux) if d.k_aux else 0), _tiles(d.n_out)
                 injs[l] = tbuf[1, l]
             L.check(L.lib.nero_mlp_tangent(C.byref(tc), n, L.stream_ptr()))
             for l in range(8):
