@@ -20,6 +20,9 @@ sys.path.insert(0, ROOT)
 
 C_SDF, C_NERF, C_APP = 524544, 604160, 1211648          # MACs per point
 PEAK_F32_MFMA = 157.3e12                                 # MI355X dense fp32 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_BF16_MFMA = 2500e12                                 # MI355X dense bf16 MFMA peak (same guide)
+# fp32-equivalent ceiling of the arithmetic the dense layers run on: the f32-input MFMA itself, or -- default -- the bf16
+# matrix pipe issuing 6 plane products per fp32 multiply-add (3-plane exact split, nero_amd/csrc/mlp_split.hip)
 
 
 def cpu_baseline(cfg, variance, step, rays=512, budget_s=15.0, max_steps=10):
@@ -126,8 +129,13 @@ def main():
         rows = [(kinds[k], rep[3 * k], rep[3 * k + 1], rep[3 * k + 2]) for k in range(4)]
         dom = max(rows, key=lambda r: r[2])
         ach = dom[3] / (dom[2] * 1e-3) / 1e12 if dom[2] > 0 else 0.0
-        roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA / 1e12, 'unit': 'TFLOP/s',
-                'frac': round(ach / (PEAK_F32_MFMA / 1e12), 4), 'traffic': None, 'kernel': dom[0],
+        from nero_amd import chain as CH
+        split = CH.GEMM_MODE['fwd'] == L.GEMM_BF16X6
+        peak = (PEAK_BF16_MFMA / 6 if split else PEAK_F32_MFMA) / 1e12
+        roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+                'frac': round(ach / peak, 4), 'traffic': None, 'kernel': dom[0],
+                'mfma': ('v_mfma_f32_32x32x16_bf16, 6 plane products per fp32 multiply-add: peak = 2500 TFLOP/s bf16 dense / 6; '
+                         'issued bf16 MFMA rate = 6 x achieved') if split else 'v_mfma_f32_32x32x2_f32',
                 'avg_launch_ms': round(dom[2] / max(dom[1], 1), 4),
                 'per_kernel': {r[0]: {'launches_per_step': r[1] / 3, 'ms_per_step': round(r[2] / 3, 3),
                                       'tflops': round(r[3] / (r[2] * 1e-3) / 1e12, 2) if r[2] > 0 else 0.0} for r in rows}}
@@ -136,17 +144,21 @@ def main():
             ts.step(args.train_step + 100 + i)
 
     if rank == 0:
+        from nero_amd import chain as _CH
+        CH_SPLIT = _CH.GEMM_MODE['fwd'] == L.GEMM_BF16X6
         # whole-step algorithmic FLOPs with the measured inner/outer split of this rank
         sampler_evals = args.rays * (64 + 3 * 16)
         flop_step = (n_in / args.steps) * 2 * (6 * C_SDF + 3 * C_APP) + (n_out / args.steps) * 2 * 3 * C_NERF + sampler_evals * 2 * C_SDF
         res = {
             'metric': 'training rays/sec (Stage-I shape, 128 samples/ray)', 'value': round(value, 1), 'unit': 'rays/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32 (dense layers: fp32 operands as 3 exact bf16 planes, 6 bf16 MFMA products, fp32 accumulate)' if CH_SPLIT else 'f32',
+            'data': 'synthetic',
             'config': {'workload': "GlossySynthetic 'bell' Stage-I shape, 4096 rays x (64+64+32) samples per GPU, "
                                    f'training-schedule step {args.train_step}', 'rays_per_gpu': args.rays,
                        'parallelism': f'dp{world}', 'optimizer': 'adam(fused)', 'inv_s': 'exp(10*0.5)'},
-            'step_mlp_flop_frac': round(flop_step / (dt / args.steps) / PEAK_F32_MFMA, 4),
+            'step_mlp_flop_frac': round(flop_step / (dt / args.steps) / (PEAK_BF16_MFMA / 6 if CH_SPLIT else PEAK_F32_MFMA), 4),
             'inner_samples_per_ray': round(n_in / args.steps / args.rays, 2),
             'roofline': roof,
         }

@@ -156,6 +156,7 @@ typedef struct {
     float* db;                          /* [n_out] or NULL                    */
     float scale;
     int accumulate;                     /* 0: overwrite, 1: add into dW/db    */
+    int gemm_mode, pad_;                /* NERO_GEMM_* (operands are plain fp32 matrices in either mode) */
 } nero_dw_job;
 
 int nero_dw_workspace_floats(int n_rows);

@@ -54,7 +54,8 @@ class BwdChain(C.Structure):
 class DwJob(C.Structure):
     _fields_ = [('d0', _fp), ('b0', _fp), ('d1', _fp), ('b1', _fp), ('ldd0', C.c_int), ('ldb0', C.c_int),
                 ('ldd1', C.c_int), ('ldb1', C.c_int), ('n_out', C.c_int), ('k_cols', C.c_int), ('dW', _fp),
-                ('ldw', C.c_int), ('col0', C.c_int), ('db', _fp), ('scale', C.c_float), ('accumulate', C.c_int)]
+                ('ldw', C.c_int), ('col0', C.c_int), ('db', _fp), ('scale', C.c_float), ('accumulate', C.c_int),
+                ('gemm_mode', C.c_int), ('pad_', C.c_int)]
 
 
 def _load():

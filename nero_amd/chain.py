@@ -12,10 +12,11 @@ from . import _lib as L
 
 
 
-# arithmetic of the dense layers (include/nero_hip.h NERO_GEMM_*): 'f32' = exact fp32 MFMA, 'bf16x6' = 3-plane split on the
-# bf16 matrix pipe (fp32-grade, ~2.6x the peak).  Per-pass selection: passes the split engine does not implement yet stay on f32.
+# arithmetic of the dense layers (include/nero_hip.h NERO_GEMM_*): 'bf16x6' (default) = 3-plane exact split on the bf16
+# matrix pipe -- fp32-grade results (same error against fp64 as the f32 MFMA, tests/test_mlp_engine.py) at 2.65x the peak;
+# 'f32' = the f32-input MFMA (an exact fmaf chain).  NERO_GEMM=f32|bf16x6 selects all passes, NERO_GEMM_FWD/_TAN/_BWD/_DW one.
 _MODE_NAMES = {'f32': L.GEMM_F32, 'bf16x6': L.GEMM_BF16X6}
-GEMM_MODE = {k: _MODE_NAMES[os.environ.get('NERO_GEMM_' + k.upper(), os.environ.get('NERO_GEMM', 'f32'))]
+GEMM_MODE = {k: _MODE_NAMES[os.environ.get('NERO_GEMM_' + k.upper(), os.environ.get('NERO_GEMM', 'bf16x6'))]
              for k in ('fwd', 'tan', 'bwd', 'dw')}
 
 
@@ -300,6 +301,7 @@ class Chain:
                     job.dW, job.ldw, job.col0 = dW.data_ptr(), dW.stride(0), c0
                     job.db = db.data_ptr() if pi == 0 else None
                     job.scale, job.accumulate = d.scale, 0
+                    job.gemm_mode = GEMM_MODE['dw']
                     L.check(L.lib.nero_dw_gemm(C.byref(job), n_rows, C.c_void_p(workspace.data_ptr()), st))
                 g['dW'], g['db'] = dW, db
                 prev = i

@@ -879,7 +879,9 @@ int nero_dw_gemm(const nero_dw_job* job, int n_rows, float* partials, void* stre
     NERO_ONCE(hipFuncSetAttribute((const void*)dw_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     NERO_ONCE(hipFuncSetAttribute((const void*)dw_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     nero_prof_begin(NERO_K_DW, 2.0 * job->n_out * job->k_cols * (job->d1 ? 2.0 : 1.0) * n_rows, (hipStream_t)stream);
-    if (k_pad <= 128)
+    if (job->gemm_mode == NERO_GEMM_BF16X6)
+        nero_split_dw(job, n_rows, rps, slices, partials, n_pad, k_pad, (hipStream_t)stream);
+    else if (k_pad <= 128)
         hipLaunchKernelGGL(dw_gemm_kernel<true>, dim3(slices), dim3(512), lds, (hipStream_t)stream, *job, n_rows, rps, partials, n_pad, k_pad);
     else
         hipLaunchKernelGGL(dw_gemm_kernel<false>, dim3(slices), dim3(512), lds, (hipStream_t)stream, *job, n_rows, rps, partials, n_pad, k_pad);

@@ -9,3 +9,5 @@ int nero_split_pack(const float* W, int nrows, int ld, int col0, int ncols, int 
 int nero_split_forward(const nero_fwd_chain* ch, int n_rows, hipStream_t stream);
 int nero_split_tangent(const nero_tan_chain* ch, int n_rows, hipStream_t stream);
 int nero_split_backward(const nero_bwd_chain* ch, int n_rows, hipStream_t stream);
+int nero_split_dw(const nero_dw_job* job, int n_rows, int rows_per_slice, int slices, float* partials, int n_pad, int k_pad,
+                  hipStream_t stream);

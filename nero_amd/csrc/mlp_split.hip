@@ -494,6 +494,151 @@ __global__ __launch_bounds__(512, 1) void bwd_split_kernel(nero_bwd_chain ch, in
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// weight-gradient GEMM:  C[n][k] = sum_r D[r][n] B[r][k]  (contraction over the batch rows; split over row slices)
+//
+// Both operands are row-major fp32 [rows][<=256] matrices in HBM and the MFMA wants, for every column, 8 consecutive batch
+// rows per lane.  A chunk of 16 rows is staged per step: thread (col = tid & 255, rh = tid >> 8) loads rows 8rh..8rh+7 of
+// its column of D and of B (dword loads, one 256-byte row segment per wave instruction), splits them into the three bf16
+// planes and writes ONE 16-byte LDS store per plane into the layout [rh][col] x 16 B -- which is exactly the fragment
+// order (lane (i, h) reads col 32t+i, half h), so operand reads are conflict-free ds_read_b128.  Chunks are double
+// buffered (global loads of chunk q+1 in flight during the 48 MFMAs per wave of chunk q).
+// 8 waves: FULL: wave (wn = w>>1, wk = w&1) owns n-tiles {2wn, 2wn+1} x k-tiles {4wk..4wk+3} (8 accumulators);
+//          NARROW (k_pad <= 128): wave w owns n-tile w x k-tiles {0..3}.
+// At 6 plane products per tile step the kernel needs ~6.5 TB/s of operand traffic to saturate the matrix pipe: it is HBM
+// bound for full 256x256 jobs.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int DWS_PLANE = 2 * 256 * 16;              // one plane of one matrix: [2][256] x 16 B = 8 KB
+constexpr int DWS_MAT = 3 * DWS_PLANE;               // 24 KB
+constexpr int DWS_STAGE = 2 * DWS_MAT;               // D + B = 48 KB
+
+__device__ __forceinline__ void dws_fetch(float (&v)[8], const float* __restrict__ src, int ld, int cols, int r0, int r1, int col, int rh) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int gr = r0 + 8 * rh + j;
+        v[j] = (col < cols && gr < r1) ? src[(size_t)gr * ld + col] : 0.f;
+    }
+}
+__device__ __forceinline__ void dws_put(char* mat, const float (&v)[8], int col, int rh) {
+    unsigned p[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split2(v[2 * j], v[2 * j + 1], p[0][j], p[1][j], p[2][j]);
+    char* dst = mat + (rh * 256 + col) * 16;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) *reinterpret_cast<uint4*>(dst + q * DWS_PLANE) = make_uint4(p[q][0], p[q][1], p[q][2], p[q][3]);
+}
+struct Fr3 { uint4 p0, p1, p2; };
+__device__ __forceinline__ Fr3 dws_frag(const char* mat, int tile, int i, int h) {
+    const char* s = mat + (h * 256 + 32 * tile + i) * 16;
+    Fr3 f;
+    f.p0 = *reinterpret_cast<const uint4*>(s);
+    f.p1 = *reinterpret_cast<const uint4*>(s + DWS_PLANE);
+    f.p2 = *reinterpret_cast<const uint4*>(s + 2 * DWS_PLANE);
+    return f;
+}
+__device__ __forceinline__ void mf6(f32x16& acc, const Fr3& a, const Fr3& b) {
+    NERO_MF(acc, a.p2, b.p0);
+    NERO_MF(acc, a.p1, b.p1);
+    NERO_MF(acc, a.p0, b.p2);
+    NERO_MF(acc, a.p1, b.p0);
+    NERO_MF(acc, a.p0, b.p1);
+    NERO_MF(acc, a.p0, b.p0);
+}
+
+template <bool NARROW>
+__global__ __launch_bounds__(512, 1) void dw_split_kernel(nero_dw_job job, int n_rows, int rows_per_slice, float* __restrict__ partials,
+                                                          int n_pad, int k_pad) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int col = tid & 255, rh = tid >> 8;
+    const int r_begin = blockIdx.x * rows_per_slice;
+    int r_end = r_begin + rows_per_slice;
+    r_end = r_end < n_rows ? r_end : n_rows;
+    const int n_tiles = n_pad >> 5, k_tiles = k_pad >> 5;
+    constexpr int NA = NARROW ? 1 : 2;                   // n-tiles per wave
+    const int nt0 = NARROW ? wave : 2 * (wave >> 1), kt0 = NARROW ? 0 : 4 * (wave & 1);
+    f32x16 acc[NA][4];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
+    float bsum = 0.f;                                    // bias gradient partial of column `col` (rows of this thread's half)
+    const int nch = r_end > r_begin ? (r_end - r_begin + 15) / 16 : 0;
+    const int total = nch * (job.d1 ? 2 : 1);
+    float vd[8], vb[8];
+    if (total > 0) {
+        dws_fetch(vd, job.d0, job.ldd0, job.n_out, r_begin, r_end, col, rh);
+        dws_fetch(vb, job.b0, job.ldb0, job.k_cols, r_begin, r_end, col, rh);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsum += vd[j];
+        dws_put(smem, vd, col, rh);
+        dws_put(smem + DWS_MAT, vb, col, rh);
+    }
+    __syncthreads();
+    for (int q = 0; q < total; ++q) {
+        const char* sD = smem + (q & 1) * DWS_STAGE;
+        const char* sB = sD + DWS_MAT;
+        const bool more = q + 1 < total;
+        const int q1 = q + 1;
+        const bool second = q1 >= nch;
+        if (more) {
+            const int r0 = r_begin + (second ? q1 - nch : q1) * 16;
+            dws_fetch(vd, second ? job.d1 : job.d0, second ? job.ldd1 : job.ldd0, job.n_out, r0, r_end, col, rh);
+            dws_fetch(vb, second ? job.b1 : job.b0, second ? job.ldb1 : job.ldb0, job.k_cols, r0, r_end, col, rh);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (nt0 < n_tiles && kt0 < k_tiles) {
+            Fr3 fa[NA];
+#pragma unroll
+            for (int a = 0; a < NA; ++a) fa[a] = dws_frag(sD, nt0 + a, i, h);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (kt0 + b < k_tiles) {
+                    const Fr3 fb = dws_frag(sB, kt0 + b, i, h);
+#pragma unroll
+                    for (int a = 0; a < NA; ++a)
+                        if (nt0 + a < n_tiles) mf6(acc[a][b], fa[a], fb);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+            if (!second) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bsum += vd[j];
+            }
+            char* nD = smem + (q1 & 1) * DWS_STAGE;
+            dws_put(nD, vd, col, rh);
+            dws_put(nD + DWS_MAT, vb, col, rh);
+        }
+        __syncthreads();
+    }
+    // this slice's partial C (row-major [n_pad][k_pad]) and bias partial, in the layout dw_reduce_kernel expects
+    float* __restrict__ P = partials + (size_t)blockIdx.x * ((size_t)n_pad * k_pad + n_pad);
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int nt = nt0 + a, kt = kt0 + b;
+            if (nt < n_tiles && kt < k_tiles) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int row = 32 * nt + (v & 3) + 8 * (v >> 2) + 4 * h;
+                    P[(size_t)row * k_pad + 32 * kt + i] = acc[a][b][v];
+                }
+            }
+        }
+    // bias: the two row-halves of a column live in threads col and col+256
+    float* red = reinterpret_cast<float*>(smem);
+    if (rh == 1) red[col] = bsum;
+    __syncthreads();
+    if (rh == 0 && col < n_pad) P[(size_t)n_pad * k_pad + col] = bsum + red[col];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // operand packing: three bf16 planes in A-fragment order
 //   out[(((t*nsteps + c)*3 + p)*64 + lane)*8 + j] = plane_p( A[32t + (lane&31)][16c + 8(lane>>5) + j] * scale )
 //   transpose == 0:  A[m][k] = W[m][col0 + k]   (m < nrows, k < ncols)       forward operand
@@ -576,5 +721,17 @@ int nero_split_backward(const nero_bwd_chain* ch, int n_rows, hipStream_t stream
     const int lds = 3 * PLANE_A;
     NERO_ONCE(hipFuncSetAttribute((const void*)bwd_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipLaunchKernelGGL(bwd_split_kernel, grid, block, lds, stream, *ch, n_rows);
+    return NERO_OK;
+}
+
+int nero_split_dw(const nero_dw_job* job, int n_rows, int rows_per_slice, int slices, float* partials, int n_pad, int k_pad,
+                  hipStream_t stream) {
+    const int lds = 2 * DWS_STAGE;
+    NERO_ONCE(hipFuncSetAttribute((const void*)dw_split_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    NERO_ONCE(hipFuncSetAttribute((const void*)dw_split_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    if (k_pad <= 128)
+        hipLaunchKernelGGL(dw_split_kernel<true>, dim3(slices), dim3(512), lds, stream, *job, n_rows, rows_per_slice, partials, n_pad, k_pad);
+    else
+        hipLaunchKernelGGL(dw_split_kernel<false>, dim3(slices), dim3(512), lds, stream, *job, n_rows, rows_per_slice, partials, n_pad, k_pad);
     return NERO_OK;
 }
