@@ -125,11 +125,13 @@ def main():
         L.lib.nero_prof_enable(0)
         rep = (C.c_double * 12)()
         L.lib.nero_prof_report(rep)
-        kinds = ['mlp_fwd_kernel', 'mlp_tan_kernel', 'mlp_bwd_kernel', 'dw_gemm_kernel']
+        from nero_amd import chain as CH
+        kinds = [('fwd_split_kernel', 'mlp_fwd_kernel'), ('tan_split_kernel', 'mlp_tan_kernel'), ('bwd_split_kernel', 'mlp_bwd_kernel'),
+                 ('dw_split_kernel', 'dw_gemm_kernel')]
+        kinds = [k[0] if CH.GEMM_MODE[m] == L.GEMM_BF16X6 else k[1] for k, m in zip(kinds, ('fwd', 'tan', 'bwd', 'dw'))]
         rows = [(kinds[k], rep[3 * k], rep[3 * k + 1], rep[3 * k + 2]) for k in range(4)]
         dom = max(rows, key=lambda r: r[2])
         ach = dom[3] / (dom[2] * 1e-3) / 1e12 if dom[2] > 0 else 0.0
-        from nero_amd import chain as CH
         split = CH.GEMM_MODE['fwd'] == L.GEMM_BF16X6
         peak = (PEAK_BF16_MFMA / 6 if split else PEAK_F32_MFMA) / 1e12
         roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',

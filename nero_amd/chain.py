@@ -79,10 +79,12 @@ class Chain:
             e = {}
             if d is not None:
                 nt = _tiles(d.n_out)
-                e['fm'] = (_r8(d.k_main) // 8) * nt * 256 if d.k_main else 0
-                e['fa'] = (_r8(d.k_aux) // 8) * nt * 256 if d.k_aux else 0
-                e['bm'] = (_r8(d.n_out) // 8) * _tiles(d.k_main) * 256 if d.k_main else 0
-                e['ba'] = (_r8(d.n_out) // 8) * _tiles(d.k_aux) * 256 if d.k_aux else 0
+                if L.GEMM_F32 in (GEMM_MODE['fwd'], GEMM_MODE['tan']):
+                    e['fm'] = (_r8(d.k_main) // 8) * nt * 256 if d.k_main else 0
+                    e['fa'] = (_r8(d.k_aux) // 8) * nt * 256 if d.k_aux else 0
+                if GEMM_MODE['bwd'] == L.GEMM_F32:
+                    e['bm'] = (_r8(d.n_out) // 8) * _tiles(d.k_main) * 256 if d.k_main else 0
+                    e['ba'] = (_r8(d.n_out) // 8) * _tiles(d.k_aux) * 256 if d.k_aux else 0
                 e['bias'] = 32 * nt
                 if L.GEMM_BF16X6 in (GEMM_MODE['fwd'], GEMM_MODE['tan']):   # three bf16 planes: 768 floats per (tile, 16-k step)
                     e['sfm'] = (_r16(d.k_main) // 16) * nt * 768 if d.k_main else 0
@@ -107,16 +109,14 @@ class Chain:
                 W = d.W.detach()
                 assert W.stride(1) == 1
                 nt = _tiles(d.n_out)
-                if d.k_main:
-                    L.check(L.lib.nero_pack_weight(C.c_void_p(W.data_ptr()), d.n_out, W.stride(0), d.main_c0, d.k_main, 0,
-                                                   C.c_float(d.scale), _r8(d.k_main), nt, C.c_void_p(p['fm'].data_ptr()), st))
-                    L.check(L.lib.nero_pack_weight(C.c_void_p(W.data_ptr()), d.n_out, W.stride(0), d.main_c0, d.k_main, 1,
-                                                   C.c_float(d.scale), _r8(d.n_out), _tiles(d.k_main), C.c_void_p(p['bm'].data_ptr()), st))
-                if d.k_aux:
-                    L.check(L.lib.nero_pack_weight(C.c_void_p(W.data_ptr()), d.n_out, W.stride(0), d.aux_c0, d.k_aux, 0,
-                                                   C.c_float(d.scale), _r8(d.k_aux), nt, C.c_void_p(p['fa'].data_ptr()), st))
-                    L.check(L.lib.nero_pack_weight(C.c_void_p(W.data_ptr()), d.n_out, W.stride(0), d.aux_c0, d.k_aux, 1,
-                                                   C.c_float(d.scale), _r8(d.n_out), _tiles(d.k_aux), C.c_void_p(p['ba'].data_ptr()), st))
+                for key, c0, kc in (('fm', d.main_c0, d.k_main), ('fa', d.aux_c0, d.k_aux)):
+                    if kc and key in p:
+                        L.check(L.lib.nero_pack_weight(C.c_void_p(W.data_ptr()), d.n_out, W.stride(0), c0, kc, 0,
+                                                       C.c_float(d.scale), _r8(kc), nt, C.c_void_p(p[key].data_ptr()), st))
+                for key, c0, kc in (('bm', d.main_c0, d.k_main), ('ba', d.aux_c0, d.k_aux)):
+                    if kc and key in p:
+                        L.check(L.lib.nero_pack_weight(C.c_void_p(W.data_ptr()), d.n_out, W.stride(0), c0, kc, 1,
+                                                       C.c_float(d.scale), _r8(d.n_out), _tiles(kc), C.c_void_p(p[key].data_ptr()), st))
                 for key, c0, kc in (('sfm', d.main_c0, d.k_main), ('sfa', d.aux_c0, d.k_aux)):
                     if kc and key in p:
                         L.check(L.lib.nero_pack_weight_split(C.c_void_p(W.data_ptr()), d.n_out, W.stride(0), c0, kc, 0,
@@ -167,8 +167,8 @@ class Chain:
                 fl.n_head, fl.head_k = h.n_head, (h.k + 3) // 4 * 4
             if d is not None:
                 rk = _r16 if split else _r8
-                fl.w_main = L.ptr(p['sfm' if split else 'fm'])
-                fl.w_aux = L.ptr(p['sfa' if split else 'fa'])
+                fl.w_main = L.ptr(p.get('sfm' if split else 'fm'))
+                fl.w_aux = L.ptr(p.get('sfa' if split else 'fa'))
                 fl.bias = p['bias'].data_ptr()
                 fl.k_main, fl.k_aux = (rk(d.k_main) if d.k_main else 0), (rk(d.k_aux) if d.k_aux else 0)
                 fl.n_tiles, fl.act = _tiles(d.n_out), d.act
@@ -222,8 +222,8 @@ class Chain:
             bl = ch.layer[i]
             j = prev_dense[i]                      # dense entry that produced this entry's input tile
             if d is not None and not (skip_last_dense and i == last):
-                bl.w_main_t = L.ptr(p['sbm' if split else 'bm'])
-                bl.w_aux_t = L.ptr(p['sba' if split else 'ba']) if need_daux else None
+                bl.w_main_t = L.ptr(p.get('sbm' if split else 'bm'))
+                bl.w_aux_t = L.ptr(p.get('sba' if split else 'ba')) if need_daux else None
                 bl.n_out = rk(d.n_out)
                 bl.k_main_tiles = _tiles(d.k_main) if d.k_main else 0
                 bl.k_aux_tiles = _tiles(d.k_aux) if d.k_aux else 0

@@ -72,6 +72,39 @@ __device__ __forceinline__ float4 load_planes4(const char* src, int plane_bytes)
     return v;
 }
 
+// ---- accumulator-layout <-> row-major global I/O through a wave-private LDS scratch -----------------------------------------
+// In the accumulator layout a wave instruction touches 32 rows x 32 bytes of a [rows][256] matrix, which is issue bound in the
+// texture path (~4k cycles per 64x256 stream).  Routing the 32x32 block through a private [32][36]-float scratch turns every
+// global access into 8 rows x 128 contiguous bytes.  Row-major mapping: pass p (0..3) -> row 8p + (lane>>3), columns 4(lane&7)..+3.
+constexpr int SCR_LD = 36;                           // floats; 144-byte rows -> conflict-free 16-byte column accesses
+constexpr int SCR_BYTES = 32 * SCR_LD * 4;           // 4608 B per wave
+__device__ __forceinline__ void rm_prefetch(float4 (&raw)[4], const float* __restrict__ gblock, int lane) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) raw[p] = *reinterpret_cast<const float4*>(gblock + (size_t)(8 * p + (lane >> 3)) * NERO_HID + 4 * (lane & 7));
+}
+// row-major registers -> accumulator-layout quads q[g] = features 8g + 4h + 0..3 of row i
+__device__ __forceinline__ void rm_to_acc(float* scr, const float4 (&raw)[4], float4 (&q)[4], int lane) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<float4*>(scr + (8 * p + (lane >> 3)) * SCR_LD + 4 * (lane & 7)) = raw[p];
+    __builtin_amdgcn_wave_barrier();
+    const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) q[g] = *reinterpret_cast<const float4*>(scr + i * SCR_LD + 8 * g + 4 * h);
+    __builtin_amdgcn_wave_barrier();
+}
+// accumulator-layout quads -> row-major global store
+__device__ __forceinline__ void acc_to_global(float* scr, const float4 (&q)[4], float* __restrict__ gblock, int lane) {
+    const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(scr + i * SCR_LD + 8 * g + 4 * h) = q[g];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+        *reinterpret_cast<float4*>(gblock + (size_t)(8 * p + (lane >> 3)) * NERO_HID + 4 * (lane & 7)) =
+            *reinterpret_cast<const float4*>(scr + (8 * p + (lane >> 3)) * SCR_LD + 4 * (lane & 7));
+    __builtin_amdgcn_wave_barrier();
+}
+
 // softplus(beta=100, threshold=20) and its derivative recovered from the output: identical to mlp_engine.hip
 __device__ __forceinline__ float log1p_small(float u) {
     return u * (1.f + u * (-0.5f + u * (0.33333334f + u * (-0.25f + u * 0.2f))));
@@ -221,10 +254,14 @@ __device__ __forceinline__ void eval_head_split(const char* planes, const float*
 // ---------------------------------------------------------------------------------------------------------------------
 // epilogue straight out of the accumulators: lane (i, h) of wave w holds, for batch rows i and 32+i, the features
 // 32w + 8g + 4h + {0..3}, g = 0..3 -> bias, activation, optional 16-byte global save, 3-way split, 8-byte plane stores
+// sv: save pointer in accumulator layout (&save[row0+i][32w+4h]); sblock/scr: row-major block pointer (&save[row0][32w]) and the
+// wave's scratch, used instead of sv when scr != nullptr
 template <int ACT>
-__device__ __forceinline__ void fwd_epilogue(const f32x16 (&acc)[2], const float4 (&bq)[4], char* dst, float* sv) {
+__device__ __forceinline__ void fwd_epilogue(const f32x16 (&acc)[2], const float4 (&bq)[4], char* dst, float* sv, float* sblock,
+                                             float* scr, int lane) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
+        float4 q[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float4 v;
@@ -232,9 +269,11 @@ __device__ __forceinline__ void fwd_epilogue(const f32x16 (&acc)[2], const float
             v.y = act_fwd<ACT>(acc[r][4 * g + 1] + bq[g].y);
             v.z = act_fwd<ACT>(acc[r][4 * g + 2] + bq[g].z);
             v.w = act_fwd<ACT>(acc[r][4 * g + 3] + bq[g].w);
-            if (sv) *reinterpret_cast<float4*>(sv + (size_t)r * 32 * NERO_HID + 8 * g) = v;
+            if (sv && !scr) *reinterpret_cast<float4*>(sv + (size_t)r * 32 * NERO_HID + 8 * g) = v;
             store_planes4(dst + r * 32 * SA + 16 * g, PLANE_A, v);
+            q[g] = v;
         }
+        if (sv && scr) acc_to_global(scr, q, sblock + (size_t)r * 32 * NERO_HID, lane);
     }
 }
 
@@ -274,9 +313,12 @@ __global__ __launch_bounds__(512, 1) void fwd_split_kernel(nero_fwd_chain ch, in
         if (live_wave && !(ch.pad_ & 1)) {
             char* dst = actp + i * SA + (32 * wave + 4 * h) * 2;
             float* sv = L.save ? L.save + (size_t)(row0 + i) * NERO_HID + 32 * wave + 4 * h : nullptr;
-            if (L.act == NERO_ACT_RELU) fwd_epilogue<NERO_ACT_RELU>(acc, bq, dst, sv);
-            else if (L.act == NERO_ACT_SOFTPLUS100) fwd_epilogue<NERO_ACT_SOFTPLUS100>(acc, bq, dst, sv);
-            else fwd_epilogue<NERO_ACT_NONE>(acc, bq, dst, sv);
+            float* sblock = L.save ? L.save + (size_t)row0 * NERO_HID + 32 * wave : nullptr;
+            // (the wide-aux variant has no LDS left for the scratch: it keeps the direct accumulator-layout stores)
+            float* scr = WIDE ? nullptr : reinterpret_cast<float*>(smem + 3 * PLANE_A + 3 * PLANE_X + wave * SCR_BYTES);
+            if (L.act == NERO_ACT_RELU) fwd_epilogue<NERO_ACT_RELU>(acc, bq, dst, sv, sblock, scr, lane);
+            else if (L.act == NERO_ACT_SOFTPLUS100) fwd_epilogue<NERO_ACT_SOFTPLUS100>(acc, bq, dst, sv, sblock, scr, lane);
+            else fwd_epilogue<NERO_ACT_NONE>(acc, bq, dst, sv, sblock, scr, lane);
         }
         __syncthreads();
     }
@@ -311,12 +353,15 @@ __global__ __launch_bounds__(512, 1) void tan_split_kernel(nero_tan_chain ch, in
         const bool live_wave = wave < L.n_tiles;
         const size_t goff = (size_t)(row0 + i) * NERO_HID + 32 * wave + 4 * h;     // + r*32*HID + 8g
         // saved activations of this lane's 32 outputs, requested before the GEMM
-        float4 pa[2][4];
+        float4 pa[2][4], pg[2][4];
         if (live_wave) {
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) pa[r][g] = *reinterpret_cast<const float4*>(L.a_saved + goff + (size_t)r * 32 * NERO_HID + 8 * g);
+                for (int g = 0; g < 4; ++g) {
+                    pa[r][g] = *reinterpret_cast<const float4*>(L.a_saved + goff + (size_t)r * 32 * NERO_HID + 8 * g);
+                    pg[r][g] = *reinterpret_cast<const float4*>(L.gbar + goff + (size_t)r * 32 * NERO_HID + 8 * g);
+                }
         }
         f32x16 acc[2];
         zero2(acc);
@@ -333,12 +378,9 @@ __global__ __launch_bounds__(512, 1) void tan_split_kernel(nero_tan_chain ch, in
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const bool live = (row0 + 32 * r + i) < n_rows;
-                float4 gq[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) gq[g] = *reinterpret_cast<const float4*>(L.gbar + goff + (size_t)r * 32 * NERO_HID + 8 * g);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float4 a = pa[r][g], gb = gq[g];
+                    const float4 a = pa[r][g], gb = pg[r][g];
                     float4 ad, ij;
                     tan_elem(a.x, acc[r][4 * g], gb.x, live, ad.x, ij.x);
                     tan_elem(a.y, acc[r][4 * g + 1], gb.y, live, ad.y, ij.y);
@@ -358,46 +400,49 @@ __global__ __launch_bounds__(512, 1) void tan_split_kernel(nero_tan_chain ch, in
 // ---------------------------------------------------------------------------------------------------------------------
 // reverse chain:  delta_{l-1} = (delta_l W_l [+ dy_head W_head]) * act'(a_{l-1}) [+ inj_{l-1}]
 // ---------------------------------------------------------------------------------------------------------------------
-template <int ACT>
-__device__ __forceinline__ void bwd_epilogue(const f32x16 (&acc)[2], const float4 (&pa)[2][4], const nero_bwd_layer& L, char* dst,
-                                             size_t goff, int row0, int i, int fbase, int n_rows) {
+template <int ACT, bool HEAD>
+__device__ __forceinline__ void bwd_epilogue(const f32x16 (&acc)[2], const float4 (&pa)[2][4], const float4 (&pi)[2][4], bool has_inj,
+                                             const nero_bwd_layer& L, char* dst, size_t goff, int row0, int i, int fbase, int n_rows) {
     const int nh = L.n_head;
-    float4 hw[4][4];                 // [j][g]: head weights of this lane's features
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            hw[j][g] = (j < nh) ? *reinterpret_cast<const float4*>(L.head_w + j * NERO_HID + fbase + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int grow = row0 + 32 * r + i;
         const bool live = grow < n_rows;
         float dj[4] = {0.f, 0.f, 0.f, 0.f};
-        if (nh > 0) {
+        if (HEAD) {
             const float4 dyh = *reinterpret_cast<const float4*>(L.head_dy + (size_t)grow * 4);
             dj[0] = dyh.x; dj[1] = dyh.y; dj[2] = dyh.z; dj[3] = dyh.w;
         }
-        float4 iq[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            iq[g] = L.inj ? *reinterpret_cast<const float4*>(L.inj + goff + (size_t)r * 32 * NERO_HID + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float4 gs = make_float4(acc[r][4 * g], acc[r][4 * g + 1], acc[r][4 * g + 2], acc[r][4 * g + 3]);
+            if (HEAD) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                gs.x = fmaf(dj[j], hw[j][g].x, gs.x); gs.y = fmaf(dj[j], hw[j][g].y, gs.y);
-                gs.z = fmaf(dj[j], hw[j][g].z, gs.z); gs.w = fmaf(dj[j], hw[j][g].w, gs.w);
+                for (int j = 0; j < 4; ++j) {
+                    if (j < nh) {
+                        const float4 hw = *reinterpret_cast<const float4*>(L.head_w + j * NERO_HID + fbase + 8 * g);
+                        gs.x = fmaf(dj[j], hw.x, gs.x); gs.y = fmaf(dj[j], hw.y, gs.y);
+                        gs.z = fmaf(dj[j], hw.z, gs.z); gs.w = fmaf(dj[j], hw.w, gs.w);
+                    }
+                }
             }
             const float4 a = pa[r][g];
             float4 d;
-            d.x = act_grad<ACT>(a.x, gs.x) + iq[g].x; d.y = act_grad<ACT>(a.y, gs.y) + iq[g].y;
-            d.z = act_grad<ACT>(a.z, gs.z) + iq[g].z; d.w = act_grad<ACT>(a.w, gs.w) + iq[g].w;
+            d.x = act_grad<ACT>(a.x, gs.x); d.y = act_grad<ACT>(a.y, gs.y);
+            d.z = act_grad<ACT>(a.z, gs.z); d.w = act_grad<ACT>(a.w, gs.w);
+            if (has_inj) { d.x += pi[r][g].x; d.y += pi[r][g].y; d.z += pi[r][g].z; d.w += pi[r][g].w; }
             if (!live) d = make_float4(0.f, 0.f, 0.f, 0.f);
             store_planes4(dst + r * 32 * SA + 16 * g, PLANE_A, d);
             if (L.delta_prev) *reinterpret_cast<float4*>(L.delta_prev + goff + (size_t)r * 32 * NERO_HID + 8 * g) = d;
         }
     }
+}
+
+template <int ACT>
+__device__ __forceinline__ void bwd_epilogue_h(const f32x16 (&acc)[2], const float4 (&pa)[2][4], const float4 (&pi)[2][4], bool has_inj,
+                                               const nero_bwd_layer& L, char* dst, size_t goff, int row0, int i, int fbase, int n_rows) {
+    if (L.n_head > 0) bwd_epilogue<ACT, true>(acc, pa, pi, has_inj, L, dst, goff, row0, i, fbase, n_rows);
+    else bwd_epilogue<ACT, false>(acc, pa, pi, has_inj, L, dst, goff, row0, i, fbase, n_rows);
 }
 
 __global__ __launch_bounds__(512, 1) void bwd_split_kernel(nero_bwd_chain ch, int n_rows) {
@@ -421,12 +466,20 @@ __global__ __launch_bounds__(512, 1) void bwd_split_kernel(nero_bwd_chain ch, in
         const int fbase = 32 * wave + 4 * h;
         const size_t goff = (size_t)(row0 + i) * NERO_HID + fbase;
         const int steps = L.n_out >> 4;
-        float4 pa[2][4];
+        // saved activations (for act') and the optional additive term of this lane's 32 outputs: requested before the GEMM
+        float4 pa[2][4], pi[2][4];
+        const bool has_inj = !first && L.inj != nullptr;
         if (!first && live_wave) {
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) pa[r][g] = *reinterpret_cast<const float4*>(L.a_prev + goff + (size_t)r * 32 * NERO_HID + 8 * g);
+            if (has_inj) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) pi[r][g] = *reinterpret_cast<const float4*>(L.inj + goff + (size_t)r * 32 * NERO_HID + 8 * g);
+            }
         }
         f32x16 acc[2];
         if (L.n_out > 0) {
@@ -485,9 +538,9 @@ __global__ __launch_bounds__(512, 1) void bwd_split_kernel(nero_bwd_chain ch, in
         }
         if (live_wave) {
             char* dst = actp + i * SA + fbase * 2;
-            if (L.act_prev == NERO_ACT_RELU) bwd_epilogue<NERO_ACT_RELU>(acc, pa, L, dst, goff, row0, i, fbase, n_rows);
-            else if (L.act_prev == NERO_ACT_SOFTPLUS100) bwd_epilogue<NERO_ACT_SOFTPLUS100>(acc, pa, L, dst, goff, row0, i, fbase, n_rows);
-            else bwd_epilogue<NERO_ACT_NONE>(acc, pa, L, dst, goff, row0, i, fbase, n_rows);
+            if (L.act_prev == NERO_ACT_RELU) bwd_epilogue_h<NERO_ACT_RELU>(acc, pa, pi, has_inj, L, dst, goff, row0, i, fbase, n_rows);
+            else if (L.act_prev == NERO_ACT_SOFTPLUS100) bwd_epilogue_h<NERO_ACT_SOFTPLUS100>(acc, pa, pi, has_inj, L, dst, goff, row0, i, fbase, n_rows);
+            else bwd_epilogue_h<NERO_ACT_NONE>(acc, pa, pi, has_inj, L, dst, goff, row0, i, fbase, n_rows);
         }
         __syncthreads();
     }
@@ -667,7 +720,7 @@ __global__ void pack_split_kernel(const float* __restrict__ W, int nrows, int ld
     for (int q = 0; q < 3; ++q) out[((size_t)tc * 3 + q) * 64 + lane] = make_uint4(p[q][0], p[q][1], p[q][2], p[q][3]);
 }
 
-inline int split_lds_bytes(int wide) { return 3 * PLANE_A + 3 * 64 * (wide ? SX_W : SX_N); }
+inline int split_lds_bytes(int wide) { return 3 * PLANE_A + 3 * 64 * (wide ? SX_W : SX_N) + (wide ? 0 : 8 * SCR_BYTES); }
 
 }  // namespace
 

@@ -106,7 +106,7 @@ class SDFField:
             for l in range(8):
                 d, p = ch.entries[l][0], ch._packed[l]
                 tl = tc.layer[l]
-                tl.w_main, tl.w_aux = L.ptr(p['sfm' if tsplit else 'fm']), L.ptr(p['sfa' if tsplit else 'fa'])
+                tl.w_main, tl.w_aux = L.ptr(p.get('sfm' if tsplit else 'fm')), L.ptr(p.get('sfa' if tsplit else 'fa'))
                 tl.a_saved, tl.gbar = fwd['saves'][l].data_ptr(), gbar[l].data_ptr()
                 tl.adot, tl.inj = tbuf[0, l].data_ptr(), tbuf[1, l].data_ptr()
                 tl.k_main, tl.k_aux, tl.n_tiles = rk(d.k_main), (rk(d.k_aux) if d.k_aux else 0), _tiles(d.n_out)
