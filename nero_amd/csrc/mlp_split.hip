@@ -564,11 +564,16 @@ constexpr int DWS_PLANE = 2 * 256 * 16;              // one plane of one matrix:
 constexpr int DWS_MAT = 3 * DWS_PLANE;               // 24 KB
 constexpr int DWS_STAGE = 2 * DWS_MAT;               // D + B = 48 KB
 
+// (branch free: out-of-range rows / columns read a clamped, valid address and are zeroed by a select, so that the whole chunk
+// loop stays one basic block and the scheduler can interleave it with the MFMA stream; requires r1 >= 1, cols >= 1)
 __device__ __forceinline__ void dws_fetch(float (&v)[8], const float* __restrict__ src, int ld, int cols, int r0, int r1, int col, int rh) {
+    const int cc = col < cols ? col : cols - 1;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int gr = r0 + 8 * rh + j;
-        v[j] = (col < cols && gr < r1) ? src[(size_t)gr * ld + col] : 0.f;
+        const int gc = gr < r1 ? gr : r1 - 1;
+        const float m = (col < cols && gr < r1) ? 1.f : 0.f;
+        v[j] = src[(size_t)gc * ld + cc] * m;           // (a multiply, not a select: keeps the load unconditional)
     }
 }
 __device__ __forceinline__ void dws_put(char* mat, const float (&v)[8], int col, int rh) {
@@ -621,52 +626,59 @@ __global__ __launch_bounds__(512, 1) void dw_split_kernel(nero_dw_job job, int n
     float bsum = 0.f;                                    // bias gradient partial of column `col` (rows of this thread's half)
     const int nch = r_end > r_begin ? (r_end - r_begin + 15) / 16 : 0;
     const int total = nch * (job.d1 ? 2 : 1);
-    float vd[8], vb[8];
+    // chunk q -> (operand pair, first row)
+    auto fetch = [&](float (&vd)[8], float (&vb)[8], int q) {
+        const bool second = q >= nch;
+        const int r0 = r_begin + (second ? q - nch : q) * 16;
+        dws_fetch(vd, second ? job.d1 : job.d0, second ? job.ldd1 : job.ldd0, job.n_out, r0, r_end, col, rh);
+        dws_fetch(vb, second ? job.b1 : job.b0, second ? job.ldb1 : job.ldb0, job.k_cols, r0, r_end, col, rh);
+    };
+    // software pipeline: chunk q is multiplied out of LDS stage q&1 while the registers of chunk q+1 are split and stored into
+    // the other stage (the compiler interleaves that VALU work with the MFMA stream) and the loads of chunk q+2 are in flight
+    float ad[8], ab[8], cd[8], cb[8];                    // chunk q+1 (landed) and chunk q+2 (in flight)
     if (total > 0) {
-        dws_fetch(vd, job.d0, job.ldd0, job.n_out, r_begin, r_end, col, rh);
-        dws_fetch(vb, job.b0, job.ldb0, job.k_cols, r_begin, r_end, col, rh);
+        fetch(ad, ab, 0);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bsum += vd[j];
-        dws_put(smem, vd, col, rh);
-        dws_put(smem + DWS_MAT, vb, col, rh);
+        for (int j = 0; j < 8; ++j) bsum += ad[j];
+        dws_put(smem, ad, col, rh);
+        dws_put(smem + DWS_MAT, ab, col, rh);
+        if (total > 1) fetch(ad, ab, 1);
     }
     __syncthreads();
     for (int q = 0; q < total; ++q) {
         const char* sD = smem + (q & 1) * DWS_STAGE;
         const char* sB = sD + DWS_MAT;
-        const bool more = q + 1 < total;
-        const int q1 = q + 1;
-        const bool second = q1 >= nch;
-        if (more) {
-            const int r0 = r_begin + (second ? q1 - nch : q1) * 16;
-            dws_fetch(vd, second ? job.d1 : job.d0, second ? job.ldd1 : job.ldd0, job.n_out, r0, r_end, col, rh);
-            dws_fetch(vb, second ? job.b1 : job.b0, second ? job.ldb1 : job.ldb0, job.k_cols, r0, r_end, col, rh);
+        // (indices past the end are clamped: the extra fetch / store is harmless -- nobody reads that stage any more)
+        fetch(cd, cb, q + 2 < total ? q + 2 : total - 1);
+        {
+            const float keep = (q + 1 < nch) ? 1.f : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bsum = fmaf(keep, ad[j], bsum);
+            char* nD = smem + ((q + 1) & 1) * DWS_STAGE;
+            dws_put(nD, ad, col, rh);
+            dws_put(nD + DWS_MAT, ab, col, rh);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (nt0 < n_tiles && kt0 < k_tiles) {
+        if (NARROW) {
+            if (nt0 < n_tiles) {
+                const Fr3 fa = dws_frag(sD, nt0, i, h);
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (b < k_tiles) mf6(acc[0][b], fa, dws_frag(sB, b, i, h));
+            }
+        } else {
+            // all 2 x 4 tiles of this wave, unconditionally (missing columns are zero planes)
             Fr3 fa[NA];
 #pragma unroll
             for (int a = 0; a < NA; ++a) fa[a] = dws_frag(sD, nt0 + a, i, h);
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                if (kt0 + b < k_tiles) {
-                    const Fr3 fb = dws_frag(sB, kt0 + b, i, h);
+                const Fr3 fb = dws_frag(sB, kt0 + b, i, h);
 #pragma unroll
-                    for (int a = 0; a < NA; ++a)
-                        if (nt0 + a < n_tiles) mf6(acc[a][b], fa[a], fb);
-                }
+                for (int a = 0; a < NA; ++a) mf6(acc[a][b], fa[a], fb);
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) {
-            if (!second) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) bsum += vd[j];
-            }
-            char* nD = smem + (q1 & 1) * DWS_STAGE;
-            dws_put(nD, vd, col, rh);
-            dws_put(nD + DWS_MAT, vb, col, rh);
-        }
+        for (int j = 0; j < 8; ++j) { ad[j] = cd[j]; ab[j] = cb[j]; }
         __syncthreads();
     }
     // this slice's partial C (row-major [n_pad][k_pad]) and bias partial, in the layout dw_reduce_kernel expects
