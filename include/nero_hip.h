@@ -56,6 +56,19 @@ int nero_pack_weight(const float* W, int nrows, int ld, int col0, int ncols, int
 int nero_pack_weight_split(const float* W, int nrows, int ld, int col0, int ncols, int transpose, float scale,
                            int kpad, int nt_count, void* out, void* stream);
 
+/* Batched form: up to NERO_MAX_PACK_JOBS packing / copy jobs of one network in ONE launch (a training step repacks ~90
+ * operand images and copies ~60 bias / head vectors; as separate launches they are pure launch latency).
+ *   kind 0: nero_pack_weight_split(W, nrows, ld, col0, ncols, transpose, scale, kpad, nt_count, out)
+ *   kind 1: nero_pack_weight(...) with the same fields
+ *   kind 2: 2-D copy  out[r*kpad + c] = W[r*ld + c],  r < nrows, c < ncols   (bias: nrows = 1; head weights [n_head][k] -> [4][256]) */
+#define NERO_MAX_PACK_JOBS 64
+typedef struct {
+    const float* W; void* out;
+    int kind, nrows, ld, col0, ncols, transpose, kpad, nt_count;
+    float scale; int pad_;
+} nero_pack_job;
+int nero_pack_batch(const nero_pack_job* jobs /*host*/, int n_jobs, void* stream);
+
 /* ---- fused MLP chain ------------------------------------------------------------------------------------------
  * One workgroup owns a tile of 64 rows and walks the whole layer list with the activations resident in LDS; every
  * dense layer is computed with v_mfma_f32_32x32x2_f32.  Replaces the nn.Linear/softplus/ReLU sequences of

@@ -51,6 +51,15 @@ class BwdChain(C.Structure):
                 ('aux_wide', C.c_int), ('gemm_mode', C.c_int), ('macs_per_row', C.c_double), ('layer', BwdLayer * MAX_LAYERS)]
 
 
+class PackJob(C.Structure):
+    _fields_ = [('W', _fp), ('out', _fp), ('kind', C.c_int), ('nrows', C.c_int), ('ld', C.c_int), ('col0', C.c_int),
+                ('ncols', C.c_int), ('transpose', C.c_int), ('kpad', C.c_int), ('nt_count', C.c_int), ('scale', C.c_float),
+                ('pad_', C.c_int)]
+
+
+MAX_PACK_JOBS = 64
+
+
 class DwJob(C.Structure):
     _fields_ = [('d0', _fp), ('b0', _fp), ('d1', _fp), ('b1', _fp), ('ldd0', C.c_int), ('ldb0', C.c_int),
                 ('ldd1', C.c_int), ('ldb1', C.c_int), ('n_out', C.c_int), ('k_cols', C.c_int), ('dW', _fp),

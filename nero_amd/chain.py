@@ -100,6 +100,14 @@ class Chain:
         buf = torch.zeros(total, dtype=torch.float32, device=self.device)
         off = 0
         packed = []
+        jobs = []
+
+        def job(kind, W, out, nrows, ld, col0, ncols, transpose, kpad, nt_count, scale=1.0):
+            j = L.PackJob()
+            j.W, j.out, j.kind, j.nrows, j.ld, j.col0, j.ncols = W.data_ptr(), out.data_ptr(), kind, nrows, ld, col0, ncols
+            j.transpose, j.kpad, j.nt_count, j.scale = transpose, kpad, nt_count, scale
+            jobs.append((j, W))
+
         for (d, h), e in zip(self.entries, sizes):
             p = {}
             for k, n in e.items():
@@ -111,27 +119,31 @@ class Chain:
                 nt = _tiles(d.n_out)
                 for key, c0, kc in (('fm', d.main_c0, d.k_main), ('fa', d.aux_c0, d.k_aux)):
                     if kc and key in p:
-                        L.check(L.lib.nero_pack_weight(C.c_void_p(W.data_ptr()), d.n_out, W.stride(0), c0, kc, 0,
-                                                       C.c_float(d.scale), _r8(kc), nt, C.c_void_p(p[key].data_ptr()), st))
+                        job(1, W, p[key], d.n_out, W.stride(0), c0, kc, 0, _r8(kc), nt, d.scale)
                 for key, c0, kc in (('bm', d.main_c0, d.k_main), ('ba', d.aux_c0, d.k_aux)):
                     if kc and key in p:
-                        L.check(L.lib.nero_pack_weight(C.c_void_p(W.data_ptr()), d.n_out, W.stride(0), c0, kc, 1,
-                                                       C.c_float(d.scale), _r8(d.n_out), _tiles(kc), C.c_void_p(p[key].data_ptr()), st))
+                        job(1, W, p[key], d.n_out, W.stride(0), c0, kc, 1, _r8(d.n_out), _tiles(kc), d.scale)
                 for key, c0, kc in (('sfm', d.main_c0, d.k_main), ('sfa', d.aux_c0, d.k_aux)):
                     if kc and key in p:
-                        L.check(L.lib.nero_pack_weight_split(C.c_void_p(W.data_ptr()), d.n_out, W.stride(0), c0, kc, 0,
-                                                             C.c_float(d.scale), _r16(kc), nt, C.c_void_p(p[key].data_ptr()), st))
+                        job(0, W, p[key], d.n_out, W.stride(0), c0, kc, 0, _r16(kc), nt, d.scale)
                 for key, c0, kc in (('sbm', d.main_c0, d.k_main), ('sba', d.aux_c0, d.k_aux)):
                     if kc and key in p:
-                        L.check(L.lib.nero_pack_weight_split(C.c_void_p(W.data_ptr()), d.n_out, W.stride(0), c0, kc, 1,
-                                                             C.c_float(d.scale), _r16(d.n_out), _tiles(kc), C.c_void_p(p[key].data_ptr()), st))
+                        job(0, W, p[key], d.n_out, W.stride(0), c0, kc, 1, _r16(d.n_out), _tiles(kc), d.scale)
                 if d.b is not None:
-                    p['bias'][:d.n_out].copy_(d.b.detach())
+                    b = d.b.detach()
+                    job(2, b, p['bias'], 1, d.n_out, 0, d.n_out, 0, 32 * nt, 0)
             if h is not None:
-                p['hw'].view(4, L.HID)[:h.n_head, :h.k].copy_(h.W.detach())
+                Wh = h.W.detach()
+                assert Wh.stride(1) == 1
+                job(2, Wh, p['hw'], h.n_head, Wh.stride(0), 0, h.k, 0, L.HID, 0)
                 if h.b is not None:
-                    p['hb'][:h.n_head].copy_(h.b.detach())
+                    job(2, h.b.detach(), p['hb'], 1, h.n_head, 0, h.n_head, 0, 4, 0)
             packed.append(p)
+        # one launch per <= 64 jobs (include/nero_hip.h nero_pack_batch)
+        for i0 in range(0, len(jobs), L.MAX_PACK_JOBS):
+            chunk = jobs[i0:i0 + L.MAX_PACK_JOBS]
+            arr = (L.PackJob * len(chunk))(*[j for j, _ in chunk])
+            L.check(L.lib.nero_pack_batch(arr, len(chunk), st))
         self._packed, self._buf = packed, buf
         return self
 

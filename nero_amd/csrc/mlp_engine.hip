@@ -695,7 +695,7 @@ __global__ __launch_bounds__(256) void head_dw_kernel(const float* __restrict__ 
     float4 s[4];
     float sb[4] = {0.f, 0.f, 0.f, 0.f};
     for (int j = 0; j < 4; ++j) s[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
+#pragma unroll 8
     for (int r = r_begin + grp; r < r_end; r += 4) {
         const float4 d = *reinterpret_cast<const float4*>(dy + (size_t)r * 4);
         const float4 av = *reinterpret_cast<const float4*>(a + (size_t)r * NERO_HID + c4);
@@ -794,6 +794,11 @@ int nero_pack_weight_split(const float* W, int nrows, int ld, int col0, int ncol
                            int nt_count, void* out, void* stream) {
     if (!W || !out || nt_count <= 0) return nero_fail(NERO_ERR_ARG, "nero_pack_weight_split: bad argument");
     return nero_split_pack(W, nrows, ld, col0, ncols, transpose, scale, kpad, nt_count, out, (hipStream_t)stream);
+}
+
+int nero_pack_batch(const nero_pack_job* jobs, int n_jobs, void* stream) {
+    if (!jobs && n_jobs > 0) return nero_fail(NERO_ERR_ARG, "nero_pack_batch: bad argument");
+    return nero_split_pack_batch(jobs, n_jobs, (hipStream_t)stream);
 }
 
 static int lds_bytes(int wide) { return (64 * LDA + 64 * (wide ? LDX_WIDE : LDX_NARROW)) * (int)sizeof(float); }
@@ -895,7 +900,7 @@ int nero_head_dw(const float* dy, const float* a, const float* extra, int n_head
                  float* partials, int accumulate, void* stream) {
     if (!dy || !a || !dWh || !partials || n_head < 1 || n_head > 4) return nero_fail(NERO_ERR_ARG, "nero_head_dw: bad argument");
     const int rows = n_rows < 1 ? 1 : n_rows;
-    int rps = 1024;                                    // rows per block (<= a few hundred partials to reduce)
+    int rps = 256;                                     // rows per block: ~5 blocks per CU in flight at 300k rows (the pass is latency bound otherwise)
     const int slices = (rows + rps - 1) / rps;
     hipLaunchKernelGGL(head_dw_kernel, dim3(slices), dim3(256), 0, (hipStream_t)stream, dy, a, extra, n_head, n_rows, rps, partials);
     const int total = n_head * NERO_HID + n_head;

@@ -11,3 +11,4 @@ int nero_split_tangent(const nero_tan_chain* ch, int n_rows, hipStream_t stream)
 int nero_split_backward(const nero_bwd_chain* ch, int n_rows, hipStream_t stream);
 int nero_split_dw(const nero_dw_job* job, int n_rows, int rows_per_slice, int slices, float* partials, int n_pad, int k_pad,
                   hipStream_t stream);
+int nero_split_pack_batch(const nero_pack_job* jobs, int n_jobs, hipStream_t stream);

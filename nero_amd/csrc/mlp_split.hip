@@ -732,6 +732,57 @@ __global__ void pack_split_kernel(const float* __restrict__ W, int nrows, int ld
     for (int q = 0; q < 3; ++q) out[((size_t)tc * 3 + q) * 64 + lane] = make_uint4(p[q][0], p[q][1], p[q][2], p[q][3]);
 }
 
+// ---- batched packing: one launch for all operand images / bias copies of a network ---------------------------------------
+struct PackBatch { nero_pack_job job[NERO_MAX_PACK_JOBS]; };
+
+__device__ __forceinline__ void pack_split_one(const nero_pack_job& J, int idx) {
+    const int nsteps = J.kpad >> 4;
+    if (idx >= J.nt_count * nsteps * 64) return;
+    const float* __restrict__ W = J.W;
+    const int lane = idx & 63, tc = idx >> 6;
+    const int c = tc % nsteps, t = tc / nsteps;
+    const int m = 32 * t + (lane & 31), k0 = 16 * c + 8 * (lane >> 5);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = k0 + j;
+        float x = 0.f;
+        if (!J.transpose) { if (m < J.nrows && k < J.ncols) x = W[(size_t)m * J.ld + J.col0 + k]; }
+        else              { if (m < J.ncols && k < J.nrows) x = W[(size_t)k * J.ld + J.col0 + m]; }
+        v[j] = x * J.scale;
+    }
+    unsigned p[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split2(v[2 * j], v[2 * j + 1], p[0][j], p[1][j], p[2][j]);
+    uint4* out = reinterpret_cast<uint4*>(J.out);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) out[((size_t)tc * 3 + q) * 64 + lane] = make_uint4(p[q][0], p[q][1], p[q][2], p[q][3]);
+}
+// the f32-MFMA B-operand order of mlp_engine.hip's pack_weight_kernel: out[((c*NT + nt)*64 + lane)*4 + t]
+__device__ __forceinline__ void pack_f32_one(const nero_pack_job& J, int idx) {
+    const int total = (J.kpad >> 3) * J.nt_count * 256;
+    if (idx >= total) return;
+    const int t = idx & 3, lane = (idx >> 2) & 63, rest = idx >> 8;
+    const int nt = rest % J.nt_count, c = rest / J.nt_count;
+    const int k = 8 * c + 4 * (lane >> 5) + t, n = 32 * nt + (lane & 31);
+    float x = 0.f;
+    if (!J.transpose) { if (n < J.nrows && k < J.ncols) x = J.W[(size_t)n * J.ld + J.col0 + k]; }
+    else              { if (k < J.nrows && n < J.ncols) x = J.W[(size_t)k * J.ld + J.col0 + n]; }
+    reinterpret_cast<float*>(J.out)[idx] = x * J.scale;
+}
+__global__ __launch_bounds__(256) void pack_batch_kernel(PackBatch B) {
+    const nero_pack_job& J = B.job[blockIdx.y];
+    for (int idx = blockIdx.x * 256 + threadIdx.x;; idx += gridDim.x * 256) {
+        if (J.kind == 0) { if (idx >= J.nt_count * (J.kpad >> 4) * 64) break; pack_split_one(J, idx); }
+        else if (J.kind == 1) { if (idx >= (J.kpad >> 3) * J.nt_count * 256) break; pack_f32_one(J, idx); }
+        else {
+            if (idx >= J.nrows * J.ncols) break;
+            const int r = idx / J.ncols, c = idx - r * J.ncols;
+            reinterpret_cast<float*>(J.out)[(size_t)r * J.kpad + c] = J.W[(size_t)r * J.ld + c];
+        }
+    }
+}
+
 inline int split_lds_bytes(int wide) { return 3 * PLANE_A + 3 * 64 * (wide ? SX_W : SX_N) + (wide ? 0 : 8 * SCR_BYTES); }
 
 }  // namespace
@@ -799,4 +850,24 @@ int nero_split_dw(const nero_dw_job* job, int n_rows, int rows_per_slice, int sl
     else
         hipLaunchKernelGGL(dw_split_kernel<false>, dim3(slices), dim3(512), lds, stream, *job, n_rows, rows_per_slice, partials, n_pad, k_pad);
     return NERO_OK;
+}
+
+int nero_split_pack_batch(const nero_pack_job* jobs, int n_jobs, hipStream_t stream) {
+    if (n_jobs <= 0) return NERO_OK;
+    if (n_jobs > NERO_MAX_PACK_JOBS) return nero_fail(NERO_ERR_ARG, "nero_pack_batch: too many jobs");
+    PackBatch B;
+    int max_work = 1;
+    for (int i = 0; i < n_jobs; ++i) {
+        const nero_pack_job& J = jobs[i];
+        if (!J.W || !J.out) return nero_fail(NERO_ERR_ARG, "nero_pack_batch: null pointer");
+        if (J.kind == 0 && (J.kpad & 15)) return nero_fail(NERO_ERR_ARG, "nero_pack_batch: split kpad must be a multiple of 16");
+        if (J.kind == 1 && (J.kpad & 7)) return nero_fail(NERO_ERR_ARG, "nero_pack_batch: kpad must be a multiple of 8");
+        B.job[i] = J;
+        const int work = J.kind == 0 ? J.nt_count * (J.kpad >> 4) * 64 : J.kind == 1 ? (J.kpad >> 3) * J.nt_count * 256 : J.nrows * J.ncols;
+        max_work = work > max_work ? work : max_work;
+    }
+    int bx = (max_work + 255) / 256;
+    bx = bx > 32 ? 32 : bx;                              // grid-stride inside the kernel
+    hipLaunchKernelGGL(pack_batch_kernel, dim3(bx, n_jobs), dim3(256), 0, stream, B);
+    return nero_check_launch("nero_pack_batch");
 }
