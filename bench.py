@@ -115,6 +115,27 @@ def main():
     rays_total = args.rays * world * args.steps
     value = rays_total / dt
 
+    # ---- the same step on the exact-fp32 MFMA engine (NERO_GEMM=f32), reported next to the headline: 2 warmup + 5 timed steps --
+    from nero_amd import chain as _CHM
+    alt = None
+    if _CHM.GEMM_MODE['fwd'] == L.GEMM_BF16X6:
+        _CHM.set_gemm_mode('f32')
+        for i in range(2):
+            ts.step(args.train_step + 200 + i)
+        sync()
+        t1 = time.time()
+        for i in range(5):
+            ts.step(args.train_step + 202 + i)
+        sync()
+        dta = torch.tensor([time.time() - t1], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(dta, op=dist.ReduceOp.MAX)
+        alt = {'value': round(args.rays * world * 5 / float(dta), 1), 'unit': 'rays/s', 'ms_per_step': round(float(dta) / 5 * 1e3, 3),
+               'steps': 5, 'mfma': 'v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain, 157.3 TFLOP/s peak)'}
+        _CHM.set_gemm_mode('bf16x6')
+        ts.step(args.train_step + 300)           # back on the default engine before the roofline leg
+        sync()
+
     # ---- roofline leg: per-launch HIP-event timing of the MFMA kernel classes, on extra (untimed) steps ------------
     roof = None
     if rank == 0:
@@ -164,6 +185,8 @@ def main():
             'inner_samples_per_ray': round(n_in / args.steps / args.rays, 2),
             'roofline': roof,
         }
+        if alt is not None:
+            res['f32_mfma_engine'] = alt
         if not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(cfg, variance, args.train_step)
         print(json.dumps(res), flush=True)

@@ -158,7 +158,6 @@ class Chain:
         ch.n_layers, ch.aux_wide = len(self.entries), int(self.aux_wide)
         split = GEMM_MODE['fwd'] == L.GEMM_BF16X6
         ch.gemm_mode = GEMM_MODE['fwd']
-        ch.pad_ = int(os.environ.get('NERO_SPLIT_DEBUG', '0'))
         ch.macs_per_row = float(sum(d.n_out * (d.k_main + d.k_aux) for d, _ in self.entries if d is not None))
         if init is not None:
             assert init.shape[0] >= rp and init.shape[1] >= self.k_init

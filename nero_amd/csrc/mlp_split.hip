@@ -139,19 +139,19 @@ __device__ __forceinline__ float act_grad(float a, float g) {
 }
 
 // ---- GEMM core ------------------------------------------------------------------------------------------------------
-// acc[r] (r = 32-row half) += sum over `n` k-steps of 16: the six significant plane products.  Operands of step c+2 are
-// requested before the 12 MFMAs of step c are issued (three rotating register buffers, as in mlp_engine.hip).
-struct OpS {
-    uint4 w0, w1, w2;            // weight planes (A operand): lane (i, h) holds 8 consecutive k of feature row i
-    uint4 x00, x01, x02;         // activation planes, rows 0..31 (B operand): lane (i, h) holds 8 consecutive k of batch row i
-    uint4 x10, x11, x12;         // rows 32..63
-};
+// acc[r] (r = 32-row half) += sum over `n` k-steps of 16: the six significant plane products.
+// Software pipeline: the weight planes (A operand, streamed from L2: 200-800 cycles under load) run THREE steps ahead in a
+// ring of four register sets; the activation planes (B operand, LDS: ~100 cycles) one step ahead in a double buffer.
+struct WF { uint4 w0, w1, w2; };                 // lane (i, h): 8 consecutive k of feature row i, per plane
+struct XF { uint4 x00, x01, x02, x10, x11, x12; };   // lane (i, h): 8 consecutive k of batch row i (rows 0..31 / 32..63), per plane
 
-__device__ __forceinline__ void ops_load(OpS& o, const uint4* wp, const char* xp, int half_bytes, int plane_bytes, int c, int wmul = 1) {
-    const uint4* w = wp + (size_t)(c * wmul) * 192;
+__device__ __forceinline__ void load_w(WF& o, const uint4* wp, int c) {
+    const uint4* w = wp + (size_t)c * 192;
     o.w0 = w[0];
     o.w1 = w[64];
     o.w2 = w[128];
+}
+__device__ __forceinline__ void load_x(XF& o, const char* xp, int half_bytes, int plane_bytes, int c) {
     const char* x = xp + c * 32;
     o.x00 = *reinterpret_cast<const uint4*>(x);
     o.x01 = *reinterpret_cast<const uint4*>(x + plane_bytes);
@@ -165,39 +165,45 @@ __device__ __forceinline__ void ops_load(OpS& o, const uint4* wp, const char* xp
 #define NERO_MF(ACC, A, B) \
     ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), ACC, 0, 0, 0)
 
-__device__ __forceinline__ void ops_compute(f32x16 (&acc)[2], const OpS& o) {
-    NERO_MF(acc[0], o.w2, o.x00); NERO_MF(acc[1], o.w2, o.x10);
-    NERO_MF(acc[0], o.w1, o.x01); NERO_MF(acc[1], o.w1, o.x11);
-    NERO_MF(acc[0], o.w0, o.x02); NERO_MF(acc[1], o.w0, o.x12);
-    NERO_MF(acc[0], o.w1, o.x00); NERO_MF(acc[1], o.w1, o.x10);
-    NERO_MF(acc[0], o.w0, o.x01); NERO_MF(acc[1], o.w0, o.x11);
-    NERO_MF(acc[0], o.w0, o.x00); NERO_MF(acc[1], o.w0, o.x10);
+__device__ __forceinline__ void ops_compute(f32x16 (&acc)[2], const WF& w, const XF& x) {
+    NERO_MF(acc[0], w.w2, x.x00); NERO_MF(acc[1], w.w2, x.x10);
+    NERO_MF(acc[0], w.w1, x.x01); NERO_MF(acc[1], w.w1, x.x11);
+    NERO_MF(acc[0], w.w0, x.x02); NERO_MF(acc[1], w.w0, x.x12);
+    NERO_MF(acc[0], w.w1, x.x00); NERO_MF(acc[1], w.w1, x.x10);
+    NERO_MF(acc[0], w.w0, x.x01); NERO_MF(acc[1], w.w0, x.x11);
+    NERO_MF(acc[0], w.w0, x.x00); NERO_MF(acc[1], w.w0, x.x10);
 }
 
-__device__ __forceinline__ void gemm_split(f32x16 (&acc)[2], const uint4* wp, const char* xp, int half_bytes, int plane_bytes, int n, int wmul = 1) {
+#define NERO_FENCE() __builtin_amdgcn_sched_barrier(0)     /* keeps hipcc from sinking the prefetches down to their first use */
+
+__device__ __forceinline__ void gemm_split(f32x16 (&acc)[2], const uint4* wp, const char* xp, int half_bytes, int plane_bytes, int n) {
     if (n <= 0) return;
-    OpS u, v, w;
+    WF wa, wb, wc, wd;
+    XF xa, xb;
     const int last = n - 1;
-    ops_load(u, wp, xp, half_bytes, plane_bytes, 0, wmul);
-    ops_load(v, wp, xp, half_bytes, plane_bytes, 1 < last ? 1 : last, wmul);
-    int c = 0;
-    __builtin_amdgcn_sched_barrier(0);
-    for (; c + 3 <= n; c += 3) {
-        ops_load(w, wp, xp, half_bytes, plane_bytes, c + 2 < last ? c + 2 : last, wmul);
-        __builtin_amdgcn_sched_barrier(0);
-        ops_compute(acc, u);
-        __builtin_amdgcn_sched_barrier(0);
-        ops_load(u, wp, xp, half_bytes, plane_bytes, c + 3 < last ? c + 3 : last, wmul);
-        __builtin_amdgcn_sched_barrier(0);
-        ops_compute(acc, v);
-        __builtin_amdgcn_sched_barrier(0);
-        ops_load(v, wp, xp, half_bytes, plane_bytes, c + 4 < last ? c + 4 : last, wmul);
-        __builtin_amdgcn_sched_barrier(0);
-        ops_compute(acc, w);
-        __builtin_amdgcn_sched_barrier(0);
+#define NERO_CL(c) ((c) < last ? (c) : last)
+    load_w(wa, wp, 0);
+    load_w(wb, wp, NERO_CL(1));
+    load_w(wc, wp, NERO_CL(2));
+    load_x(xa, xp, half_bytes, plane_bytes, 0);
+    NERO_FENCE();
+    for (int c = 0; c < n; c += 4) {
+        load_w(wd, wp, NERO_CL(c + 3)); load_x(xb, xp, half_bytes, plane_bytes, NERO_CL(c + 1)); NERO_FENCE();
+        ops_compute(acc, wa, xa); NERO_FENCE();
+        if (c + 1 < n) {
+            load_w(wa, wp, NERO_CL(c + 4)); load_x(xa, xp, half_bytes, plane_bytes, NERO_CL(c + 2)); NERO_FENCE();
+            ops_compute(acc, wb, xb); NERO_FENCE();
+        }
+        if (c + 2 < n) {
+            load_w(wb, wp, NERO_CL(c + 5)); load_x(xb, xp, half_bytes, plane_bytes, NERO_CL(c + 3)); NERO_FENCE();
+            ops_compute(acc, wc, xa); NERO_FENCE();
+        }
+        if (c + 3 < n) {
+            load_w(wc, wp, NERO_CL(c + 6)); load_x(xa, xp, half_bytes, plane_bytes, NERO_CL(c + 4)); NERO_FENCE();
+            ops_compute(acc, wd, xb); NERO_FENCE();
+        }
     }
-    if (c < n) ops_compute(acc, u);
-    if (c + 1 < n) ops_compute(acc, v);
+#undef NERO_CL
 }
 
 __device__ __forceinline__ void zero2(f32x16 (&acc)[2]) {
@@ -305,12 +311,12 @@ __global__ __launch_bounds__(512, 1) void fwd_split_kernel(nero_fwd_chain ch, in
         if (live_wave) {
             const int sm = L.k_main >> 4, sx = L.k_aux >> 4;
             gemm_split(acc, reinterpret_cast<const uint4*>(L.w_main) + (size_t)wave * sm * 192 + lane, actp + i * SA + 16 * h,
-                       32 * SA, PLANE_A, sm, (ch.pad_ & 2) ? 0 : 1);
+                       32 * SA, PLANE_A, sm);
             gemm_split(acc, reinterpret_cast<const uint4*>(L.w_aux) + (size_t)wave * sx * 192 + lane, auxp + i * SX + 16 * h,
-                       32 * SX, PLANE_X, sx, (ch.pad_ & 2) ? 0 : 1);
+                       32 * SX, PLANE_X, sx);
         }
         __syncthreads();                                   // every wave is done reading the input planes
-        if (live_wave && !(ch.pad_ & 1)) {
+        if (live_wave) {
             char* dst = actp + i * SA + (32 * wave + 4 * h) * 2;
             float* sv = L.save ? L.save + (size_t)(row0 + i) * NERO_HID + 32 * wave + 4 * h : nullptr;
             float* sblock = L.save ? L.save + (size_t)row0 * NERO_HID + 32 * wave : nullptr;
