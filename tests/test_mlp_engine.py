@@ -172,3 +172,54 @@ def test_sdf_normal_and_second_order_weight_grads():
         assert rel(grads[l][1], P[f'sdf_network.lin{l}.bias'].grad) < 1e-4, l
     # sdf-only evaluation path used by the sampler
     assert rel(field.sdf(xc)[:, 0], y[:, 0]) < 2e-5
+
+
+@pytest.mark.parametrize('transpose', [0, 1])
+def test_split_operand_planes_are_exact_and_in_fragment_order(transpose):
+    """nero_pack_weight_split / nero_pack_batch (include/nero_hip.h): the three bf16 planes of every element sum EXACTLY
+    (bit for bit, in fp32) to W*scale -- the property the fp32-grade claim of NERO_GEMM_BF16X6 rests on -- and sit at
+    out[(((t*(kpad/16) + c)*3 + p)*64 + lane)*8 + j] = plane_p(A[32t + (lane&31)][16c + 8(lane>>5) + j]), zero outside."""
+    import ctypes as C
+    import numpy as np
+    from nero_amd import _lib as L
+    g = torch.Generator().manual_seed(3)
+    nrows, ld, col0, ncols, scale = 70, 150, 5, 123, 0.70710678
+    # wide dynamic range incl. tiny values, zeros and negative numbers
+    W = (torch.randn(nrows, ld, generator=g) * torch.exp(torch.randn(nrows, ld, generator=g) * 6)).cuda()
+    W[3, 7] = 0.0
+    M, K = (nrows, ncols) if not transpose else (ncols, nrows)
+    kpad, nt = (K + 15) // 16 * 16, (M + 31) // 32
+    n_u16 = nt * (kpad // 16) * 3 * 64 * 8
+    outs = []
+    for batched in (False, True):
+        out = torch.zeros(n_u16 // 2, dtype=torch.int32, device='cuda')
+        if not batched:
+            L.check(L.lib.nero_pack_weight_split(C.c_void_p(W.data_ptr()), nrows, ld, col0, ncols, transpose, C.c_float(scale),
+                                                 kpad, nt, C.c_void_p(out.data_ptr()), L.stream_ptr()))
+        else:
+            j = L.PackJob()
+            j.W, j.out, j.kind, j.nrows, j.ld, j.col0, j.ncols = W.data_ptr(), out.data_ptr(), 0, nrows, ld, col0, ncols
+            j.transpose, j.kpad, j.nt_count, j.scale = transpose, kpad, nt, scale
+            arr = (L.PackJob * 1)(j)
+            L.check(L.lib.nero_pack_batch(arr, 1, L.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append(out.cpu().numpy().view(np.uint16).reshape(nt, kpad // 16, 3, 64, 8))
+    assert np.array_equal(outs[0], outs[1])
+    img = outs[0]
+    planes = (img.astype(np.uint32) << 16).view(np.float32)                  # bf16 -> fp32, exact
+    total = (planes[:, :, 0] + planes[:, :, 1]) + planes[:, :, 2]            # [nt, steps, 64, 8]; each partial sum is exact in fp32
+    Wn = (W.cpu().numpy()[:, col0:col0 + ncols] * np.float32(scale)).astype(np.float32)
+    A = Wn if not transpose else Wn.T
+    want = np.zeros((nt * 32, kpad), np.float32)
+    want[:M, :K] = A
+    lane = np.arange(64)
+    for t in range(nt):
+        for c in range(kpad // 16):
+            rows = 32 * t + (lane & 31)
+            cols = 16 * c + 8 * (lane >> 5)
+            blk = np.stack([want[rows, cols + j] for j in range(8)], -1)      # [64, 8]
+            assert np.array_equal(total[t, c].view(np.uint32), blk.view(np.uint32)), (t, c)
+    # plane magnitudes: |x1| <= 2^-8 |x0|, |x2| <= 2^-8 |x1| wherever x0 != 0
+    p0, p1, p2 = np.abs(planes[:, :, 0]), np.abs(planes[:, :, 1]), np.abs(planes[:, :, 2])
+    nz = p0 > 0
+    assert (p1[nz] <= p0[nz] * 2.0 ** -8).all() and (p2[nz] <= p0[nz] * 2.0 ** -16).all()
