@@ -381,9 +381,12 @@ __global__ __launch_bounds__(512, 1) void tan_split_kernel(nero_tan_chain ch, in
         __syncthreads();
         if (live_wave) {
             char* dst = actp + i * SA + (32 * wave + 4 * h) * 2;
+            float* scr = reinterpret_cast<float*>(smem + 3 * PLANE_A + 3 * PLANE_X + wave * SCR_BYTES);
+            const size_t boff = (size_t)row0 * NERO_HID + 32 * wave;
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const bool live = (row0 + 32 * r + i) < n_rows;
+                float4 adq[4], ijq[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const float4 a = pa[r][g], gb = pg[r][g];
@@ -393,10 +396,12 @@ __global__ __launch_bounds__(512, 1) void tan_split_kernel(nero_tan_chain ch, in
                     tan_elem(a.z, acc[r][4 * g + 2], gb.z, live, ad.z, ij.z);
                     tan_elem(a.w, acc[r][4 * g + 3], gb.w, live, ad.w, ij.w);
                     store_planes4(dst + r * 32 * SA + 16 * g, PLANE_A, ad);
-                    const size_t o = goff + (size_t)r * 32 * NERO_HID + 8 * g;
-                    *reinterpret_cast<float4*>(L.adot + o) = live ? ad : make_float4(0.f, 0.f, 0.f, 0.f);
-                    *reinterpret_cast<float4*>(L.inj + o) = ij;
+                    adq[g] = live ? ad : make_float4(0.f, 0.f, 0.f, 0.f);
+                    ijq[g] = ij;
                 }
+                // row-major (128-byte segment) stores through the wave's LDS scratch
+                acc_to_global(scr, adq, L.adot + boff + (size_t)r * 32 * NERO_HID, lane);
+                acc_to_global(scr, ijq, L.inj + boff + (size_t)r * 32 * NERO_HID, lane);
             }
         }
         __syncthreads();
@@ -408,13 +413,15 @@ __global__ __launch_bounds__(512, 1) void tan_split_kernel(nero_tan_chain ch, in
 // ---------------------------------------------------------------------------------------------------------------------
 template <int ACT, bool HEAD>
 __device__ __forceinline__ void bwd_epilogue(const f32x16 (&acc)[2], const float4 (&pa)[2][4], const float4 (&pi)[2][4], bool has_inj,
-                                             const nero_bwd_layer& L, char* dst, size_t goff, int row0, int i, int fbase, int n_rows) {
+                                             const nero_bwd_layer& L, char* dst, size_t boff, float* scr, int lane, int row0, int i,
+                                             int fbase, int n_rows) {
     const int nh = L.n_head;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int grow = row0 + 32 * r + i;
         const bool live = grow < n_rows;
         float dj[4] = {0.f, 0.f, 0.f, 0.f};
+        float4 dq[4];
         if (HEAD) {
             const float4 dyh = *reinterpret_cast<const float4*>(L.head_dy + (size_t)grow * 4);
             dj[0] = dyh.x; dj[1] = dyh.y; dj[2] = dyh.z; dj[3] = dyh.w;
@@ -439,16 +446,19 @@ __device__ __forceinline__ void bwd_epilogue(const f32x16 (&acc)[2], const float
             if (has_inj) { d.x += pi[r][g].x; d.y += pi[r][g].y; d.z += pi[r][g].z; d.w += pi[r][g].w; }
             if (!live) d = make_float4(0.f, 0.f, 0.f, 0.f);
             store_planes4(dst + r * 32 * SA + 16 * g, PLANE_A, d);
-            if (L.delta_prev) *reinterpret_cast<float4*>(L.delta_prev + goff + (size_t)r * 32 * NERO_HID + 8 * g) = d;
+            dq[g] = d;
         }
+        // row-major (128-byte segment) store through the wave's LDS scratch
+        if (L.delta_prev) acc_to_global(scr, dq, L.delta_prev + boff + (size_t)r * 32 * NERO_HID, lane);
     }
 }
 
 template <int ACT>
 __device__ __forceinline__ void bwd_epilogue_h(const f32x16 (&acc)[2], const float4 (&pa)[2][4], const float4 (&pi)[2][4], bool has_inj,
-                                               const nero_bwd_layer& L, char* dst, size_t goff, int row0, int i, int fbase, int n_rows) {
-    if (L.n_head > 0) bwd_epilogue<ACT, true>(acc, pa, pi, has_inj, L, dst, goff, row0, i, fbase, n_rows);
-    else bwd_epilogue<ACT, false>(acc, pa, pi, has_inj, L, dst, goff, row0, i, fbase, n_rows);
+                                               const nero_bwd_layer& L, char* dst, size_t boff, float* scr, int lane, int row0, int i,
+                                               int fbase, int n_rows) {
+    if (L.n_head > 0) bwd_epilogue<ACT, true>(acc, pa, pi, has_inj, L, dst, boff, scr, lane, row0, i, fbase, n_rows);
+    else bwd_epilogue<ACT, false>(acc, pa, pi, has_inj, L, dst, boff, scr, lane, row0, i, fbase, n_rows);
 }
 
 __global__ __launch_bounds__(512, 1) void bwd_split_kernel(nero_bwd_chain ch, int n_rows) {
@@ -544,9 +554,11 @@ __global__ __launch_bounds__(512, 1) void bwd_split_kernel(nero_bwd_chain ch, in
         }
         if (live_wave) {
             char* dst = actp + i * SA + fbase * 2;
-            if (L.act_prev == NERO_ACT_RELU) bwd_epilogue_h<NERO_ACT_RELU>(acc, pa, pi, has_inj, L, dst, goff, row0, i, fbase, n_rows);
-            else if (L.act_prev == NERO_ACT_SOFTPLUS100) bwd_epilogue_h<NERO_ACT_SOFTPLUS100>(acc, pa, pi, has_inj, L, dst, goff, row0, i, fbase, n_rows);
-            else bwd_epilogue_h<NERO_ACT_NONE>(acc, pa, pi, has_inj, L, dst, goff, row0, i, fbase, n_rows);
+            float* scr = reinterpret_cast<float*>(smem + 3 * PLANE_A + wave * SCR_BYTES);
+            const size_t boff = (size_t)row0 * NERO_HID + 32 * wave;
+            if (L.act_prev == NERO_ACT_RELU) bwd_epilogue_h<NERO_ACT_RELU>(acc, pa, pi, has_inj, L, dst, boff, scr, lane, row0, i, fbase, n_rows);
+            else if (L.act_prev == NERO_ACT_SOFTPLUS100) bwd_epilogue_h<NERO_ACT_SOFTPLUS100>(acc, pa, pi, has_inj, L, dst, boff, scr, lane, row0, i, fbase, n_rows);
+            else bwd_epilogue_h<NERO_ACT_NONE>(acc, pa, pi, has_inj, L, dst, boff, scr, lane, row0, i, fbase, n_rows);
         }
         __syncthreads();
     }
@@ -824,13 +836,10 @@ int nero_split_tangent(const nero_tan_chain* ch, int n_rows, hipStream_t stream)
     for (int l = 0; l < ch->n_layers; ++l)
         if ((ch->layer[l].k_main | ch->layer[l].k_aux) & 15)
             return nero_fail(NERO_ERR_ARG, "nero_mlp_tangent(bf16x6): k_main / k_aux must be multiples of 16");
-    if (ch->aux_wide) {
-        NERO_ONCE(hipFuncSetAttribute((const void*)tan_split_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, split_lds_bytes(1)));
-        hipLaunchKernelGGL(tan_split_kernel<true>, grid, block, split_lds_bytes(1), stream, *ch, n_rows);
-    } else {
-        NERO_ONCE(hipFuncSetAttribute((const void*)tan_split_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, split_lds_bytes(0)));
-        hipLaunchKernelGGL(tan_split_kernel<false>, grid, block, split_lds_bytes(0), stream, *ch, n_rows);
-    }
+    // (the wide-aux LDS layout has no room for the epilogue's store scratch; only the SDF network -- narrow aux -- has a tangent pass)
+    if (ch->aux_wide) return nero_fail(NERO_ERR_UNSUPPORTED, "nero_mlp_tangent(bf16x6): aux_wide chains are not supported");
+    NERO_ONCE(hipFuncSetAttribute((const void*)tan_split_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, split_lds_bytes(0)));
+    hipLaunchKernelGGL(tan_split_kernel<false>, grid, block, split_lds_bytes(0), stream, *ch, n_rows);
     return NERO_OK;
 }
 
@@ -840,7 +849,7 @@ int nero_split_backward(const nero_bwd_chain* ch, int n_rows, hipStream_t stream
         if (ch->layer[l].n_out & 15) return nero_fail(NERO_ERR_ARG, "nero_mlp_backward(bf16x6): n_out must be a multiple of 16");
     if (ch->d_aux && (ch->ld_daux & 3)) return nero_fail(NERO_ERR_ARG, "nero_mlp_backward(bf16x6): ld_daux must be a multiple of 4");
     if (ch->d_init && (ch->ld_dinit & 3)) return nero_fail(NERO_ERR_ARG, "nero_mlp_backward(bf16x6): ld_dinit must be a multiple of 4");
-    const int lds = 3 * PLANE_A;
+    const int lds = 3 * PLANE_A + 8 * SCR_BYTES;
     NERO_ONCE(hipFuncSetAttribute((const void*)bwd_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipLaunchKernelGGL(bwd_split_kernel, grid, block, lds, stream, *ch, n_rows);
     return NERO_OK;
