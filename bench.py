@@ -21,8 +21,12 @@ sys.path.insert(0, ROOT)
 C_SDF, C_NERF, C_APP = 524544, 604160, 1211648          # MACs per point
 PEAK_F32_MFMA = 157.3e12                                 # MI355X dense fp32 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_BF16_MFMA = 2500e12                                 # MI355X dense bf16 MFMA peak (same guide)
-# fp32-equivalent ceiling of the arithmetic the dense layers run on: the f32-input MFMA itself, or -- default -- the bf16
-# matrix pipe issuing 6 plane products per fp32 multiply-add (3-plane exact split, nero_amd/csrc/mlp_split.hip)
+# fp32-equivalent ceilings of the arithmetic the dense layers run on (nero_amd/chain.py GEMM_MODE): the f32-input MFMA itself,
+# the bf16 matrix pipe issuing 6 plane products per fp32 multiply-add (mlp_split.hip), the fp16 pipe issuing 3 (mlp_f16x3.hip)
+PEAK_OF_MODE = {0: PEAK_F32_MFMA, 1: PEAK_BF16_MFMA / 6, 2: PEAK_BF16_MFMA / 3}
+MFMA_OF_MODE = {0: 'v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain)',
+                1: 'v_mfma_f32_32x32x16_bf16, 3 exact bf16 planes per operand, 6 plane products per fp32 multiply-add: peak = 2500 / 6',
+                2: 'v_mfma_f32_32x32x16_f16, 2 block-scaled fp16 planes per operand, 3 plane products per fp32 multiply-add: peak = 2500 / 3'}
 
 
 def cpu_baseline(cfg, variance, step, rays=512, budget_s=15.0, max_steps=10):
@@ -118,7 +122,8 @@ def main():
     # ---- the same step on the exact-fp32 MFMA engine (NERO_GEMM=f32), reported next to the headline: 2 warmup + 5 timed steps --
     from nero_amd import chain as _CHM
     alt = None
-    if _CHM.GEMM_MODE['fwd'] == L.GEMM_BF16X6:
+    if _CHM.GEMM_MODE['fwd'] != L.GEMM_F32:
+        _saved_modes = dict(_CHM.GEMM_MODE)
         _CHM.set_gemm_mode('f32')
         for i in range(2):
             ts.step(args.train_step + 200 + i)
@@ -132,7 +137,7 @@ def main():
             dist.all_reduce(dta, op=dist.ReduceOp.MAX)
         alt = {'value': round(args.rays * world * 5 / float(dta), 1), 'unit': 'rays/s', 'ms_per_step': round(float(dta) / 5 * 1e3, 3),
                'steps': 5, 'mfma': 'v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain, 157.3 TFLOP/s peak)'}
-        _CHM.set_gemm_mode('bf16x6')
+        _CHM.GEMM_MODE.update(_saved_modes)
         ts.step(args.train_step + 300)           # back on the default engine before the roofline leg
         sync()
 
@@ -147,28 +152,29 @@ def main():
         rep = (C.c_double * 12)()
         L.lib.nero_prof_report(rep)
         from nero_amd import chain as CH
-        kinds = [('fwd_split_kernel', 'mlp_fwd_kernel'), ('tan_split_kernel', 'mlp_tan_kernel'), ('bwd_split_kernel', 'mlp_bwd_kernel'),
-                 ('dw_split_kernel', 'dw_gemm_kernel')]
-        kinds = [k[0] if CH.GEMM_MODE[m] == L.GEMM_BF16X6 else k[1] for k, m in zip(kinds, ('fwd', 'tan', 'bwd', 'dw'))]
-        rows = [(kinds[k], rep[3 * k], rep[3 * k + 1], rep[3 * k + 2]) for k in range(4)]
+        kname = {'fwd': ('mlp_fwd_kernel', 'fwd_split_kernel', 'fwd_f16_kernel'), 'tan': ('mlp_tan_kernel', 'tan_split_kernel', 'tan_f16_kernel'),
+                 'bwd': ('mlp_bwd_kernel', 'bwd_split_kernel', 'bwd_f16_kernel'), 'dw': ('dw_gemm_kernel', 'dw_split_kernel', 'dw_split_kernel')}
+        passes = ('fwd', 'tan', 'bwd', 'dw')
+        kinds = [kname[m][CH.GEMM_MODE[m]] for m in passes]
+        peaks = [PEAK_OF_MODE[CH.GEMM_MODE[m]] for m in passes]
+        rows = [(kinds[k], rep[3 * k], rep[3 * k + 1], rep[3 * k + 2], peaks[k], CH.GEMM_MODE[passes[k]]) for k in range(4)]
         dom = max(rows, key=lambda r: r[2])
         ach = dom[3] / (dom[2] * 1e-3) / 1e12 if dom[2] > 0 else 0.0
-        split = CH.GEMM_MODE['fwd'] == L.GEMM_BF16X6
-        peak = (PEAK_BF16_MFMA / 6 if split else PEAK_F32_MFMA) / 1e12
+        peak = dom[4] / 1e12
         roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
-                'frac': round(ach / peak, 4), 'traffic': None, 'kernel': dom[0],
-                'mfma': ('v_mfma_f32_32x32x16_bf16, 6 plane products per fp32 multiply-add: peak = 2500 TFLOP/s bf16 dense / 6; '
-                         'issued bf16 MFMA rate = 6 x achieved') if split else 'v_mfma_f32_32x32x2_f32',
+                'frac': round(ach / peak, 4), 'traffic': None, 'kernel': dom[0], 'mfma': MFMA_OF_MODE[dom[5]],
                 'avg_launch_ms': round(dom[2] / max(dom[1], 1), 4),
                 'per_kernel': {r[0]: {'launches_per_step': r[1] / 3, 'ms_per_step': round(r[2] / 3, 3),
-                                      'tflops': round(r[3] / (r[2] * 1e-3) / 1e12, 2) if r[2] > 0 else 0.0} for r in rows}}
+                                      'tflops': round(r[3] / (r[2] * 1e-3) / 1e12, 2) if r[2] > 0 else 0.0,
+                                      'peak': round(r[4] / 1e12, 1)} for r in rows}}
     elif world > 1:
         for i in range(3):
             ts.step(args.train_step + 100 + i)
 
     if rank == 0:
         from nero_amd import chain as _CH
-        CH_SPLIT = _CH.GEMM_MODE['fwd'] == L.GEMM_BF16X6
+        CH_SPLIT = _CH.GEMM_MODE['fwd'] != L.GEMM_F32
+        CH_MODES = {k: {0: 'f32', 1: 'bf16x6', 2: 'f16x3'}[v] for k, v in _CH.GEMM_MODE.items()}
         # whole-step algorithmic FLOPs with the measured inner/outer split of this rank
         sampler_evals = args.rays * (64 + 3 * 16)
         flop_step = (n_in / args.steps) * 2 * (6 * C_SDF + 3 * C_APP) + (n_out / args.steps) * 2 * 3 * C_NERF + sampler_evals * 2 * C_SDF
@@ -176,12 +182,13 @@ def main():
             'metric': 'training rays/sec (Stage-I shape, 128 samples/ray)', 'value': round(value, 1), 'unit': 'rays/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32 (dense layers: fp32 operands as 3 exact bf16 planes, 6 bf16 MFMA products, fp32 accumulate)' if CH_SPLIT else 'f32',
+            'dtype': ('f32 (dense layers: fp32 operands carried as exact / block-scaled 16-bit plane pairs or triples on the bf16/fp16 '
+                      f'matrix pipe with fp32 accumulation, fp32-grade error; modes {CH_MODES})') if CH_SPLIT else 'f32',
             'data': 'synthetic',
             'config': {'workload': "GlossySynthetic 'bell' Stage-I shape, 4096 rays x (64+64+32) samples per GPU, "
                                    f'training-schedule step {args.train_step}', 'rays_per_gpu': args.rays,
                        'parallelism': f'dp{world}', 'optimizer': 'adam(fused)', 'inv_s': 'exp(10*0.5)'},
-            'step_mlp_flop_frac': round(flop_step / (dt / args.steps) / (PEAK_BF16_MFMA / 6 if CH_SPLIT else PEAK_F32_MFMA), 4),
+            'step_mlp_flop_frac': round(flop_step / (dt / args.steps) / PEAK_OF_MODE[_CH.GEMM_MODE['fwd']], 4),
             'inner_samples_per_ray': round(n_in / args.steps / args.rays, 2),
             'roofline': roof,
         }

@@ -30,7 +30,10 @@ enum { NERO_ACT_NONE = 0, NERO_ACT_RELU = 1, NERO_ACT_SOFTPLUS100 = 2 };
  * BF16X6: every fp32 operand is carried as three bf16 planes (exact 3-way split) and each product is the sum of the six
  * significant plane products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- dropped terms <= 3*2^-27 relative, i.e.
  * below fp32's own rounding; 417 TFLOP/s fp32-equivalent peak.  Packed operands are mode specific. */
-enum { NERO_GEMM_F32 = 0, NERO_GEMM_BF16X6 = 1 };
+/* F16X3: operands as two fp16 planes (h, l*2^11) of their block-scaled value (per activation row / per weight matrix, exact
+ * powers of two), three plane products in two accumulator sets -- half the MFMA count of BF16X6 at the same error class
+ * (representation error <= 2^-24 of the block maximum, dropped term <= 2^-24 of the product). */
+enum { NERO_GEMM_F32 = 0, NERO_GEMM_BF16X6 = 1, NERO_GEMM_F16X3 = 2 };
 enum { NERO_OK = 0, NERO_ERR_ARG = -1, NERO_ERR_LAUNCH = -2, NERO_ERR_UNSUPPORTED = -3 };
 
 const char* nero_last_error(void);
@@ -60,7 +63,9 @@ int nero_pack_weight_split(const float* W, int nrows, int ld, int col0, int ncol
  * operand images and copies ~60 bias / head vectors; as separate launches they are pure launch latency).
  *   kind 0: nero_pack_weight_split(W, nrows, ld, col0, ncols, transpose, scale, kpad, nt_count, out)
  *   kind 1: nero_pack_weight(...) with the same fields
- *   kind 2: 2-D copy  out[r*kpad + c] = W[r*ld + c],  r < nrows, c < ncols   (bias: nrows = 1; head weights [n_head][k] -> [4][256]) */
+ *   kind 2: 2-D copy  out[r*kpad + c] = W[r*ld + c],  r < nrows, c < ncols   (bias: nrows = 1; head weights [n_head][k] -> [4][256])
+ *   kind 3: NERO_GEMM_F16X3 operand: out = [256-byte header: float 2^ew][two fp16 planes of A * 2^-ew in A-fragment order,
+ *           (((t*(kpad/16) + c)*2 + p)*64 + lane)*16 bytes], ew = exponent of max|A|; `out` must be zero-filled by the caller */
 #define NERO_MAX_PACK_JOBS 64
 typedef struct {
     const float* W; void* out;

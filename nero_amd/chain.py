@@ -12,18 +12,29 @@ from . import _lib as L
 
 
 
-# arithmetic of the dense layers (include/nero_hip.h NERO_GEMM_*): 'bf16x6' (default) = 3-plane exact split on the bf16
-# matrix pipe -- fp32-grade results (same error against fp64 as the f32 MFMA, tests/test_mlp_engine.py) at 2.65x the peak;
-# 'f32' = the f32-input MFMA (an exact fmaf chain).  NERO_GEMM=f32|bf16x6 selects all passes, NERO_GEMM_FWD/_TAN/_BWD/_DW one.
-_MODE_NAMES = {'f32': L.GEMM_F32, 'bf16x6': L.GEMM_BF16X6}
-GEMM_MODE = {k: _MODE_NAMES[os.environ.get('NERO_GEMM_' + k.upper(), os.environ.get('NERO_GEMM', 'bf16x6'))]
+# arithmetic of the dense layers (include/nero_hip.h NERO_GEMM_*), all fp32-grade (tests/test_mlp_engine.py runs every test in
+# every mode against the same fp64 reference and tolerance):
+#   'f16x3'  (default for the forward / tangent / reverse chain kernels) two block-scaled fp16 planes, 3 MFMA products
+#   'bf16x6' (default for the weight-gradient GEMM; f16x3 does not fit its 64 accumulator tiles) three bf16 planes, 6 products
+#   'f32'    the f32-input MFMA, an exact fmaf chain
+# NERO_GEMM=<mode> selects all passes, NERO_GEMM_FWD / _TAN / _BWD / _DW one pass.
+_MODE_NAMES = {'f32': L.GEMM_F32, 'bf16x6': L.GEMM_BF16X6, 'f16x3': L.GEMM_F16X3}
+_DEFAULT = {'fwd': 'f16x3', 'tan': 'f16x3', 'bwd': 'f16x3', 'dw': 'bf16x6'}
+
+
+def _resolve(mode, k):
+    return _MODE_NAMES['bf16x6' if (mode == 'f16x3' and k == 'dw') else mode]
+
+
+GEMM_MODE = {k: _resolve(os.environ.get('NERO_GEMM_' + k.upper(), os.environ.get('NERO_GEMM', _DEFAULT[k])), k)
              for k in ('fwd', 'tan', 'bwd', 'dw')}
 
 
 def set_gemm_mode(mode, passes=('fwd', 'tan', 'bwd', 'dw')):
-    """select the dense-layer arithmetic ('f32' | 'bf16x6') for the given passes; chains must be (re)packed afterwards"""
+    """select the dense-layer arithmetic ('f32' | 'bf16x6' | 'f16x3' | 'default') for the given passes; chains must be
+    (re)packed afterwards.  'f16x3' on the weight-gradient pass means bf16x6."""
     for k in passes:
-        GEMM_MODE[k] = _MODE_NAMES[mode]
+        GEMM_MODE[k] = _resolve(_DEFAULT[k] if mode == 'default' else mode, k)
 
 
 def _r8(x):
@@ -89,6 +100,12 @@ class Chain:
                 if L.GEMM_BF16X6 in (GEMM_MODE['fwd'], GEMM_MODE['tan']):   # three bf16 planes: 768 floats per (tile, 16-k step)
                     e['sfm'] = (_r16(d.k_main) // 16) * nt * 768 if d.k_main else 0
                     e['sfa'] = (_r16(d.k_aux) // 16) * nt * 768 if d.k_aux else 0
+                if L.GEMM_F16X3 in (GEMM_MODE['fwd'], GEMM_MODE['tan']):     # 64-float header + two fp16 planes: 512 floats per (tile, step)
+                    e['hfm'] = 64 + (_r16(d.k_main) // 16) * nt * 512 if d.k_main else 0
+                    e['hfa'] = 64 + (_r16(d.k_aux) // 16) * nt * 512 if d.k_aux else 0
+                if GEMM_MODE['bwd'] == L.GEMM_F16X3:
+                    e['hbm'] = 64 + (_r16(d.n_out) // 16) * _tiles(d.k_main) * 512 if d.k_main else 0
+                    e['hba'] = 64 + (_r16(d.n_out) // 16) * _tiles(d.k_aux) * 512 if d.k_aux else 0
                 if GEMM_MODE['bwd'] == L.GEMM_BF16X6:
                     e['sbm'] = (_r16(d.n_out) // 16) * _tiles(d.k_main) * 768 if d.k_main else 0
                     e['sba'] = (_r16(d.n_out) // 16) * _tiles(d.k_aux) * 768 if d.k_aux else 0
@@ -129,6 +146,12 @@ class Chain:
                 for key, c0, kc in (('sbm', d.main_c0, d.k_main), ('sba', d.aux_c0, d.k_aux)):
                     if kc and key in p:
                         job(0, W, p[key], d.n_out, W.stride(0), c0, kc, 1, _r16(d.n_out), _tiles(kc), d.scale)
+                for key, c0, kc in (('hfm', d.main_c0, d.k_main), ('hfa', d.aux_c0, d.k_aux)):
+                    if kc and key in p:
+                        job(3, W, p[key], d.n_out, W.stride(0), c0, kc, 0, _r16(kc), nt, d.scale)
+                for key, c0, kc in (('hbm', d.main_c0, d.k_main), ('hba', d.aux_c0, d.k_aux)):
+                    if kc and key in p:
+                        job(3, W, p[key], d.n_out, W.stride(0), c0, kc, 1, _r16(d.n_out), _tiles(kc), d.scale)
                 if d.b is not None:
                     b = d.b.detach()
                     job(2, b, p['bias'], 1, d.n_out, 0, d.n_out, 0, 32 * nt, 0)
@@ -156,7 +179,8 @@ class Chain:
         ch.init, ch.ld_init, ch.k_init = L.ptr(init), (init.stride(0) if init is not None else 0), self.k_init
         ch.aux, ch.ld_aux, ch.k_aux = L.ptr(aux), (aux.stride(0) if aux is not None else 0), self.k_aux
         ch.n_layers, ch.aux_wide = len(self.entries), int(self.aux_wide)
-        split = GEMM_MODE['fwd'] == L.GEMM_BF16X6
+        split = GEMM_MODE['fwd'] != L.GEMM_F32
+        fkeys = {L.GEMM_F32: ('fm', 'fa'), L.GEMM_BF16X6: ('sfm', 'sfa'), L.GEMM_F16X3: ('hfm', 'hfa')}[GEMM_MODE['fwd']]
         ch.gemm_mode = GEMM_MODE['fwd']
         ch.macs_per_row = float(sum(d.n_out * (d.k_main + d.k_aux) for d, _ in self.entries if d is not None))
         if init is not None:
@@ -178,8 +202,8 @@ class Chain:
                 fl.n_head, fl.head_k = h.n_head, (h.k + 3) // 4 * 4
             if d is not None:
                 rk = _r16 if split else _r8
-                fl.w_main = L.ptr(p.get('sfm' if split else 'fm'))
-                fl.w_aux = L.ptr(p.get('sfa' if split else 'fa'))
+                fl.w_main = L.ptr(p.get(fkeys[0]))
+                fl.w_aux = L.ptr(p.get(fkeys[1]))
                 fl.bias = p['bias'].data_ptr()
                 fl.k_main, fl.k_aux = (rk(d.k_main) if d.k_main else 0), (rk(d.k_aux) if d.k_aux else 0)
                 fl.n_tiles, fl.act = _tiles(d.n_out), d.act
@@ -202,7 +226,8 @@ class Chain:
         saves = fwd['saves']
         ch = L.BwdChain()
         ch.n_layers, ch.aux_wide = len(self.entries), 0
-        split = GEMM_MODE['bwd'] == L.GEMM_BF16X6
+        split = GEMM_MODE['bwd'] != L.GEMM_F32
+        bkeys = {L.GEMM_F32: ('bm', 'ba'), L.GEMM_BF16X6: ('sbm', 'sba'), L.GEMM_F16X3: ('hbm', 'hba')}[GEMM_MODE['bwd']]
         ch.gemm_mode = GEMM_MODE['bwd']
         rk = _r16 if split else _r8
         last = len(self.entries) - 1
@@ -233,8 +258,8 @@ class Chain:
             bl = ch.layer[i]
             j = prev_dense[i]                      # dense entry that produced this entry's input tile
             if d is not None and not (skip_last_dense and i == last):
-                bl.w_main_t = L.ptr(p.get('sbm' if split else 'bm'))
-                bl.w_aux_t = L.ptr(p.get('sba' if split else 'ba')) if need_daux else None
+                bl.w_main_t = L.ptr(p.get(bkeys[0]))
+                bl.w_aux_t = L.ptr(p.get(bkeys[1])) if need_daux else None
                 bl.n_out = rk(d.n_out)
                 bl.k_main_tiles = _tiles(d.k_main) if d.k_main else 0
                 bl.k_aux_tiles = _tiles(d.k_aux) if d.k_aux else 0

@@ -1,0 +1,786 @@
+// mlp_f16x3.hip -- the fused MLP-chain passes on the fp16 matrix pipe with fp32-grade arithmetic and HALF the MFMA count of
+// the bf16x6 engine (gemm_mode NERO_GEMM_F16X3).
+//
+// An fp32 operand is carried as TWO fp16 planes of its block-scaled value xs = x * 2^-e:
+//        xs = h + 2^-11 * l,      h = fp16(xs),   l = fp16((xs - h) * 2^11)            (round to nearest)
+// fp16 keeps 11 significant bits, so |xs - h| <= 2^-12 |xs|, the scaled remainder has the magnitude of xs/2 (no subnormal
+// trouble of its own) and |xs - h - 2^-11 l| <= 2^-24 |xs|: the pair represents xs to fp32's own half-ulp.  A product is
+//        w x = [ hw hx  +  2^-11 (hw lx + lw hx) ] * 2^(ew + ex),          dropped: 2^-22 lw lx <= 2^-24 |w x|
+// i.e. THREE MFMAs in two accumulator sets (H: hw hx, L: hw lx + lw hx), combined as H + 2^-11 L in the epilogue.
+// Range: fp16 overflows at 65504 and loses precision below 2^-14, so every operand is scaled by an exact power of two:
+// activations per ROW (64 per tile; exponent of the row maximum, kept in LDS next to the planes), weights per MATRIX (exponent in
+// the packed image's header).  Elements more than 2^14 below their row's maximum lose relative -- not absolute -- precision,
+// which a dot product cannot see.  Scales are applied back exactly in the epilogue.
+//
+// Kernel shape: as mlp_split.hip (512 threads own 64 rows, transposed product, wave w = feature tile w for both 32-row halves,
+// epilogue straight out of the accumulators) with: two planes instead of three (LDS 68 KB), 6 MFMAs per k-step of 16 instead
+// of 12, and one more barrier per layer for the row-maximum exchange between the 8 waves.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/nero_hip.h"
+#include "common.h"
+#include "mlp_split.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr float BETA = 100.0f;
+constexpr int SA = 528;                 // bytes per row of a main plane: 256 fp16 + 16 B pad
+constexpr int PLANE_A = 64 * SA;
+constexpr int SX_N = 112, SX_W = 208;   // aux plane row strides (48 / 96 columns + 16 B)
+constexpr float LO = 2048.f, LO_INV = 1.f / 2048.f;
+constexpr int HDR_BYTES = 256;          // packed-image header: float[0] = 2^ew (the factor results are multiplied by), uint[1] = max bits
+constexpr int SCR_LD = 36, SCR_BYTES = 32 * SCR_LD * 4;
+
+// ---- scaling -----------------------------------------------------------------------------------------------------------
+// exponent e with m * 2^-e in [0.5, 1) for normal m > 0 (0 for m == 0 / denormal), clamped to [-40, 40]
+__device__ __forceinline__ int scale_exp(float m) {
+    const int eb = (__float_as_uint(m) >> 23) & 0xff;
+    int e = eb ? eb - 126 : 0;
+    e = e < -40 ? -40 : (e > 40 ? 40 : e);
+    return e;
+}
+__device__ __forceinline__ float pow2i(int e) { return __uint_as_float((unsigned)(127 + e) << 23); }
+
+// ---- fp32 <-> fp16 plane pairs -----------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned pk_f16(float a, float b) {       // v_cvt_pk_f16_f32 (RN): a -> low half
+    f32x2 v = {a, b};
+    f16x2 c = __builtin_convertvector(v, f16x2);
+    return __builtin_bit_cast(unsigned, c);
+}
+__device__ __forceinline__ void split2h(float a, float b, unsigned& h, unsigned& l) {     // a, b already block-scaled
+    h = pk_f16(a, b);
+    const f16x2 hh = __builtin_bit_cast(f16x2, h);
+    l = pk_f16((a - (float)hh[0]) * LO, (b - (float)hh[1]) * LO);
+}
+__device__ __forceinline__ void store_planes4h(char* dst, int plane_bytes, float4 v) {
+    unsigned h0, l0, h1, l1;
+    split2h(v.x, v.y, h0, l0);
+    split2h(v.z, v.w, h1, l1);
+    *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(dst + plane_bytes) = make_uint2(l0, l1);
+}
+__device__ __forceinline__ float4 load_planes4h(const char* src, int plane_bytes) {       // -> block-scaled values
+    const uint2 a = *reinterpret_cast<const uint2*>(src);
+    const uint2 b = *reinterpret_cast<const uint2*>(src + plane_bytes);
+    const f16x2 a0 = __builtin_bit_cast(f16x2, a.x), a1 = __builtin_bit_cast(f16x2, a.y);
+    const f16x2 b0 = __builtin_bit_cast(f16x2, b.x), b1 = __builtin_bit_cast(f16x2, b.y);
+    float4 v;
+    v.x = fmaf((float)b0[0], LO_INV, (float)a0[0]);
+    v.y = fmaf((float)b0[1], LO_INV, (float)a0[1]);
+    v.z = fmaf((float)b1[0], LO_INV, (float)a1[0]);
+    v.w = fmaf((float)b1[1], LO_INV, (float)a1[1]);
+    return v;
+}
+
+// ---- activations (identical to mlp_split.hip) ---------------------------------------------------------------------------
+__device__ __forceinline__ float log1p_small(float u) {
+    return u * (1.f + u * (-0.5f + u * (0.33333334f + u * (-0.25f + u * 0.2f))));
+}
+__device__ __forceinline__ float softplus100(float x) {
+    const float bx = BETA * x;
+    const float u = __expf(-fabsf(bx));
+    const float ls = log1p_small(u), lg = __logf(1.f + u);
+    const float l = u < 0.0625f ? ls : lg;
+    const float r = fmaxf(x, 0.f) + l * (1.0f / BETA);
+    return bx > 20.f ? x : r;
+}
+template <int ACT>
+__device__ __forceinline__ float act_fwd(float x) {
+    if (ACT == NERO_ACT_RELU) return fmaxf(x, 0.f);
+    if (ACT == NERO_ACT_SOFTPLUS100) return softplus100(x);
+    return x;
+}
+
+// ---- accumulator-layout -> row-major global store through a wave-private LDS scratch (as mlp_split.hip) -----------------
+__device__ __forceinline__ void acc_to_global(float* scr, const float4 (&q)[4], float* __restrict__ gblock, int lane) {
+    const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(scr + i * SCR_LD + 8 * g + 4 * h) = q[g];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+        *reinterpret_cast<float4*>(gblock + (size_t)(8 * p + (lane >> 3)) * NERO_HID + 4 * (lane & 7)) =
+            *reinterpret_cast<const float4*>(scr + (8 * p + (lane >> 3)) * SCR_LD + 4 * (lane & 7));
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---- GEMM core ------------------------------------------------------------------------------------------------------------
+// accH[r] += wh xh,  accL[r] += wh xl + wl xh  over `n` k-steps of 16 (r = 32-row half).  Weight planes three steps ahead in a
+// ring of four register sets (L2 stream), activation planes one step ahead in a double buffer (LDS).
+struct WF { uint4 wh, wl; };
+struct XF { uint4 xh0, xl0, xh1, xl1; };
+
+__device__ __forceinline__ void load_w(WF& o, const uint4* wp, int c) {
+    const uint4* w = wp + (size_t)c * 128;
+    o.wh = w[0];
+    o.wl = w[64];
+}
+__device__ __forceinline__ void load_x(XF& o, const char* xp, int half_bytes, int plane_bytes, int c) {
+    const char* x = xp + c * 32;
+    o.xh0 = *reinterpret_cast<const uint4*>(x);
+    o.xl0 = *reinterpret_cast<const uint4*>(x + plane_bytes);
+    x += half_bytes;
+    o.xh1 = *reinterpret_cast<const uint4*>(x);
+    o.xl1 = *reinterpret_cast<const uint4*>(x + plane_bytes);
+}
+#define NERO_MFH(ACC, A, B) \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), ACC, 0, 0, 0)
+__device__ __forceinline__ void ops_compute(f32x16 (&aH)[2], f32x16 (&aL)[2], const WF& w, const XF& x) {
+    NERO_MFH(aL[0], w.wl, x.xh0); NERO_MFH(aL[1], w.wl, x.xh1);
+    NERO_MFH(aH[0], w.wh, x.xh0); NERO_MFH(aH[1], w.wh, x.xh1);
+    NERO_MFH(aL[0], w.wh, x.xl0); NERO_MFH(aL[1], w.wh, x.xl1);
+}
+#define NERO_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+__device__ __forceinline__ void gemm_f16x3(f32x16 (&aH)[2], f32x16 (&aL)[2], const uint4* wp, const char* xp, int half_bytes,
+                                           int plane_bytes, int n) {
+    if (n <= 0) return;
+    WF wa, wb, wc, wd;
+    XF xa, xb;
+    const int last = n - 1;
+#define NERO_CL(c) ((c) < last ? (c) : last)
+    load_w(wa, wp, 0);
+    load_w(wb, wp, NERO_CL(1));
+    load_w(wc, wp, NERO_CL(2));
+    load_x(xa, xp, half_bytes, plane_bytes, 0);
+    NERO_FENCE();
+    for (int c = 0; c < n; c += 4) {
+        load_w(wd, wp, NERO_CL(c + 3)); load_x(xb, xp, half_bytes, plane_bytes, NERO_CL(c + 1)); NERO_FENCE();
+        ops_compute(aH, aL, wa, xa); NERO_FENCE();
+        if (c + 1 < n) {
+            load_w(wa, wp, NERO_CL(c + 4)); load_x(xa, xp, half_bytes, plane_bytes, NERO_CL(c + 2)); NERO_FENCE();
+            ops_compute(aH, aL, wb, xb); NERO_FENCE();
+        }
+        if (c + 2 < n) {
+            load_w(wb, wp, NERO_CL(c + 5)); load_x(xb, xp, half_bytes, plane_bytes, NERO_CL(c + 3)); NERO_FENCE();
+            ops_compute(aH, aL, wc, xa); NERO_FENCE();
+        }
+        if (c + 3 < n) {
+            load_w(wc, wp, NERO_CL(c + 6)); load_x(xa, xp, half_bytes, plane_bytes, NERO_CL(c + 4)); NERO_FENCE();
+            ops_compute(aH, aL, wd, xb); NERO_FENCE();
+        }
+    }
+#undef NERO_CL
+}
+
+__device__ __forceinline__ void zero2(f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[r][v] = 0.f;
+}
+
+// rows [row0, row0+64) x first k columns (k multiple of 4, <= 256) of a row-major fp32 matrix -> scaled plane pairs + the per-row
+// scale rs[row] = 2^e.  8 threads per row: each keeps its float4s in registers, the row maximum is a 3-step shuffle.
+__device__ __forceinline__ void load_planes_scaled(char* planes, int stride, int plane_bytes, float* rs, const float* __restrict__ src,
+                                                   int ld, int k, int row0, int n_rows, int tid) {
+    const int r = tid >> 3, q = tid & 7;
+    const int k16 = (k + 15) & ~15, q4 = k16 >> 2;
+    int gr = row0 + r;
+    gr = gr < n_rows ? gr : n_rows - 1;
+    const float* rowp = src + (size_t)gr * ld;
+    float4 v[8];
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c4 = 4 * (q + 8 * j);
+        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c4 < k) v[j] = *reinterpret_cast<const float4*>(rowp + c4);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[j].x), fabsf(v[j].y)), fmaxf(fabsf(v[j].z), fabsf(v[j].w))));
+    }
+    m = fmaxf(m, __shfl_xor(m, 1));
+    m = fmaxf(m, __shfl_xor(m, 2));
+    m = fmaxf(m, __shfl_xor(m, 4));
+    const int e = scale_exp(m);
+    const float inv = pow2i(-e);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c4 = 4 * (q + 8 * j);
+        if (q + 8 * j < q4) {
+            const float4 s = make_float4(v[j].x * inv, v[j].y * inv, v[j].z * inv, v[j].w * inv);
+            store_planes4h(planes + r * stride + c4 * 2, plane_bytes, s);
+        }
+    }
+    if (q == 0) rs[r] = pow2i(e);
+}
+
+// VALU head on the current activation planes: out[r][j] = b[j] + sum_k x[r][k] W[j][k], k < hk (8 threads per row)
+__device__ __forceinline__ void eval_head_f16(const char* planes, const float* rs, const float* __restrict__ w, const float* __restrict__ b,
+                                              float* __restrict__ out, int n_head, int hk, int row0, int tid) {
+    const int r = tid >> 3, q = tid & 7;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c4 = 4 * q; c4 < hk; c4 += 32) {
+        const float4 x = load_planes4h(planes + r * SA + c4 * 2, PLANE_A);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < n_head) {
+                const float4 ww = *reinterpret_cast<const float4*>(w + j * NERO_HID + c4);
+                s[j] = fmaf(x.x, ww.x, fmaf(x.y, ww.y, fmaf(x.z, ww.z, fmaf(x.w, ww.w, s[j]))));
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s[j] += __shfl_xor(s[j], 1);
+        s[j] += __shfl_xor(s[j], 2);
+        s[j] += __shfl_xor(s[j], 4);
+    }
+    if (q == 0) {
+        const float sc = rs[r];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < n_head) out[(size_t)(row0 + r) * 4 + j] = s[j] * sc + (b ? b[j] : 0.f);
+    }
+}
+
+// LDS carve-up shared by the chain kernels
+struct Lds {
+    char* actp; char* auxp; float* rs_main; float* rs_aux; float* rmax; char* scr;
+};
+template <int SX>
+__device__ __forceinline__ Lds carve(char* smem) {
+    Lds l;
+    l.actp = smem;
+    l.auxp = smem + 2 * PLANE_A;
+    char* p = l.auxp + 2 * 64 * SX;
+    l.rs_main = reinterpret_cast<float*>(p);
+    l.rs_aux = l.rs_main + 64;
+    l.rmax = l.rs_aux + 64;                          // [64 rows][8 waves]
+    l.scr = reinterpret_cast<char*>(l.rmax + 64 * 8);
+    return l;
+}
+inline int f16_lds_bytes(int wide) { return 2 * PLANE_A + 2 * 64 * (wide ? SX_W : SX_N) + (64 + 64 + 512) * 4 + 8 * SCR_BYTES; }
+
+// row maxima of this wave's 64x32 block (two rows per lane) -> rmax[row][wave]
+__device__ __forceinline__ void publish_rowmax(float* rmax, float m0, float m1, int wave, int i, int h) {
+    m0 = fmaxf(m0, __shfl_xor(m0, 32));
+    m1 = fmaxf(m1, __shfl_xor(m1, 32));
+    if (h == 0) { rmax[i * 8 + wave] = m0; rmax[(32 + i) * 8 + wave] = m1; }
+}
+__device__ __forceinline__ float row_max8(const float* rmax, int row) {
+    const float4 a = *reinterpret_cast<const float4*>(rmax + row * 8);
+    const float4 b = *reinterpret_cast<const float4*>(rmax + row * 8 + 4);
+    return fmaxf(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward chain
+// ---------------------------------------------------------------------------------------------------------------------
+template <int ACT>
+__device__ __forceinline__ void fwd_values(const f32x16 (&aH)[2], const f32x16 (&aL)[2], const float4 (&bq)[4], const float (&U)[2],
+                                           float4 (&val)[2][4], float (&m)[2]) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        m[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 v;
+            v.x = act_fwd<ACT>(fmaf(fmaf(aL[r][4 * g], LO_INV, aH[r][4 * g]), U[r], bq[g].x));
+            v.y = act_fwd<ACT>(fmaf(fmaf(aL[r][4 * g + 1], LO_INV, aH[r][4 * g + 1]), U[r], bq[g].y));
+            v.z = act_fwd<ACT>(fmaf(fmaf(aL[r][4 * g + 2], LO_INV, aH[r][4 * g + 2]), U[r], bq[g].z));
+            v.w = act_fwd<ACT>(fmaf(fmaf(aL[r][4 * g + 3], LO_INV, aH[r][4 * g + 3]), U[r], bq[g].w));
+            val[r][g] = v;
+            m[r] = fmaxf(m[r], fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+    }
+}
+
+template <bool WIDE>
+__global__ __launch_bounds__(512, 1) void fwd_f16_kernel(nero_fwd_chain ch, int n_rows) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SX = WIDE ? SX_W : SX_N;
+    constexpr int PLANE_X = 64 * SX;
+    const Lds S = carve<SX>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int row0 = blockIdx.x * 64;
+    if (ch.init) load_planes_scaled(S.actp, SA, PLANE_A, S.rs_main, ch.init, ch.ld_init, ch.k_init, row0, n_rows, tid);
+    if (ch.aux) load_planes_scaled(S.auxp, SX, PLANE_X, S.rs_aux, ch.aux, ch.ld_aux, ch.k_aux, row0, n_rows, tid);
+    __syncthreads();
+    for (int l = 0; l < ch.n_layers; ++l) {
+        const nero_fwd_layer& L = ch.layer[l];
+        if (L.n_head > 0) eval_head_f16(S.actp, S.rs_main, L.head_w, L.head_b, L.head_out, L.n_head, L.head_k, row0, tid);
+        if (L.n_tiles == 0) continue;
+        const bool live_wave = wave < L.n_tiles;
+        f32x16 aH[2], aL[2];
+        zero2(aH);
+        zero2(aL);
+        float4 bq[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            bq[g] = (live_wave && L.bias) ? *reinterpret_cast<const float4*>(L.bias + 32 * wave + 8 * g + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float U[2] = {1.f, 1.f};                           // result unit of the accumulators, per 32-row half (this lane's rows i, 32+i)
+        if (live_wave) {
+            const int sm = L.k_main >> 4, sx = L.k_aux >> 4;
+            if (sx > 0) {
+                const float wsc = *reinterpret_cast<const float*>(L.w_aux);
+                gemm_f16x3(aH, aL, reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(L.w_aux) + HDR_BYTES) + (size_t)wave * sx * 128 + lane,
+                           S.auxp + i * SX + 16 * h, 32 * SX, PLANE_X, sx);
+                U[0] = wsc * S.rs_aux[i];
+                U[1] = wsc * S.rs_aux[32 + i];
+            }
+            if (sm > 0) {
+                const float wsc = *reinterpret_cast<const float*>(L.w_main);
+                const float u0 = wsc * S.rs_main[i], u1 = wsc * S.rs_main[32 + i];
+                if (sx > 0) {
+                    // bring the aux partial sums into the main part's unit (exact: powers of two)
+                    const float r0 = U[0] / u0, r1 = U[1] / u1;
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) { aH[0][v] *= r0; aL[0][v] *= r0; aH[1][v] *= r1; aL[1][v] *= r1; }
+                }
+                U[0] = u0;
+                U[1] = u1;
+                gemm_f16x3(aH, aL, reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(L.w_main) + HDR_BYTES) + (size_t)wave * sm * 128 + lane,
+                           S.actp + i * SA + 16 * h, 32 * SA, PLANE_A, sm);
+            }
+        }
+        // values, optional saves, row maxima
+        float4 val[2][4];
+        float m[2] = {0.f, 0.f};
+        if (live_wave) {
+            if (L.act == NERO_ACT_RELU) fwd_values<NERO_ACT_RELU>(aH, aL, bq, U, val, m);
+            else if (L.act == NERO_ACT_SOFTPLUS100) fwd_values<NERO_ACT_SOFTPLUS100>(aH, aL, bq, U, val, m);
+            else fwd_values<NERO_ACT_NONE>(aH, aL, bq, U, val, m);
+            if (L.save) {
+                float* scr = reinterpret_cast<float*>(S.scr + wave * SCR_BYTES);
+                float* sblock = L.save + (size_t)row0 * NERO_HID + 32 * wave;
+                acc_to_global(scr, val[0], sblock, lane);
+                acc_to_global(scr, val[1], sblock + (size_t)32 * NERO_HID, lane);
+            }
+        }
+        publish_rowmax(S.rmax, m[0], m[1], wave, i, h);
+        __syncthreads();                                   // row maxima visible; every wave is done reading the input planes
+        {
+            const int e0 = scale_exp(row_max8(S.rmax, i)), e1 = scale_exp(row_max8(S.rmax, 32 + i));
+            if (live_wave) {
+                const float inv0 = pow2i(-e0), inv1 = pow2i(-e1);
+                char* dst = S.actp + i * SA + (32 * wave + 4 * h) * 2;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 a = val[0][g], b = val[1][g];
+                    store_planes4h(dst + 16 * g, PLANE_A, make_float4(a.x * inv0, a.y * inv0, a.z * inv0, a.w * inv0));
+                    store_planes4h(dst + 32 * SA + 16 * g, PLANE_A, make_float4(b.x * inv1, b.y * inv1, b.z * inv1, b.w * inv1));
+                }
+            }
+            // (nobody reads rs_main between the barrier above and the one below: the units U were taken before the GEMM)
+            if (wave == 0 && h == 0) { S.rs_main[i] = pow2i(e0); S.rs_main[32 + i] = pow2i(e1); }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// tangent chain (softplus networks):  adot_l = s_l * (W_l adot_{l-1}),  inj_l = gbar_l * beta (1-s_l) * zdot_l
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float softplus100_grad_from_out(float a) {
+    const float ba = BETA * a;
+    const float ps = ba * (1.f + ba * (-0.5f + ba * (0.16666667f + ba * (-0.041666668f))));
+    const float pe = 1.f - __expf(-ba);
+    const float r = ba < 0.03125f ? ps : pe;
+    return ba > 20.f ? 1.f : r;
+}
+template <int ACT>
+__device__ __forceinline__ float act_grad(float a, float g) {
+    if (ACT == NERO_ACT_RELU) return a > 0.f ? g : 0.f;
+    if (ACT == NERO_ACT_SOFTPLUS100) return g * softplus100_grad_from_out(a);
+    return g;
+}
+__device__ __forceinline__ void tan_elem(float a, float zd, float gb, bool live, float& ad, float& ij) {
+    const float s = softplus100_grad_from_out(a);
+    ad = s * zd;
+    const float r2 = (BETA * a > 20.f) ? 0.f : BETA * (1.f - s);
+    ij = live ? gb * r2 * zd : 0.f;
+}
+__device__ __forceinline__ float amax4(float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
+__device__ __forceinline__ float4 scale4(float4 v, float s) { return make_float4(v.x * s, v.y * s, v.z * s, v.w * s); }
+
+// shared tail of the three chain kernels: publish row maxima, barrier, rescale + store this wave's 64x32 block as plane pairs,
+// new row scales, barrier
+__device__ __forceinline__ void commit_planes(const Lds& S, const float4 (&val)[2][4], float m0, float m1, bool live_wave, int wave,
+                                              int i, int h) {
+    publish_rowmax(S.rmax, m0, m1, wave, i, h);
+    __syncthreads();                                   // row maxima visible; every wave is done reading the input planes
+    const int e0 = scale_exp(row_max8(S.rmax, i)), e1 = scale_exp(row_max8(S.rmax, 32 + i));
+    if (live_wave) {
+        const float inv0 = pow2i(-e0), inv1 = pow2i(-e1);
+        char* dst = S.actp + i * SA + (32 * wave + 4 * h) * 2;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            store_planes4h(dst + 16 * g, PLANE_A, scale4(val[0][g], inv0));
+            store_planes4h(dst + 32 * SA + 16 * g, PLANE_A, scale4(val[1][g], inv1));
+        }
+    }
+    if (wave == 0 && h == 0) { S.rs_main[i] = pow2i(e0); S.rs_main[32 + i] = pow2i(e1); }
+    __syncthreads();
+}
+
+// aux part first (its own unit), converted into the main part's unit, then the main part: returns the unit of the result
+__device__ __forceinline__ void gemm_two_sources(f32x16 (&aH)[2], f32x16 (&aL)[2], float (&U)[2], const Lds& S, const float* w_main,
+                                                 const float* w_aux, int sm, int sx, int SXb, int PLANE_Xb, int wave, int lane, int i, int h) {
+    if (sx > 0) {
+        const float wsc = *w_aux;
+        gemm_f16x3(aH, aL, reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w_aux) + HDR_BYTES) + (size_t)wave * sx * 128 + lane,
+                   S.auxp + i * SXb + 16 * h, 32 * SXb, PLANE_Xb, sx);
+        U[0] = wsc * S.rs_aux[i];
+        U[1] = wsc * S.rs_aux[32 + i];
+    }
+    if (sm > 0) {
+        const float wsc = *w_main;
+        const float u0 = wsc * S.rs_main[i], u1 = wsc * S.rs_main[32 + i];
+        if (sx > 0) {
+            const float r0 = U[0] / u0, r1 = U[1] / u1;    // exact: powers of two
+#pragma unroll
+            for (int v = 0; v < 16; ++v) { aH[0][v] *= r0; aL[0][v] *= r0; aH[1][v] *= r1; aL[1][v] *= r1; }
+        }
+        U[0] = u0;
+        U[1] = u1;
+        gemm_f16x3(aH, aL, reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w_main) + HDR_BYTES) + (size_t)wave * sm * 128 + lane,
+                   S.actp + i * SA + 16 * h, 32 * SA, PLANE_A, sm);
+    }
+}
+
+__global__ __launch_bounds__(512, 1) void tan_f16_kernel(nero_tan_chain ch, int n_rows) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SX = SX_N;
+    constexpr int PLANE_X = 64 * SX;
+    const Lds S = carve<SX>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int row0 = blockIdx.x * 64;
+    if (ch.init) load_planes_scaled(S.actp, SA, PLANE_A, S.rs_main, ch.init, ch.ld_init, ch.k_init, row0, n_rows, tid);
+    if (ch.aux) load_planes_scaled(S.auxp, SX, PLANE_X, S.rs_aux, ch.aux, ch.ld_aux, ch.k_aux, row0, n_rows, tid);
+    __syncthreads();
+    for (int l = 0; l < ch.n_layers; ++l) {
+        const nero_tan_layer& L = ch.layer[l];
+        const bool live_wave = wave < L.n_tiles;
+        const size_t goff = (size_t)(row0 + i) * NERO_HID + 32 * wave + 4 * h;     // + r*32*HID + 8g
+        const size_t boff = (size_t)row0 * NERO_HID + 32 * wave;
+        float4 pa[2][4], pg[2][4];
+        if (live_wave) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    pa[r][g] = *reinterpret_cast<const float4*>(L.a_saved + goff + (size_t)r * 32 * NERO_HID + 8 * g);
+                    pg[r][g] = *reinterpret_cast<const float4*>(L.gbar + goff + (size_t)r * 32 * NERO_HID + 8 * g);
+                }
+        }
+        f32x16 aH[2], aL[2];
+        zero2(aH);
+        zero2(aL);
+        float U[2] = {1.f, 1.f};
+        if (live_wave) gemm_two_sources(aH, aL, U, S, L.w_main, L.w_aux, L.k_main >> 4, L.k_aux >> 4, SX, PLANE_X, wave, lane, i, h);
+        float4 val[2][4];
+        float m[2] = {0.f, 0.f};
+        if (live_wave) {
+            float* scr = reinterpret_cast<float*>(S.scr + wave * SCR_BYTES);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const bool live = (row0 + 32 * r + i) < n_rows;
+                float4 ijq[4], adq[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 a = pa[r][g], gb = pg[r][g];
+                    float4 ad, ij;
+                    tan_elem(a.x, fmaf(aL[r][4 * g], LO_INV, aH[r][4 * g]) * U[r], gb.x, live, ad.x, ij.x);
+                    tan_elem(a.y, fmaf(aL[r][4 * g + 1], LO_INV, aH[r][4 * g + 1]) * U[r], gb.y, live, ad.y, ij.y);
+                    tan_elem(a.z, fmaf(aL[r][4 * g + 2], LO_INV, aH[r][4 * g + 2]) * U[r], gb.z, live, ad.z, ij.z);
+                    tan_elem(a.w, fmaf(aL[r][4 * g + 3], LO_INV, aH[r][4 * g + 3]) * U[r], gb.w, live, ad.w, ij.w);
+                    val[r][g] = ad;
+                    m[r] = fmaxf(m[r], amax4(ad));
+                    adq[g] = live ? ad : make_float4(0.f, 0.f, 0.f, 0.f);
+                    ijq[g] = ij;
+                }
+                acc_to_global(scr, adq, L.adot + boff + (size_t)r * 32 * NERO_HID, lane);
+                acc_to_global(scr, ijq, L.inj + boff + (size_t)r * 32 * NERO_HID, lane);
+            }
+        }
+        commit_planes(S, val, m[0], m[1], live_wave, wave, i, h);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// reverse chain:  delta_{l-1} = (delta_l W_l [+ dy_head W_head]) * act'(a_{l-1}) [+ inj_{l-1}]
+// ---------------------------------------------------------------------------------------------------------------------
+template <int ACT, bool HEAD>
+__device__ __forceinline__ void bwd_values(const float4 (&gq)[2][4], const float4 (&pa)[2][4], size_t goff, bool has_inj,
+                                           const nero_bwd_layer& L, int row0, int i, int fbase, int n_rows, float4 (&val)[2][4],
+                                           float (&m)[2]) {
+    const int nh = L.n_head;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int grow = row0 + 32 * r + i;
+        const bool live = grow < n_rows;
+        float dj[4] = {0.f, 0.f, 0.f, 0.f};
+        if (HEAD) {
+            const float4 dyh = *reinterpret_cast<const float4*>(L.head_dy + (size_t)grow * 4);
+            dj[0] = dyh.x; dj[1] = dyh.y; dj[2] = dyh.z; dj[3] = dyh.w;
+        }
+        m[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 gs = gq[r][g];
+            if (HEAD) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j < nh) {
+                        const float4 hw = *reinterpret_cast<const float4*>(L.head_w + j * NERO_HID + fbase + 8 * g);
+                        gs.x = fmaf(dj[j], hw.x, gs.x); gs.y = fmaf(dj[j], hw.y, gs.y);
+                        gs.z = fmaf(dj[j], hw.z, gs.z); gs.w = fmaf(dj[j], hw.w, gs.w);
+                    }
+                }
+            }
+            const float4 a = pa[r][g];
+            float4 d;
+            d.x = act_grad<ACT>(a.x, gs.x); d.y = act_grad<ACT>(a.y, gs.y);
+            d.z = act_grad<ACT>(a.z, gs.z); d.w = act_grad<ACT>(a.w, gs.w);
+            if (has_inj) {
+                const float4 ij = *reinterpret_cast<const float4*>(L.inj + goff + (size_t)r * 32 * NERO_HID + 8 * g);
+                d.x += ij.x; d.y += ij.y; d.z += ij.z; d.w += ij.w;
+            }
+            if (!live) d = make_float4(0.f, 0.f, 0.f, 0.f);
+            val[r][g] = d;
+            m[r] = fmaxf(m[r], amax4(d));
+        }
+    }
+}
+template <int ACT>
+__device__ __forceinline__ void bwd_values_h(const float4 (&gq)[2][4], const float4 (&pa)[2][4], size_t goff, bool has_inj,
+                                             const nero_bwd_layer& L, int row0, int i, int fbase, int n_rows, float4 (&val)[2][4],
+                                             float (&m)[2]) {
+    if (L.n_head > 0) bwd_values<ACT, true>(gq, pa, goff, has_inj, L, row0, i, fbase, n_rows, val, m);
+    else bwd_values<ACT, false>(gq, pa, goff, has_inj, L, row0, i, fbase, n_rows, val, m);
+}
+
+__global__ __launch_bounds__(512, 1) void bwd_f16_kernel(nero_bwd_chain ch, int n_rows) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Lds S = carve<SX_N>(smem);                   // (the aux planes are unused by the reverse walk)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int row0 = blockIdx.x * 64;
+    if (ch.dy) load_planes_scaled(S.actp, SA, PLANE_A, S.rs_main, ch.dy, ch.ld_dy, ch.k_dy, row0, n_rows, tid);
+    else {
+        for (int idx = tid; idx < 2 * PLANE_A / 16; idx += 512) reinterpret_cast<uint4*>(S.actp)[idx] = make_uint4(0u, 0u, 0u, 0u);
+        if (tid < 64) S.rs_main[tid] = 1.f;
+    }
+    __syncthreads();
+    for (int l = ch.n_layers - 1; l >= 0; --l) {
+        const nero_bwd_layer& L = ch.layer[l];
+        const bool first = (L.a_prev == nullptr);
+        if (first && ch.d_init == nullptr && !(ch.d_aux && L.w_aux_t)) break;
+        const int nt = L.k_main_tiles;
+        const bool live_wave = wave < nt;
+        const int fbase = 32 * wave + 4 * h;
+        const size_t goff = (size_t)(row0 + i) * NERO_HID + fbase;
+        const size_t boff = (size_t)row0 * NERO_HID + 32 * wave;
+        const int steps = L.n_out >> 4;
+        float4 pa[2][4];                                   // saved activations of this lane's outputs, requested before the GEMM
+        const bool has_inj = !first && L.inj != nullptr;
+        if (!first && live_wave) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) pa[r][g] = *reinterpret_cast<const float4*>(L.a_prev + goff + (size_t)r * 32 * NERO_HID + 8 * g);
+        }
+        float4 gq[2][4];                                   // incoming gradient of this lane's outputs, true units
+        const float rs0 = S.rs_main[i], rs1 = S.rs_main[32 + i];
+        if (L.n_out > 0) {
+            f32x16 aH[2], aL[2];
+            if (ch.d_aux && L.w_aux_t) {
+                zero2(aH);
+                zero2(aL);
+                if (wave < L.k_aux_tiles) {
+                    const float wsc = *L.w_aux_t;
+                    gemm_f16x3(aH, aL, reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(L.w_aux_t) + HDR_BYTES) + (size_t)wave * steps * 128 + lane,
+                               S.actp + i * SA + 16 * h, 32 * SA, PLANE_A, steps);
+                    const float u[2] = {wsc * rs0, wsc * rs1};
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int f = fbase + 8 * g;
+                            if (f < ch.ld_daux)
+                                *reinterpret_cast<float4*>(ch.d_aux + (size_t)(row0 + 32 * r + i) * ch.ld_daux + f) =
+                                    make_float4(fmaf(aL[r][4 * g], LO_INV, aH[r][4 * g]) * u[r], fmaf(aL[r][4 * g + 1], LO_INV, aH[r][4 * g + 1]) * u[r],
+                                                fmaf(aL[r][4 * g + 2], LO_INV, aH[r][4 * g + 2]) * u[r], fmaf(aL[r][4 * g + 3], LO_INV, aH[r][4 * g + 3]) * u[r]);
+                        }
+                }
+            }
+            zero2(aH);
+            zero2(aL);
+            float u[2] = {1.f, 1.f};
+            if (live_wave) {
+                const float wsc = *L.w_main_t;
+                gemm_f16x3(aH, aL, reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(L.w_main_t) + HDR_BYTES) + (size_t)wave * steps * 128 + lane,
+                           S.actp + i * SA + 16 * h, 32 * SA, PLANE_A, steps);
+                u[0] = wsc * rs0;
+                u[1] = wsc * rs1;
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    gq[r][g] = make_float4(fmaf(aL[r][4 * g], LO_INV, aH[r][4 * g]) * u[r], fmaf(aL[r][4 * g + 1], LO_INV, aH[r][4 * g + 1]) * u[r],
+                                           fmaf(aL[r][4 * g + 2], LO_INV, aH[r][4 * g + 2]) * u[r], fmaf(aL[r][4 * g + 3], LO_INV, aH[r][4 * g + 3]) * u[r]);
+            if (first) {
+                if (ch.d_init && live_wave) {
+                    const int ldi = ch.ld_dinit;
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int f = fbase + 8 * g;
+                            if (f < ldi) {
+                                float4 v = gq[r][g];
+                                float4* dstp = reinterpret_cast<float4*>(ch.d_init + (size_t)(row0 + 32 * r + i) * ldi + f);
+                                if (ch.accumulate_dinit) { const float4 o = *dstp; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                                *dstp = v;
+                            }
+                        }
+                }
+                break;
+            }
+        } else {
+            // head-only pseudo layer: the incoming gradient is the current content of the planes
+            if (first) break;
+            if (live_wave) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    gq[0][g] = scale4(load_planes4h(S.actp + i * SA + (fbase + 8 * g) * 2, PLANE_A), rs0);
+                    gq[1][g] = scale4(load_planes4h(S.actp + (32 + i) * SA + (fbase + 8 * g) * 2, PLANE_A), rs1);
+                }
+            }
+        }
+        float4 val[2][4];
+        float m[2] = {0.f, 0.f};
+        if (live_wave) {
+            if (L.act_prev == NERO_ACT_RELU) bwd_values_h<NERO_ACT_RELU>(gq, pa, goff, has_inj, L, row0, i, fbase, n_rows, val, m);
+            else if (L.act_prev == NERO_ACT_SOFTPLUS100) bwd_values_h<NERO_ACT_SOFTPLUS100>(gq, pa, goff, has_inj, L, row0, i, fbase, n_rows, val, m);
+            else bwd_values_h<NERO_ACT_NONE>(gq, pa, goff, has_inj, L, row0, i, fbase, n_rows, val, m);
+            if (L.delta_prev) {
+                float* scr = reinterpret_cast<float*>(S.scr + wave * SCR_BYTES);
+                acc_to_global(scr, val[0], L.delta_prev + boff, lane);
+                acc_to_global(scr, val[1], L.delta_prev + boff + (size_t)32 * NERO_HID, lane);
+            }
+        }
+        commit_planes(S, val, m[0], m[1], live_wave, wave, i, h);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// operand packing: header + two fp16 planes in A-fragment order
+//   image = [256-byte header: float 2^ew, uint bits(max |A|)] [ (((t*nsteps + c)*2 + p)*64 + lane) * 16 bytes ]
+//   plane_p of A[32t + (lane&31)][16c + 8(lane>>5) + j] * 2^-ew;   transpose as in nero_pack_weight_split
+// Two passes per batch: pack_max (atomicMax of |A| into the zero-initialised header) and the pack itself.
+// ---------------------------------------------------------------------------------------------------------------------
+struct PackBatchH { nero_pack_job job[NERO_MAX_PACK_JOBS]; };
+
+__device__ __forceinline__ float pack_elem(const nero_pack_job& J, int m, int k) {
+    float x = 0.f;
+    if (!J.transpose) { if (m < J.nrows && k < J.ncols) x = J.W[(size_t)m * J.ld + J.col0 + k]; }
+    else              { if (m < J.ncols && k < J.nrows) x = J.W[(size_t)k * J.ld + J.col0 + m]; }
+    return x * J.scale;
+}
+
+__global__ __launch_bounds__(256) void pack_max_kernel(PackBatchH B) {
+    const nero_pack_job& J = B.job[blockIdx.y];
+    if (J.kind != 3) return;
+    const int nsteps = J.kpad >> 4, total = J.nt_count * nsteps * 64;
+    float m = 0.f;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int lane = idx & 63, tc = idx >> 6;
+        const int c = tc % nsteps, t = tc / nsteps;
+        const int mm = 32 * t + (lane & 31), k0 = 16 * c + 8 * (lane >> 5);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(pack_elem(J, mm, k0 + j)));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(J.out) + 1, __float_as_uint(m));
+}
+
+__global__ __launch_bounds__(256) void pack_f16_kernel(PackBatchH B) {
+    const nero_pack_job& J = B.job[blockIdx.y];
+    if (J.kind != 3) return;
+    const int nsteps = J.kpad >> 4, total = J.nt_count * nsteps * 64;
+    const int e = scale_exp(__uint_as_float(reinterpret_cast<const unsigned*>(J.out)[1]));
+    const float inv = pow2i(-e);
+    uint4* out = reinterpret_cast<uint4*>(reinterpret_cast<char*>(J.out) + HDR_BYTES);
+    if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<float*>(J.out)[0] = pow2i(e);
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int lane = idx & 63, tc = idx >> 6;
+        const int c = tc % nsteps, t = tc / nsteps;
+        const int mm = 32 * t + (lane & 31), k0 = 16 * c + 8 * (lane >> 5);
+        unsigned hp[4], lp[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split2h(pack_elem(J, mm, k0 + 2 * j) * inv, pack_elem(J, mm, k0 + 2 * j + 1) * inv, hp[j], lp[j]);
+        out[((size_t)tc * 2 + 0) * 64 + lane] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+        out[((size_t)tc * 2 + 1) * 64 + lane] = make_uint4(lp[0], lp[1], lp[2], lp[3]);
+    }
+}
+
+}  // namespace
+
+// ---- host side (dispatched from mlp_engine.hip / mlp_split.hip) --------------------------------------------------------------
+int nero_f16_pack_batch(const nero_pack_job* jobs, int n_jobs, hipStream_t stream) {
+    PackBatchH B;
+    int max_work = 1, any = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        B.job[i] = jobs[i];
+        if (jobs[i].kind != 3) continue;
+        any = 1;
+        if (jobs[i].kpad & 15) return nero_fail(NERO_ERR_ARG, "nero_pack_batch: f16x3 kpad must be a multiple of 16");
+        const int work = jobs[i].nt_count * (jobs[i].kpad >> 4) * 64;
+        max_work = work > max_work ? work : max_work;
+    }
+    if (!any) return NERO_OK;
+    int bx = (max_work + 255) / 256;
+    bx = bx > 32 ? 32 : bx;
+    hipLaunchKernelGGL(pack_max_kernel, dim3(bx, n_jobs), dim3(256), 0, stream, B);
+    hipLaunchKernelGGL(pack_f16_kernel, dim3(bx, n_jobs), dim3(256), 0, stream, B);
+    return nero_check_launch("nero_pack_batch(f16x3)");
+}
+
+int nero_f16_forward(const nero_fwd_chain* ch, int n_rows, hipStream_t stream) {
+    const dim3 grid((n_rows + 63) / 64), block(512);
+    for (int l = 0; l < ch->n_layers; ++l)
+        if ((ch->layer[l].k_main | ch->layer[l].k_aux) & 15)
+            return nero_fail(NERO_ERR_ARG, "nero_mlp_forward(f16x3): k_main / k_aux must be multiples of 16");
+    if (ch->aux_wide) {
+        NERO_ONCE(hipFuncSetAttribute((const void*)fwd_f16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, f16_lds_bytes(1)));
+        hipLaunchKernelGGL(fwd_f16_kernel<true>, grid, block, f16_lds_bytes(1), stream, *ch, n_rows);
+    } else {
+        NERO_ONCE(hipFuncSetAttribute((const void*)fwd_f16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, f16_lds_bytes(0)));
+        hipLaunchKernelGGL(fwd_f16_kernel<false>, grid, block, f16_lds_bytes(0), stream, *ch, n_rows);
+    }
+    return NERO_OK;
+}
+
+int nero_f16_tangent(const nero_tan_chain* ch, int n_rows, hipStream_t stream) {
+    const dim3 grid((n_rows + 63) / 64), block(512);
+    for (int l = 0; l < ch->n_layers; ++l)
+        if ((ch->layer[l].k_main | ch->layer[l].k_aux) & 15)
+            return nero_fail(NERO_ERR_ARG, "nero_mlp_tangent(f16x3): k_main / k_aux must be multiples of 16");
+    if (ch->aux_wide) return nero_fail(NERO_ERR_UNSUPPORTED, "nero_mlp_tangent(f16x3): aux_wide chains are not supported");
+    NERO_ONCE(hipFuncSetAttribute((const void*)tan_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, f16_lds_bytes(0)));
+    hipLaunchKernelGGL(tan_f16_kernel, grid, block, f16_lds_bytes(0), stream, *ch, n_rows);
+    return NERO_OK;
+}
+
+int nero_f16_backward(const nero_bwd_chain* ch, int n_rows, hipStream_t stream) {
+    const dim3 grid((n_rows + 63) / 64), block(512);
+    for (int l = 0; l < ch->n_layers; ++l)
+        if (ch->layer[l].n_out & 15) return nero_fail(NERO_ERR_ARG, "nero_mlp_backward(f16x3): n_out must be a multiple of 16");
+    if (ch->d_aux && (ch->ld_daux & 3)) return nero_fail(NERO_ERR_ARG, "nero_mlp_backward(f16x3): ld_daux must be a multiple of 4");
+    if (ch->d_init && (ch->ld_dinit & 3)) return nero_fail(NERO_ERR_ARG, "nero_mlp_backward(f16x3): ld_dinit must be a multiple of 4");
+    NERO_ONCE(hipFuncSetAttribute((const void*)bwd_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, f16_lds_bytes(0)));
+    hipLaunchKernelGGL(bwd_f16_kernel, grid, block, f16_lds_bytes(0), stream, *ch, n_rows);
+    return NERO_OK;
+}

@@ -12,3 +12,8 @@ int nero_split_backward(const nero_bwd_chain* ch, int n_rows, hipStream_t stream
 int nero_split_dw(const nero_dw_job* job, int n_rows, int rows_per_slice, int slices, float* partials, int n_pad, int k_pad,
                   hipStream_t stream);
 int nero_split_pack_batch(const nero_pack_job* jobs, int n_jobs, hipStream_t stream);
+// fp16 two-plane engine (mlp_f16x3.hip)
+int nero_f16_pack_batch(const nero_pack_job* jobs, int n_jobs, hipStream_t stream);
+int nero_f16_forward(const nero_fwd_chain* ch, int n_rows, hipStream_t stream);
+int nero_f16_tangent(const nero_tan_chain* ch, int n_rows, hipStream_t stream);
+int nero_f16_backward(const nero_bwd_chain* ch, int n_rows, hipStream_t stream);

@@ -793,6 +793,7 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(PackBatch B) {
     for (int idx = blockIdx.x * 256 + threadIdx.x;; idx += gridDim.x * 256) {
         if (J.kind == 0) { if (idx >= J.nt_count * (J.kpad >> 4) * 64) break; pack_split_one(J, idx); }
         else if (J.kind == 1) { if (idx >= (J.kpad >> 3) * J.nt_count * 256) break; pack_f32_one(J, idx); }
+        else if (J.kind == 3) break;                      // fp16 two-plane operands: nero_f16_pack_batch
         else {
             if (idx >= J.nrows * J.ncols) break;
             const int r = idx / J.ncols, c = idx - r * J.ncols;
@@ -878,11 +879,12 @@ int nero_split_pack_batch(const nero_pack_job* jobs, int n_jobs, hipStream_t str
         if (J.kind == 0 && (J.kpad & 15)) return nero_fail(NERO_ERR_ARG, "nero_pack_batch: split kpad must be a multiple of 16");
         if (J.kind == 1 && (J.kpad & 7)) return nero_fail(NERO_ERR_ARG, "nero_pack_batch: kpad must be a multiple of 8");
         B.job[i] = J;
-        const int work = J.kind == 0 ? J.nt_count * (J.kpad >> 4) * 64 : J.kind == 1 ? (J.kpad >> 3) * J.nt_count * 256 : J.nrows * J.ncols;
+        const int work = J.kind == 0 ? J.nt_count * (J.kpad >> 4) * 64 : J.kind == 1 ? (J.kpad >> 3) * J.nt_count * 256 : J.kind == 3 ? 0 : J.nrows * J.ncols;
         max_work = work > max_work ? work : max_work;
     }
     int bx = (max_work + 255) / 256;
     bx = bx > 32 ? 32 : bx;                              // grid-stride inside the kernel
     hipLaunchKernelGGL(pack_batch_kernel, dim3(bx, n_jobs), dim3(256), 0, stream, B);
-    return nero_check_launch("nero_pack_batch");
+    const int rc = nero_f16_pack_batch(jobs, n_jobs, stream);
+    return rc != NERO_OK ? rc : nero_check_launch("nero_pack_batch");
 }

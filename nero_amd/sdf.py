@@ -98,7 +98,8 @@ class SDFField:
             tc.init, tc.ld_init, tc.k_init = ehat.data_ptr(), LD_PE, LD_PE
             tc.aux, tc.ld_aux, tc.k_aux = ehat.data_ptr(), LD_PE, LD_PE
             tc.n_layers, tc.aux_wide = 8, 0
-            tsplit = GEMM_MODE['tan'] == L.GEMM_BF16X6
+            tsplit = GEMM_MODE['tan'] != L.GEMM_F32
+            tkeys = {L.GEMM_F32: ('fm', 'fa'), L.GEMM_BF16X6: ('sfm', 'sfa'), L.GEMM_F16X3: ('hfm', 'hfa')}[GEMM_MODE['tan']]
             tc.gemm_mode = GEMM_MODE['tan']
             rk = _r16 if tsplit else _r8
             tc.macs_per_row = float(sum(ch.entries[l][0].n_out * (ch.entries[l][0].k_main + ch.entries[l][0].k_aux) for l in range(8)))
@@ -106,7 +107,7 @@ class SDFField:
             for l in range(8):
                 d, p = ch.entries[l][0], ch._packed[l]
                 tl = tc.layer[l]
-                tl.w_main, tl.w_aux = L.ptr(p.get('sfm' if tsplit else 'fm')), L.ptr(p.get('sfa' if tsplit else 'fa'))
+                tl.w_main, tl.w_aux = L.ptr(p.get(tkeys[0])), L.ptr(p.get(tkeys[1]))
                 tl.a_saved, tl.gbar = fwd['saves'][l].data_ptr(), gbar[l].data_ptr()
                 tl.adot, tl.inj = tbuf[0, l].data_ptr(), tbuf[1, l].data_ptr()
                 tl.k_main, tl.k_aux, tl.n_tiles = rk(d.k_main), (rk(d.k_aux) if d.k_aux else 0), _tiles(d.n_out)

@@ -23,7 +23,7 @@ X = torch.zeros(rp, 128, device='cuda'); X[:n_rows, :k_in] = torch.randn(n_rows,
 A = torch.zeros(rp, 40, device='cuda'); A[:n_rows, :k_aux] = torch.randn(n_rows, k_aux, generator=g).cuda()
 for act, name in ((L.ACT_RELU, 'relu'), (L.ACT_SOFTPLUS100, 'softplus')):
     ref = None
-    for mode in ('f32', 'bf16x6'):
+    for mode in ('f32', 'bf16x6', 'f16x3'):
         CH.GEMM_MODE['fwd'] = CH._MODE_NAMES[mode]
         ch = Chain([(Dense(W0, b0, act, k_in), None), (Dense(W1, b1, act, 256, 0, k_aux, 256), None),
                     (Dense(W2, b2, act, 256), None), (None, Head(W3, b3))], k_init=128, k_aux=40).pack()
@@ -49,7 +49,7 @@ def timeit(f, n=5):
     for _ in range(n): f()
     torch.cuda.synchronize(); return (time.time() - t) / n
 flop = 2 * 8 * 256 * 256 * N
-for mode in ('f32', 'bf16x6'):
+for mode in ('f32', 'bf16x6', 'f16x3'):
     CH.GEMM_MODE['fwd'] = CH._MODE_NAMES[mode]
     for name, act in (('relu', L.ACT_RELU), ('softplus', L.ACT_SOFTPLUS100)):
         ch = Chain([(Dense(W, b, act, 256), None) for W, b in Ws[:7]] + [(Dense(Ws[7][0], Ws[7][1], L.ACT_NONE, 256), None)], k_init=256).pack()

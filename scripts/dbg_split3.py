@@ -17,7 +17,7 @@ def timeit(f, n=5):
     for _ in range(n): f()
     torch.cuda.synchronize(); return (time.time() - t) / n
 flop = 2 * 8 * 256 * 256 * N
-for mode in ('f32', 'bf16x6'):
+for mode in ('f32', 'bf16x6', 'f16x3'):
     CH.set_gemm_mode(mode)
     for name, act in (('relu', L.ACT_RELU), ('softplus', L.ACT_SOFTPLUS100)):
         ch = Chain([(Dense(W, b, act, 256), None) for W, b in Ws[:7]] + [(Dense(Ws[7][0], Ws[7][1], L.ACT_NONE, 256), None)], k_init=256).pack()

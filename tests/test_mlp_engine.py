@@ -9,13 +9,15 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=['f32', 'bf16x6'], autouse=True)
+
+
+@pytest.fixture(params=['f32', 'bf16x6', 'f16x3'], autouse=True)
 def gemm_mode(request):
-    """every engine test runs on both dense-layer arithmetics (include/nero_hip.h NERO_GEMM_*): the exact fp32 MFMA and the
-    3-plane bf16 split, against the same fp64 reference and the same tolerance."""
+    """every engine test runs on all dense-layer arithmetics (include/nero_hip.h NERO_GEMM_*): the exact fp32 MFMA, the
+    3-plane bf16 split and the 2-plane block-scaled fp16 split, against the same fp64 reference and the same tolerance."""
     from nero_amd import chain
     old = dict(chain.GEMM_MODE)
-    chain.set_gemm_mode(request.param)
+    chain.set_gemm_mode(request.param)          # ('f16x3' keeps the weight-gradient GEMM on bf16x6: the shipped default)
     yield request.param
     chain.GEMM_MODE.update(old)
 
