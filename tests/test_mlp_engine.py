@@ -225,3 +225,50 @@ def test_split_operand_planes_are_exact_and_in_fragment_order(transpose):
     p0, p1, p2 = np.abs(planes[:, :, 0]), np.abs(planes[:, :, 1]), np.abs(planes[:, :, 2])
     nz = p0 > 0
     assert (p1[nz] <= p0[nz] * 2.0 ** -8).all() and (p2[nz] <= p0[nz] * 2.0 ** -16).all()
+
+
+@pytest.mark.parametrize('transpose', [0, 1])
+def test_f16x3_operand_planes_reconstruct_to_fp32_precision(transpose):
+    """nero_pack_batch kind 3 (NERO_GEMM_F16X3 operand): header float[0] = 2^e with max|A| * 2^-e in [0.5, 1); the plane pair
+    (h + l / 2048) * 2^e reproduces A to <= 2^-24 of the block maximum for every element, and to <= 2^-22 relative for every
+    element within 2^14 of the maximum (the fp16 normal range) -- the bound the fp32-grade claim of the engine rests on."""
+    import ctypes as C
+    import numpy as np
+    from nero_amd import _lib as L
+    g = torch.Generator().manual_seed(5)
+    nrows, ld, col0, ncols, scale = 70, 150, 5, 123, 0.70710678
+    W = (torch.randn(nrows, ld, generator=g) * torch.exp(torch.randn(nrows, ld, generator=g) * 3)).cuda()
+    W[3, 7] = 0.0
+    M, K = (nrows, ncols) if not transpose else (ncols, nrows)
+    kpad, nt = (K + 15) // 16 * 16, (M + 31) // 32
+    n_bytes = 256 + nt * (kpad // 16) * 2 * 64 * 16
+    out = torch.zeros(n_bytes // 4, dtype=torch.int32, device='cuda')
+    j = L.PackJob()
+    j.W, j.out, j.kind, j.nrows, j.ld, j.col0, j.ncols = W.data_ptr(), out.data_ptr(), 3, nrows, ld, col0, ncols
+    j.transpose, j.kpad, j.nt_count, j.scale = transpose, kpad, nt, scale
+    L.check(L.lib.nero_pack_batch((L.PackJob * 1)(j), 1, L.stream_ptr()))
+    torch.cuda.synchronize()
+    raw = out.cpu().numpy()
+    sc = raw[:1].view(np.float32)[0]
+    Wn = (W.cpu().numpy()[:, col0:col0 + ncols] * np.float32(scale)).astype(np.float32)
+    A = Wn if not transpose else Wn.T
+    amax = np.abs(A).max()
+    assert sc == 2.0 ** np.ceil(np.log2(amax)) or 0.5 <= amax / sc < 1.0
+    planes = raw[64:].view(np.float16).reshape(nt, kpad // 16, 2, 64, 8).astype(np.float64)
+    rec = (planes[:, :, 0] + planes[:, :, 1] / 2048.0) * float(sc)            # [nt, steps, 64, 8]
+    want = np.zeros((nt * 32, kpad), np.float64)
+    want[:M, :K] = A
+    lane = np.arange(64)
+    err_abs, err_rel = 0.0, 0.0
+    for t in range(nt):
+        for c in range(kpad // 16):
+            rows = 32 * t + (lane & 31)
+            cols = 16 * c + 8 * (lane >> 5)
+            blk = np.stack([want[rows, cols + jj] for jj in range(8)], -1)
+            d = np.abs(rec[t, c] - blk)
+            err_abs = max(err_abs, d.max())
+            big = np.abs(blk) >= amax * 2.0 ** -13
+            if big.any():
+                err_rel = max(err_rel, (d[big] / np.abs(blk[big])).max())
+    assert err_abs <= 2.0 ** -24 * float(sc), (err_abs, sc)
+    assert err_rel <= 2.0 ** -22, err_rel
