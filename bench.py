@@ -29,6 +29,19 @@ MFMA_OF_MODE = {0: 'v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain)',
                 2: 'v_mfma_f32_32x32x16_f16, 2 block-scaled fp16 planes per operand, 3 plane products per fp32 multiply-add: peak = 2500 / 3'}
 
 
+def hbm_traffic_per_launch(kernel):
+    """average HBM bytes per launch of `kernel` from the committed PMC summary (scripts/prof_traffic.sh), or None"""
+    path = os.path.join(ROOT, 'profiles', 'r01_hbm_traffic_per_kernel.csv')
+    try:
+        for line in open(path):
+            f = line.strip().split(',')
+            if len(f) == 5 and f[0] == kernel:
+                return int((float(f[3]) + float(f[4])) * 1024)
+    except OSError:
+        pass
+    return None
+
+
 def cpu_baseline(cfg, variance, step, rays=512, budget_s=15.0, max_steps=10):
     """the oracle (a port of the reference's torch path, oracle/nero_oracle.py) timed on this box's host cores on a bounded
     sample of the same workload: `rays` rays x (64+64+32) samples, forward + loss + backward, 1 step."""
@@ -162,7 +175,9 @@ def main():
         ach = dom[3] / (dom[2] * 1e-3) / 1e12 if dom[2] > 0 else 0.0
         peak = dom[4] / 1e12
         roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
-                'frac': round(ach / peak, 4), 'traffic': None, 'kernel': dom[0], 'mfma': MFMA_OF_MODE[dom[5]],
+                'frac': round(ach / peak, 4), 'traffic': hbm_traffic_per_launch(dom[0]), 'kernel': dom[0], 'mfma': MFMA_OF_MODE[dom[5]],
+                'traffic_source': 'profiles/r01_hbm_traffic_per_kernel.csv: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, '
+                                  'separate passes, bytes per launch (null if the kernel is not in that file)',
                 'avg_launch_ms': round(dom[2] / max(dom[1], 1), 4),
                 'per_kernel': {r[0]: {'launches_per_step': r[1] / 3, 'ms_per_step': round(r[2] / 3, 3),
                                       'tflops': round(r[3] / (r[2] * 1e-3) / 1e12, 2) if r[2] > 0 else 0.0,
