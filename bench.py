@@ -154,6 +154,20 @@ def main():
         ts.step(args.train_step + 300)           # back on the default engine before the roofline leg
         sync()
 
+    # ---- forward-only (inference) rays/s on the default engines: 2 warmup + 5 timed renders --------------------
+    for i in range(2):
+        ts.forward_only(args.train_step + 400 + i)
+    sync()
+    t2 = time.time()
+    for i in range(5):
+        ts.forward_only(args.train_step + 402 + i)
+    sync()
+    dtf = torch.tensor([time.time() - t2], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(dtf, op=dist.ReduceOp.MAX)
+    fwd_only = {'value': round(args.rays * world * 5 / float(dtf), 1), 'unit': 'rays/s', 'ms_per_render': round(float(dtf) / 5 * 1e3, 3),
+                'what': "renderer.render(is_train=False): sampler + render forward + the reference's validation extras, no loss / backward"}
+
     # ---- roofline leg: per-launch HIP-event timing of the MFMA kernel classes, on extra (untimed) steps ------------
     roof = None
     if rank == 0:
@@ -204,7 +218,9 @@ def main():
                                    f'training-schedule step {args.train_step}', 'rays_per_gpu': args.rays,
                        'parallelism': f'dp{world}', 'optimizer': 'adam(fused)', 'inv_s': 'exp(10*0.5)'},
             'step_mlp_flop_frac': round(flop_step / (dt / args.steps) / PEAK_OF_MODE[_CH.GEMM_MODE['fwd']], 4),
+            'step_mlp_flop_frac_of_f32_mfma_peak': round(flop_step / (dt / args.steps) / PEAK_F32_MFMA, 4),
             'inner_samples_per_ray': round(n_in / args.steps / args.rays, 2),
+            'forward_only': fwd_only,
             'roofline': roof,
         }
         if alt is not None:

@@ -101,6 +101,18 @@ class ShapeTrainStep:
         self.cursor += G
         return self.pool['o'][s], self.pool['d'][s], self.pool['gt'][s]
 
+    def forward_only(self, step):
+        """one inference render of the next ray batch: the reference's is_train=False path (sampler + render forward + the
+        validation extras of compute_validation_info), no loss / backward / optimiser; `step` only sets the cosine anneal"""
+        net = self.net
+        o, d, _ = self._batch()
+        near, far = net.near_far_from_sphere(o, d)
+        with torch.no_grad():
+            # (a schedule step below occ_loss_step: inference does not evaluate the occlusion loss)
+            out = net.render(o, d, near, far, None, 0, net.get_anneal_val(step), is_train=False,
+                             step=min(step, net.cfg['occ_loss_step'] - 1))
+        return out['ray_rgb']
+
     def step(self, step):
         net = self.net
         lr = warm_up_cos_lr(step)
