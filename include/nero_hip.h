@@ -299,14 +299,16 @@ int nero_mc_human_encode(const float* dirs, const int* idx, const float* pt, int
                          void* stream);
 int nero_mc_encode_hit(const float* dirs, const float* pos, const float* face_normals, const int* idx, int n, float* X /*[rows,128]*/,
                        void* stream);
-/* human_raw [miss rows,4] / hmask [miss rows] may be NULL (shader_cfg.human_lights false) */
+/* human_raw [miss rows,4] / hmask [miss rows] may be NULL (shader_cfg.human_lights false).
+ * geometry_type: 0 = 'schlick' (geometry_schlick, network/field.py:892-903), 1 = 'ggx_smith' (geometry_ggx_smith_correlated, :905-913) */
 int nero_mc_combine_fwd(const float* pt, const float* dirs, const float* depth, const int* slot, const float* outer_raw,
                         const float* inner_raw, const float* human_raw, const float* hmask, float exp_max, float inner_exp_max, int P,
-                        int Dd, int Ds, float* rgb_lin, float* dl_mean, float* sl_mean, float* spec_lin /*or NULL*/, void* stream);
+                        int Dd, int Ds, int geometry_type, float* rgb_lin, float* dl_mean, float* sl_mean, float* spec_lin /*or NULL*/,
+                        void* stream);
 int nero_mc_combine_bwd(const float* pt, const float* dirs, const float* depth, const int* slot, const float* outer_raw,
                         const float* inner_raw, const float* human_raw, const float* hmask, float exp_max, float inner_exp_max, int P,
-                        int Dd, int Ds, const float* d_rgb, const float* d_dl, float* d_outer_raw, float* d_inner_raw, float* d_human_raw,
-                        float* d_mat5, float* d_wspec, void* stream);
+                        int Dd, int Ds, int geometry_type, const float* d_rgb, const float* d_dl, float* d_outer_raw, float* d_inner_raw,
+                        float* d_human_raw, float* d_mat5, float* d_wspec, void* stream);
 int nero_mc_dir_bwd(const float* pt, const float* dirs, const float* face_normals, const int* slot, const float* tab_s,
                     const float* dX_miss, const float* dX_hit, const float* d_wspec, int P, int Dd, int Ds, float* d_mat5, int sphere,
                     const float* dXh /*or NULL*/, const float* poses /*[P,3,4] or NULL*/, void* stream);

@@ -274,9 +274,10 @@ __global__ void mc_encode_hit_kernel(const float* __restrict__ dirs, const float
 // estimator (shade_mixed, field.py:950-998).  One wave per point; lane handles directions lane, lane+64, ...
 // slot[row] >= 0: miss row index into outer_raw; < 0: hit row index -(slot)-1 into inner_raw.
 // ---------------------------------------------------------------------------------------------------------------------
-struct Brdf { float H[3], hlen, hov, nol, noh, fc, gv, gl, denv, denl, dg, t, dden, prob, W, N, Q; };
+struct Brdf { float H[3], hlen, hov, nol, noh, fc, gv, gl, denv, denl, dg, t, dden, prob, W, N, Q, G, sv, sl, Tv, Tl; };
 
-__device__ __forceinline__ void brdf_terms(const float* q, const float* w, bool diffuse, float wd, float ws, Brdf& b) {
+// geom: 0 = Schlick-GGX product (geometry_schlick, field.py:892-903), 1 = height-correlated Smith (geometry_ggx_smith_correlated, :905-913)
+__device__ __forceinline__ void brdf_terms(const float* q, const float* w, bool diffuse, float wd, float ws, int geom, Brdf& b) {
     const float* v = q; const float* n = q + 3;
     const float r = q[10], nov = q[14];
     float h[3] = {v[0] + w[0], v[1] + w[1], v[2] + w[2]};
@@ -291,16 +292,26 @@ __device__ __forceinline__ void brdf_terms(const float* q, const float* w, bool 
     b.denv = nov * (1.f - k) + k + 1e-5f; b.denl = b.nol * (1.f - k) + k + 1e-5f;
     b.gv = nov / b.denv; b.gl = b.nol / b.denl;
     const float a2 = r * r;
+    if (geom == 0) b.G = b.gv * b.gl;
+    else {
+        // G = 1 / (1 + f(nov) + f(nol)), f(c) = 0.5 sqrt(1 + a2 (1-c^2)/(c^2+1e-7)) - 0.5   =>   G = 2 / (sv + sl)
+        const float cv2 = nov * nov, cl2 = b.nol * b.nol;
+        b.Tv = (1.f - cv2) / (cv2 + 1e-7f);
+        b.Tl = (1.f - cl2) / (cl2 + 1e-7f);
+        b.sv = sqrtf(1.f + a2 * b.Tv);
+        b.sl = sqrtf(1.f + a2 * b.Tl);
+        b.G = 2.f / (b.sv + b.sl);
+    }
     b.t = b.noh * b.noh * (a2 - 1.f) + 1.f;
     b.dden = 3.14159265358979f * b.t * b.t + 1e-4f;
     b.dg = a2 / b.dden;
     b.prob = diffuse ? b.nol / 3.14159265358979f * wd : b.dg * b.noh / (4.f * b.hov + 1e-5f) * ws;
-    b.N = b.dg * b.gv * b.gl;
+    b.N = b.dg * b.G;
     b.Q = 4.f * nov * b.prob + 1e-5f;
     b.W = b.N / b.Q;
 }
 
-struct Lights { const float* outer_raw; const float* inner_raw; const float* human_raw; const float* hmask; float emax, imax; };
+struct Lights { const float* outer_raw; const float* inner_raw; const float* human_raw; const float* hmask; float emax, imax; int geom; };
 
 // L = near * ( miss: outer (1-hw) + hl hw ; hit: inner )      (get_lights, field.py:866-879)
 __device__ __forceinline__ void light_value(int s, const Lights& P_, float near, float* L, float* outer, float* hl, float& hw, float& hw_raw) {
@@ -336,7 +347,7 @@ __global__ __launch_bounds__(64) void mc_combine_fwd_kernel(const float* __restr
         const size_t row = (size_t)p * D + j;
         const float w[3] = {dirs[row * 3], dirs[row * 3 + 1], dirs[row * 3 + 2]};
         Brdf b;
-        brdf_terms(q, w, j < Dd, wd, ws, b);
+        brdf_terms(q, w, j < Dd, wd, ws, LP.geom, b);
         float L[3], ou[3], hl[3], hw, hwr;
         light_value(slot[row], LP, depth[row] > 1e-5f ? 1.f : 0.f, L, ou, hl, hw, hwr);
         for (int c = 0; c < 3; ++c) {
@@ -388,7 +399,7 @@ __global__ __launch_bounds__(64) void mc_combine_bwd_kernel(const float* __restr
         const bool diffuse = j < Dd;
         const float w[3] = {dirs[row * 3], dirs[row * 3 + 1], dirs[row * 3 + 2]};
         Brdf b;
-        brdf_terms(q, w, diffuse, wd, ws, b);
+        brdf_terms(q, w, diffuse, wd, ws, LP.geom, b);
         const float near = depth[row] > 1e-5f ? 1.f : 0.f;
         const int s = slot[row];
         float L[3], ou[3], hl[3], hw, hwr;
@@ -432,13 +443,23 @@ __global__ __launch_bounds__(64) void mc_combine_bwd_kernel(const float* __restr
             reinterpret_cast<float4*>(d_inner_raw)[kk] = make_float4(o4[0], o4[1], o4[2], 0.f);
         }
         // W = N / Q
-        float dDg = dW * b.gv * b.gl / b.Q;
+        float dDg = dW * b.G / b.Q;
         const float dG = dW * b.dg / b.Q;
         const float dprob = -dW * b.N / (b.Q * b.Q) * 4.f * nov;
-        const float dgl = dG * b.gv, dgv = dG * b.gl;
-        // g(x) = x / (x(1-k)+k+eps): dg/dk = -x(1-x)/den^2 ; dg/dx = (k+eps)/den^2
-        dr += 0.5f * (dgv * (-nov * (1.f - nov) / (b.denv * b.denv)) + dgl * (-b.nol * (1.f - b.nol) / (b.denl * b.denl)));
-        float dnol = dgl * (k + 1e-5f) / (b.denl * b.denl);
+        float dnol;
+        if (LP.geom == 0) {
+            const float dgl = dG * b.gv, dgv = dG * b.gl;
+            // g(x) = x / (x(1-k)+k+eps): dg/dk = -x(1-x)/den^2 ; dg/dx = (k+eps)/den^2
+            dr += 0.5f * (dgv * (-nov * (1.f - nov) / (b.denv * b.denv)) + dgl * (-b.nol * (1.f - b.nol) / (b.denl * b.denl)));
+            dnol = dgl * (k + 1e-5f) / (b.denl * b.denl);
+        } else {
+            // G = 2/(sv+sl): dG/ds = -G^2/2;  ds/da2 = T/(2s);  dsl/dnol = a2 T'(nol)/(2 sl),  T'(c) = -2c(1+eps)/(c^2+eps)^2
+            const float ds = dG * (-0.5f * b.G * b.G);
+            const float a2g = r * r;
+            dr += ds * (b.Tv / (2.f * b.sv) + b.Tl / (2.f * b.sl)) * 2.f * r;
+            const float cl2 = b.nol * b.nol + 1e-7f;
+            dnol = ds * a2g * (-2.f * b.nol * (1.f + 1e-7f) / (cl2 * cl2)) / (2.f * b.sl);
+        }
         float dnoh = 0.f, dhov = 0.f;
         if (!diffuse) {
             const float e = 4.f * b.hov + 1e-5f;
@@ -605,9 +626,10 @@ int nero_mc_encode_hit(const float* dirs, const float* pos, const float* face_no
 
 int nero_mc_combine_fwd(const float* pt, const float* dirs, const float* depth, const int* slot, const float* outer_raw,
                         const float* inner_raw, const float* human_raw, const float* hmask, float exp_max, float inner_exp_max, int P,
-                        int Dd, int Ds, float* rgb_lin, float* dl_mean, float* sl_mean, float* spec_lin, void* stream) {
+                        int Dd, int Ds, int geometry_type, float* rgb_lin, float* dl_mean, float* sl_mean, float* spec_lin, void* stream) {
     if (P == 0) return NERO_OK;
-    Lights LP{outer_raw, inner_raw, human_raw, hmask, exp_max, inner_exp_max};
+    if (geometry_type != 0 && geometry_type != 1) return nero_fail(NERO_ERR_UNSUPPORTED, "nero_mc_combine_fwd: unknown geometry_type");
+    Lights LP{outer_raw, inner_raw, human_raw, hmask, exp_max, inner_exp_max, geometry_type};
     hipLaunchKernelGGL(mc_combine_fwd_kernel, dim3(P), dim3(64), 0, (hipStream_t)stream, pt, dirs, depth, slot, LP, P, Dd, Ds, rgb_lin,
                        dl_mean, sl_mean, spec_lin);
     return nero_check_launch("nero_mc_combine_fwd");
@@ -615,10 +637,11 @@ int nero_mc_combine_fwd(const float* pt, const float* dirs, const float* depth, 
 
 int nero_mc_combine_bwd(const float* pt, const float* dirs, const float* depth, const int* slot, const float* outer_raw,
                         const float* inner_raw, const float* human_raw, const float* hmask, float exp_max, float inner_exp_max, int P,
-                        int Dd, int Ds, const float* d_rgb, const float* d_dl, float* d_outer_raw, float* d_inner_raw, float* d_human_raw,
-                        float* d_mat5, float* d_wspec, void* stream) {
+                        int Dd, int Ds, int geometry_type, const float* d_rgb, const float* d_dl, float* d_outer_raw, float* d_inner_raw,
+                        float* d_human_raw, float* d_mat5, float* d_wspec, void* stream) {
     if (P == 0) return NERO_OK;
-    Lights LP{outer_raw, inner_raw, human_raw, hmask, exp_max, inner_exp_max};
+    if (geometry_type != 0 && geometry_type != 1) return nero_fail(NERO_ERR_UNSUPPORTED, "nero_mc_combine_bwd: unknown geometry_type");
+    Lights LP{outer_raw, inner_raw, human_raw, hmask, exp_max, inner_exp_max, geometry_type};
     hipLaunchKernelGGL(mc_combine_bwd_kernel, dim3(P), dim3(64), 0, (hipStream_t)stream, pt, dirs, depth, slot, LP, P, Dd, Ds, d_rgb,
                        d_dl, d_outer_raw, d_inner_raw, d_human_raw, d_mat5, d_wspec);
     return nero_check_launch("nero_mc_combine_bwd");

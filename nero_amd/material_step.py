@@ -13,12 +13,15 @@ from .fields import fibonacci_az_el
 from .shape_step import _p, _st, predictor_entries
 
 
+GEOMETRY_TYPES = {'schlick': 0, 'ggx_smith': 1}      # include/nero_hip.h nero_mc_combine_*: geometry_type
+
+
 class MaterialKernels:
     def __init__(self, eff, cfg, device='cuda'):
         if cfg['outer_light_version'] not in ('direction', 'sphere_direction'):
             raise NotImplementedError(cfg['outer_light_version'])
-        if cfg['geometry_type'] != 'schlick':
-            raise NotImplementedError("HIP MC shader: geometry_type 'schlick' only")
+        if cfg['geometry_type'] not in GEOMETRY_TYPES:
+            raise NotImplementedError(cfg['geometry_type'])
         self.device, self.cfg = device, cfg
         f = eff['feats']
         ent = [(Dense(W, b, L.ACT_RELU, 51 if i == 0 else 256), None) for i, (W, b) in enumerate(f[:4])]
@@ -180,7 +183,7 @@ class MCShade(torch.autograd.Function):
         rgb, dl, sl, sp = (torch.empty((Pn, 3), **f32) for _ in range(4))
         L.check(lib.nero_mc_combine_fwd(_p(pt), _p(dirs), _p(depth), _p(slot), _p(outer_raw), _p(inner_raw), _p(human_raw), _p(hmask),
                                         C.c_float(cfg['light_exp_max']), C.c_float(cfg['inner_light_exp_max']), Pn, Dd, Ds,
-                                        _p(rgb), _p(dl), _p(sl), _p(sp), st))
+                                        GEOMETRY_TYPES[cfg['geometry_type']], _p(rgb), _p(dl), _p(sl), _p(sp), st))
         ctx.S = dict(K=K, names=names, P=Pn, pt=pt, dirs=dirs, depth=depth, fnrm=fnrm, slot=slot, Xm=Xm, Xh=Xh, fo=fo, fi=fi,
                      fh=fh, Xhum=Xhum, hmask=hmask, poses=poses,
                      n_miss=n_miss, n_hit=n_hit, shapes=[tuple(p.shape) for p in params])
@@ -207,7 +210,7 @@ class MCShade(torch.autograd.Function):
                                         _p(fo['heads'][3] if fo else None), _p(fi['heads'][3] if fi else None),
                                         _p(fh['heads'][3] if fh else None), _p(S['hmask']),
                                         C.c_float(cfg['light_exp_max']), C.c_float(cfg['inner_light_exp_max']), Pn, Dd, Ds,
-                                        _p(d_rgb.contiguous()), _p(d_dl.contiguous() if d_dl is not None else None),
+                                        GEOMETRY_TYPES[cfg['geometry_type']], _p(d_rgb.contiguous()), _p(d_dl.contiguous() if d_dl is not None else None),
                                         _p(d_or), _p(d_ir), _p(d_hr), _p(d_mat5), _p(d_w), st))
         ws = torch.empty(L.lib.nero_dw_workspace_floats(max(n_miss, n_hit, 1)), **f32)
         G = {}

@@ -255,3 +255,4 @@ if __name__ == '__main__':
     run_material_case('mat_bell', dict(msmall, human_lights=False, outer_light_version='direction'), P_=24, step=5000)
     run_material_case('mat_bell_early', dict(msmall, human_lights=False, outer_light_version='direction'), P_=24, step=500)
     run_material_case('mat_bear', dict(msmall, human_lights=True, outer_light_version='sphere_direction'), P_=24, step=5000)
+    run_material_case('mat_bell_smith', dict(msmall, human_lights=False, outer_light_version='direction', geometry_type='ggx_smith'), P_=24, step=5000)

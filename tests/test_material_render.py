@@ -30,7 +30,7 @@ def rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
-@pytest.mark.parametrize('name', ['mat_bell', 'mat_bell_early', 'mat_bear'])
+@pytest.mark.parametrize('name', ['mat_bell', 'mat_bell_early', 'mat_bear', 'mat_bell_smith'])
 def test_mc_shading_outputs_loss_and_grads(name):
     from nero_amd.renderer import NeROMaterialRenderer
     z, meta = load_golden(name)
