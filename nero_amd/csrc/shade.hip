@@ -248,7 +248,7 @@ __global__ void sdf_alpha_bwd_kernel(const float* __restrict__ sdf4, const float
 // Xi = [PE8(p)(51), IDE(refl,rough)(72), pad] ld 128,  Xo = [PE8(p)(51), PE6(refl)(39), pad] ld 96
 // mat[k] = { metallic, roughness, albedo(3), -, -, - } (after sigmoid) is written here too.
 // ------------------------------------------------------------------------------------------------------------------
-__global__ void shade_encode_kernel(const float* __restrict__ x4, const float* __restrict__ geo, const float* __restrict__ m_raw,
+__global__ __launch_bounds__(128) void shade_encode_kernel(const float* __restrict__ x4, const float* __restrict__ geo, const float* __restrict__ m_raw,
                                     const float* __restrict__ r_raw, const float* __restrict__ a_raw, int n, int n_pad,
                                     float* __restrict__ mat, float* __restrict__ Xd, float* __restrict__ Xs, float* __restrict__ Xi,
                                     float* __restrict__ Xo) {
@@ -337,7 +337,7 @@ __global__ void human_encode_kernel(const float* __restrict__ x4, const float* _
 }
 
 // dXh [rows,24] -> extra[k] = { d_refl(3), d_rough }
-__global__ void human_encode_bwd_kernel(const float* __restrict__ x4, const float* __restrict__ geo, const float* __restrict__ mat,
+__global__ __launch_bounds__(128) void human_encode_bwd_kernel(const float* __restrict__ x4, const float* __restrict__ geo, const float* __restrict__ mat,
                                         const int* __restrict__ idx, int T, const float* __restrict__ poses, int n,
                                         const float* __restrict__ dXh, float* __restrict__ extra) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -539,7 +539,7 @@ __global__ void shade_combine_bwd_kernel(const float* __restrict__ geo, const fl
 
 // backward of the encodings: dXd, dXs [rows,72], dXi [rows,128] (cols 51..122 = IDE part) -> d_geo (d_nhat, d_refl; d_NoV
 // already there), total roughness gradient; then the RAW material head gradients dm_raw/dr_raw/da_raw [rows,4]
-__global__ void shade_encode_bwd_kernel(const float* __restrict__ geo, const float* __restrict__ mat, const float* __restrict__ dXd,
+__global__ __launch_bounds__(128) void shade_encode_bwd_kernel(const float* __restrict__ geo, const float* __restrict__ mat, const float* __restrict__ dXd,
                                         const float* __restrict__ dXs, const float* __restrict__ dXi, const float* __restrict__ dmat,
                                         int n, int n_pad, float* __restrict__ d_geo, float* __restrict__ dm_raw,
                                         float* __restrict__ dr_raw, float* __restrict__ da_raw, const float* __restrict__ extra) {
