@@ -77,9 +77,18 @@ __global__ void ray_points_pe_kernel(const float* __restrict__ o, const float* _
     out[39] = 0.f;
 }
 
+// Per-ray working arrays live in LDS as columns of a [index][64 lanes] table (lane-consecutive -> conflict-free): the scans
+// below are dependent chains of ~100 steps per ray, and private (scratch) arrays would make every step a trip through the
+// global-memory path.  Storage only -- the arithmetic and its order are unchanged.
+struct Col {
+    float* p;
+    __device__ __forceinline__ float& operator[](int i) const { return p[i << 6]; }
+};
+__device__ __forceinline__ Col ray_col(float* smem, int table, int n_max) { return Col{smem + (size_t)table * n_max * 64 + (threadIdx.x & 63)}; }
+inline int ray_tables_bytes(int tables, int n_max) { return tables * n_max * 64 * (int)sizeof(float); }
+
 // deterministic inverse-CDF sampling of `m` values from bins z[0..n) with weights w[0..n-1)   (field.py:399-429, det=True)
-__device__ void sample_pdf_det(const float* zb, const float* w, int n, int m, float* out, int* inds_out) {
-    float cdf[MAXS];
+__device__ void sample_pdf_det(const Col& zb, const Col& w, const Col& cdf, int n, int m, float* out, int* inds_out) {
     // scans: float64 running value, rounded to float32 only where an element is stored (torch-CPU cumsum semantics)
     double acc = 0.0;
     for (int i = 0; i < n - 1; ++i) acc += (double)(w[i] + 1e-5f);
@@ -114,7 +123,8 @@ __global__ void upsample_kernel(const float* __restrict__ o, const float* __rest
     if (r >= R) return;
     // renderer.py:434-438: inv_s = min(exp(10 v), 64*2^i) (clip_sample_variance) or the fixed 64*2^i (variance == NULL)
     const float inv_s = variance ? fminf(expf(variance[0] * 10.0f), inv_s_cap) : inv_s_cap;
-    float zl[MAXS], w[MAXS];
+    extern __shared__ float ray_smem[];
+    const Col zl = ray_col(ray_smem, 0, n), w = ray_col(ray_smem, 1, n), cdf = ray_col(ray_smem, 2, n);
     const float ox = o[r * 3], oy = o[r * 3 + 1], oz = o[r * 3 + 2];
     const float dx = d[r * 3], dy = d[r * 3 + 1], dz_ = d[r * 3 + 2];
     for (int i = 0; i < n; ++i) zl[i] = z[(size_t)r * ldz + i];
@@ -145,7 +155,7 @@ __global__ void upsample_kernel(const float* __restrict__ o, const float* __rest
     if (w_out) for (int i = 0; i < n - 1; ++i) w_out[(size_t)r * (n - 1) + i] = w[i];
     float zn[32];
     int ind[32];
-    sample_pdf_det(zl, w, n, m, zn, inds_out ? ind : nullptr);
+    sample_pdf_det(zl, w, cdf, n, m, zn, inds_out ? ind : nullptr);
     for (int j = 0; j < m; ++j) {
         z_new[(size_t)r * m + j] = zn[j];
         if (inds_out) inds_out[(size_t)r * m + j] = ind[j];
@@ -157,11 +167,13 @@ __global__ void sample_pdf_kernel(const float* __restrict__ bins, int ldb, const
                                   float* __restrict__ out, int* __restrict__ inds_out) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
-    float zl[MAXS], wl[MAXS], zn[32];
+    extern __shared__ float ray_smem[];
+    const Col zl = ray_col(ray_smem, 0, n), wl = ray_col(ray_smem, 1, n), cdf = ray_col(ray_smem, 2, n);
+    float zn[32];
     int ind[32];
     for (int i = 0; i < n; ++i) zl[i] = bins[(size_t)r * ldb + i];
     for (int i = 0; i < n - 1; ++i) wl[i] = w[(size_t)r * ldw + i];
-    sample_pdf_det(zl, wl, n, m, zn, inds_out ? ind : nullptr);
+    sample_pdf_det(zl, wl, cdf, n, m, zn, inds_out ? ind : nullptr);
     for (int j = 0; j < m; ++j) {
         out[(size_t)r * m + j] = zn[j];
         if (inds_out) inds_out[(size_t)r * m + j] = ind[j];
@@ -175,7 +187,8 @@ __global__ void merge_sorted_kernel(float* __restrict__ z, int ldz, int n, float
                                     int R, int* __restrict__ index_out) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
-    float za[MAXS], sa[MAXS];
+    extern __shared__ float ray_smem[];
+    const Col za = ray_col(ray_smem, 0, n), sa = ray_col(ray_smem, 1, n);
     const bool hs = sdf != nullptr && sdf_new != nullptr;
     for (int i = 0; i < n; ++i) { za[i] = z[(size_t)r * ldz + i]; if (hs) sa[i] = sdf[(size_t)r * lds + i]; }
     int i = 0, j = 0;
@@ -361,14 +374,16 @@ int nero_upsample(const float* o, const float* d, const float* z, int ldz, const
                   const float* variance, float inv_s_cap, int m, int R, float* z_new, float* w_out, int* inds_out, void* stream) {
     if (!o || !d || !z || !sdf || !z_new || n > MAXS || n < 2 || m > 32) return nero_fail(NERO_ERR_ARG, "nero_upsample: bad argument");
     if (R == 0) return NERO_OK;
-    hipLaunchKernelGGL(upsample_kernel, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, o, d, z, ldz, sdf, lds, n, variance, inv_s_cap, m, R, z_new, w_out, inds_out);
+    NERO_ONCE(hipFuncSetAttribute((const void*)upsample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ray_tables_bytes(3, MAXS)));
+    hipLaunchKernelGGL(upsample_kernel, dim3((R + 63) / 64), dim3(64), ray_tables_bytes(3, n), (hipStream_t)stream, o, d, z, ldz, sdf, lds, n, variance, inv_s_cap, m, R, z_new, w_out, inds_out);
     return nero_check_launch("nero_upsample");
 }
 
 int nero_sample_pdf(const float* bins, int ldb, const float* w, int ldw, int n, int m, int R, float* out, int* inds_out, void* stream) {
     if (!bins || !w || !out || n > MAXS || n < 2 || m > 32) return nero_fail(NERO_ERR_ARG, "nero_sample_pdf: bad argument");
     if (R == 0) return NERO_OK;
-    hipLaunchKernelGGL(sample_pdf_kernel, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, bins, ldb, w, ldw, n, m, R, out, inds_out);
+    NERO_ONCE(hipFuncSetAttribute((const void*)sample_pdf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ray_tables_bytes(3, MAXS)));
+    hipLaunchKernelGGL(sample_pdf_kernel, dim3((R + 63) / 64), dim3(64), ray_tables_bytes(3, n), (hipStream_t)stream, bins, ldb, w, ldw, n, m, R, out, inds_out);
     return nero_check_launch("nero_sample_pdf");
 }
 
@@ -376,7 +391,8 @@ int nero_merge_sorted(float* z, int ldz, int n, float* sdf, int lds, const float
                       int R, int* index_out, void* stream) {
     if (!z || !z_new || n + m > MAXS) return nero_fail(NERO_ERR_ARG, "nero_merge_sorted: bad argument");
     if (R == 0) return NERO_OK;
-    hipLaunchKernelGGL(merge_sorted_kernel, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, z, ldz, n, sdf, lds, z_new, m, sdf_new, ldsn, R, index_out);
+    NERO_ONCE(hipFuncSetAttribute((const void*)merge_sorted_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ray_tables_bytes(2, MAXS)));
+    hipLaunchKernelGGL(merge_sorted_kernel, dim3((R + 63) / 64), dim3(64), ray_tables_bytes(2, n), (hipStream_t)stream, z, ldz, n, sdf, lds, z_new, m, sdf_new, ldsn, R, index_out);
     return nero_check_launch("nero_merge_sorted");
 }
 
