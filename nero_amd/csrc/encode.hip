@@ -1,6 +1,7 @@
 // encode.hip -- positional encodings and their Jacobian products (gfx950).  HBM-bound elementwise kernels: one thread per
 // row, rows are written as whole padded records so the MLP-chain kernels can load them with 16-byte accesses.
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 #include "../../include/nero_hip.h"
 #include "common.h"
 
@@ -33,15 +34,37 @@ __global__ void pe_vjp_kernel(const float* __restrict__ x, int ldx, const float*
     if (r >= n) return;
     const float* a = e0 + (size_t)r * ld0;
     const float* b = e1 ? e1 + (size_t)r * ld1 : nullptr;
+    // the <= 40 values of the row(s) are fetched first, as 16-byte loads where the layout allows: interleaved with the
+    // trigonometric code below, the 4-byte loads of a 160-byte row were spread over so many cycles that every cache line was
+    // re-fetched from HBM ~10 times (rocprofv3 FETCH_SIZE: 959 MB per launch for 96 MB of input)
+    const int nv = 3 + 6 * n_freq;                     // <= 40 (checked by the host wrapper)
+    float e[40];
+    const bool vec = ((ld0 | (e1 ? ld1 : 0)) & 3) == 0 && (((uintptr_t)e0 | (uintptr_t)e1) & 15) == 0;
+    if (vec) {
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            if (4 * j < nv) {
+                float4 va = *reinterpret_cast<const float4*>(a + 4 * j);
+                if (b) { const float4 vb = *reinterpret_cast<const float4*>(b + 4 * j); va.x += vb.x; va.y += vb.y; va.z += vb.z; va.w += vb.w; }
+                e[4 * j] = va.x; e[4 * j + 1] = va.y; e[4 * j + 2] = va.z; e[4 * j + 3] = va.w;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 40; ++j)
+            if (j < nv) e[j] = a[j] + (b ? b[j] : 0.f);
+    }
     for (int c = 0; c < 3; ++c) {
         const float xc = x[(size_t)r * ldx + c];
-        float acc = a[c] + (b ? b[c] : 0.f);
+        float acc = e[c];
         float f = 1.f;
-        for (int k = 0; k < n_freq; ++k) {
-            const float es = a[3 + 6 * k + c] + (b ? b[3 + 6 * k + c] : 0.f);
-            const float ec = a[3 + 6 * k + 3 + c] + (b ? b[3 + 6 * k + 3 + c] : 0.f);
-            acc += f * (cosf(xc * f) * es - sinf(xc * f) * ec);
-            f *= 2.f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            if (k < n_freq) {
+                const float es = e[3 + 6 * k + c], ec = e[3 + 6 * k + 3 + c];
+                acc += f * (cosf(xc * f) * es - sinf(xc * f) * ec);
+                f *= 2.f;
+            }
         }
         out[(size_t)r * ldo + c] = acc;
     }
@@ -81,7 +104,7 @@ int nero_encode_pe(const float* x, int ldx, int dim, int n_freq, int n, float* o
 
 int nero_pe_vjp(const float* x, int ldx, const float* e0, int ld0, const float* e1, int ld1, int n_freq, int n,
                 float* out, int ldo, void* stream) {
-    if (!x || !e0 || !out) return nero_fail(NERO_ERR_ARG, "nero_pe_vjp: bad argument");
+    if (!x || !e0 || !out || n_freq < 0 || n_freq > 6) return nero_fail(NERO_ERR_ARG, "nero_pe_vjp: bad argument (n_freq <= 6)");
     if (n == 0) return NERO_OK;
     hipLaunchKernelGGL(pe_vjp_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, ldx, e0, ld0, e1, ld1, n_freq, n, out, ldo);
     return nero_check_launch("nero_pe_vjp");
