@@ -225,7 +225,7 @@ def main():
         }
         if alt is not None:
             res['f32_mfma_engine'] = alt
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # (rank 0 at N = 1 only)
             res['cpu_baseline'] = cpu_baseline(cfg, variance, args.train_step)
         print(json.dumps(res), flush=True)
     if world > 1:
