@@ -240,9 +240,11 @@ int nero_sdf_alpha_bwd(const float* sdf4, const float* grad, const float* x4, co
 
 /* ---- split-sum shader algebra (AppShadingNetwork.forward, network/field.py:591-651; IDE utils/ref_utils.py:53-117;
  *      dr.texture field.py:612; linear_to_srgb utils/raw_utils.py:4-10) ------------------------------------------------ */
+/* sphere_direction != 0 (shader_config.sphere_direction, field.py:558-562, 582-586): Xd / Xs rows are 144 wide,
+ * [IDE(v, .) | IDE(normalised sphere exit point of the ray (offset_points_to_sphere(p), v), .)] for v = normal / reflection */
 int nero_shade_encode(const float* x4, const float* geo, const float* m_raw, const float* r_raw, const float* a_raw, int n,
-                      float* mat /*[rows,8]*/, float* Xd /*[rows,72]*/, float* Xs /*[rows,72]*/, float* Xi /*[rows,128]*/,
-                      float* Xo /*[rows,96]*/, void* stream);
+                      float* mat /*[rows,8]*/, float* Xd /*[rows,72|144]*/, float* Xs /*[rows,72|144]*/, float* Xi /*[rows,128]*/,
+                      float* Xo /*[rows,96]*/, int sphere_direction, void* stream);
 /* Lh [rows,4] raw human-light head + hmask [rows] (from nero_human_encode), or NULL/NULL when shader_config.human_light is off */
 int nero_shade_combine_fwd(const float* geo, const float* mat, const float* Ld, const float* Ls, const float* Li, const float* Lo,
                            const float* lut /*[256,256,2]*/, float exp_max, int n, float* color /*[n,3]*/, float* occ_prob,
@@ -256,7 +258,8 @@ int nero_shade_inter_results(const float* geo, const float* mat, const float* Ld
                              const float* lut, float exp_max, int n, const float* Lh, const float* hmask, float* rec, void* stream);
 /* extra [rows,4] = { d_refl(3), d_rough } from nero_human_encode_bwd, or NULL */
 int nero_shade_encode_bwd(const float* geo, const float* mat, const float* dXd, const float* dXs, const float* dXi, const float* dmat,
-                          int n, float* d_geo, float* dm_raw, float* dr_raw, float* da_raw, const float* extra, void* stream);
+                          int n, float* d_geo, float* dm_raw, float* dr_raw, float* da_raw, const float* extra,
+                          const float* x4 /*sample positions [rows,4]; needed when sphere_direction*/, int sphere_direction, void* stream);
 /* human ("photo capturer") light input (predict_human_light, network/field.py:536-552; get_camera_plane_intersection :348-367;
  * IPE :369-378): Xh [rows,24], hmask [rows]; poses [R,3,4] human-frame poses per RAY, sample k belongs to ray idx[k]/T */
 int nero_human_encode(const float* x4, const float* geo, const float* mat, const int* idx, int T, const float* poses, int n,

@@ -248,15 +248,43 @@ __global__ void sdf_alpha_bwd_kernel(const float* __restrict__ sdf4, const float
 // Xi = [PE8(p)(51), IDE(refl,rough)(72), pad] ld 128,  Xo = [PE8(p)(51), PE6(refl)(39), pad] ld 96
 // mat[k] = { metallic, roughness, albedo(3), -, -, - } (after sigmoid) is written here too.
 // ------------------------------------------------------------------------------------------------------------------
+// shader_config.sphere_direction (field.py:558-562, 582-586): the direction v is complemented by the normalised exit point of the ray
+// (q, v) on the unit sphere, q = offset_points_to_sphere(p) (:380-388), t = get_sphere_intersection(q, v) (:390-396)
+struct SphereDir { float q[3], b, S, t, len, s[3]; };
+__device__ __forceinline__ SphereDir sphere_dir(const float* p, const float* v) {
+    SphereDir e;
+    const float pn = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+    for (int c = 0; c < 3; ++c) e.q[c] = pn > 0.999f ? p[c] / pn * 0.999f : p[c];
+    e.b = e.q[0] * v[0] + e.q[1] * v[1] + e.q[2] * v[2];
+    const float xtx = e.q[0] * e.q[0] + e.q[1] * e.q[1] + e.q[2] * e.q[2];
+    e.S = sqrtf(e.b * e.b - xtx + 1.f + 1e-6f);
+    e.t = -e.b + e.S;
+    float u[3];
+    for (int c = 0; c < 3; ++c) u[c] = e.q[c] + v[c] * e.t;
+    e.len = fmaxf(sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]), 1e-12f);
+    for (int c = 0; c < 3; ++c) e.s[c] = u[c] / e.len;
+    return e;
+}
+// dL/dv from gs = dL/ds:  gu = (gs - s <s,gs>) / |u|,  dv = t gu + q (b/S - 1) <v,gu>
+__device__ __forceinline__ void sphere_dir_vjp(const SphereDir& e, const float* v, const float* gs, float* dv) {
+    const float sg = e.s[0] * gs[0] + e.s[1] * gs[1] + e.s[2] * gs[2];
+    float gu[3];
+    for (int c = 0; c < 3; ++c) gu[c] = (gs[c] - e.s[c] * sg) / e.len;
+    const float vg = v[0] * gu[0] + v[1] * gu[1] + v[2] * gu[2];
+    const float k = (e.b / e.S - 1.f) * vg;
+    for (int c = 0; c < 3; ++c) dv[c] += e.t * gu[c] + e.q[c] * k;
+}
+
 __global__ __launch_bounds__(128) void shade_encode_kernel(const float* __restrict__ x4, const float* __restrict__ geo, const float* __restrict__ m_raw,
                                     const float* __restrict__ r_raw, const float* __restrict__ a_raw, int n, int n_pad,
                                     float* __restrict__ mat, float* __restrict__ Xd, float* __restrict__ Xs, float* __restrict__ Xi,
-                                    float* __restrict__ Xo) {
+                                    float* __restrict__ Xo, int sphere) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_pad) return;
-    float* xd = Xd + (size_t)k * 72; float* xs = Xs + (size_t)k * 72; float* xi = Xi + (size_t)k * 128; float* xo = Xo + (size_t)k * 96;
+    const int ldd = sphere ? 144 : 72;
+    float* xd = Xd + (size_t)k * ldd; float* xs = Xs + (size_t)k * ldd; float* xi = Xi + (size_t)k * 128; float* xo = Xo + (size_t)k * 96;
     if (k >= n) {
-        for (int c = 0; c < 72; ++c) { xd[c] = 0.f; xs[c] = 0.f; }
+        for (int c = 0; c < ldd; ++c) { xd[c] = 0.f; xs[c] = 0.f; }
         for (int c = 0; c < 128; ++c) xi[c] = 0.f;
         for (int c = 0; c < 96; ++c) xo[c] = 0.f;
         return;
@@ -274,6 +302,15 @@ __global__ __launch_bounds__(128) void shade_encode_kernel(const float* __restri
     for (int c = 0; c < 72; ++c) { xs[c] = e[c]; xi[51 + c] = e[c]; }
     float pe[51];
     const float p[3] = {x4[(size_t)k * 4], x4[(size_t)k * 4 + 1], x4[(size_t)k * 4 + 2]};
+    if (sphere) {
+        const float nv[3] = {q[0], q[1], q[2]}, rv[3] = {q[4], q[5], q[6]};
+        const SphereDir sn = sphere_dir(p, nv);
+        ide_forward(sn.s[0], sn.s[1], sn.s[2], 1.0f, e);
+        for (int c = 0; c < 72; ++c) xd[72 + c] = e[c];
+        const SphereDir sr = sphere_dir(p, rv);
+        ide_forward(sr.s[0], sr.s[1], sr.s[2], r, e);
+        for (int c = 0; c < 72; ++c) xs[72 + c] = e[c];
+    }
     pe3(p, 8, pe);
     for (int c = 0; c < 51; ++c) { xi[c] = pe[c]; xo[c] = pe[c]; }
     for (int c = 123; c < 128; ++c) xi[c] = 0.f;
@@ -542,7 +579,8 @@ __global__ void shade_combine_bwd_kernel(const float* __restrict__ geo, const fl
 __global__ __launch_bounds__(128) void shade_encode_bwd_kernel(const float* __restrict__ geo, const float* __restrict__ mat, const float* __restrict__ dXd,
                                         const float* __restrict__ dXs, const float* __restrict__ dXi, const float* __restrict__ dmat,
                                         int n, int n_pad, float* __restrict__ d_geo, float* __restrict__ dm_raw,
-                                        float* __restrict__ dr_raw, float* __restrict__ da_raw, const float* __restrict__ extra) {
+                                        float* __restrict__ dr_raw, float* __restrict__ da_raw, const float* __restrict__ extra,
+                                        const float* __restrict__ x4, int sphere) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_pad) return;
     float4 z4 = make_float4(0, 0, 0, 0);
@@ -554,13 +592,33 @@ __global__ __launch_bounds__(128) void shade_encode_bwd_kernel(const float* __re
     const float* mo = mat + (size_t)k * 8;
     const float* dm = dmat + (size_t)k * 8;
     const float m = mo[0], r = mo[1];
+    const int ldd = sphere ? 144 : 72;
     float g[72];
     float dnx = 0.f, dny = 0.f, dnz = 0.f, dk1 = 0.f;
-    for (int c = 0; c < 72; ++c) g[c] = dXd[(size_t)k * 72 + c];
+    for (int c = 0; c < 72; ++c) g[c] = dXd[(size_t)k * ldd + c];
     ide_backward(q[0], q[1], q[2], 1.0f, g, dnx, dny, dnz, dk1);
     float drx = 0.f, dry = 0.f, drz = 0.f, dkr = 0.f;
-    for (int c = 0; c < 72; ++c) g[c] = dXs[(size_t)k * 72 + c] + dXi[(size_t)k * 128 + 51 + c];
+    for (int c = 0; c < 72; ++c) g[c] = dXs[(size_t)k * ldd + c] + dXi[(size_t)k * 128 + 51 + c];
     ide_backward(q[4], q[5], q[6], r, g, drx, dry, drz, dkr);
+    if (sphere) {
+        const float p[3] = {x4[(size_t)k * 4], x4[(size_t)k * 4 + 1], x4[(size_t)k * 4 + 2]};
+        const float nv[3] = {q[0], q[1], q[2]}, rv[3] = {q[4], q[5], q[6]};
+        float gs[3], dv[3], dk = 0.f;
+        const SphereDir sn = sphere_dir(p, nv);
+        for (int c = 0; c < 72; ++c) g[c] = dXd[(size_t)k * ldd + 72 + c];
+        gs[0] = gs[1] = gs[2] = 0.f;
+        ide_backward(sn.s[0], sn.s[1], sn.s[2], 1.0f, g, gs[0], gs[1], gs[2], dk);
+        dv[0] = dv[1] = dv[2] = 0.f;
+        sphere_dir_vjp(sn, nv, gs, dv);
+        dnx += dv[0]; dny += dv[1]; dnz += dv[2];
+        const SphereDir sr = sphere_dir(p, rv);
+        for (int c = 0; c < 72; ++c) g[c] = dXs[(size_t)k * ldd + 72 + c];
+        gs[0] = gs[1] = gs[2] = 0.f;
+        ide_backward(sr.s[0], sr.s[1], sr.s[2], r, g, gs[0], gs[1], gs[2], dkr);
+        dv[0] = dv[1] = dv[2] = 0.f;
+        sphere_dir_vjp(sr, rv, gs, dv);
+        drx += dv[0]; dry += dv[1]; drz += dv[2];
+    }
     float d_r = dm[1] + dkr;
     if (extra) {                                   // human-light branch: d_refl(3), d_rough
         const float* ex = extra + (size_t)k * 4;
@@ -697,11 +755,11 @@ int nero_sdf_alpha_bwd(const float* sdf4, const float* grad, const float* x4, co
 }
 
 int nero_shade_encode(const float* x4, const float* geo, const float* m_raw, const float* r_raw, const float* a_raw, int n,
-                      float* mat, float* Xd, float* Xs, float* Xi, float* Xo, void* stream) {
+                      float* mat, float* Xd, float* Xs, float* Xi, float* Xo, int sphere_direction, void* stream) {
     CHECK_IDE();
     const int n_pad = NERO_ROW_PAD(n);
     if (n_pad == 0) return NERO_OK;
-    hipLaunchKernelGGL(shade_encode_kernel, GRID1D(n_pad), x4, geo, m_raw, r_raw, a_raw, n, n_pad, mat, Xd, Xs, Xi, Xo);
+    hipLaunchKernelGGL(shade_encode_kernel, GRID1D(n_pad), x4, geo, m_raw, r_raw, a_raw, n, n_pad, mat, Xd, Xs, Xi, Xo, sphere_direction);
     return nero_check_launch("nero_shade_encode");
 }
 
@@ -731,11 +789,14 @@ int nero_shade_combine_bwd(const float* geo, const float* mat, const float* Ld, 
 }
 
 int nero_shade_encode_bwd(const float* geo, const float* mat, const float* dXd, const float* dXs, const float* dXi, const float* dmat,
-                          int n, float* d_geo, float* dm_raw, float* dr_raw, float* da_raw, const float* extra, void* stream) {
+                          int n, float* d_geo, float* dm_raw, float* dr_raw, float* da_raw, const float* extra, const float* x4,
+                          int sphere_direction, void* stream) {
     CHECK_IDE();
     const int n_pad = NERO_ROW_PAD(n);
     if (n_pad == 0) return NERO_OK;
-    hipLaunchKernelGGL(shade_encode_bwd_kernel, GRID1D(n_pad), geo, mat, dXd, dXs, dXi, dmat, n, n_pad, d_geo, dm_raw, dr_raw, da_raw, extra);
+    if (sphere_direction && !x4) return nero_fail(NERO_ERR_ARG, "nero_shade_encode_bwd: sphere_direction needs x4");
+    hipLaunchKernelGGL(shade_encode_bwd_kernel, GRID1D(n_pad), geo, mat, dXd, dXs, dXi, dmat, n, n_pad, d_geo, dm_raw, dr_raw, da_raw, extra, x4,
+                       sphere_direction);
     return nero_check_launch("nero_shade_encode_bwd");
 }
 

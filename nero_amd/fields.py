@@ -112,8 +112,6 @@ class AppShadingNetwork(nn.Module):
     def __init__(self, cfg):
         super().__init__()
         self.cfg = {**self.default_cfg, **cfg}
-        if self.cfg['sphere_direction']:
-            raise NotImplementedError('shader_config.sphere_direction is not supported by the HIP path yet')
         self.metallic_predictor = Predictor(256 + 3, 1)
         if self.cfg['metallic_init'] != 0:
             nn.init.constant_(self.metallic_predictor[-2].bias, self.cfg['metallic_init'])
@@ -123,7 +121,7 @@ class AppShadingNetwork(nn.Module):
         self.albedo_predictor = Predictor(256 + 3, 3)
         self.register_buffer('FG_LUT', torch.from_numpy(brdf_lut.fg_lut()).reshape(1, 256, 256, 2))
         pos_dim = 3 + 3 * 2 * self.cfg['light_pos_freq']
-        self.outer_light = Predictor(72, 3)
+        self.outer_light = Predictor(72 * 2 if self.cfg['sphere_direction'] else 72, 3)
         nn.init.constant_(self.outer_light[-2].bias, np.log(0.5))
         self.inner_light = Predictor(pos_dim + 72, 3)
         nn.init.constant_(self.inner_light[-2].bias, np.log(0.5))

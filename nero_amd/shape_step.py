@@ -51,7 +51,9 @@ class ShapeKernels:
                                 (None, Head(*nf['rgb']))], k_init=256, k_aux=32, device=device)
         self.mat = [Chain(predictor_entries(eff[k], 256, 3), k_init=256, k_aux=8, device=device)
                     for k in ('metallic', 'roughness', 'albedo')]
-        self.outer_light = Chain(predictor_entries(eff['outer_light'], 72), k_init=72, device=device)
+        self.sphere = int(bool(shader_cfg.get('sphere_direction', False)))
+        self.ld_outer = 144 if self.sphere else 72          # [IDE(v) | IDE(sphere exit point)] with shader_config.sphere_direction
+        self.outer_light = Chain(predictor_entries(eff['outer_light'], self.ld_outer), k_init=self.ld_outer, device=device)
         self.inner_light = Chain(predictor_entries(eff['inner_light'], 123), k_init=128, device=device)
         self.inner_weight = Chain(predictor_entries(eff['inner_weight'], 90), k_init=96, device=device)
         self.human_light = Chain(predictor_entries(eff['human'], 24), k_init=24, device=device) if self.human else None
@@ -211,10 +213,10 @@ class RenderCore(torch.autograd.Function):
             feat = sctx['feat']
             mats = [c.forward(feat, x8, n_in) for c in K.mat]
             mat = torch.empty((rpi, 8), **f32)
-            Xo2 = torch.empty((2 * rpi, 72), **f32)           # rows [0,rpi): IDE(n,1) ; rows [rpi,2rpi): IDE(refl, rough)
+            Xo2 = torch.empty((2 * rpi, K.ld_outer), **f32)   # rows [0,rpi): IDE(n,1) ; rows [rpi,2rpi): IDE(refl, rough)
             Xi, Xo = torch.empty((rpi, 128), **f32), torch.empty((rpi, 96), **f32)
             L.check(lib.nero_shade_encode(_p(x4), _p(geo), _p(mats[0]['heads'][3]), _p(mats[1]['heads'][3]), _p(mats[2]['heads'][3]),
-                                          n_in, _p(mat), _p(Xo2[:rpi]), _p(Xo2[rpi:]), _p(Xi), _p(Xo), st))
+                                          n_in, _p(mat), _p(Xo2[:rpi]), _p(Xo2[rpi:]), _p(Xi), _p(Xo), K.sphere, st))
             f_out = K.outer_light.forward(Xo2, None, rpi + n_in)
             f_in = K.inner_light.forward(Xi, None, n_in)
             f_w = K.inner_weight.forward(Xo, None, n_in)
@@ -311,7 +313,7 @@ class RenderCore(torch.autograd.Function):
             dmr, drr, dar = (torch.empty((rpi, 4), **f32) for _ in range(3))
             dX = ob['d_init']
             L.check(lib.nero_shade_encode_bwd(_p(geo), _p(mat), _p(dX[:rpi]), _p(dX[rpi:]), _p(ib['d_init']), _p(dmat), n_in,
-                                              _p(d_geo), _p(dmr), _p(drr), _p(dar), _p(extra), st))
+                                              _p(d_geo), _p(dmr), _p(drr), _p(dar), _p(extra), _p(S['x4']), K.sphere, st))
             d_feat = torch.empty((rpi, 256), **f32)
             feat = S['sctx']['feat']
             for j, (c, name, dh) in enumerate(zip(K.mat, ('metallic_predictor', 'roughness_predictor', 'albedo_predictor'), (dmr, drr, dar))):
@@ -427,9 +429,9 @@ def validation_info(K, cfg, shader_cfg, lut, variance, o, d, z_vals, weights, po
     x8[:, :3] = x4[:, :3]
     mats = [c.forward(sctx['feat'], x8, R, save=False) for c in K.mat]
     mat = torch.empty((rp, 8), **f32)
-    Xo2, Xi, Xo = torch.empty((2 * rp, 72), **f32), torch.empty((rp, 128), **f32), torch.empty((rp, 96), **f32)
+    Xo2, Xi, Xo = torch.empty((2 * rp, K.ld_outer), **f32), torch.empty((rp, 128), **f32), torch.empty((rp, 96), **f32)
     L.check(lib.nero_shade_encode(_p(x4), _p(geo), _p(mats[0]['heads'][3]), _p(mats[1]['heads'][3]), _p(mats[2]['heads'][3]), R,
-                                  _p(mat), _p(Xo2[:rp]), _p(Xo2[rp:]), _p(Xi), _p(Xo), st))
+                                  _p(mat), _p(Xo2[:rp]), _p(Xo2[rp:]), _p(Xi), _p(Xo), K.sphere, st))
     Lh2 = K.outer_light.forward(Xo2, None, rp + R, save=False)['heads'][3]
     Li = K.inner_light.forward(Xi, None, R, save=False)['heads'][3]
     Lo = K.inner_weight.forward(Xo, None, R, save=False)['heads'][3]

@@ -249,6 +249,7 @@ if __name__ == '__main__':
     run_case('bell_occcap', dict(small, occ_loss_max_pn=24), R=48, step=25000, variance=0.5, occ_keys_seed=5)
     run_case('bell_c1', dict(n_samples=32, n_importance=32, n_bg_samples=32), R=32, step=25000, variance=0.3)
     run_case('bell_s500', dict(small, freeze_inv_s_step=15000), R=48, step=500, variance=0.3)
+    run_case('bell_sphdir', dict(small, shader_config={'sphere_direction': True}), R=48, step=25000, variance=0.3)
     run_validation_case('bell_val', dict(small), R=48, step=25000, variance=0.5)
     run_validation_case('bear_val', dict(small, shader_config={'human_light': True}), R=48, step=25000, variance=0.5)
     msmall = dict(diffuse_sample_num=16, specular_sample_num=8)

@@ -361,6 +361,12 @@ def human_light(P, pts, refl, poses, rough):
     return hl[..., :3], torch.clamp(hl[..., 3:], 0.0, 1.0)
 
 
+def offset_points_to_sphere(points):
+    """network/field.py:380-388: points outside radius 0.999 are pulled back onto that sphere."""
+    norm = torch.norm(points, dim=-1, keepdim=True)
+    return torch.where(norm > 0.999, points / norm * 0.999, points)
+
+
 def sphere_exit_dist(pts, dirs):
     """network/field.py:390-396."""
     dtx = torch.sum(pts * dirs, -1, keepdim=True)
@@ -369,10 +375,17 @@ def sphere_exit_dist(pts, dirs):
 
 
 def app_shading(P, scfg, pts, grads, view, feat, poses, want_inter=False):
-    """AppShadingNetwork.forward, split-sum shading (network/field.py:591-651).  'sphere_direction' unsupported here
-    (not used by any BASELINE config)."""
-    if scfg.get('sphere_direction', False):
-        raise NotImplementedError
+    """AppShadingNetwork.forward, split-sum shading (network/field.py:591-651), incl. shader_config.sphere_direction
+    (predict_specular_lights :558-562, predict_diffuse_lights :582-586)."""
+    sphere = scfg.get('sphere_direction', False)
+
+    def outer_in(direction, roughness):
+        enc = ide(direction, roughness)
+        if not sphere:
+            return enc
+        q = offset_points_to_sphere(pts)
+        sph = F.normalize(q + direction * sphere_exit_dist(q, direction), dim=-1)
+        return torch.cat([enc, ide(sph, roughness)], -1)
     exp_max = scfg.get('light_exp_max', 0.0)
     n = F.normalize(grads, dim=-1)
     v = F.normalize(view, dim=-1)
@@ -384,13 +397,13 @@ def app_shading(P, scfg, pts, grads, view, feat, poses, want_inter=False):
     albedo = predictor(P, 'color_network.albedo_predictor', fx, torch.sigmoid)
 
     diff_albedo = (1 - metallic) * albedo
-    diff_light = predictor(P, 'color_network.outer_light', ide(n, 1.0), _exp_act(exp_max))
+    diff_light = predictor(P, 'color_network.outer_light', outer_in(n, 1.0), _exp_act(exp_max))
     diff_color = diff_albedo * diff_light
 
     spec_albedo = 0.04 * (1 - metallic) + metallic * albedo
     enc_r = ide(refl, rough)
     enc_p = pos_enc(pts, scfg.get('light_pos_freq', 8))
-    direct = predictor(P, 'color_network.outer_light', enc_r, _exp_act(exp_max))
+    direct = predictor(P, 'color_network.outer_light', outer_in(refl, rough), _exp_act(exp_max))
     hl, hw = 0, 0
     if scfg.get('human_light', False):
         hl, hw = human_light(P, pts, refl, poses, rough)
