@@ -1,11 +1,14 @@
-"""Pre-integrated split-sum BRDF table FG(NoV, roughness) used by the Stage-I shader.
+"""Split-sum BRDF table FG(NoV, roughness) used by the Stage-I shader.
 
-The reference ships this table as a binary asset (assets/bsdf_256_256.bin, loaded at network/field.py:510, indexed
-[roughness (v), NoV (u), 2]); reference checkpoints also carry it as the buffer `color_network.FG_LUT`, which
-load_state_dict restores verbatim.  For from-scratch construction this module *computes* the table instead of copying
-the asset:   A = int (1-Fc) G2 VoH/(NoH NoV),  B = int Fc G2 VoH/(NoH NoV)   over GGX-importance-sampled half vectors,
-Fc = (1-VoH)^5, G2 = height-correlated Smith, alpha = roughness^2, texel centres at ((i+.5)/256).  Midpoint
-quadrature, float64, deterministic.  tests/test_brdf_lut.py bounds |ours - reference| (<= 2e-3 abs).
+The table is INPUT DATA of the reference: it ships as the binary asset assets/bsdf_256_256.bin, read relative to the working
+directory at network/field.py:510 ([1, 256 (roughness, v), 256 (NoV, u), 2] float32), and reference checkpoints carry it as the
+buffer `color_network.FG_LUT` (restored verbatim by load_state_dict).  `fg_lut()` therefore loads that asset, resolved in this
+order: explicit `path` (shader_config key `fg_lut_path`) -> $NERO_FG_LUT -> `assets/bsdf_256_256.bin` relative to the working
+directory (exactly what the reference does; nero_amd dropped into the reference tree reproduces it bit for bit).  Only when none
+of these exists does it fall back -- with a loud warning -- to a table this module *computes* (GGX importance sampling,
+height-correlated Smith G2, alpha = roughness^2, midpoint quadrature in float64).  The computed table is NOT the reference's:
+measured |computed - asset| is 5.0e-4 mean, 2.25e-2 max (grazing NoV, low roughness), so renders from it differ from the
+reference at grazing angles (tests/test_fg_lut.py pins both facts).
 """
 import os
 
@@ -45,11 +48,48 @@ def compute_fg_lut(res=256, n_phi=48, n_theta=256):
     return out.float().numpy()
 
 
-def fg_lut():
-    """[256(roughness), 256(NoV), 2] float32; computed once and cached in-tree."""
+REFERENCE_ASSET = os.path.join('assets', 'bsdf_256_256.bin')      # network/field.py:510, relative to the working directory
+
+
+def load_asset(path):
+    """-> [256,256,2] float32 from a raw little-endian float32 file (the reference's format) or an .npy / .npz('lut')"""
+    if path.endswith('.npz'):
+        return np.ascontiguousarray(np.load(path)['lut'], dtype=np.float32).reshape(256, 256, 2)
+    if path.endswith('.npy'):
+        return np.ascontiguousarray(np.load(path), dtype=np.float32).reshape(256, 256, 2)
+    return np.fromfile(path, dtype=np.float32).reshape(256, 256, 2)
+
+
+def resolve_asset(path=None):
+    """-> path of the reference FG table or None (see module docstring for the order)"""
+    if path:
+        if not os.path.exists(path):
+            raise FileNotFoundError(f'shader_config.fg_lut_path = {path!r} does not exist')
+        return path
+    for cand in (os.environ.get('NERO_FG_LUT'), REFERENCE_ASSET):
+        if cand and os.path.exists(cand):
+            return cand
+    return None
+
+
+def computed_fg_lut():
+    """[256,256,2] float32: the table this module integrates itself (cached in-tree)"""
     if os.path.exists(_CACHE):
         return np.load(_CACHE)
     lut = compute_fg_lut()
     os.makedirs(os.path.dirname(_CACHE), exist_ok=True)
     np.save(_CACHE, lut)
     return lut
+
+
+def fg_lut(path=None):
+    """[256(roughness), 256(NoV), 2] float32: the reference asset when it can be found, else the computed table (warns)."""
+    found = resolve_asset(path)
+    if found is not None:
+        return load_asset(found)
+    import warnings
+    warnings.warn('nero_amd: the reference FG table assets/bsdf_256_256.bin was not found (working directory, $NERO_FG_LUT, '
+                  'shader_config.fg_lut_path); falling back to a COMPUTED split-sum table that differs from it by up to 2.3e-2 at '
+                  'grazing angles.  Run from the reference tree, set NERO_FG_LUT, or load a reference checkpoint (its FG_LUT buffer '
+                  'replaces this table).', RuntimeWarning, stacklevel=2)
+    return computed_fg_lut()

@@ -41,6 +41,7 @@ struct Builder {
     std::vector<float> cen;          // centroids [nT,3]
     std::vector<float> bmin, bmax;   // per-triangle boxes
     std::vector<Node> nodes;
+    int max_depth = 0;               // deepest inner node (root = 1): the traversal stack holds at most one entry per level
 
     void tri_box(int lo, int hi, float* mn, float* mx) const {
         for (int a = 0; a < 3; ++a) { mn[a] = 1e30f; mx[a] = -1e30f; }
@@ -50,9 +51,10 @@ struct Builder {
         }
     }
     // returns child reference for triangles [lo,hi)
-    int build(int lo, int hi) {
+    int build(int lo, int hi, int depth = 1) {
         const int n = hi - lo;
         if (n <= 4) return -(lo * 8 + n) - 1;
+        max_depth = std::max(max_depth, depth);
         float cmn[3] = {1e30f, 1e30f, 1e30f}, cmx[3] = {-1e30f, -1e30f, -1e30f};
         for (int i = lo; i < hi; ++i)
             for (int a = 0; a < 3; ++a) { cmn[a] = std::min(cmn[a], cen[order[i] * 3 + a]); cmx[a] = std::max(cmx[a], cen[order[i] * 3 + a]); }
@@ -68,8 +70,8 @@ struct Builder {
         std::memset(&nd, 0, sizeof(nd));
         tri_box(lo, mid, nd.lmin, nd.lmax);
         tri_box(mid, hi, nd.rmin, nd.rmax);
-        const int l = build(lo, mid);
-        const int r = build(mid, hi);
+        const int l = build(lo, mid, depth + 1);
+        const int r = build(mid, hi, depth + 1);
         nd.left = l; nd.right = r;
         nodes[me] = nd;
         return me;
@@ -185,6 +187,9 @@ int nero_bvh_create(const float* verts, int nV, const int* tris, int nT, void** 
     }
     B.nodes.reserve((size_t)nT / 2 + 16);
     const int root = B.build(0, nT);
+    // closest-first descent pushes at most one deferred sibling per level: the 64-entry private stack of trace_kernel must cover
+    // the tree depth, otherwise a far subtree would be dropped silently (median split: depth = ceil(log2(nT / 4)) + 1 <= 30)
+    if (B.max_depth > 64) return nero_fail(NERO_ERR_UNSUPPORTED, "nero_bvh_create: BVH deeper than the 64-entry traversal stack");
     std::vector<Tri> T((size_t)nT);
     for (int i = 0; i < nT; ++i) {
         const int t = B.order[i];
@@ -202,8 +207,15 @@ int nero_bvh_create(const float* verts, int nV, const int* tris, int nT, void** 
         delete h;
         return nero_fail(NERO_ERR_LAUNCH, "nero_bvh_create: hipMalloc failed");
     }
-    if (!B.nodes.empty()) (void)hipMemcpy(h->b.d_nodes, B.nodes.data(), B.nodes.size() * sizeof(Node), hipMemcpyHostToDevice);
-    (void)hipMemcpy(h->b.d_tris, T.data(), (size_t)nT * sizeof(Tri), hipMemcpyHostToDevice);
+    hipError_t e0 = hipSuccess;
+    if (!B.nodes.empty()) e0 = hipMemcpy(h->b.d_nodes, B.nodes.data(), B.nodes.size() * sizeof(Node), hipMemcpyHostToDevice);
+    const hipError_t e1 = hipMemcpy(h->b.d_tris, T.data(), (size_t)nT * sizeof(Tri), hipMemcpyHostToDevice);
+    if (e0 != hipSuccess || e1 != hipSuccess) {
+        (void)hipFree(h->b.d_nodes);
+        (void)hipFree(h->b.d_tris);
+        delete h;
+        return nero_fail(NERO_ERR_LAUNCH, "nero_bvh_create: hipMemcpy of the BVH failed");
+    }
     *handle = h;
     return NERO_OK;
 }

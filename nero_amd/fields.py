@@ -107,6 +107,7 @@ class AppShadingNetwork(nn.Module):
     default_cfg = {
         'human_light': False, 'sphere_direction': False, 'light_pos_freq': 8, 'inner_init': -0.95,
         'roughness_init': 0.0, 'metallic_init': 0.0, 'light_exp_max': 0.0,
+        'fg_lut_path': None,        # (ours) explicit location of the reference's assets/bsdf_256_256.bin; default: cwd-relative like field.py:510
     }
 
     def __init__(self, cfg):
@@ -119,7 +120,7 @@ class AppShadingNetwork(nn.Module):
         if self.cfg['roughness_init'] != 0:
             nn.init.constant_(self.roughness_predictor[-2].bias, self.cfg['roughness_init'])
         self.albedo_predictor = Predictor(256 + 3, 3)
-        self.register_buffer('FG_LUT', torch.from_numpy(brdf_lut.fg_lut()).reshape(1, 256, 256, 2))
+        self.register_buffer('FG_LUT', torch.from_numpy(brdf_lut.fg_lut(self.cfg['fg_lut_path'])).reshape(1, 256, 256, 2))
         pos_dim = 3 + 3 * 2 * self.cfg['light_pos_freq']
         self.outer_light = Predictor(72 * 2 if self.cfg['sphere_direction'] else 72, 3)
         nn.init.constant_(self.outer_light[-2].bias, np.log(0.5))

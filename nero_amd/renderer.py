@@ -31,6 +31,12 @@ class NeROShapeRenderer(nn.Module):
         if c['std_act'] != 'exp' or c['sdf_activation'] != 'none' or c['sdf_freq'] != 6 or c['sdf_n_layers'] != 8 \
                 or c['sdf_d_out'] != 257:
             raise NotImplementedError('only the configuration family used by the shipped YAMLs is implemented in HIP')
+        sc = c['shader_config']
+        if sc.get('light_pos_freq', 8) != 8:
+            # the HIP encoders (shade_encode / mc_encode_hit) hard-wire PE-8 for the light-MLP position input
+            raise NotImplementedError('shader_config.light_pos_freq != 8 is not implemented in HIP')
+        if c['n_importance'] % c['up_sample_steps'] != 0:
+            raise NotImplementedError('n_importance must be a multiple of up_sample_steps')
         self.sdf_network, self.deviation_network, self.outer_nerf, self.color_network = build_shape_fields(c)
         if training:
             self._init_dataset()
@@ -50,13 +56,18 @@ class NeROShapeRenderer(nn.Module):
         else:
             ids = list(database.get_img_ids())
             train_ids, test_ids = ids, ids[:1]
-        self.database, self.train_ids, self.test_ids = database, np.asarray(train_ids), test_ids
-        imgs = np.stack([np.asarray(database.get_image(i)) for i in train_ids], 0).astype(np.float32)
-        if imgs.max() > 1.5:
-            imgs = imgs / 255.0                                   # color_map_forward (utils/base_utils.py)
-        Ks = np.stack([database.get_K(i) for i in train_ids], 0).astype(np.float32)
-        poses = np.stack([database.get_pose(i) for i in train_ids], 0).astype(np.float32)
-        self.set_ray_pool(torch.from_numpy(imgs), torch.from_numpy(Ks), torch.from_numpy(poses))
+        self.database, self.train_ids, self.test_ids = database, np.asarray(train_ids), list(test_ids)
+
+        def info(ids):                                            # build_imgs_info (network/renderer.py:17-26)
+            imgs = np.stack([np.asarray(database.get_image(i)) for i in ids], 0).astype(np.float32)
+            if imgs.max() > 1.5:
+                imgs = imgs / 255.0                               # color_map_forward (utils/base_utils.py)
+            Ks = np.stack([database.get_K(i) for i in ids], 0).astype(np.float32)
+            poses = np.stack([database.get_pose(i) for i in ids], 0).astype(np.float32)
+            return torch.from_numpy(imgs), torch.from_numpy(Ks), torch.from_numpy(poses)
+        self.test_imgs_info = dict(zip(('imgs', 'Ks', 'poses'), info(self.test_ids)))     # imgs [n,h,w,3], unshuffled, host
+        self.train_num, self.test_num = len(self.train_ids), len(self.test_ids)
+        self.set_ray_pool(*info(train_ids))
 
     def set_ray_pool(self, imgs, Ks, poses, device=None):
         """imgs [imn,h,w,3] in [0,1], Ks [imn,3,3], poses [imn,3,4] (world->camera).  Builds the pool of every training pixel
@@ -68,11 +79,13 @@ class NeROShapeRenderer(nn.Module):
         coords = torch.stack([xs + 0.5, ys + 0.5, torch.ones_like(xs, dtype=torch.float32)], -1).reshape(1, h * w, 3).float()
         dirs = coords @ torch.inverse(Ks.to(device)).permute(0, 2, 1)                      # imn, h*w, 3
         self.train_poses = poses.to(device).float()
-        self._human_poses_img = self.get_human_coordinate_poses(self.train_poses)
+        self._train_human_poses = self.get_human_coordinate_poses(self.train_poses)   # per IMAGE [imn,3,4]; never overwritten
         self.train_batch = {'dirs': dirs.reshape(-1, 3).contiguous(), 'rgbs': imgs.to(device).reshape(-1, 3).float().contiguous(),
                             'idxs': torch.arange(imn, device=device).repeat_interleave(h * w)}
         self.tbn = imn * h * w
-        self._test_views = [(poses[i].cpu().numpy(), Ks[i].cpu().numpy(), (h, w)) for i in range(imn)]
+        if not hasattr(self, 'test_imgs_info'):                  # pool given directly (no database): validate on the first view
+            self.test_imgs_info = {'imgs': imgs[:1].cpu().float(), 'Ks': Ks[:1].cpu().float(), 'poses': poses[:1].cpu().float()}
+            self.test_ids, self.database = [0], None
         self._shuffle_train_batch()
 
     def _shuffle_train_batch(self):
@@ -80,15 +93,20 @@ class NeROShapeRenderer(nn.Module):
         perm = torch.randperm(self.tbn, device=self.train_batch['dirs'].device)
         self.train_batch = {k: v[perm] for k, v in self.train_batch.items()}
 
-    def _process_ray_batch(self, ray_batch, poses):
-        """world-space rays of a pool slice (network/renderer.py:258-272)"""
+    def _process_ray_batch(self, ray_batch, poses, human_poses_img=None):
+        """world-space rays of a pool slice (network/renderer.py:258-272).  `human_poses_img` [imn,3,4]: the per-image human
+        frames of `poses` when the caller has them cached; computed here otherwise, like the reference does on every call."""
         idxs = ray_batch['idxs']
+        if idxs.dim() == 2:
+            idxs = idxs[..., 0]                                   # the reference's pools carry idxs as [rn,1]
         Rm, t = poses[:, :, :3], poses[:, :, 3:]
         rays_o = (Rm.permute(0, 2, 1) @ -t)[idxs, :, 0]
         rays_d = (Rm[idxs].permute(0, 2, 1) @ ray_batch['dirs'].unsqueeze(-1))[..., 0]
         rays_d = torch.nn.functional.normalize(rays_d, dim=-1)
         near, far = self.near_far_from_sphere(rays_o, rays_d)
-        return rays_o, rays_d, near, far, self._human_poses_img[idxs]
+        if human_poses_img is None:
+            human_poses_img = self.get_human_coordinate_poses(poses)
+        return rays_o, rays_d, near, far, human_poses_img[idxs]
 
     def train_step(self, step):
         rn = self.cfg['train_ray_num']
@@ -97,7 +115,7 @@ class NeROShapeRenderer(nn.Module):
         self.train_batch_i += rn
         if self.train_batch_i + rn >= self.tbn:
             self._shuffle_train_batch()
-        rays_o, rays_d, near, far, human_poses = self._process_ray_batch(batch, self.train_poses)
+        rays_o, rays_d, near, far, human_poses = self._process_ray_batch(batch, self.train_poses, self._train_human_poses)
         outputs = self.render(rays_o, rays_d, near, far, human_poses, -1, self.get_anneal_val(step), is_train=True, step=step)
         outputs['loss_rgb'] = self.compute_rgb_loss(outputs['ray_rgb'], batch['rgbs'])
         return outputs
@@ -115,11 +133,11 @@ class NeROShapeRenderer(nn.Module):
         hp_img = self.get_human_coordinate_poses(pose)
         outs = {}
         with torch.no_grad():
+            kern = self._kernels()                                # packed ONCE per image (and cached across images), not per chunk
             for i in range(0, h * w, chunk):
                 batch = {'dirs': dirs[i:i + chunk], 'idxs': torch.zeros(min(chunk, h * w - i), dtype=torch.long, device=dev)}
-                self._human_poses_img = hp_img
-                ro, rd, near, far, hp = self._process_ray_batch(batch, pose)
-                o = self.render(ro, rd, near, far, hp, 0, 0, is_train=not extras, step=step)
+                ro, rd, near, far, hp = self._process_ray_batch(batch, pose, hp_img)
+                o = self.render(ro, rd, near, far, hp, 0, 0, is_train=not extras, step=step, _kern=kern)
                 for k, v in o.items():
                     if not k.startswith('_') and torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == ro.shape[0]:
                         outs.setdefault(k, []).append(v)
@@ -129,7 +147,8 @@ class NeROShapeRenderer(nn.Module):
         """SDF on a resolution^3 grid for marching cubes (extract_fields, network/field.py:1090-1108; used by extract_mesh.py:24-27):
         value-only SDF chain, points outside the unit sphere set to `outside_val`.  -> float32 numpy [res,res,res] (x,y,z order)"""
         dev = next(self.parameters()).device
-        _, _, K = self._kernels()
+        with torch.no_grad():
+            _, _, K = self._kernels()
         axes = [torch.linspace(bound_min[a], bound_max[a], resolution, device=dev) for a in range(3)]
         u = torch.empty(resolution ** 3, dtype=torch.float32, device=dev)
         with torch.no_grad():
@@ -145,12 +164,56 @@ class NeROShapeRenderer(nn.Module):
         """network/renderer.py:189-222 -> [h,w,3] numpy image"""
         return self.render_image(pose, K, h, w)['ray_rgb'].reshape(h, w, 3).cpu().numpy()
 
+    @staticmethod
+    def _downsample_view(img, K, ratio):
+        """imgs_info_downsample (network/renderer.py:46-61) for one [h,w,3] image: Gaussian blur (sigma = 1/(3 ratio), cv2's
+        kernel-size rule and BORDER_REFLECT101, utils/base_utils.py:119-125), bilinear resize with half-pixel centres
+        (cv2.INTER_LINEAR), K scaled by diag(dw/w, dh/h, 1).  Host-side glue, restated in torch (cv2 is not a dependency)."""
+        h, w, _ = img.shape
+        dh, dw = int(ratio * h), int(ratio * w)
+        sigma = (1 / ratio) / 3
+        ks = int(np.ceil(((sigma - 0.8) / 0.3 + 1) * 2 + 1))
+        ks = ks + 1 if ks % 2 == 0 else ks
+        x = torch.arange(ks, dtype=torch.float32) - (ks - 1) / 2
+        g = torch.exp(-x ** 2 / (2 * sigma ** 2))
+        g = g / g.sum()
+        t = img.permute(2, 0, 1).unsqueeze(0).float()
+        if ks > 1 and min(h, w) > ks // 2:
+            t = torch.nn.functional.pad(t, (ks // 2,) * 4, mode='reflect')
+            t = torch.nn.functional.conv2d(t, g.view(1, 1, 1, ks).repeat(3, 1, 1, 1), groups=3)
+            t = torch.nn.functional.conv2d(t, g.view(1, 1, ks, 1).repeat(3, 1, 1, 1), groups=3)
+        t = torch.nn.functional.interpolate(t, size=(dh, dw), mode='bilinear', align_corners=False)
+        Kd = torch.diag(torch.tensor([dw / w, dh / h, 1.0])) @ K
+        return t[0].permute(1, 2, 0).contiguous(), Kd
+
     def test_step(self, index, step):
-        """network/renderer.py:274-317 without the database-specific depth/mask lookup and the cv2 down-sampling (dataset IO is out
-        of scope): renders test view `index` of the pool's poses at full resolution with all validation outputs."""
-        pose, K, (h, w) = self._test_views[index]
-        out = self.render_image(pose, K, h, w, step=step, extras=True)
+        """network/renderer.py:274-317: renders view test_ids[index] of the TEST split (down-sampled by downsample_ratio when
+        test_downsample_ratio) with all validation outputs, plus loss_rgb / gt_rgb and -- when the database provides
+        get_depth -- gt_depth / gt_mask (nearest-neighbour down-sampled like cv2.INTER_NEAREST)."""
+        info = self.test_imgs_info
+        img, K, pose = info['imgs'][index].float(), info['Ks'][index].float(), info['poses'][index].float()
+        gt_depth = gt_mask = None
+        db = getattr(self, 'database', None)
+        if db is not None and hasattr(db, 'get_depth'):
+            dm = db.get_depth(self.test_ids[index])
+            if dm is not None:
+                gt_depth, gt_mask = torch.from_numpy(np.asarray(dm[0], np.float32)), torch.from_numpy(np.asarray(dm[1]).astype(np.int32))
+        if self.cfg['test_downsample_ratio']:
+            ratio = self.cfg['downsample_ratio']
+            img, K = self._downsample_view(img, K, ratio)
+            if gt_depth is not None:
+                dh, dw = int(ratio * gt_depth.shape[0]), int(ratio * gt_depth.shape[1])
+                near = lambda a: torch.nn.functional.interpolate(a[None, None].float(), size=(dh, dw), mode='nearest')[0, 0]
+                gt_depth, gt_mask = near(gt_depth), near(gt_mask).to(torch.int32)
+        h, w, _ = img.shape
+        out = self.render_image(pose.numpy(), K.numpy(), h, w, step=step, extras=True)
+        gt = img.reshape(h * w, 3).to(out['ray_rgb'].device)
+        out['loss_rgb'] = self.compute_rgb_loss(out['ray_rgb'], gt)
+        out['gt_rgb'] = gt.reshape(h, w, 3)
         out['ray_rgb'] = out['ray_rgb'].reshape(h, w, 3)
+        if gt_depth is not None:
+            out['gt_depth'], out['gt_mask'] = gt_depth.unsqueeze(-1), gt_mask.unsqueeze(-1)
+        self.zero_grad()
         return out
 
     def forward(self, data):
@@ -191,10 +254,21 @@ class NeROShapeRenderer(nn.Module):
 
     # ------------------------------------------------------------------------------------------------------------
     def _kernels(self):
-        """effective weights (autograd tensors) + packed HIP chains for the current parameter values"""
+        """effective weights (autograd tensors) + packed HIP chains for the current parameter values.  Under no_grad (inference:
+        render_image / nvs / test_step / extract_fields) the packed operand images are cached and re-used until a parameter changes
+        (storage pointer or torch's in-place version counter), so a multi-chunk render packs the ten networks once."""
         from .shape_step import ShapeKernels, flatten_effective, unflatten_effective
+        from .chain import GEMM_MODE
+        key = None
+        if not torch.is_grad_enabled():
+            key = (tuple((p.data_ptr(), p._version) for p in self.parameters()), tuple(sorted(GEMM_MODE.items())))
+            cached = getattr(self, '_kern_cache', None)
+            if cached is not None and cached[0] == key:
+                return cached[1]
         names, eff = flatten_effective(self)
         K = ShapeKernels(unflatten_effective(names, [t.detach() for t in eff]), self.color_network.cfg, eff[0].device).pack()
+        if key is not None:
+            self._kern_cache = (key, (names, eff, K))
         return names, eff, K
 
     def sample_ray(self, rays_o, rays_d, near, far, perturb, rand1=None, rand_bg=None, K=None, trace=None):
@@ -216,13 +290,13 @@ class NeROShapeRenderer(nn.Module):
                               self.deviation_network.variance.detach(), rand1, rand_bg, trace)
 
     def render(self, rays_o, rays_d, near, far, human_poses, perturb_overwrite=-1, cos_anneal_ratio=0.0, is_train=True,
-               step=None, rand1=None, rand_bg=None, z_vals=None, occ_keys=None):
+               step=None, rand1=None, rand_bg=None, z_vals=None, occ_keys=None, _kern=None):
         """same contract as the reference (network/renderer.py:445-463); extra keyword-only style arguments rand1 / rand_bg /
         z_vals allow tests to inject the random draws or teacher-force the sample positions."""
         perturb = self.cfg['perturb']
         if perturb_overwrite >= 0:
             perturb = perturb_overwrite
-        names, eff, K = self._kernels()
+        names, eff, K = _kern if _kern is not None else self._kernels()
         if z_vals is None:
             z_vals = self.sample_ray(rays_o, rays_d, near, far, perturb, rand1, rand_bg, K)
         return self.render_core(rays_o, rays_d, z_vals, human_poses, cos_anneal_ratio=cos_anneal_ratio, step=step,
@@ -408,28 +482,60 @@ class NeROMaterialRenderer(nn.Module):
         outs = [self.trace(rays_o[i:i + batch_size], rays_d[i:i + batch_size]) for i in range(0, rays_o.shape[0], batch_size)]
         return tuple(torch.cat(x, 0) for x in zip(*outs))
 
+    def _trace_views(self, Ks, poses, h, w, device):
+        """camera rays of every pixel of every view (pixel centres +0.5, network/renderer.py:756-776), traced through the mesh on the
+        device in chunks of 2^20.  -> rays_o, rays_d, inters, normals [imn*h*w,3], depth [imn*h*w,1], hit [imn*h*w]"""
+        ys, xs = torch.meshgrid(torch.arange(h, device=device), torch.arange(w, device=device), indexing='ij')
+        coords = torch.stack([xs + 0.5, ys + 0.5, torch.ones_like(xs, dtype=torch.float32)], -1).reshape(1, h * w, 3).float()
+        Rm, t = poses[:, :, :3], poses[:, :, 3:]
+        rays_d = torch.nn.functional.normalize((coords @ torch.inverse(Ks.to(device)).permute(0, 2, 1)) @ Rm, dim=-1)
+        rays_o = (-Rm.permute(0, 2, 1) @ t).permute(0, 2, 1).repeat(1, h * w, 1)
+        if float(torch.max(torch.norm(rays_o.reshape(-1, 3), dim=-1) + 1.0)) > 10.0:
+            print('warning!!! a camera is farther than 10 from the origin: beyond the ray tracer miss distance')
+        rays_o, rays_d = rays_o.reshape(-1, 3).contiguous(), rays_d.reshape(-1, 3).contiguous()
+        return (rays_o, rays_d) + self.trace_in_batch(rays_o, rays_d)
+
+    def _init_dataset(self, database=None):
+        """network/renderer.py:681-698 with a database object of the reference's BaseDatabase interface (see NeROShapeRenderer)."""
+        if database is None:
+            try:
+                from dataset.database import get_database_split, parse_database_name
+            except ImportError as e:
+                raise ImportError('no database object given and the reference `dataset.database` module is not importable') from e
+            database = parse_database_name(self.cfg['database_name'])
+            train_ids, test_ids = get_database_split(database, 'validation')
+        else:
+            ids = list(database.get_img_ids())
+            train_ids, test_ids = ids, ids[:1]
+        self.database, self.train_ids, self.test_ids = database, np.asarray(train_ids), list(test_ids)
+
+        def info(ids):
+            imgs = np.stack([np.asarray(database.get_image(i)) for i in ids], 0).astype(np.float32)
+            if imgs.max() > 1.5:
+                imgs = imgs / 255.0
+            return (torch.from_numpy(imgs), torch.from_numpy(np.stack([database.get_K(i) for i in ids], 0).astype(np.float32)),
+                    torch.from_numpy(np.stack([database.get_pose(i) for i in ids], 0).astype(np.float32)))
+        self.test_imgs_info = dict(zip(('imgs', 'Ks', 'poses'), info(self.test_ids)))
+        self.train_num, self.test_num = len(self.train_ids), len(self.test_ids)
+        self.set_ray_pool(*info(train_ids))
+
     def set_ray_pool(self, imgs, Ks, poses, device=None):
         """imgs [imn,h,w,3] in [0,1], Ks [imn,3,3], poses [imn,3,4].  Traces all imn*h*w camera rays through the mesh on the device
         (chunks of 2^20 like the reference) and keeps the hits as the training pool -- no host round trip, and one human-frame
         pose per IMAGE (indexed per sample) instead of the reference's per-pixel [N,3,4] copy."""
         device = device or next(self.parameters()).device
         imn, h, w, _ = imgs.shape
-        ys, xs = torch.meshgrid(torch.arange(h, device=device), torch.arange(w, device=device), indexing='ij')
-        coords = torch.stack([xs + 0.5, ys + 0.5, torch.ones_like(xs, dtype=torch.float32)], -1).reshape(1, h * w, 3).float()
         poses = poses.to(device).float()
-        Rm, t = poses[:, :, :3], poses[:, :, 3:]
-        rays_d = torch.nn.functional.normalize((coords @ torch.inverse(Ks.to(device)).permute(0, 2, 1)) @ Rm, dim=-1)
-        rays_o = (-Rm.permute(0, 2, 1) @ t).permute(0, 2, 1).repeat(1, h * w, 1)
-        if float(torch.max(torch.norm(rays_o.reshape(-1, 3), dim=-1) + 1.0)) > 10.0:
-            print('warning!!! a camera is farther than 10 from the origin: beyond the ray tracer miss distance')
-        inters, normals, depth, hit = self.trace_in_batch(rays_o.reshape(-1, 3).contiguous(), rays_d.reshape(-1, 3).contiguous())
+        rays_o, rays_d, inters, normals, depth, hit = self._trace_views(Ks, poses, h, w, device)
         idx = torch.arange(imn, device=device).repeat_interleave(h * w)
         rgb = imgs.to(device).reshape(-1, 3).float()
         self._human_poses_img = self.get_human_coordinate_poses(poses)
         keep = torch.nonzero(hit)[:, 0]
-        self.train_batch = {'rays_o': rays_o.reshape(-1, 3)[keep], 'rays_d': rays_d.reshape(-1, 3)[keep], 'inters': inters[keep],
+        self.train_batch = {'rays_o': rays_o[keep], 'rays_d': rays_d[keep], 'inters': inters[keep],
                             'normals': normals[keep], 'depth': depth[keep], 'img_idx': idx[keep], 'rgb': rgb[keep]}
         self.tbn = keep.numel()
+        if not hasattr(self, 'test_imgs_info'):
+            self.test_imgs_info = {'imgs': imgs[:1].cpu().float(), 'Ks': Ks[:1].cpu().float(), 'poses': poses[:1].cpu().float()}
         self._shuffle_train_batch()
 
     def _shuffle_train_batch(self):
@@ -447,9 +553,37 @@ class NeROMaterialRenderer(nn.Module):
             self._shuffle_train_batch()
         return out
 
+    def test_step(self, index):
+        """network/renderer.py:846-887: shade every mesh-hitting pixel of test view `index` (no random azimuth, no grad), zeros
+        elsewhere.  -> dict of [h,w,C]: rgb_gt, rgb_pr, specular_light/color, diffuse_light/color, albedo, metallic, roughness
+        (square-rooted: the network predicts roughness^2)."""
+        info = self.test_imgs_info
+        device = next(self.parameters()).device
+        img, K, pose = info['imgs'][index:index + 1].float(), info['Ks'][index:index + 1].float(), info['poses'][index:index + 1].float()
+        _, h, w, _ = img.shape
+        pose = pose.to(device)
+        keys = {'rgb_gt': 3, 'rgb_pr': 3, 'specular_light': 3, 'specular_color': 3, 'diffuse_light': 3, 'diffuse_color': 3,
+                'albedo': 3, 'metallic': 1, 'roughness': 1}
+        out = {k: torch.zeros(h * w, d, device=device) for k, d in keys.items()}
+        with torch.no_grad():
+            rays_o, rays_d, inters, normals, depth, hit = self._trace_views(K, pose, h, w, device)
+            hp = self.get_human_coordinate_poses(pose)
+            rgb = img.to(device).reshape(-1, 3)
+            trn = self.cfg['test_ray_num']
+            for ri in range(0, h * w, trn):
+                sel = torch.nonzero(hit[ri:ri + trn])[:, 0] + ri
+                if sel.numel() == 0:
+                    continue
+                so = self.shade(inters[sel].contiguous(), -rays_d[sel], normals[sel].contiguous(), hp[:1].expand(sel.numel(), 3, 4), False)
+                out['rgb_gt'][sel] = rgb[sel]
+                for k in ('rgb_pr', 'specular_light', 'specular_color', 'diffuse_color', 'diffuse_light', 'albedo', 'metallic'):
+                    out[k][sel] = so[k]
+                out['roughness'][sel] = torch.sqrt(so['roughness'])
+        return {k: v.reshape(h, w, -1) for k, v in out.items()}
+
     def forward(self, data):
         if 'eval' in data:
-            raise NotImplementedError('validation (test_step) is not on the HIP path yet')
+            return self.test_step(data['index'])
         return {k: v for k, v in self.train_step(data['step']).items() if not k.startswith('_')}
 
     def predict_materials_of_vertices(self, vertices, batch_size=8192):

@@ -3,6 +3,8 @@ The reference's tracer is the un-vendored third-party `_raytracing` CUDA extensi
 /root/reference): parity of the HIP BVH is therefore pinned against this restatement of the contract NeRO relies on
 (raytracing/raytracer.py:21-54; network/renderer.py:719-729): closest hit with t > 0, geometric face normal from the vertex
 winding, depth >= 10 <=> miss.  'parity unpinned' w.r.t. the third-party binary itself."""
+import os
+
 import numpy as np
 
 
@@ -36,3 +38,41 @@ def trace_bruteforce(verts, tris, o, d, miss_depth=10.0):
     nrm[h] = nn / np.linalg.norm(nn, axis=1, keepdims=True)
     pos = o + depth[:, None] * d
     return pos, nrm, depth, tri
+
+
+_C_SRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'tracer_oracle.c')
+_C_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_build', 'libtracer_oracle.so')
+
+
+def build_c(force=False):
+    """gcc-compile oracle/csrc/tracer_oracle.c (the C restatement of trace_bruteforce) into oracle/_build/.  -> library path"""
+    import subprocess
+    if force or not os.path.exists(_C_LIB) or os.path.getmtime(_C_LIB) < os.path.getmtime(_C_SRC):
+        os.makedirs(os.path.dirname(_C_LIB), exist_ok=True)
+        subprocess.check_call(['gcc', '-O2', '-fopenmp', '-shared', '-fPIC', '-o', _C_LIB, _C_SRC, '-lm'])
+    return _C_LIB
+
+
+def trace_bruteforce_margins(verts, tris, o, d, miss_depth=10.0, eps_edge=1e-4, eps_t=1e-4):
+    """trace_bruteforce through its C restatement (oracle/csrc/tracer_oracle.c: identical float64 arithmetic and predicates,
+    OpenMP over rays; tests/test_tracer_oracle_c.py pins it to the numpy version above), plus a per-ray AMBIGUITY flag: True
+    when the fp64 answer sits within `eps_edge` (barycentric units) of a triangle edge that could change the closest hit, or a
+    candidate intersection lies within `eps_t` of the ray origin (the 1e-5 self-intersection offset of Stage-II secondary rays,
+    network/field.py:859).  A float32 tracer may legitimately answer differently on exactly those rays and on no others.
+    -> pos [n,3], nrm [n,3], depth [n], tri [n], ambiguous [n] bool"""
+    import ctypes as C
+    lib = C.CDLL(build_c())
+    V = np.ascontiguousarray(verts, dtype=np.float32)
+    F = np.ascontiguousarray(tris, dtype=np.int32)
+    O = np.ascontiguousarray(o, dtype=np.float64)
+    D = np.ascontiguousarray(d, dtype=np.float64)
+    n = O.shape[0]
+    pos, nrm, depth = np.empty((n, 3)), np.empty((n, 3)), np.empty(n)
+    tri, amb = np.empty(n, np.int64), np.zeros(n, np.uint8)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib.tracer_oracle_trace.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double,
+                                        C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = lib.tracer_oracle_trace(P(V), V.shape[0], P(F), F.shape[0], P(O), P(D), n, miss_depth, eps_edge, eps_t, P(pos), P(nrm), P(depth),
+                                 P(tri), P(amb))
+    assert rc == 0
+    return pos, nrm, depth, tri, amb.astype(bool)

@@ -1,0 +1,149 @@
+"""CPU tier: host-side logic of the drop-in renderers against vectors dumped from the UNMODIFIED reference
+(oracle/gen_golden_r2.py -> tests/golden/pools.npz, ref_state.json; oracle/gen_golden.py -> the render cases):
+a1 helpers (get_human_coordinate_poses, _process_ray_batch, near_far_from_sphere; network/renderer.py:230-272), the Stage-I ray
+pool (network/renderer.py:167-187), the state_dict surface, and the C restatement of the tracer oracle."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import GOLDEN, load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _pools():
+    return np.load(os.path.join(GOLDEN, 'pools.npz'))
+
+
+def _shape_net(cfg=None):
+    from nero_amd.renderer import NeROShapeRenderer
+    torch.manual_seed(0)
+    return NeROShapeRenderer(cfg or {}, training=False)
+
+
+def test_human_coordinate_poses_vs_reference():
+    z = _pools()
+    net = _shape_net()
+    poses = torch.from_numpy(z['poses'])
+    assert np.abs(net.get_human_coordinate_poses(poses).numpy() - z['human_poses_img']).max() < 1e-6
+    assert np.abs(_shape_net({'fixed_camera': True}).get_human_coordinate_poses(poses).numpy() - z['human_poses_img_fixed']).max() < 1e-6
+    assert torch.equal(poses, torch.from_numpy(z['poses']))                      # the input is not modified
+    # and the per-ray frames stored with every render case
+    for name in ('bell_s25000', 'bear_s25000', 'bell_val'):
+        g, _ = load_golden(name)
+        if 'poses_img' in g.files:
+            hp = net.get_human_coordinate_poses(torch.from_numpy(g['poses_img']))
+            assert np.abs(hp.numpy() - g['human_poses']).max() < 1e-6, name
+
+
+def test_process_ray_batch_vs_reference():
+    z = _pools()
+    net = _shape_net()
+    sel = torch.from_numpy(z['s1/sel'])
+    batch = {'dirs': torch.from_numpy(z['s1/dirs'])[sel], 'idxs': torch.from_numpy(z['s1/idxs'])[sel]}      # idxs [n,1] like the reference
+    poses = torch.from_numpy(z['poses'])
+    ro, rd, near, far, hp = net._process_ray_batch(batch, poses)
+    for got, key in ((ro, 'rays_o'), (rd, 'rays_d'), (near, 'near'), (far, 'far'), (hp, 'human_poses')):
+        assert got.shape == z['s1/' + key].shape, key
+        assert np.abs(got.numpy() - z['s1/' + key]).max() < 2e-6, key
+    # cached per-image frames give the same answer
+    hp2 = net._process_ray_batch(batch, poses, net.get_human_coordinate_poses(poses))[4]
+    assert torch.equal(hp, hp2)
+
+
+def test_stage1_pool_contents_vs_reference_construct_ray_batch():
+    """set_ray_pool (device-side pool build) == NeROShapeRenderer._construct_ray_batch of the reference, before the shuffle"""
+    z = _pools()
+    net = _shape_net()
+    net._shuffle_train_batch = lambda: setattr(net, 'train_batch_i', 0)           # keep construction order
+    net.set_ray_pool(torch.from_numpy(z['imgs']), torch.from_numpy(z['Ks']), torch.from_numpy(z['poses']), device='cpu')
+    assert net.tbn == z['s1/dirs'].shape[0]
+    assert np.abs(net.train_batch['dirs'].numpy() - z['s1/dirs']).max() < 2e-6
+    assert np.array_equal(net.train_batch['rgbs'].numpy(), z['s1/rgbs'])
+    assert np.array_equal(net.train_batch['idxs'].numpy(), z['s1/idxs'][:, 0])
+    assert np.abs(net._train_human_poses.numpy() - z['human_poses_img']).max() < 1e-6
+
+
+def test_shuffle_is_a_permutation_and_epoch_wraps():
+    z = _pools()
+    net = _shape_net({'train_ray_num': 100})
+    net.set_ray_pool(torch.from_numpy(z['imgs']), torch.from_numpy(z['Ks']), torch.from_numpy(z['poses']), device='cpu')
+    key = lambda a: np.sort((a * 1e4).round().astype(np.int64).view([('', np.int64)] * 3), axis=0)
+    assert np.array_equal(key(net.train_batch['rgbs'].numpy()), key(z['s1/rgbs']))
+    assert not np.array_equal(net.train_batch['rgbs'].numpy(), z['s1/rgbs'])
+
+
+@pytest.mark.parametrize('which,cfg', [('shape_bell', {}), ('shape_bear', {'shader_config': {'human_light': True}}),
+                                       ('shape_sphdir', {'shader_config': {'sphere_direction': True}})])
+def test_state_dict_surface_matches_reference_constructor(which, cfg):
+    """keys, shapes and dtypes of the reference constructor's state_dict; a dict with that surface loads with strict=True"""
+    man = json.load(open(os.path.join(GOLDEN, 'ref_state.json')))[which]
+    net = _shape_net(cfg)
+    sd = net.state_dict()
+    assert set(sd.keys()) == set(man.keys())
+    for k, (shape, dtype) in man.items():
+        assert list(sd[k].shape) == shape and str(sd[k].dtype) == dtype, k
+    fake = {k: torch.full(shape, 0.25, dtype=getattr(torch, dtype.split('.')[1])) for k, (shape, dtype) in man.items()}
+    net.load_state_dict(fake, strict=True)
+    assert float(net.color_network.FG_LUT.mean()) == 0.25            # buffers are restored from the checkpoint too
+
+
+@pytest.mark.parametrize('which,cfg', [('material_bell', {'human_lights': False, 'outer_light_version': 'direction'}),
+                                       ('material_bear', {'human_lights': True, 'outer_light_version': 'sphere_direction'})])
+def test_material_state_dict_surface(which, cfg):
+    from tests.helpers import MatHolder
+    man = json.load(open(os.path.join(GOLDEN, 'ref_state.json')))[which]
+    net = MatHolder(cfg)
+    sd = net.state_dict()
+    assert set(sd.keys()) == set(man.keys())
+    for k, (shape, dtype) in man.items():
+        assert list(sd[k].shape) == shape and str(sd[k].dtype) == dtype, k
+    net.load_state_dict({k: torch.zeros(shape, dtype=getattr(torch, dtype.split('.')[1])) for k, (shape, dtype) in man.items()}, strict=True)
+
+
+@pytest.mark.skipif(not os.path.exists('/root/reference/network/renderer.py'), reason='reference tree not present (GPU box)')
+def test_reference_constructed_state_dict_loads_strict():
+    """a state_dict produced by the REFERENCE constructor (through the import shim, in a subprocess: the shim patches torch and
+    changes the working directory) loads into nero_amd with strict=True and yields identical effective weights"""
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "from oracle import ref_shim\n"
+        "renderer, field = ref_shim.load_reference()\n"
+        "torch.manual_seed(11)\n"
+        "ref = renderer.NeROShapeRenderer({'shader_config': {'human_light': True}}, training=False)\n"
+        "sd = ref.state_dict()\n"
+        "from nero_amd.renderer import NeROShapeRenderer\n"
+        "torch.manual_seed(99)\n"
+        "net = NeROShapeRenderer({'shader_config': {'human_light': True}}, training=False)\n"
+        "r = net.load_state_dict(sd, strict=True)\n"
+        "assert not r.missing_keys and not r.unexpected_keys\n"
+        "W_ref = ref.sdf_network.lin3.weight if hasattr(ref.sdf_network.lin3, 'weight') else None\n"
+        "W = net.sdf_network.effective()[3][0]\n"
+        "g, v = sd['sdf_network.lin3.weight_g'], sd['sdf_network.lin3.weight_v']\n"
+        "assert torch.allclose(W, g * v / v.norm(dim=1, keepdim=True), atol=1e-7)\n"
+        "assert torch.equal(net.color_network.FG_LUT, sd['color_network.FG_LUT'])\n"
+        "print('STRICT_OK', len(sd))\n" % ROOT)
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
+    assert 'STRICT_OK 137' in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_tracer_oracle_c_restatement_equals_numpy_oracle():
+    from nero_amd.synthetic import icosphere
+    from oracle.tracer_oracle import trace_bruteforce, trace_bruteforce_margins
+    v, f = icosphere(3, 0.5, 0.15)
+    f = np.ascontiguousarray(f[:, ::-1])
+    rg = np.random.default_rng(0)
+    o = rg.normal(size=(1500, 3))
+    o = o / np.linalg.norm(o, axis=1, keepdims=True) * 2
+    d = -o / 2 + rg.normal(size=(1500, 3)) * 0.2
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    a = trace_bruteforce(v, f, o, d)
+    b = trace_bruteforce_margins(v, f, o, d)
+    assert np.array_equal(a[3], b[3]) and np.abs(a[2] - b[2]).max() < 1e-12 and np.abs(a[1] - b[1]).max() < 1e-12
+    assert np.abs(a[0] - b[0]).max() < 1e-12
+    assert 0.3 < (b[3] >= 0).mean() < 1.0 and b[4].mean() < 0.01
