@@ -1,15 +1,26 @@
 """bench.py -- Stage-I training rays/sec on MI355X (BASELINE.json metric).  One JSON line on rank 0.
 
-  python bench.py --gpus 1 --steps K --warmup W
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+  python bench.py --gpus N --steps K --warmup W
+        N = 1: runs in this process.  N > 1 without a torch.distributed environment: bench.py re-launches itself as
+        `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`
+        (one rank per GPU over RCCL) and forwards the one JSON line; launched that way by the driver it just runs as a rank.
 
 A step = one full training step of the GlossySynthetic 'bell' Stage-I shape configuration (configs[1]): 4096 rays per GPU x
-(64 coarse + 64 importance + 32 background) samples, hierarchical sampling (112 no-grad SDF evals/ray), render forward, loss,
-backward including the second-order SDF term, flat RCCL gradient all-reduce, fused Adam.  Weak scaling: 4096 rays per rank.
+(64 coarse + 64 importance + 32 background) samples, hierarchical sampling (112 no-grad SDF evals/ray), render forward, loss
+(incl. the occlusion loss: schedule step 25000), backward including the second-order SDF term, flat RCCL gradient all-reduce,
+fused Adam.  Weak scaling: 4096 rays per rank.  Inputs are resident in HBM (device ray pool).
+
+Besides the contract fields the line carries: `roofline` (dominant MFMA kernel, live HIP-event timing), `protocol_8d` (SURVEY.md
+8d: median of >= 50 steps after >= 10 warm-up), `forward_only`, `f32_mfma_engine`, `stage2` (BASELINE configs[3]: P = 4096 surface
+points x 128+128 and the YAML default 512+256 MC directions), `torch_gpu_baseline` (the same algorithm as plain PyTorch ops on
+the same MI355X: the ">= 10x reference single-GPU PyTorch" yard-stick of north_star; the reference itself cannot travel to the GPU
+box) and `cpu_baseline` (the oracle on the host cores).  The two baselines are the only places that touch oracle/.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -19,32 +30,35 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 C_SDF, C_NERF, C_APP = 524544, 604160, 1211648          # MACs per point
+C_MAT, C_OUTER, C_INNER = 1078272, 150272, 163328       # Stage II
 PEAK_F32_MFMA = 157.3e12                                 # MI355X dense fp32 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
-PEAK_BF16_MFMA = 2500e12                                 # MI355X dense bf16 MFMA peak (same guide)
+PEAK_BF16_MFMA = 2500e12                                 # MI355X dense bf16 / fp16 MFMA peak (same guide)
 # fp32-equivalent ceilings of the arithmetic the dense layers run on (nero_amd/chain.py GEMM_MODE): the f32-input MFMA itself,
 # the bf16 matrix pipe issuing 6 plane products per fp32 multiply-add (mlp_split.hip), the fp16 pipe issuing 3 (mlp_f16x3.hip)
 PEAK_OF_MODE = {0: PEAK_F32_MFMA, 1: PEAK_BF16_MFMA / 6, 2: PEAK_BF16_MFMA / 3}
 MFMA_OF_MODE = {0: 'v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain)',
                 1: 'v_mfma_f32_32x32x16_bf16, 3 exact bf16 planes per operand, 6 plane products per fp32 multiply-add: peak = 2500 / 6',
                 2: 'v_mfma_f32_32x32x16_f16, 2 block-scaled fp16 planes per operand, 3 plane products per fp32 multiply-add: peak = 2500 / 3'}
+BELL = {'freeze_inv_s_step': 15000, 'apply_occ_loss': True, 'occ_loss_step': 20000}      # configs/shape/syn/bell.yaml
+VARIANCE = 0.5
 
 
 def hbm_traffic_per_launch(kernel):
-    """average HBM bytes per launch of `kernel` from the committed PMC summary (scripts/prof_traffic.sh), or None"""
-    path = os.path.join(ROOT, 'profiles', 'r01_hbm_traffic_per_kernel.csv')
-    try:
-        for line in open(path):
-            f = line.strip().split(',')
-            if len(f) == 5 and f[0] == kernel:
-                return int((float(f[3]) + float(f[4])) * 1024)
-    except OSError:
-        pass
-    return None
+    """average HBM bytes per launch of `kernel` from the newest committed PMC summary (scripts/prof_traffic.sh), or None"""
+    for name in ('r02_hbm_traffic_per_kernel.csv', 'r01_hbm_traffic_per_kernel.csv'):
+        try:
+            for line in open(os.path.join(ROOT, 'profiles', name)):
+                f = line.strip().split(',')
+                if len(f) == 5 and f[0] == kernel:
+                    return int((float(f[3]) + float(f[4])) * 1024), name
+        except OSError:
+            pass
+    return None, None
 
 
 def cpu_baseline(cfg, variance, step, rays=512, budget_s=15.0, max_steps=10):
     """the oracle (a port of the reference's torch path, oracle/nero_oracle.py) timed on this box's host cores on a bounded
-    sample of the same workload: `rays` rays x (64+64+32) samples, forward + loss + backward, 1 step."""
+    sample of the same workload: `rays` rays x (64+64+32) samples, forward + loss + backward."""
     from oracle import nero_oracle as O
     from nero_amd.renderer import NeROShapeRenderer
     from nero_amd.synthetic import perturb_state, synthetic_rays
@@ -57,7 +71,7 @@ def cpu_baseline(cfg, variance, step, rays=512, budget_s=15.0, max_steps=10):
     sd = {k: v for k, v in net.named_parameters()}
     sd.update({k: v for k, v in net.named_buffers()})
     g = torch.Generator().manual_seed(3)
-    rand1, rand_bg = torch.rand(rays, 1, generator=g), torch.rand(rays, 32, generator=g)
+    rand1, rand_bg, keys = torch.rand(rays, 1, generator=g), torch.rand(rays, 32, generator=g), torch.rand(rays * 160, generator=g)
     c = {**O.DEFAULT_CFG, **cfg}
     near, far = O.near_far_from_sphere(o, d)
     t0, n = time.time(), 0
@@ -66,7 +80,7 @@ def cpu_baseline(cfg, variance, step, rays=512, budget_s=15.0, max_steps=10):
             if p.grad is not None:
                 p.grad = None
         P = O.effective_params(sd)
-        out = O.render(P, c, o, d, near, far, torch.zeros(rays, 3, 4), step, O.anneal(c, step), rand1, rand_bg)
+        out = O.render(P, c, o, d, near, far, torch.zeros(rays, 3, 4), step, O.anneal(c, step), rand1, rand_bg, keys)
         loss = O.training_loss(c, out, gt, step)
         loss.backward()
         n += 1
@@ -74,6 +88,148 @@ def cpu_baseline(cfg, variance, step, rays=512, budget_s=15.0, max_steps=10):
     return {'value': rays * n / dt, 'unit': 'rays/s', 'cores': cores, 'kind': 'port',
             'sample': f'{rays} rays x (64+64+32) samples, oracle (torch-CPU port of the reference path) forward+loss+backward, '
                       f'{n} step(s), {dt:.1f} s'}
+
+
+def torch_gpu_baseline(cfg, variance, step, rays, dev, warmup=10, steps=50):
+    """BASELINE.md section 3 'GPU reference denominator': the same algorithm (oracle/nero_oracle.py: per-layer ATen GEMMs through
+    hipBLASLt, boolean-mask gathers, autograd double backward -- what the reference's PyTorch path does) on THIS MI355X, same
+    workload, same schedule step, fused Adam; median of `steps` after `warmup`."""
+    from oracle import nero_oracle as O
+    from nero_amd.renderer import NeROShapeRenderer
+    from nero_amd.synthetic import perturb_state, synthetic_rays
+    torch.manual_seed(6033)
+    net = NeROShapeRenderer(cfg, training=False)
+    perturb_state(net, variance)
+    net = net.to(dev)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)
+    o, d, _, gt = synthetic_rays(rays * 4, seed=1)
+    o, d, gt = o.to(dev), d.to(dev), gt.to(dev)
+    c = {**O.DEFAULT_CFG, **cfg}
+    zeros = torch.zeros(rays, 3, 4, device=dev)
+    prev = torch.get_default_device()
+    torch.set_default_device(dev)                       # the oracle creates its temporaries on the default device (like renderer.py:609)
+    try:
+        def one(i):
+            s = slice((i % 4) * rays, (i % 4 + 1) * rays)
+            opt.zero_grad(set_to_none=True)
+            sd = {k: v for k, v in net.named_parameters()}
+            sd.update({k: v for k, v in net.named_buffers()})
+            P = O.effective_params(sd)
+            near, far = O.near_far_from_sphere(o[s], d[s])
+            out = O.render(P, c, o[s], d[s], near, far, zeros, step, O.anneal(c, step), torch.rand(rays, 1), torch.rand(rays, 32),
+                           torch.rand(rays * 160))
+            O.training_loss(c, out, gt[s], step).backward()
+            opt.step()
+        for i in range(warmup):
+            one(i)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        torch.cuda.synchronize()
+        ev[0].record()
+        for i in range(steps):
+            one(i)
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+        peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    finally:
+        torch.set_default_device(prev)
+    med = ms[len(ms) // 2]
+    return {'value': round(rays / (med * 1e-3), 1), 'unit': 'rays/s', 'ms_per_step_median': round(med, 2), 'ms_per_step_min': round(ms[0], 2),
+            'ms_per_step_max': round(ms[-1], 2), 'warmup': warmup, 'steps': steps, 'kind': 'port',
+            'what': f'oracle/nero_oracle.py (torch port of the reference path) on the same MI355X, {rays} rays x (64+64+32), schedule step '
+                    f'{step}, fp32 ATen ops + fused Adam, peak {peak:.1f} GiB'}
+
+
+def stage2_bench(dev, P_=4096, configs=((128, 128), (512, 256)), warmup=5, steps=20, subdiv=7):
+    """BASELINE configs[3]: Stage-II material step -- materials, direction sampling, BVH trace of P*D secondary
+    rays, hit / miss light MLPs, microfacet estimator, regularisers, backward, fused Adam -- on a 327 680-triangle bumpy icosphere
+    (stand-in for the extracted shape mesh).  pts/s, light-rays/s, tracer rays/s and the MLP-FLOP fraction of section 8d's model
+    3 * [2 C_mat + D ((1-h) C_outer + h C_inner)] MACs per point with the measured hit fraction h."""
+    import numpy as np
+    from nero_amd import chain as CH
+    from nero_amd.renderer import NeROMaterialRenderer
+    from nero_amd.synthetic import icosphere, synthetic_rays
+    v, f = icosphere(subdiv, 0.5, 0.2)
+    f = np.ascontiguousarray(f[:, ::-1])
+    out = {'mesh_triangles': int(f.shape[0]), 'points': P_, 'configs': []}
+    o, d, _, gt = synthetic_rays(8 * P_, seed=5, window=110)
+    o, d, gt = o.to(dev), d.to(dev), gt.to(dev)
+    for Dd, Ds in configs:
+        torch.manual_seed(6033)
+        net = NeROMaterialRenderer({'shader_cfg': dict(diffuse_sample_num=Dd, specular_sample_num=Ds, human_lights=False, outer_light_version='direction'),
+                                    'database_name': 'syn/bell'}, mesh=(v, f)).to(dev)
+        inters, normals, depth, hit = net.trace(o, d)
+        sel = torch.nonzero(hit)[:P_, 0]
+        assert sel.numel() == P_, sel.numel()
+        pts, view, nrm, g = inters[sel].contiguous(), -d[sel].contiguous(), normals[sel].contiguous(), gt[sel]
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)
+        tracer = net.ray_tracer
+        rec = {'n': 0, 'hit': 0, 'ms': 0.0, 'on': False}
+
+        class Timed:                                            # times nero_bvh_trace on the secondary rays of the untimed extra step
+            def trace(self, ro, rd):
+                if not rec['on']:
+                    return tracer.trace(ro, rd)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = tracer.trace(ro, rd)
+                e1.record()
+                torch.cuda.synchronize()
+                rec['ms'] += e0.elapsed_time(e1)
+                rec['n'] += ro.shape[0]
+                rec['hit'] += int((r[2] < 10).sum())
+                return r
+        net.ray_tracer = Timed()
+
+        def step(i):
+            opt.zero_grad(set_to_none=True)
+            so = net.shade_train(pts, view, nrm, None, g, 5000 + i)
+            (so['loss_rgb'].mean() + so['loss_mat_reg'].mean() + so['loss_diffuse_light'].mean()).backward()
+            opt.step()
+        for i in range(warmup):
+            step(i)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        torch.cuda.synchronize()
+        t0 = time.time()
+        ev[0].record()
+        for i in range(steps):
+            step(i)
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        wall = (time.time() - t0) / steps
+        ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+        rec['on'] = True
+        step(0)
+        torch.cuda.synchronize()
+        D = Dd + Ds
+        h = rec['hit'] / max(rec['n'], 1)
+        flop_pt = 2 * 3 * (2 * C_MAT + D * ((1 - h) * C_OUTER + h * C_INNER))
+        peak = PEAK_OF_MODE[CH.GEMM_MODE['fwd']]
+        out['configs'].append({
+            'directions': f'{Dd}+{Ds}', 'ms_per_step': round(wall * 1e3, 3), 'ms_per_step_median': round(ms[len(ms) // 2], 3),
+            'points_per_s': round(P_ / wall, 1), 'light_rays_per_s': round(P_ * D / wall, 1),
+            'tracer_rays_per_s': round(rec['n'] / (rec['ms'] * 1e-3), 1) if rec['ms'] > 0 else None, 'tracer_ms': round(rec['ms'], 3),
+            'hit_fraction': round(h, 4), 'mlp_mflop_per_point': round(flop_pt / 1e6, 1),
+            'mlp_flop_frac': round(flop_pt * P_ / wall / peak, 4), 'mlp_flop_frac_peak_tflops': round(peak / 1e12, 1),
+            'warmup': warmup, 'steps': steps})
+        del net, opt
+        torch.cuda.empty_cache()
+    return out
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside a torch.distributed launcher: become the launcher"""
+    if torch.cuda.device_count() < n:
+        print(json.dumps({'error': f'--gpus {n} requested but this node exposes {torch.cuda.device_count()} GPU(s)'}), flush=True)
+        return 2
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -84,8 +240,11 @@ def main():
     ap.add_argument('--rays', type=int, default=4096)
     ap.add_argument('--train-step', type=int, default=25000, help='training-schedule step the batch is evaluated at')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--quick', action='store_true', help='headline + roofline only (development runs)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -105,15 +264,21 @@ def main():
     from nero_amd.train import ShapeTrainStep
     import ctypes as C
 
-    cfg = {'freeze_inv_s_step': 15000, 'apply_occ_loss': True, 'occ_loss_step': 20000}      # configs/shape/syn/bell.yaml
-    variance = 0.5
-    ts = ShapeTrainStep(cfg, rays_per_rank=args.rays, device=dev, variance=variance, rank=rank, world=world)
+    cfg = dict(BELL)
+    ts = ShapeTrainStep(cfg, rays_per_rank=args.rays, device=dev, variance=VARIANCE, rank=rank, world=world)
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        t = torch.tensor([x], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t)
+
+    # ---- the contract: W untimed steps, then EXACTLY K steps between barrier + synchronize, max over ranks -----------------------
     for i in range(args.warmup):
         info = ts.step(args.train_step + i)
     sync()
@@ -124,20 +289,33 @@ def main():
         n_in += info['n_in']
         n_out += info['n_out']
     sync()
-    dt = time.time() - t0
-    tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt)
-    rays_total = args.rays * world * args.steps
-    value = rays_total / dt
+    dt = max_over_ranks(time.time() - t0)
+    value = args.rays * world * args.steps / dt
+
+    # ---- SURVEY.md 8d protocol: median of >= 50 steps (HIP events at the step boundaries) after >= 10 warm-up steps ------------
+    proto = None
+    if not args.quick:
+        for i in range(max(0, 10 - args.warmup - args.steps)):
+            ts.step(args.train_step + 500 + i)
+        n8 = 50
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(n8 + 1)]
+        sync()
+        ev[0].record()
+        for i in range(n8):
+            ts.step(args.train_step + 600 + i)
+            ev[i + 1].record()
+        sync()
+        ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(n8))
+        med = max_over_ranks(ms[n8 // 2])
+        proto = {'steps': n8, 'warmup': max(10, args.warmup + args.steps), 'ms_per_step_median': round(med, 3), 'ms_per_step_min': round(ms[0], 3),
+                 'ms_per_step_max': round(ms[-1], 3), 'rays_per_s_at_median': round(args.rays * world / (med * 1e-3), 1)}
 
     # ---- the same step on the exact-fp32 MFMA engine (NERO_GEMM=f32), reported next to the headline: 2 warmup + 5 timed steps --
-    from nero_amd import chain as _CHM
+    from nero_amd import chain as CH
     alt = None
-    if _CHM.GEMM_MODE['fwd'] != L.GEMM_F32:
-        _saved_modes = dict(_CHM.GEMM_MODE)
-        _CHM.set_gemm_mode('f32')
+    if CH.GEMM_MODE['fwd'] != L.GEMM_F32 and not args.quick:
+        saved = dict(CH.GEMM_MODE)
+        CH.set_gemm_mode('f32')
         for i in range(2):
             ts.step(args.train_step + 200 + i)
         sync()
@@ -145,28 +323,27 @@ def main():
         for i in range(5):
             ts.step(args.train_step + 202 + i)
         sync()
-        dta = torch.tensor([time.time() - t1], device=dev, dtype=torch.float64)
-        if world > 1:
-            dist.all_reduce(dta, op=dist.ReduceOp.MAX)
-        alt = {'value': round(args.rays * world * 5 / float(dta), 1), 'unit': 'rays/s', 'ms_per_step': round(float(dta) / 5 * 1e3, 3),
+        dta = max_over_ranks(time.time() - t1)
+        alt = {'value': round(args.rays * world * 5 / dta, 1), 'unit': 'rays/s', 'ms_per_step': round(dta / 5 * 1e3, 3),
                'steps': 5, 'mfma': 'v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain, 157.3 TFLOP/s peak)'}
-        _CHM.GEMM_MODE.update(_saved_modes)
+        CH.GEMM_MODE.update(saved)
         ts.step(args.train_step + 300)           # back on the default engine before the roofline leg
         sync()
 
     # ---- forward-only (inference) rays/s on the default engines: 2 warmup + 5 timed renders --------------------
-    for i in range(2):
-        ts.forward_only(args.train_step + 400 + i)
-    sync()
-    t2 = time.time()
-    for i in range(5):
-        ts.forward_only(args.train_step + 402 + i)
-    sync()
-    dtf = torch.tensor([time.time() - t2], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(dtf, op=dist.ReduceOp.MAX)
-    fwd_only = {'value': round(args.rays * world * 5 / float(dtf), 1), 'unit': 'rays/s', 'ms_per_render': round(float(dtf) / 5 * 1e3, 3),
-                'what': "renderer.render(is_train=False): sampler + render forward + the reference's validation extras, no loss / backward"}
+    fwd_only = None
+    if not args.quick:
+        for i in range(2):
+            ts.forward_only(args.train_step + 400 + i)
+        sync()
+        t2 = time.time()
+        for i in range(5):
+            ts.forward_only(args.train_step + 402 + i)
+        sync()
+        dtf = max_over_ranks(time.time() - t2)
+        fwd_only = {'value': round(args.rays * world * 5 / dtf, 1), 'unit': 'rays/s', 'ms_per_render': round(dtf / 5 * 1e3, 3),
+                    'what': "renderer.render(is_train=False): sampler + render forward + the reference's validation extras, no loss / "
+                            'backward; packed operand images cached across renders (weights unchanged)'}
 
     # ---- roofline leg: per-launch HIP-event timing of the MFMA kernel classes, on extra (untimed) steps ------------
     roof = None
@@ -178,7 +355,6 @@ def main():
         L.lib.nero_prof_enable(0)
         rep = (C.c_double * 12)()
         L.lib.nero_prof_report(rep)
-        from nero_amd import chain as CH
         kname = {'fwd': ('mlp_fwd_kernel', 'fwd_split_kernel', 'fwd_f16_kernel'), 'tan': ('mlp_tan_kernel', 'tan_split_kernel', 'tan_f16_kernel'),
                  'bwd': ('mlp_bwd_kernel', 'bwd_split_kernel', 'bwd_f16_kernel'), 'dw': ('dw_gemm_kernel', 'dw_split_kernel', 'dw_split_kernel')}
         passes = ('fwd', 'tan', 'bwd', 'dw')
@@ -188,10 +364,11 @@ def main():
         dom = max(rows, key=lambda r: r[2])
         ach = dom[3] / (dom[2] * 1e-3) / 1e12 if dom[2] > 0 else 0.0
         peak = dom[4] / 1e12
+        traffic, tsrc = hbm_traffic_per_launch(dom[0])
         roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
-                'frac': round(ach / peak, 4), 'traffic': hbm_traffic_per_launch(dom[0]), 'kernel': dom[0], 'mfma': MFMA_OF_MODE[dom[5]],
-                'traffic_source': 'profiles/r01_hbm_traffic_per_kernel.csv: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, '
-                                  'separate passes, bytes per launch (null if the kernel is not in that file)',
+                'frac': round(ach / peak, 4), 'traffic': traffic, 'kernel': dom[0], 'mfma': MFMA_OF_MODE[dom[5]],
+                'traffic_source': f'profiles/{tsrc}: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, separate passes, '
+                                  'bytes per launch' if tsrc else None,
                 'avg_launch_ms': round(dom[2] / max(dom[1], 1), 4),
                 'per_kernel': {r[0]: {'launches_per_step': r[1] / 3, 'ms_per_step': round(r[2] / 3, 3),
                                       'tflops': round(r[3] / (r[2] * 1e-3) / 1e12, 2) if r[2] > 0 else 0.0,
@@ -201,10 +378,9 @@ def main():
             ts.step(args.train_step + 100 + i)
 
     if rank == 0:
-        from nero_amd import chain as _CH
-        CH_SPLIT = _CH.GEMM_MODE['fwd'] != L.GEMM_F32
-        CH_MODES = {k: {0: 'f32', 1: 'bf16x6', 2: 'f16x3'}[v] for k, v in _CH.GEMM_MODE.items()}
-        # whole-step algorithmic FLOPs (BASELINE.md §4) with the measured inner/outer split of this rank
+        split = CH.GEMM_MODE['fwd'] != L.GEMM_F32
+        modes = {k: {0: 'f32', 1: 'bf16x6', 2: 'f16x3'}[v] for k, v in CH.GEMM_MODE.items()}
+        # whole-step algorithmic FLOPs (BASELINE.md section 4) with the measured inner/outer split of this rank
         sampler_evals = args.rays * (64 + 3 * 16)
         flop_step = (n_in / args.steps) * 2 * (6 * C_SDF + 3 * C_APP) + (n_out / args.steps) * 2 * 3 * C_NERF + sampler_evals * 2 * C_SDF
         res = {
@@ -212,21 +388,31 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': ('f32 (dense layers: fp32 operands carried as exact / block-scaled 16-bit plane pairs or triples on the bf16/fp16 '
-                      f'matrix pipe with fp32 accumulation, fp32-grade error; modes {CH_MODES})') if CH_SPLIT else 'f32',
+                      f'matrix pipe with fp32 accumulation, fp32-grade error; modes {modes})') if split else 'f32',
             'data': 'synthetic',
             'config': {'workload': "GlossySynthetic 'bell' Stage-I shape, 4096 rays x (64+64+32) samples per GPU, "
                                    f'training-schedule step {args.train_step}', 'rays_per_gpu': args.rays,
                        'parallelism': f'dp{world}', 'optimizer': 'adam(fused)', 'inv_s': 'exp(10*0.5)'},
-            'step_mlp_flop_frac': round(flop_step / (dt / args.steps) / PEAK_OF_MODE[_CH.GEMM_MODE['fwd']], 4),
+            'step_mlp_flop_frac': round(flop_step / (dt / args.steps) / PEAK_OF_MODE[CH.GEMM_MODE['fwd']], 4),
             'step_mlp_flop_frac_of_f32_mfma_peak': round(flop_step / (dt / args.steps) / PEAK_F32_MFMA, 4),
             'inner_samples_per_ray': round(n_in / args.steps / args.rays, 2),
-            'forward_only': fwd_only,
-            'roofline': roof,
+            'protocol_8d': proto, 'forward_only': fwd_only, 'roofline': roof,
         }
         if alt is not None:
             res['f32_mfma_engine'] = alt
-        if not args.no_cpu_baseline and world == 1:          # (rank 0 at N = 1 only)
-            res['cpu_baseline'] = cpu_baseline(cfg, variance, args.train_step)
+        if world == 1 and not args.quick:          # (baselines and the Stage-II leg: rank 0 at N = 1 only)
+            del ts
+            import gc
+            gc.unfreeze()
+            gc.collect()
+            torch.cuda.empty_cache()
+            res['stage2'] = stage2_bench(dev)
+            torch.cuda.empty_cache()
+            tg = torch_gpu_baseline(cfg, VARIANCE, args.train_step, args.rays, dev)
+            res['torch_gpu_baseline'] = tg
+            res['x_torch_gpu_baseline'] = round(res['protocol_8d']['rays_per_s_at_median'] / tg['value'], 2)
+            if not args.no_cpu_baseline:
+                res['cpu_baseline'] = cpu_baseline(cfg, VARIANCE, args.train_step)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -1,6 +1,7 @@
 """Data-parallel plumbing for the render step: ray sharding and the single flat gradient all-reduce (RCCL over xGMI on
-MI355X: backend 'nccl'; 'gloo' on CPU for tests).  The reference is single-GPU (train/trainer.py:68-72 raises for
-multi_gpus); rays are independent given the weights, so this is the only communication the path needs."""
+MI355X: backend 'nccl'; 'gloo' on CPU / for several ranks sharing one device in tests).  The reference is single-GPU
+(train/trainer.py:68-72 raises for multi_gpus); rays are independent given the weights, so this is the only communication
+the path needs."""
 import torch
 import torch.distributed as dist
 
@@ -11,14 +12,51 @@ def rank_slice(cursor, rays_per_rank, rank):
     return slice(lo, lo + rays_per_rank)
 
 
+def _all_reduce_sum(t, group=None):
+    """sum-all-reduce in place.  RCCL reduces device buffers directly; gloo (CPU tests, or two ranks on ONE device where RCCL
+    refuses duplicate GPUs) goes through a host copy."""
+    if t.is_cuda and dist.get_backend(group) == 'gloo':
+        h = t.cpu()
+        dist.all_reduce(h, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, group=group)
+
+
+class GradBucket:
+    """ONE persistent flat fp32 buffer holding every parameter gradient (8.8 MB for the bell shape model).  Each `p.grad` is a
+    VIEW into it for the whole run, so autograd accumulates straight into the bucket: no per-step flatten / unflatten copies and
+    no re-assignment of `p.grad` (the optimiser keeps seeing the same tensors).  A step is
+        bucket.zero()  ->  backward  ->  bucket.all_reduce_mean(world)  ->  optimiser
+    i.e. one memset and one collective.  The payload crosses xGMI in ~0.1 ms against a ~30 ms step, so it is not split into
+    overlapped sub-buckets: the whole backward is a single autograd node and there is nothing to hide it behind."""
+
+    def __init__(self, params):
+        self.params = [p for p in params]
+        dev, n = self.params[0].device, sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce_mean(self, world, group=None):
+        if world <= 1:
+            return
+        _all_reduce_sum(self.flat, group)
+        self.flat.mul_(1.0 / world)
+
+
 def allreduce_mean_grads(params, world, group=None):
-    """ONE collective per step: flatten every gradient into a single fp32 bucket (8.8 MB for the bell shape model),
-    all-reduce (sum), divide by world, scatter back.  Parameters without a gradient contribute zeros."""
+    """bucket-less variant (kept for callers that own their .grad tensors): flatten, all-reduce (sum), divide, scatter back."""
     if world <= 1:
         return
     grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
     flat = torch._utils._flatten_dense_tensors(grads)
-    dist.all_reduce(flat, group=group)
+    _all_reduce_sum(flat, group)
     flat.div_(world)
     for p, g in zip(params, torch._utils._unflatten_dense_tensors(flat, grads)):
         p.grad = g.contiguous()
@@ -31,6 +69,24 @@ def global_count_weight(local_count, world, device, group=None):
     if world <= 1:
         return 1.0
     t = torch.tensor([float(local_count)], dtype=torch.float64, device=device)
-    dist.all_reduce(t, group=group)
+    _all_reduce_sum(t, group)
     total = float(t.item())
     return float(local_count) * world / total if total > 0 else 1.0
+
+
+def global_count_weights(local_counts, world, device, group=None):
+    """global_count_weight for several per-sample loss terms at once (eikonal: inner-sample count; occlusion loss: candidate
+    count) with ONE small all-reduce"""
+    if world <= 1:
+        return [1.0] * len(local_counts)
+    t = torch.tensor([float(c) for c in local_counts], dtype=torch.float64, device=device)
+    _all_reduce_sum(t, group)
+    tot = t.tolist()
+    return [float(c) * world / g if g > 0 else 1.0 for c, g in zip(local_counts, tot)]
+
+
+def per_rank_occ_cap(max_pn, world):
+    """the reference caps the occlusion-loss candidate set at occ_loss_max_pn per PROCESS (network/renderer.py:535-541); with
+    `world` ranks each takes max_pn / world so that the global candidate budget stays what the single-process step uses
+    (SURVEY.md §8e)."""
+    return max(1, int(max_pn) // max(1, int(world)))

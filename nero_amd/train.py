@@ -10,7 +10,7 @@ import gc
 import torch
 import torch.distributed as dist  # noqa: F401
 
-from .parallel import allreduce_mean_grads, global_count_weight, rank_slice
+from .parallel import GradBucket, global_count_weights, per_rank_occ_cap, rank_slice
 
 from .renderer import NeROShapeRenderer
 from .synthetic import perturb_state, synthetic_rays
@@ -25,12 +25,12 @@ def warm_up_cos_lr(step, total_step=300000, warm_up_end=5000, learning_rate=5e-4
     return f * learning_rate
 
 
-def shape_training_loss(net, out, gt, step, eikonal_weight=0.1, eikonal_rank_weight=1.0):
+def shape_training_loss(net, out, gt, step, eikonal_weight=0.1, eikonal_rank_weight=1.0, occ_rank_weight=1.0):
     """sum of the means of every `loss*` entry the reference's loss objects produce for the shape stage
     (train/trainer.py:127-137; network/loss.py: NeRFRenderLoss, EikonalLoss, OccLoss, InitSDFRegLoss)."""
     loss = net.compute_rgb_loss(out['ray_rgb'], gt).mean() + (out['gradient_error'] * eikonal_weight).mean() * eikonal_rank_weight
     if 'loss_occ' in out:
-        loss = loss + out['loss_occ'].mean()
+        loss = loss + out['loss_occ'].mean() * occ_rank_weight
     if step < 1000 and 'sdf_vals' in out:
         norm = torch.norm(out['sdf_pts'], dim=-1)
         sdf = out['sdf_vals']
@@ -54,11 +54,14 @@ class ShapeTrainStep:
                  rank=0, world=1, prime_fraction=0.35):
         self.device, self.rank, self.world, self.R = device, rank, world, rays_per_rank
         torch.manual_seed(seed)
+        if world > 1:                  # global occlusion-loss candidate budget = the single-process cap
+            cfg = {**cfg, 'occ_loss_max_pn': per_rank_occ_cap({**NeROShapeRenderer.default_cfg, **cfg}['occ_loss_max_pn'], world)}
         self.net = NeROShapeRenderer(cfg, training=False)
         if variance is not None:
             perturb_state(self.net, variance)
         self.net = self.net.to(device)
         self.params = [p for p in self.net.parameters()]
+        self.bucket = GradBucket(self.params)                    # p.grad = views of one flat buffer, for the whole run
         self.opt = torch.optim.Adam(self.params, lr=1e-3, fused=(device != 'cpu'))
         self.eik_w = eikonal_weight
         o, d, poses, gt = synthetic_rays(pool_rays, seed=1)
@@ -81,7 +84,7 @@ class ShapeTrainStep:
         near, far = self.net.near_far_from_sphere(o, d)
         out = self.net.render(o, d, near, far, None, -1, 0.5, is_train=True, step=25000)
         shape_training_loss(self.net, out, self.pool['gt'][:64], 25000).backward()
-        self.opt.zero_grad(set_to_none=True)
+        self.bucket.zero()
         torch.cuda.synchronize()
 
     def prime_allocator(self, fraction=0.35, cap_bytes=64 << 30):
@@ -113,20 +116,26 @@ class ShapeTrainStep:
                              step=min(step, net.cfg['occ_loss_step'] - 1))
         return out['ray_rgb']
 
-    def step(self, step):
+    def forward_backward(self, step):
+        """render + loss + backward of this rank's slice of the next global batch; gradients land in the flat bucket"""
         net = self.net
-        lr = warm_up_cos_lr(step)
-        for g in self.opt.param_groups:
-            g['lr'] = lr
-        self.opt.zero_grad(set_to_none=True)
+        self.bucket.zero()
         o, d, gt = self._batch()
         near, far = net.near_far_from_sphere(o, d)
         out = net.render(o, d, near, far, None, -1, net.get_anneal_val(step), is_train=True, step=step)
-        # data parallel: the eikonal mean runs over each rank's own inner samples -> weight it by the global count
-        w = global_count_weight(out['_state']['n_in'], self.world, self.device)
-        loss = shape_training_loss(net, out, gt, step, self.eik_w, w)
+        # data parallel: the eikonal mean runs over each rank's own inner samples and the occlusion loss over its own candidate
+        # set -> weight both by their global counts so that N ranks reproduce the single-process means (SURVEY.md 8e)
+        w_eik, w_occ = global_count_weights([out['_state']['n_in'], out.get('_occ_count', 0)], self.world, self.device)
+        loss = shape_training_loss(net, out, gt, step, self.eik_w, w_eik, w_occ)
         loss.backward()
-        allreduce_mean_grads(self.params, self.world)
-        self.opt.step()
         st = out['_state']
         return {'loss': loss.detach(), 'n_in': st['n_in'], 'n_out': st['n_out']}
+
+    def step(self, step):
+        lr = warm_up_cos_lr(step)
+        for g in self.opt.param_groups:
+            g['lr'] = lr
+        info = self.forward_backward(step)
+        self.bucket.all_reduce_mean(self.world)
+        self.opt.step()
+        return info

@@ -53,12 +53,14 @@ def build_c(force=False):
     return _C_LIB
 
 
-def trace_bruteforce_margins(verts, tris, o, d, miss_depth=10.0, eps_edge=1e-4, eps_t=1e-4):
+def trace_bruteforce_margins(verts, tris, o, d, miss_depth=10.0, eps_edge=2e-5, eps_t=2e-6):
     """trace_bruteforce through its C restatement (oracle/csrc/tracer_oracle.c: identical float64 arithmetic and predicates,
     OpenMP over rays; tests/test_tracer_oracle_c.py pins it to the numpy version above), plus a per-ray AMBIGUITY flag: True
     when the fp64 answer sits within `eps_edge` (barycentric units) of a triangle edge that could change the closest hit, or a
-    candidate intersection lies within `eps_t` of the ray origin (the 1e-5 self-intersection offset of Stage-II secondary rays,
-    network/field.py:859).  A float32 tracer may legitimately answer differently on exactly those rays and on no others.
+    candidate intersection lies within `eps_t` of the ray origin (Stage-II secondary rays start 1e-5 off the surface along the
+    direction, network/field.py:859: the triangle they left sits at t = -1e-5 cos(theta), i.e. at ~0 for grazing directions).
+    The defaults are ~20x the float32 rounding of Moeller-Trumbore at this scene scale (coordinates ~0.5, ulp 6e-8): a float32
+    tracer may legitimately answer differently on exactly those rays and on no others.
     -> pos [n,3], nrm [n,3], depth [n], tri [n], ambiguous [n] bool"""
     import ctypes as C
     lib = C.CDLL(build_c())

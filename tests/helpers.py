@@ -115,11 +115,12 @@ def assert_grads_fp32_grade(g_hip, g_cpu32, g_cpu64, tol=1e-4, floor_factor=3.0,
     per tensor, err = max|a-b| / max|b|.  (Tensors whose whole gradient is ~1e-5 carry ReLU / clamp gates sitting at ~0 that
     flip between fp32 evaluation orders -- one flip perturbs every tensor of that MLP; torch-fp32 is off by the same amount.)
     No unconditional loose cap.  -> dict of per-tensor (err_hip, floor)."""
-    floors = {}
+    floors, own = {}, []
     for k, g64 in g_cpu64.items():
         if float(g64.abs().max()) >= 1e-12:
             grp = _mlp_of(k)
-            floors[grp] = max(floors.get(grp, 0.0), rel_err(g_cpu32[k], g64))
+            own.append(rel_err(g_cpu32[k], g64))
+            floors[grp] = max(floors.get(grp, 0.0), own[-1])
     rep, bad = {}, {}
     for k, g64 in g_cpu64.items():
         gh = g_hip[k]
@@ -131,5 +132,41 @@ def assert_grads_fp32_grade(g_hip, g_cpu32, g_cpu64, tol=1e-4, floor_factor=3.0,
             bad[k] = (e_hip, e_floor)
     assert not bad, f'{where}: gradients beyond max({tol}, {floor_factor} x fp32-torch noise floor): {bad}'
     vals = np.array([v[0] for v in rep.values()])
-    assert np.median(vals) < 2e-5, (where, float(np.median(vals)))
+    med_floor = float(np.median(own)) if own else 0.0
+    assert np.median(vals) < max(2e-5, floor_factor * med_floor), (where, float(np.median(vals)), med_floor)
     return rep
+
+
+class CTracer:
+    """RayTracer-shaped wrapper over the fp64 brute-force oracle (C restatement), remembering the ambiguity flags"""
+
+    def __init__(self, v, f, replay=None):
+        """replay: a CTracer whose recorded answers are returned call by call instead of tracing (an fp64 oracle run then sees
+        exactly the hits of the fp32 run: its own, slightly different secondary rays would flip razor-edge rays)"""
+        self.v, self.f, self.amb, self.hit, self.raw = v, f, [], [], []
+        self.replay, self.calls = replay, 0
+
+    def trace(self, o, d):
+        from oracle.tracer_oracle import trace_bruteforce_margins
+        if self.replay is not None:
+            pos, nrm, depth = self.replay.raw[self.calls]
+            self.calls += 1
+            assert pos.shape[0] == o.shape[0]
+            f = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(o.dtype).to(o.device)
+            return f(pos), f(nrm), f(depth)
+        pos, nrm, depth, tri, amb = trace_bruteforce_margins(self.v, self.f, o.detach().cpu().numpy(), d.detach().cpu().numpy())
+        pos, nrm, depth = pos.astype(np.float32), nrm.astype(np.float32), depth.astype(np.float32)       # the tracer contract is float32
+        self.raw.append((pos, nrm, depth))
+        self.amb.append(amb)
+        self.hit.append(tri >= 0)
+        f = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(o.dtype).to(o.device)
+        return f(pos), f(nrm), f(depth)
+
+
+def tracer_contract(tr):
+    """NeROMaterialRenderer.trace over a RayTracer-shaped object (network/renderer.py:719-729)"""
+    def fn(o, d):
+        pos, nrm, depth = tr.trace(o, d)
+        depth = depth.reshape(-1, 1)
+        return pos, torch.nn.functional.normalize(-nrm, dim=-1), depth, (depth < 10)[:, 0]
+    return fn

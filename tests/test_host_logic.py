@@ -147,3 +147,22 @@ def test_tracer_oracle_c_restatement_equals_numpy_oracle():
     assert np.array_equal(a[3], b[3]) and np.abs(a[2] - b[2]).max() < 1e-12 and np.abs(a[1] - b[1]).max() < 1e-12
     assert np.abs(a[0] - b[0]).max() < 1e-12
     assert 0.3 < (b[3] >= 0).mean() < 1.0 and b[4].mean() < 0.01
+
+
+def test_bench_gpus_flag_spawns_one_rank_per_gpu(monkeypatch):
+    """`python bench.py --gpus N` without a torch.distributed environment re-launches itself under torch.distributed.run with
+    N ranks on 127.0.0.1 (the flag used to be parsed and ignored)"""
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module('bench')
+    calls = {}
+    monkeypatch.setattr(bench.torch.cuda, 'device_count', lambda: 8)
+    monkeypatch.setattr(bench.subprocess, 'call', lambda cmd, env=None: calls.update(cmd=cmd, env=env) or 0)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '8', '--steps', '3', '--warmup', '1'])
+    assert bench.spawn_ranks(8) == 0
+    cmd = calls['cmd']
+    assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1'] and '--nproc-per-node=8' in cmd
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[-6:] == ['--gpus', '8', '--steps', '3', '--warmup', '1']
+    assert calls['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    monkeypatch.setattr(bench.torch.cuda, 'device_count', lambda: 1)
+    assert bench.spawn_ranks(2) == 2                                   # refuses to fake ranks it has no GPU for

@@ -39,7 +39,9 @@ def test_mc_shading_outputs_loss_and_grads(name):
     sd.update({k: v for k, v in ref.named_buffers()})
     P = O.effective_params(sd)
     rcfg = {'shader_cfg': meta['shader_cfg']}
-    oo = M.material_train_outputs(P, rcfg, oracle_trace_fn(), T(z, 'pts'), T(z, 'view'), T(z, 'normals'), T(z, 'human_poses'),
+    from tests.helpers import CTracer, tracer_contract
+    tr32 = CTracer(*golden_mesh())
+    oo = M.material_train_outputs(P, rcfg, tracer_contract(tr32), T(z, 'pts'), T(z, 'view'), T(z, 'normals'), T(z, 'human_poses'),
                                   T(z, 'gt'), meta['step'], T(z, 'rand_d'), T(z, 'rand_s'), T(z, 'reg_ang'), T(z, 'reg_eps'))
     loss_o = M.material_training_loss(oo)
     loss_o.backward()
@@ -48,7 +50,7 @@ def test_mc_shading_outputs_loss_and_grads(name):
     net.load_state_dict(ref.state_dict())
     net = net.cuda()
     hip_tracer = net.ray_tracer
-    net.ray_tracer = OracleTracer(*golden_mesh())
+    net.ray_tracer = CTracer(*golden_mesh())
     c = lambda k: T(z, k, 'cuda')
     out = net.shade_train(c('pts'), c('view'), c('normals'), c('human_poses'), c('gt'), meta['step'], c('rand_d'), c('rand_s'),
                           c('reg_ang'), c('reg_eps'))
@@ -60,20 +62,16 @@ def test_mc_shading_outputs_loss_and_grads(name):
     loss = out['loss_rgb'].mean() + out['loss_mat_reg'].mean() + out['loss_diffuse_light'].mean()
     assert abs(float(loss) - float(loss_o)) < 2e-5
     loss.backward()
-    worst = {}
-    for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
-        gq = q.grad if q.grad is not None else torch.zeros_like(q)
-        gp = p.grad if p.grad is not None else torch.zeros_like(p)
-        if gq.abs().max() < 1e-12 and gp.abs().max() < 1e-12:
-            continue
-        worst[k] = rel(gp, gq)
-    vals = np.array(list(worst.values()))
-    # only 24 points x 24 directions: single ReLU-unit sign flips between fp32 evaluation orders show up at the 1e-2 level in the
-    # smallest tensors (cf. scripts/dbg_grads64.py for Stage I); typical agreement is 1e-5
-    bad = {k: v for k, v in worst.items() if v > 5e-2}
-    assert not bad, bad
-    print(sorted(worst.items(), key=lambda kv: -kv[1])[:6])
-    assert np.quantile(vals, 0.9) < 5e-3 and np.median(vals) < 3e-4, (np.quantile(vals, 0.9), np.median(vals))
+    # gradients: within 1e-4 of an fp64 oracle run unless fp32 torch itself is equally off (tests/helpers.py)
+    from tests.helpers import assert_grads_fp32_grade, named_grads
+    ref64 = build_material_case(meta).double()
+    sd64 = {k: v for k, v in ref64.named_parameters()}
+    sd64.update({k: v for k, v in ref64.named_buffers()})
+    d = lambda k: T(z, k).double()
+    o64 = M.material_train_outputs(O.effective_params(sd64), rcfg, tracer_contract(CTracer(*golden_mesh(), replay=tr32)), d('pts'), d('view'), d('normals'),
+                                   d('human_poses'), d('gt'), meta['step'], d('rand_d'), d('rand_s'), d('reg_ang'), d('reg_eps'))
+    M.material_training_loss(o64).backward()
+    assert_grads_fp32_grade(named_grads(net), named_grads(ref), named_grads(ref64), where=name)
 
 
 def test_mc_shading_with_hip_tracer_close_to_oracle():
@@ -88,6 +86,8 @@ def test_mc_shading_with_hip_tracer_close_to_oracle():
     with torch.no_grad():
         out = net.shade(c('pts'), c('view'), c('normals'), c('human_poses'), True, meta['step'], c('rand_d'), c('rand_s'))
     err = (out['rgb_pr'].cpu() - torch.from_numpy(z['rgb'])).abs().max(-1)[0]
+    # 24 points x 24 directions: the explicit razor-edge accounting is tests/test_parity_at_size.py (P = 512 x 256); here only
+    # the plumbing -- the majority of points must be exact
     assert (err < 1e-4).float().mean() > 0.7 and err.max() < 0.1
 
 
@@ -115,3 +115,38 @@ def test_material_trainer_entry_point_and_pretrace():
     assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
     mats = net.predict_materials_of_vertices(torch.from_numpy(v).cuda())
     assert mats['albedo'].shape == (v.shape[0], 3) and np.isfinite(mats['roughness']).all()
+
+
+def test_stage2_pretrace_pool_vs_reference_construct_ray_batch():
+    """set_ray_pool (device-side pre-trace through the HIP BVH) against NeROMaterialRenderer._construct_ray_batch of the
+    unmodified reference run behind the fp64 tracer oracle on the same 3-view toy database (tests/golden/pools.npz, made by
+    oracle/gen_golden_r2.py): hit set, ray origins / directions, surface points, normals, depths, colours, human frames"""
+    import os
+    from nero_amd.renderer import NeROMaterialRenderer
+    from tests.helpers import GOLDEN
+    z = np.load(os.path.join(GOLDEN, 'pools.npz'))
+    torch.manual_seed(0)
+    net = NeROMaterialRenderer({'shader_cfg': dict(diffuse_sample_num=16, specular_sample_num=8, human_lights=True),
+                                'database_name': 'real/x', 'train_ray_num': 64, 'test_ray_num': 50}, mesh=golden_mesh()).cuda()
+    net._shuffle_train_batch = lambda: setattr(net, 'train_batch_i', 0)           # keep construction order
+    net.set_ray_pool(torch.from_numpy(z['imgs']), torch.from_numpy(z['Ks']), torch.from_numpy(z['poses']))
+    assert net.tbn == z['s2/rays_o'].shape[0]                                     # identical hit set (360 camera rays, 86 hits)
+    tb = {k: v.cpu().numpy() for k, v in net.train_batch.items()}
+    assert np.abs(tb['rays_o'] - z['s2/rays_o']).max() < 2e-6 and np.abs(tb['rays_d'] - z['s2/rays_d']).max() < 2e-6
+    assert np.abs(tb['inters'] - z['s2/inters']).max() < 2e-5
+    assert np.abs(tb['normals'] - z['s2/normals']).max() < 2e-5
+    assert np.abs(tb['depth'] - z['s2/depth']).max() < 2e-5
+    assert np.array_equal(tb['rgb'], z['s2/rgb'])
+    hp = net._human_poses_img[net.train_batch['img_idx']].cpu().numpy()            # one frame per image, indexed per sample
+    assert np.abs(hp - z['s2/human_poses']).max() < 1e-6
+    # test_step (network/renderer.py:846-887) on the pool's first view: shapes, zeros off the mesh, finite on it
+    ev = net({'eval': True, 'index': 0, 'step': 0})
+    h, w = z['imgs'].shape[1:3]
+    for k, c in (('rgb_gt', 3), ('rgb_pr', 3), ('specular_light', 3), ('specular_color', 3), ('diffuse_light', 3), ('diffuse_color', 3),
+                 ('albedo', 3), ('metallic', 1), ('roughness', 1)):
+        assert ev[k].shape == (h, w, c), k
+    hit0 = torch.from_numpy(z['s2t/hit_mask'])                                      # reference hit mask of view 1
+    ev1_pose = net.test_imgs_info                                                   # (pool given directly: validates on view 0)
+    assert torch.isfinite(ev['rgb_pr']).all() and float(ev['rgb_pr'].abs().sum()) > 0
+    off = ev['rgb_gt'].abs().sum(-1) == 0
+    assert float(ev['rgb_pr'][off].abs().sum()) == 0.0

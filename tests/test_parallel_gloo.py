@@ -76,3 +76,58 @@ def test_two_rank_allreduce_matches_big_batch():
         assert float((g - ref).abs().max()) / scale < 2e-4
         n += 1
     assert n > 50
+
+
+def _bucket_worker(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from oracle import nero_oracle as O
+    from nero_amd.parallel import GradBucket, global_count_weight, rank_slice
+    from nero_amd.synthetic import synthetic_rays
+    R = 6
+    o, d, _, gt = synthetic_rays(world * R, seed=1, window=200)
+    s = rank_slice(0, R, rank)
+    net = _small_net()
+    bucket = GradBucket(net.parameters())
+    views = [p.grad for p in net.parameters()]
+    for it in range(2):                                        # two steps: the views must survive zero() / backward / all-reduce
+        bucket.zero()
+        sd = {k: v for k, v in net.named_parameters()}
+        sd.update({k: v for k, v in net.named_buffers()})
+        cfg = {**O.DEFAULT_CFG, **net.cfg}
+        near, far = O.near_far_from_sphere(o[s], d[s])
+        out = O.render(O.effective_params(sd), cfg, o[s], d[s], near, far, torch.zeros(R, 3, 4), 5000, 0.1)
+        w = global_count_weight(out['n_inner'], world, 'cpu')
+        (O.rgb_loss(cfg, out['ray_rgb'], gt[s]).mean() + (out['gradient_error'] * 0.1).mean() * w).backward()
+        bucket.all_reduce_mean(world)
+    assert all(p.grad is v for p, v in zip(net.parameters(), views))
+    assert all(p.grad.data_ptr() >= bucket.flat.data_ptr() for p in net.parameters())
+    if rank == 0:
+        ret['dp'] = [p.grad.clone() for p in net.parameters()]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_persistent_grad_bucket_matches_big_batch():
+    from nero_amd.parallel import per_rank_occ_cap
+    from nero_amd.synthetic import synthetic_rays
+    assert per_rank_occ_cap(2048, 8) == 256 and per_rank_occ_cap(2048, 1) == 2048 and per_rank_occ_cap(3, 8) == 1
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_bucket_worker, args=(2, port, ret), nprocs=2, join=True)
+    o, d, _, gt = synthetic_rays(12, seed=1, window=200)
+    torch.set_num_threads(4)
+    net = _small_net()
+    params = _grads(net, o, d, gt, lambda n: 1.0)
+    n = 0
+    for p, g in zip(params, ret['dp']):
+        ref = p.grad if p.grad is not None else torch.zeros_like(p)
+        scale = float(ref.abs().max())
+        if scale < 1e-12:
+            continue
+        assert float((g - ref).abs().max()) / scale < 2e-4
+        n += 1
+    assert n > 50

@@ -246,3 +246,49 @@ def test_training_reduces_the_loss():
         last = v
         assert np.isfinite(v)
     assert last < 0.8 * first, (first, last)
+
+
+def test_train_eval_train_sequence_with_several_training_images():
+    """the Trainer's normal loop: train -> validate -> train (the eval path used to overwrite the per-image human
+    frames with the single test view's, so the next train step indexed out of bounds for imn > 1).  Also the drop-in surface of
+    test_step (network/renderer.py:274-317): test split view, down-sampling, loss_rgb / gt_rgb / gt_depth / gt_mask."""
+    from nero_amd.renderer import NeROShapeRenderer
+    from nero_amd.synthetic import look_at_pose
+
+    class FakeDB:
+        def __init__(self):
+            rg = np.random.default_rng(0)
+            self.imgs = rg.uniform(0, 1, (4, 32, 40, 3)).astype(np.float32)
+            self.K = np.array([[40., 0, 20], [0, 40., 16], [0, 0, 1]], np.float32)
+            self.poses = [look_at_pose(np.array(c, dtype=np.float64)) for c in ([3, 0, 0.5], [0, 3, 1.0], [-2, -2, 1.5], [2, -2, 0.7])]
+        def get_img_ids(self): return [0, 1, 2, 3]
+        def get_image(self, i): return self.imgs[i]
+        def get_K(self, i): return self.K
+        def get_pose(self, i): return self.poses[i]
+        def get_depth(self, i): return np.full((32, 40), 2.0 + i, np.float32), np.ones((32, 40), bool)
+
+    torch.manual_seed(1)
+    net = NeROShapeRenderer({'train_ray_num': 256, 'test_ray_num': 100, 'n_samples': 16, 'n_importance': 16, 'n_bg_samples': 8,
+                             'shader_config': {'human_light': True}, 'downsample_ratio': 0.5}, training=False).cuda()
+    net._init_dataset(FakeDB())
+    hp_before = net._train_human_poses.clone()
+    o1 = net({'step': 25000})
+    ev = net({'eval': True, 'index': 0, 'step': 25000})
+    assert torch.equal(net._train_human_poses, hp_before) and net._train_human_poses.shape[0] == 4
+    for k in ('ray_rgb', 'gt_rgb', 'loss_rgb', 'gt_depth', 'gt_mask', 'depth', 'normal', 'metallic', 'roughness', 'occ_prob_gt', 'human_light'):
+        assert k in ev, k
+    assert ev['ray_rgb'].shape == (16, 20, 3) and ev['gt_rgb'].shape == (16, 20, 3) and ev['loss_rgb'].shape == (16 * 20,)
+    assert ev['gt_depth'].shape == (16, 20, 1) and float(ev['gt_depth'].mean()) == 2.0          # view test_ids[0] = image 0, nearest
+    o2 = net({'step': 25001})
+    loss = o2['loss_rgb'].mean() + (o2['gradient_error'] * 0.1).mean() + o2['loss_occ'].mean()
+    loss.backward()
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+    # inference cache: a second validation render re-uses the packed operand images, a parameter update invalidates them
+    k1 = net._kern_cache[1][2]
+    net({'eval': True, 'index': 0, 'step': 25000})
+    assert net._kern_cache[1][2] is k1
+    with torch.no_grad():
+        net.sdf_network.lin8.bias.add_(0.01)
+    ev2 = net({'eval': True, 'index': 0, 'step': 25000})
+    assert net._kern_cache[1][2] is not k1
+    assert float((ev2['depth'] - ev['depth']).abs().max()) > 1e-4
