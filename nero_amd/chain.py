@@ -16,14 +16,17 @@ from . import _lib as L
 # every mode against the same fp64 reference and tolerance):
 #   'f16x3'  (default for the forward / tangent / reverse chain kernels) two block-scaled fp16 planes, 3 MFMA products
 #   'bf16x6' (default for the weight-gradient GEMM; f16x3 does not fit its 64 accumulator tiles) three bf16 planes, 6 products
+#   'f16x3r' the f16x3 arithmetic and operand images on the row-owner kernels (mlp_ro.hip): activations in registers, weights
+#            streamed through LDS, heads on the matrix pipe
 #   'f32'    the f32-input MFMA, an exact fmaf chain
 # NERO_GEMM=<mode> selects all passes, NERO_GEMM_FWD / _TAN / _BWD / _DW one pass.
-_MODE_NAMES = {'f32': L.GEMM_F32, 'bf16x6': L.GEMM_BF16X6, 'f16x3': L.GEMM_F16X3}
+_MODE_NAMES = {'f32': L.GEMM_F32, 'bf16x6': L.GEMM_BF16X6, 'f16x3': L.GEMM_F16X3, 'f16x3r': L.GEMM_F16X3R}
+_F16 = (L.GEMM_F16X3, L.GEMM_F16X3R)          # the two engines that share the kind-3 packed images
 _DEFAULT = {'fwd': 'f16x3', 'tan': 'f16x3', 'bwd': 'f16x3', 'dw': 'bf16x6'}
 
 
 def _resolve(mode, k):
-    return _MODE_NAMES['bf16x6' if (mode == 'f16x3' and k == 'dw') else mode]
+    return _MODE_NAMES['bf16x6' if (mode in ('f16x3', 'f16x3r') and k == 'dw') else mode]
 
 
 GEMM_MODE = {k: _resolve(os.environ.get('NERO_GEMM_' + k.upper(), os.environ.get('NERO_GEMM', _DEFAULT[k])), k)
@@ -100,10 +103,10 @@ class Chain:
                 if L.GEMM_BF16X6 in (GEMM_MODE['fwd'], GEMM_MODE['tan']):   # three bf16 planes: 768 floats per (tile, 16-k step)
                     e['sfm'] = (_r16(d.k_main) // 16) * nt * 768 if d.k_main else 0
                     e['sfa'] = (_r16(d.k_aux) // 16) * nt * 768 if d.k_aux else 0
-                if L.GEMM_F16X3 in (GEMM_MODE['fwd'], GEMM_MODE['tan']):     # 64-float header + two fp16 planes: 512 floats per (tile, step)
+                if GEMM_MODE['fwd'] in _F16 or GEMM_MODE['tan'] in _F16:       # 64-float header + two fp16 planes: 512 floats per (tile, step)
                     e['hfm'] = 64 + (_r16(d.k_main) // 16) * nt * 512 if d.k_main else 0
                     e['hfa'] = 64 + (_r16(d.k_aux) // 16) * nt * 512 if d.k_aux else 0
-                if GEMM_MODE['bwd'] == L.GEMM_F16X3:
+                if GEMM_MODE['bwd'] in _F16:
                     e['hbm'] = 64 + (_r16(d.n_out) // 16) * _tiles(d.k_main) * 512 if d.k_main else 0
                     e['hba'] = 64 + (_r16(d.n_out) // 16) * _tiles(d.k_aux) * 512 if d.k_aux else 0
                 if GEMM_MODE['bwd'] == L.GEMM_BF16X6:
@@ -112,6 +115,8 @@ class Chain:
             if h is not None:
                 e['hw'] = 4 * L.HID
                 e['hb'] = 4
+                if GEMM_MODE['fwd'] == L.GEMM_F16X3R:                             # head as one 32-row MFMA tile over the input
+                    e['hwp'] = 64 + (_r16(h.k) // 16) * 512
             sizes.append(e)
         total = sum(sum(e.values()) for e in sizes)
         buf = torch.zeros(total, dtype=torch.float32, device=self.device)
@@ -159,6 +164,8 @@ class Chain:
                 Wh = h.W.detach()
                 assert Wh.stride(1) == 1
                 job(2, Wh, p['hw'], h.n_head, Wh.stride(0), 0, h.k, 0, L.HID, 0)
+                if 'hwp' in p:
+                    job(3, Wh, p['hwp'], h.n_head, Wh.stride(0), 0, h.k, 0, _r16(h.k), 1)
                 if h.b is not None:
                     job(2, h.b.detach(), p['hb'], 1, h.n_head, 0, h.n_head, 0, 4, 0)
             packed.append(p)
@@ -180,7 +187,7 @@ class Chain:
         ch.aux, ch.ld_aux, ch.k_aux = L.ptr(aux), (aux.stride(0) if aux is not None else 0), self.k_aux
         ch.n_layers, ch.aux_wide = len(self.entries), int(self.aux_wide)
         split = GEMM_MODE['fwd'] != L.GEMM_F32
-        fkeys = {L.GEMM_F32: ('fm', 'fa'), L.GEMM_BF16X6: ('sfm', 'sfa'), L.GEMM_F16X3: ('hfm', 'hfa')}[GEMM_MODE['fwd']]
+        fkeys = {L.GEMM_F32: ('fm', 'fa'), L.GEMM_BF16X6: ('sfm', 'sfa'), L.GEMM_F16X3: ('hfm', 'hfa'), L.GEMM_F16X3R: ('hfm', 'hfa')}[GEMM_MODE['fwd']]
         ch.gemm_mode = GEMM_MODE['fwd']
         ch.macs_per_row = float(sum(d.n_out * (d.k_main + d.k_aux) for d, _ in self.entries if d is not None))
         if init is not None:
@@ -200,6 +207,8 @@ class Chain:
                 heads[i] = ho
                 fl.head_w, fl.head_b, fl.head_out = p['hw'].data_ptr(), p['hb'].data_ptr(), ho.data_ptr()
                 fl.n_head, fl.head_k = h.n_head, (h.k + 3) // 4 * 4
+                if GEMM_MODE['fwd'] == L.GEMM_F16X3R:
+                    fl.head_w, fl.head_k = p['hwp'].data_ptr(), _r16(h.k)
             if d is not None:
                 rk = _r16 if split else _r8
                 fl.w_main = L.ptr(p.get(fkeys[0]))
@@ -227,7 +236,7 @@ class Chain:
         ch = L.BwdChain()
         ch.n_layers, ch.aux_wide = len(self.entries), 0
         split = GEMM_MODE['bwd'] != L.GEMM_F32
-        bkeys = {L.GEMM_F32: ('bm', 'ba'), L.GEMM_BF16X6: ('sbm', 'sba'), L.GEMM_F16X3: ('hbm', 'hba')}[GEMM_MODE['bwd']]
+        bkeys = {L.GEMM_F32: ('bm', 'ba'), L.GEMM_BF16X6: ('sbm', 'sba'), L.GEMM_F16X3: ('hbm', 'hba'), L.GEMM_F16X3R: ('hbm', 'hba')}[GEMM_MODE['bwd']]
         ch.gemm_mode = GEMM_MODE['bwd']
         rk = _r16 if split else _r8
         last = len(self.entries) - 1

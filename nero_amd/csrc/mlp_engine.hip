@@ -810,8 +810,9 @@ int nero_mlp_forward(const nero_fwd_chain* ch, int n_rows, void* stream) {
         return nero_fail(NERO_ERR_ARG, "nero_mlp_forward: init/aux width out of range");
     const dim3 grid((n_rows + 63) / 64), block(256);
     nero_prof_begin(NERO_K_FWD, 2.0 * ch->macs_per_row * n_rows, (hipStream_t)stream);
-    if (ch->gemm_mode == NERO_GEMM_BF16X6 || ch->gemm_mode == NERO_GEMM_F16X3) {
-        const int rc = ch->gemm_mode == NERO_GEMM_F16X3 ? nero_f16_forward(ch, n_rows, (hipStream_t)stream)
+    if (ch->gemm_mode == NERO_GEMM_BF16X6 || ch->gemm_mode == NERO_GEMM_F16X3 || ch->gemm_mode == NERO_GEMM_F16X3R) {
+        const int rc = ch->gemm_mode == NERO_GEMM_F16X3R ? nero_ro_forward(ch, n_rows, (hipStream_t)stream)
+                     : ch->gemm_mode == NERO_GEMM_F16X3 ? nero_f16_forward(ch, n_rows, (hipStream_t)stream)
                                                         : nero_split_forward(ch, n_rows, (hipStream_t)stream);
         nero_prof_end(NERO_K_FWD, (hipStream_t)stream);
         return rc != NERO_OK ? rc : nero_check_launch("nero_mlp_forward(split)");
@@ -832,8 +833,8 @@ int nero_mlp_tangent(const nero_tan_chain* ch, int n_rows, void* stream) {
     if (n_rows == 0) return NERO_OK;
     const dim3 grid((n_rows + 63) / 64), block(256);
     nero_prof_begin(NERO_K_TAN, 2.0 * ch->macs_per_row * n_rows, (hipStream_t)stream);
-    if (ch->gemm_mode == NERO_GEMM_BF16X6 || ch->gemm_mode == NERO_GEMM_F16X3) {
-        const int rc = ch->gemm_mode == NERO_GEMM_F16X3 ? nero_f16_tangent(ch, n_rows, (hipStream_t)stream)
+    if (ch->gemm_mode == NERO_GEMM_BF16X6 || ch->gemm_mode == NERO_GEMM_F16X3 || ch->gemm_mode == NERO_GEMM_F16X3R) {
+        const int rc = ch->gemm_mode != NERO_GEMM_BF16X6 ? nero_f16_tangent(ch, n_rows, (hipStream_t)stream)
                                                         : nero_split_tangent(ch, n_rows, (hipStream_t)stream);
         nero_prof_end(NERO_K_TAN, (hipStream_t)stream);
         return rc != NERO_OK ? rc : nero_check_launch("nero_mlp_tangent(bf16x6)");
@@ -855,8 +856,8 @@ int nero_mlp_backward(const nero_bwd_chain* ch, int n_rows, void* stream) {
     const dim3 grid((n_rows + 63) / 64), block(256);
     NERO_ONCE(hipFuncSetAttribute((const void*)mlp_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(0)));
     nero_prof_begin(NERO_K_BWD, 2.0 * ch->macs_per_row * n_rows, (hipStream_t)stream);
-    if (ch->gemm_mode == NERO_GEMM_BF16X6 || ch->gemm_mode == NERO_GEMM_F16X3) {
-        const int rc = ch->gemm_mode == NERO_GEMM_F16X3 ? nero_f16_backward(ch, n_rows, (hipStream_t)stream)
+    if (ch->gemm_mode == NERO_GEMM_BF16X6 || ch->gemm_mode == NERO_GEMM_F16X3 || ch->gemm_mode == NERO_GEMM_F16X3R) {
+        const int rc = ch->gemm_mode != NERO_GEMM_BF16X6 ? nero_f16_backward(ch, n_rows, (hipStream_t)stream)
                                                         : nero_split_backward(ch, n_rows, (hipStream_t)stream);
         nero_prof_end(NERO_K_BWD, (hipStream_t)stream);
         return rc != NERO_OK ? rc : nero_check_launch("nero_mlp_backward(bf16x6)");

@@ -140,11 +140,11 @@ def assert_grads_fp32_grade(g_hip, g_cpu32, g_cpu64, tol=1e-4, floor_factor=3.0,
 class CTracer:
     """RayTracer-shaped wrapper over the fp64 brute-force oracle (C restatement), remembering the ambiguity flags"""
 
-    def __init__(self, v, f, replay=None):
+    def __init__(self, v, f, replay=None, eps_edge=2e-5, eps_t=2e-6):
         """replay: a CTracer whose recorded answers are returned call by call instead of tracing (an fp64 oracle run then sees
         exactly the hits of the fp32 run: its own, slightly different secondary rays would flip razor-edge rays)"""
         self.v, self.f, self.amb, self.hit, self.raw = v, f, [], [], []
-        self.replay, self.calls = replay, 0
+        self.replay, self.calls, self.eps = replay, 0, (eps_edge, eps_t)
 
     def trace(self, o, d):
         from oracle.tracer_oracle import trace_bruteforce_margins
@@ -154,7 +154,8 @@ class CTracer:
             assert pos.shape[0] == o.shape[0]
             f = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(o.dtype).to(o.device)
             return f(pos), f(nrm), f(depth)
-        pos, nrm, depth, tri, amb = trace_bruteforce_margins(self.v, self.f, o.detach().cpu().numpy(), d.detach().cpu().numpy())
+        pos, nrm, depth, tri, amb = trace_bruteforce_margins(self.v, self.f, o.detach().cpu().numpy(), d.detach().cpu().numpy(),
+                                                             eps_edge=self.eps[0], eps_t=self.eps[1])
         pos, nrm, depth = pos.astype(np.float32), nrm.astype(np.float32), depth.astype(np.float32)       # the tracer contract is float32
         self.raw.append((pos, nrm, depth))
         self.amb.append(amb)

@@ -77,7 +77,8 @@ def test_hip_ide_vs_reference_generate_ide_fn():
     # specular: the kernel's own sigmoid(raw) roughness drives the attenuation exp(-l(l+1)/2 r), l <= 16
     r_k = mat[:, 1:2].cpu()
     assert np.abs(r_k.numpy() - z['rough']).max() < 2e-7
-    assert np.abs(Xs.cpu().numpy() - z['ide_rough']).max() < 3e-5                      # vs the reference at ITS roughness
+    # vs the reference at ITS roughness: the logit -> sigmoid round trip of this test moves r by a few ulp, amplified by l(l+1)/2 = 136
+    assert np.abs(Xs.cpu().numpy() - z['ide_rough']).max() < 2e-4
     assert np.abs(Xs.cpu().numpy() - O.ide(torch.from_numpy(z['dirs']), r_k).numpy()).max() < 2e-6     # vs the oracle at the kernel's roughness
     # light-MLP inputs: Xi = [PE-8(p) | IDE(refl, rough)], Xo = [PE-8(p) | PE-6(refl)]   (field.py:566-571)
     pe8 = O.pos_enc(pts.cpu(), 8).numpy()
