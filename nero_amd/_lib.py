@@ -6,7 +6,7 @@ import os
 import torch  # noqa: F401  -- must come first: libnero_hip.so has to bind to the HIP runtime torch already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libnero_hip.so')
+LIB_PATH = os.environ.get('NERO_HIP_LIB') or os.path.join(_HERE, 'libnero_hip.so')     # (override: kernel-variant experiments)
 
 MAX_LAYERS = 10
 HID = 256

@@ -51,7 +51,7 @@ class SDFField:
 
     def pack(self):
         self.full.pack()
-        self.value_only._packed = self.full._packed[:8] + [{k: v for k, v in self.full._packed[8].items() if k in ('hw', 'hb')}]
+        self.value_only._packed = self.full._packed[:8] + [{k: v for k, v in self.full._packed[8].items() if k in ('hw', 'hb', 'hwp')}]
         return self
 
     # -- no-grad value evaluation (sampler, occ-loss march, mesh extraction) --------------------------------------
