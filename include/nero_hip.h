@@ -187,6 +187,26 @@ int nero_dw_gemm(const nero_dw_job* job /*host*/, int n_rows, float* partials, v
 int nero_head_dw(const float* dy /*[rows,4]*/, const float* a /*[rows,256]*/, const float* extra, int n_head, int n_rows,
                  float* dWh /*[n_head,256]*/, float* dbh, float* partials, int accumulate, void* stream);
 
+/* ---- trainer-loop fusion (replaces the per-Linear nn.utils.weight_norm reparametrisation, network/field.py:
+ *      118-119, 323-331, and torch.optim.Adam over ~125 tensors, train/trainer.py:105-170, ~750 tiny kernels per step) -------------
+ * One job per weight-normed matrix (dim = 0: one norm per output row).  forward: w_eff = g v / ||v||_row, inv_norm = 1 / ||v||_row.
+ * adam: dg = <dW, v> inv_norm, dv = g inv_norm (dW - <dW, v> inv_norm^2 v), then Adam on g and v in place (m_*, v_* = first / second
+ * moment buffers).  Plain jobs: Adam on p given grad.  Hyper-parameters and operation order of torch.optim.Adam (fused). */
+#define NERO_MAX_WN_JOBS 40
+#define NERO_MAX_ADAM_JOBS 96
+typedef struct {
+    const float* v; const float* g;      /* forward inputs: weight_v [rows, cols], weight_g [rows]                                */
+    float* w_eff; float* inv_norm;       /* forward outputs / backward inputs                                                     */
+    float* v_rw; float* g_rw;            /* the same parameters, writable (updated in place by the Adam step)                     */
+    const float* dW;                     /* dL/dW_eff [rows, cols]                                                                */
+    float* m_v; float* v_v; float* m_g; float* v_g;
+    int rows, cols;
+} nero_wn_job;
+typedef struct { float* p; const float* grad; float* m; float* v; int n; int pad_; } nero_adam_job;
+int nero_wn_forward_batch(const nero_wn_job* jobs /*host*/, int n_jobs, void* stream);
+int nero_wn_adam_batch(const nero_wn_job* wn /*host*/, int n_wn, const nero_adam_job* plain /*host*/, int n_plain, float lr, float beta1,
+                       float beta2, float eps, int step /*1-based*/, void* stream);
+
 /* ---- encodings --------------------------------------------------------------------------------------------------
  * Positional encoding rows [x, sin(2^k x), cos(2^k x)]_{k<n_freq}, zero padded to ldo, rows >= n zero
  * (Embedder, network/field.py:14-58). */

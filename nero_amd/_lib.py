@@ -67,6 +67,18 @@ class DwJob(C.Structure):
                 ('gemm_mode', C.c_int), ('pad_', C.c_int)]
 
 
+class WnJob(C.Structure):
+    _fields_ = [('v', _fp), ('g', _fp), ('w_eff', _fp), ('inv_norm', _fp), ('v_rw', _fp), ('g_rw', _fp), ('dW', _fp), ('m_v', _fp),
+                ('v_v', _fp), ('m_g', _fp), ('v_g', _fp), ('rows', C.c_int), ('cols', C.c_int)]
+
+
+class AdamJob(C.Structure):
+    _fields_ = [('p', _fp), ('grad', _fp), ('m', _fp), ('v', _fp), ('n', C.c_int), ('pad_', C.c_int)]
+
+
+MAX_WN_JOBS, MAX_ADAM_JOBS = 40, 96
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '

@@ -75,6 +75,15 @@ class Head:
         self.n_head, self.k = W.shape
 
 
+def run_pack_jobs(jobs):
+    """launch a list of (PackJob, keep-alive) in as few nero_pack_batch calls as possible (<= MAX_PACK_JOBS jobs each)"""
+    st = L.stream_ptr()
+    for i0 in range(0, len(jobs), L.MAX_PACK_JOBS):
+        chunk = jobs[i0:i0 + L.MAX_PACK_JOBS]
+        arr = (L.PackJob * len(chunk))(*[j for j, _ in chunk])
+        L.check(L.lib.nero_pack_batch(arr, len(chunk), st))
+
+
 class Chain:
     def __init__(self, entries, k_init, k_aux=0, aux_wide=False, device='cuda'):
         """entries: list of (Dense|None, Head|None).  k_init / k_aux: padded widths (multiples of 4) of the init / aux
@@ -85,9 +94,8 @@ class Chain:
         self._packed = None
 
     # ------------------------------------------------------------------------------------------------------------
-    def pack(self):
-        """(re)build the packed operand images from the current effective weights (call once per optimisation step)."""
-        st = L.stream_ptr()
+    def _sizes(self):
+        """per entry: {image key: float count} for the current GEMM modes"""
         sizes = []
         for d, h in self.entries:
             e = {}
@@ -118,8 +126,21 @@ class Chain:
                 if GEMM_MODE['fwd'] == L.GEMM_F16X3R:                             # head as one 32-row MFMA tile over the input
                     e['hwp'] = 64 + (_r16(h.k) // 16) * 512
             sizes.append(e)
+        return sizes
+
+    def pack_floats(self):
+        """size (floats) of this chain's packed operand images under the current GEMM modes"""
+        return sum(sum(e.values()) for e in self._sizes())
+
+    def pack(self, buf=None, run=True):
+        """(re)build the packed operand images from the current effective weights (call once per optimisation step).
+        buf: a ZERO-FILLED float32 buffer of pack_floats() elements to carve the images from (default: a fresh one).
+        run=False: do not launch; return the list of (PackJob, keep-alive tensor) for a batched launch (run_pack_jobs)."""
+        sizes = self._sizes()
         total = sum(sum(e.values()) for e in sizes)
-        buf = torch.zeros(total, dtype=torch.float32, device=self.device)
+        if buf is None:
+            buf = torch.zeros(total, dtype=torch.float32, device=self.device)
+        assert buf.numel() >= total
         off = 0
         packed = []
         jobs = []
@@ -169,12 +190,10 @@ class Chain:
                 if h.b is not None:
                     job(2, h.b.detach(), p['hb'], 1, h.n_head, 0, h.n_head, 0, 4, 0)
             packed.append(p)
-        # one launch per <= 64 jobs (include/nero_hip.h nero_pack_batch)
-        for i0 in range(0, len(jobs), L.MAX_PACK_JOBS):
-            chunk = jobs[i0:i0 + L.MAX_PACK_JOBS]
-            arr = (L.PackJob * len(chunk))(*[j for j, _ in chunk])
-            L.check(L.lib.nero_pack_batch(arr, len(chunk), st))
         self._packed, self._buf = packed, buf
+        if not run:
+            return jobs
+        run_pack_jobs(jobs)
         return self
 
     # ------------------------------------------------------------------------------------------------------------

@@ -236,17 +236,9 @@ __device__ __forceinline__ const char* chunk_begin(FwdShared& S, char* smem, int
 }
 
 // ---- epilogue element ------------------------------------------------------------------------------------------------------------
-// softplus(beta = 100) on the hardware exp2 / log2 units: max(x,0) + ln(1 + exp(-|100 x|)) / 100.  Absolute error <= 1e-9 (the
-// rounding of 1 + t for small t), i.e. far below one fp32 ulp of the row maximum the value is block-scaled against; beyond
-// 100 x > 20 the correction term is < 2e-11 and the result rounds to x, which is torch's threshold rule (network/field.py:124).
-__device__ __forceinline__ float softplus100_hw(float x) {
-    const float t = __builtin_amdgcn_exp2f(-fabsf(x) * 144.26950408889634f);
-    const float l = __builtin_amdgcn_logf(1.0f + t);
-    return fmaf(l, 0.0069314718055994531f, fmaxf(x, 0.f));
-}
 template <int ACT>
 __device__ __forceinline__ float act_hw(float z) {
-    if (ACT == NERO_ACT_SOFTPLUS100) return softplus100_hw(z);
+    if (ACT == NERO_ACT_SOFTPLUS100) return softplus100(z);
     if (ACT == NERO_ACT_RELU) return fmaxf(z, 0.f);
     return z;
 }
@@ -266,7 +258,7 @@ __device__ __forceinline__ void fwd_epi_elem(int c, int act, const f32x16& Hp, c
 #endif
     const float z = fmaf(fmaf(Lp[c], LO_INV, Hp[c]), U, f4_get(E.bq[c >> 2], c & 3));
     float y;
-    if (act == NERO_ACT_SOFTPLUS100) y = softplus100_hw(z);
+    if (act == NERO_ACT_SOFTPLUS100) y = softplus100(z);
     else y = act == NERO_ACT_RELU ? fmaxf(z, 0.f) : z;
     m_run = fmaxf(m_run, fabsf(y));
     f4_set(E.yq, c & 3, y);

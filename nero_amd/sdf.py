@@ -49,10 +49,13 @@ class SDFField:
         self.value_only = Chain(self.full.entries[:8] + [(None, self.full.entries[8][1])], k_init=LD_PE, k_aux=LD_PE, device=device)
         self._ones = None
 
-    def pack(self):
-        self.full.pack()
+    def pack(self, buf=None, run=True):
+        jobs = self.full.pack(buf, run)
         self.value_only._packed = self.full._packed[:8] + [{k: v for k, v in self.full._packed[8].items() if k in ('hw', 'hb', 'hwp')}]
-        return self
+        return self if run else jobs
+
+    def pack_floats(self):
+        return self.full.pack_floats()
 
     # -- no-grad value evaluation (sampler, occ-loss march, mesh extraction) --------------------------------------
     def sdf_from_pe(self, pe, n):

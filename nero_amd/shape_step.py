@@ -59,10 +59,24 @@ class ShapeKernels:
         self.human_light = Chain(predictor_entries(eff['human'], 24), k_init=24, device=device) if self.human else None
 
     def pack(self):
-        self.sdf.pack()
-        for c in [self.nerf_trunk, self.nerf_head, self.outer_light, self.inner_light, self.inner_weight, self.human_light] + self.mat:
-            if c is not None:
-                c.pack()
+        """(re)pack the operand images of all ten networks: ONE zero-filled flat buffer (kept and re-used while its size fits) and
+        the pack jobs of every chain batched into a handful of launches (nero_pack_batch takes 64 jobs) -- ~10 launches per step
+        instead of ~35 plus as many allocations."""
+        from .chain import run_pack_jobs
+        parts = [self.sdf, self.nerf_trunk, self.nerf_head, self.outer_light, self.inner_light, self.inner_weight, self.human_light] + self.mat
+        parts = [c for c in parts if c is not None]
+        sizes = [(c.pack_floats() + 63) // 64 * 64 for c in parts]          # 256-byte aligned images
+        total = sum(sizes)
+        flat = getattr(self, '_flat', None)
+        if flat is None or flat.numel() != total:
+            flat = self._flat = torch.zeros(total, dtype=torch.float32, device=self.device)
+        else:
+            flat.zero_()
+        jobs, off = [], 0
+        for c, n in zip(parts, sizes):
+            jobs += c.pack(flat[off:off + n], run=False)
+            off += n
+        run_pack_jobs(jobs)
         return self
 
 

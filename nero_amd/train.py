@@ -46,12 +46,110 @@ def shape_training_loss(net, out, gt, step, eikonal_weight=0.1, eikonal_rank_wei
     return loss
 
 
+class FusedShapeOptimizer:
+    """Trainer-loop fusion for the Stage-I model.  Replaces, per step, ~40 torch._weight_norm launches, their
+    ~35 backward launches, the per-parameter gradient fills and torch's multi-tensor Adam by
+        nero_wn_forward_batch   (1 launch: every effective weight W = g v / ||v|| into persistent buffers the packed operand images
+                                 are built from -- the chain descriptors are built ONCE, the pointers never change)
+        nero_wn_adam_batch      (2 launches: weight-norm backward fused with Adam for (g, v); plain Adam for biases, the NeRF++
+                                 Linear weights and the variance)
+    The render step's autograd node hands dL/dW_eff to leaf tensors whose .grad are views of ONE flat bucket, which is also the
+    all-reduce payload (dg, dv are linear in dW_eff, so reducing dW_eff is equivalent to reducing the parameter gradients)."""
+
+    def __init__(self, net, device, betas=(0.9, 0.999), eps=1e-8):
+        import ctypes as C
+        from . import _lib as L
+        from .shape_step import ShapeKernels, unflatten_effective
+        self.L, self.C, self.net, self.device = L, C, net, device
+        self.betas, self.eps, self.t = betas, eps, 0
+        lins = self._linears(net)                     # [(name prefix in flatten_effective order, nn.Linear)]
+        f32 = dict(dtype=torch.float32, device=device)
+        self.names, self.eff, leaves = [], [], []
+        self._wn, self._plain = [], []                # (lin, w_eff, inv_norm) / plain parameters
+        for name, lin in lins:
+            if hasattr(lin, 'weight_g'):
+                w = torch.empty(lin.weight_v.shape, **f32).requires_grad_(True)
+                self._wn.append((lin, w, torch.empty(lin.weight_v.shape[0], **f32)))
+                leaves.append(w)
+            else:
+                w = lin.weight
+                self._plain.append(w)
+                leaves.append(w)
+            self._plain.append(lin.bias)
+            leaves.append(lin.bias)
+            self.names += [name + '.weight', name + '.bias']
+            self.eff += [w, lin.bias]
+        assert len(self._wn) <= L.MAX_WN_JOBS
+        self.variance = net.deviation_network.variance
+        self._plain.append(self.variance)
+        leaves.append(self.variance)
+        # the sdf last layer is consumed as [Dense(W[1:]) | Head(W[0:1])] by the kernels: views of the same leaf
+        from .parallel import GradBucket
+        self.bucket = GradBucket(leaves)              # .grad of every leaf = view of one flat buffer
+        # Adam moments: (m, v) for weight_v / weight_g of every weight-normed Linear and for every plain tensor
+        n_state = sum(l.weight_v.numel() + l.weight_g.numel() for l, _, _ in self._wn) + sum(p.numel() for p in self._plain)
+        self.m, self.v = torch.zeros(n_state, **f32), torch.zeros(n_state, **f32)
+        off = 0
+        self._wn_jobs = (L.WnJob * max(1, len(self._wn)))()
+        for j, (lin, w, inv) in zip(self._wn_jobs, self._wn):
+            rows, cols = lin.weight_v.shape
+            assert lin.weight_v.is_contiguous() and lin.weight_g.is_contiguous()
+            j.v = j.v_rw = lin.weight_v.data_ptr()
+            j.g = j.g_rw = lin.weight_g.data_ptr()
+            j.w_eff, j.inv_norm, j.dW, j.rows, j.cols = w.data_ptr(), inv.data_ptr(), w.grad.data_ptr(), rows, cols
+            j.m_v, j.v_v = self.m[off:].data_ptr(), self.v[off:].data_ptr()
+            off += rows * cols
+            j.m_g, j.v_g = self.m[off:].data_ptr(), self.v[off:].data_ptr()
+            off += rows
+        self._plain_jobs = (L.AdamJob * len(self._plain))()
+        for j, p_ in zip(self._plain_jobs, self._plain):
+            assert p_.is_contiguous()
+            j.p, j.grad, j.m, j.v, j.n = p_.data_ptr(), p_.grad.data_ptr(), self.m[off:].data_ptr(), self.v[off:].data_ptr(), p_.numel()
+            off += p_.numel()
+        self.reparametrise()
+        self.K = ShapeKernels(unflatten_effective(self.names, [t.detach() for t in self.eff]), net.color_network.cfg, device)
+
+    @staticmethod
+    def _linears(net):
+        out = [(f'sdf.{l}', getattr(net.sdf_network, f'lin{l}')) for l in range(net.sdf_network.n_lin)]
+        nf = net.outer_nerf
+        out += [(f'nerf.pts.{i}', lin) for i, lin in enumerate(nf.pts_linears)]
+        out += [('nerf.views', nf.views_linears[0]), ('nerf.feature', nf.feature_linear), ('nerf.alpha', nf.alpha_linear), ('nerf.rgb', nf.rgb_linear)]
+        cn = net.color_network
+        preds = ['metallic_predictor', 'roughness_predictor', 'albedo_predictor', 'outer_light', 'inner_light', 'inner_weight']
+        if cn.cfg['human_light']:
+            preds.append('human_light_predictor')
+        for pn in preds:
+            out += [(f'{pn}.{i}', getattr(cn, pn)[k]) for i, k in enumerate((0, 2, 4, 6))]
+        return out
+
+    def reparametrise(self):
+        """effective weights of every weight-normed Linear from the current (g, v): one launch"""
+        L, C = self.L, self.C
+        L.check(L.lib.nero_wn_forward_batch(self._wn_jobs, len(self._wn), L.stream_ptr()))
+
+    def kernels(self):
+        """(names, effective leaves, packed chains) for NeROShapeRenderer.render(_kern=...), repacked from the current parameters"""
+        self.reparametrise()
+        return self.names, self.eff, self.K.pack()
+
+    def zero_grad(self):
+        self.bucket.zero()
+
+    def step(self, lr, world=1):
+        L, C = self.L, self.C
+        self.bucket.all_reduce_mean(world)
+        self.t += 1
+        L.check(L.lib.nero_wn_adam_batch(self._wn_jobs, len(self._wn), self._plain_jobs, len(self._plain), C.c_float(lr),
+                                         C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps), self.t, L.stream_ptr()))
+
+
 class ShapeTrainStep:
     """one process = one GPU.  Every rank holds the same weights and a disjoint slice of each global ray batch
     (rank-strided); gradients are summed with ONE flat all-reduce per step and divided by world size."""
 
     def __init__(self, cfg, rays_per_rank=4096, pool_rays=262144, device='cuda', seed=6033, variance=None, eikonal_weight=0.1,
-                 rank=0, world=1, prime_fraction=0.35):
+                 rank=0, world=1, prime_fraction=0.35, fused=None):
         self.device, self.rank, self.world, self.R = device, rank, world, rays_per_rank
         torch.manual_seed(seed)
         if world > 1:                  # global occlusion-loss candidate budget = the single-process cap (SURVEY.md 8e)
@@ -61,8 +159,16 @@ class ShapeTrainStep:
             perturb_state(self.net, variance)
         self.net = self.net.to(device)
         self.params = [p for p in self.net.parameters()]
-        self.bucket = GradBucket(self.params)                    # p.grad = views of one flat buffer, for the whole run
-        self.opt = torch.optim.Adam(self.params, lr=1e-3, fused=(device != 'cpu'))
+        # fused trainer loop (weight-norm + Adam kernels, persistent effective-weight buffers) on the GPU; `fused=False` keeps the
+        # torch path (torch._weight_norm autograd + torch.optim.Adam), which is also what the drop-in renderer runs under an
+        # external optimiser
+        self.fused = (device != 'cpu') if fused is None else fused
+        if self.fused:
+            self.fopt = FusedShapeOptimizer(self.net, device)
+            self.bucket = self.fopt.bucket
+        else:
+            self.bucket = GradBucket(self.params)                # p.grad = views of one flat buffer, for the whole run
+            self.opt = torch.optim.Adam(self.params, lr=1e-3, fused=(device != 'cpu'))
         self.eik_w = eikonal_weight
         o, d, poses, gt = synthetic_rays(pool_rays, seed=1)
         self.pool = {'o': o.to(device), 'd': d.to(device), 'gt': gt.to(device)}
@@ -82,7 +188,7 @@ class ShapeTrainStep:
         are paid at construction, not inside the first training step"""
         o, d = self.pool['o'][:64], self.pool['d'][:64]
         near, far = self.net.near_far_from_sphere(o, d)
-        out = self.net.render(o, d, near, far, None, -1, 0.5, is_train=True, step=25000)
+        out = self.net.render(o, d, near, far, None, -1, 0.5, is_train=True, step=25000, _kern=self.fopt.kernels() if self.fused else None)
         shape_training_loss(self.net, out, self.pool['gt'][:64], 25000).backward()
         self.bucket.zero()
         torch.cuda.synchronize()
@@ -122,7 +228,8 @@ class ShapeTrainStep:
         self.bucket.zero()
         o, d, gt = self._batch()
         near, far = net.near_far_from_sphere(o, d)
-        out = net.render(o, d, near, far, None, -1, net.get_anneal_val(step), is_train=True, step=step)
+        out = net.render(o, d, near, far, None, -1, net.get_anneal_val(step), is_train=True, step=step,
+                         _kern=self.fopt.kernels() if self.fused else None)
         # data parallel: the eikonal mean runs over each rank's own inner samples and the occlusion loss over its own candidate
         # set -> weight both by their global counts so that N ranks reproduce the single-process means
         w_eik, w_occ = global_count_weights([out['_state']['n_in'], out.get('_occ_count', 0)], self.world, self.device)
@@ -133,9 +240,12 @@ class ShapeTrainStep:
 
     def step(self, step):
         lr = warm_up_cos_lr(step)
-        for g in self.opt.param_groups:
-            g['lr'] = lr
         info = self.forward_backward(step)
-        self.bucket.all_reduce_mean(self.world)
-        self.opt.step()
+        if self.fused:
+            self.fopt.step(lr, self.world)            # all-reduce of the flat dL/dW_eff bucket + weight-norm backward + Adam
+        else:
+            for g in self.opt.param_groups:
+                g['lr'] = lr
+            self.bucket.all_reduce_mean(self.world)
+            self.opt.step()
         return info

@@ -24,14 +24,14 @@ def test_struct_layouts_match_header():
     """ctypes mirrors of the descriptor structs must have the sizes the C compiler gives them."""
     import subprocess, tempfile
     from nero_amd import _lib as L
-    src = '#include <stdio.h>\n#include "nero_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(nero_fwd_layer), sizeof(nero_fwd_chain), sizeof(nero_tan_layer), sizeof(nero_tan_chain), sizeof(nero_bwd_layer), sizeof(nero_bwd_chain), sizeof(nero_dw_job), sizeof(nero_pack_job));}'
+    src = '#include <stdio.h>\n#include "nero_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(nero_fwd_layer), sizeof(nero_fwd_chain), sizeof(nero_tan_layer), sizeof(nero_tan_chain), sizeof(nero_bwd_layer), sizeof(nero_bwd_chain), sizeof(nero_dw_job), sizeof(nero_pack_job), sizeof(nero_wn_job), sizeof(nero_adam_job));}'
     with tempfile.TemporaryDirectory() as td:
         c = os.path.join(td, 's.c')
         open(c, 'w').write(src)
         exe = os.path.join(td, 's')
         subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), c, '-o', exe])
         sizes = [int(x) for x in subprocess.check_output([exe]).split()]
-    mine = [ctypes.sizeof(t) for t in (L.FwdLayer, L.FwdChain, L.TanLayer, L.TanChain, L.BwdLayer, L.BwdChain, L.DwJob, L.PackJob)]
+    mine = [ctypes.sizeof(t) for t in (L.FwdLayer, L.FwdChain, L.TanLayer, L.TanChain, L.BwdLayer, L.BwdChain, L.DwJob, L.PackJob, L.WnJob, L.AdamJob)]
     assert sizes == mine, (sizes, mine)
 
 

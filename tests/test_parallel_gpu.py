@@ -49,7 +49,7 @@ def test_two_ranks_on_one_device_reproduce_the_big_batch_gradient():
     ref, got = ts.bucket.flat.cpu(), ret['flat']
     off = 0
     worst = 0.0
-    for p in ts.params:
+    for p in ts.bucket.params:                                # the leaves of the flat bucket (fused trainer: effective weights)
         a, b = got[off:off + p.numel()], ref[off:off + p.numel()]
         off += p.numel()
         scale = float(b.abs().max())

@@ -1,0 +1,81 @@
+"""GPU tier: the fused trainer loop (nero_wn_forward_batch + batched operand packing + nero_wn_adam_batch)
+against the torch path it replaces (torch._weight_norm with autograd + torch.optim.Adam, i.e. what the reference's Trainer does:
+nn.utils.weight_norm in network/field.py:118-119, 323-331 and train/trainer.py:105-170)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CFG = {'n_samples': 16, 'n_importance': 16, 'n_bg_samples': 8, 'freeze_inv_s_step': 15000, 'perturb': 0.0, 'apply_occ_loss': True,
+       'occ_loss_step': 20000, 'shader_config': {'human_light': True}}
+
+
+def test_weight_norm_kernels_vs_torch():
+    """forward: W = g v / ||v||_row; backward + Adam: one step against torch autograd through torch._weight_norm + torch.optim.Adam"""
+    from nero_amd import _lib as L
+    g0 = torch.Generator().manual_seed(0)
+    shapes = [(256, 259), (217, 256), (3, 256), (257, 256)]
+    vs = [torch.randn(s, generator=g0).cuda() for s in shapes]
+    gs = [(torch.rand(s[0], 1, generator=g0) + 0.5).cuda() for s in shapes]
+    dWs = [torch.randn(s, generator=g0).cuda() * 1e-3 for s in shapes]
+    bias, dbias = torch.randn(300, generator=g0).cuda(), torch.randn(300, generator=g0).cuda() * 1e-2
+    # torch reference
+    ref_p = [t.clone().requires_grad_(True) for t in vs + gs] + [bias.clone().requires_grad_(True)]
+    opt = torch.optim.Adam(ref_p, lr=3e-4)
+    n = len(shapes)
+    for it in range(2):
+        opt.zero_grad()
+        loss = sum((torch._weight_norm(ref_p[i], ref_p[n + i], 0) * dWs[i]).sum() for i in range(n)) + (ref_p[-1] * dbias).sum()
+        loss.backward()
+        opt.step()
+    # fused kernels
+    v2, g2, b2 = [t.clone() for t in vs], [t.clone() for t in gs], bias.clone()
+    weff = [torch.empty_like(t) for t in vs]
+    inv = [torch.empty(s[0], device='cuda') for s in shapes]
+    z = lambda t: torch.zeros_like(t)
+    mv, vv, mg, vg = [z(t) for t in vs], [z(t) for t in vs], [z(t) for t in gs], [z(t) for t in gs]
+    mb, vb = z(bias), z(bias)
+    jobs = (L.WnJob * n)()
+    for i, j in enumerate(jobs):
+        j.v = j.v_rw = v2[i].data_ptr(); j.g = j.g_rw = g2[i].data_ptr(); j.w_eff = weff[i].data_ptr(); j.inv_norm = inv[i].data_ptr()
+        j.dW = dWs[i].data_ptr(); j.m_v, j.v_v, j.m_g, j.v_g = mv[i].data_ptr(), vv[i].data_ptr(), mg[i].data_ptr(), vg[i].data_ptr()
+        j.rows, j.cols = shapes[i]
+    pj = (L.AdamJob * 1)()
+    pj[0].p, pj[0].grad, pj[0].m, pj[0].v, pj[0].n = b2.data_ptr(), dbias.data_ptr(), mb.data_ptr(), vb.data_ptr(), 300
+    for it in range(2):
+        L.check(L.lib.nero_wn_forward_batch(jobs, n, L.stream_ptr()))
+        if it == 0:
+            for i in range(n):
+                want = torch._weight_norm(vs[i], gs[i], 0)
+                assert float((weff[i] - want).abs().max() / want.abs().max()) < 1e-6
+        L.check(L.lib.nero_wn_adam_batch(jobs, n, pj, 1, C.c_float(3e-4), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-8), it + 1, L.stream_ptr()))
+    torch.cuda.synchronize()
+    for got, want, p0 in zip(v2 + g2 + [b2], ref_p, vs + gs + [bias]):
+        upd = (want.detach() - p0).abs().max()
+        assert float((got - want.detach()).abs().max()) <= 2e-3 * float(upd) + 1e-9
+
+
+def test_fused_training_steps_match_the_torch_path():
+    from nero_amd.train import ShapeTrainStep
+    runs = {}
+    for fused in (False, True):
+        ts = ShapeTrainStep(CFG, rays_per_rank=192, pool_rays=768, device='cuda:0', variance=0.4, prime_fraction=0.0, fused=fused)
+        p0 = {k: v.detach().clone() for k, v in ts.net.state_dict().items()}
+        losses = [float(ts.step(25000 + i)['loss']) for i in range(3)]
+        torch.cuda.synchronize()
+        runs[fused] = (p0, {k: v.detach().clone() for k, v in ts.net.state_dict().items()}, losses)
+    (p0, pr, lr_), (q0, pf, lf) = runs[False], runs[True]
+    assert all(torch.equal(p0[k], q0[k]) for k in p0)
+    assert np.allclose(lr_, lf, rtol=0, atol=2e-5), (lr_, lf)
+    worst = 0.0
+    for k in pr:
+        if k.endswith('FG_LUT'):
+            continue
+        upd = float((pr[k] - p0[k]).abs().max())
+        err = float((pf[k] - pr[k]).abs().max())
+        assert err <= 2e-2 * upd + 1e-8, (k, err, upd)          # 3 Adam steps: the update direction m / sqrt(v) is sign-like per element
+        worst = max(worst, err / (upd + 1e-12))
+    assert upd > 0
