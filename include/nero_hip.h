@@ -94,6 +94,9 @@ typedef struct {
     int n_head;            /* 0..4                                                                                    */
     int act;               /* NERO_ACT_*                                                                              */
     int head_k;            /* columns of the input tile the head reads (multiple of 4, <= 256)                        */
+    uint32_t* relu_mask;   /* optional [rows_pad, 8] (F16X3 engine, ReLU layers): bit 16h + v of word [row][tile] = output
+                              feature 32 tile + 4h + (v&3) + 8(v>>2) is > 0.  The reverse pass then reads 32 B per row
+                              instead of the 1 KiB saved activation row (which only the weight-gradient GEMM still needs) */
 } nero_fwd_layer;
 
 typedef struct {
@@ -147,6 +150,7 @@ typedef struct {
     int k_main_tiles, k_aux_tiles, n_head;
     int act_prev;          /* activation that produced a_prev                                                         */
     int pad_;
+    const uint32_t* mask_prev; /* optional relu_mask of the layer that produced a_prev (F16X3 engine): replaces reading a_prev */
 } nero_bwd_layer;
 
 typedef struct {

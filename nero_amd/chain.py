@@ -219,6 +219,13 @@ class Chain:
         n_save = sum(1 for i in self.dense_idx if save or i == last_dense)
         sbuf = torch.empty((n_save, rp, L.HID), dtype=torch.float32, device=self.device)
         si = 0
+        # ReLU sign masks (32 B per row and layer) for the reverse pass of the fp16 tile engine: it then skips the 1 KiB/row read of
+        # the saved activation (the weight-gradient GEMM still reads it)
+        masks = [None] * len(self.entries)
+        relu_idx = [i for i in self.dense_idx if save and self.entries[i][0].act == L.ACT_RELU] if GEMM_MODE['fwd'] == L.GEMM_F16X3 else []
+        mbuf = torch.empty((len(relu_idx), rp, 8), dtype=torch.int32, device=self.device) if relu_idx else None
+        for k, i in enumerate(relu_idx):
+            masks[i] = mbuf[k]
         for i, ((d, h), p) in enumerate(zip(self.entries, self._packed)):
             fl = ch.layer[i]
             if h is not None:
@@ -239,8 +246,10 @@ class Chain:
                     saves[i] = sbuf[si]
                     si += 1
                     fl.save = saves[i].data_ptr()
+                if masks[i] is not None:
+                    fl.relu_mask = masks[i].data_ptr()
         L.check(L.lib.nero_mlp_forward(C.byref(ch), n_rows, L.stream_ptr()))
-        return {'saves': saves, 'heads': heads, '_keep': (init, aux)}
+        return {'saves': saves, 'heads': heads, 'masks': masks, '_keep': (init, aux)}
 
     # ------------------------------------------------------------------------------------------------------------
     def backward(self, fwd, n_rows, dy=None, head_dys=None, need_dinit=False, need_daux=False, injs=None,
@@ -299,6 +308,9 @@ class Chain:
             if j is not None:
                 bl.a_prev = saves[j].data_ptr()
                 bl.act_prev = self.entries[j][0].act
+                mk = fwd.get('masks')
+                if mk is not None and mk[j] is not None and GEMM_MODE['bwd'] == L.GEMM_F16X3:
+                    bl.mask_prev = mk[j].data_ptr()
                 bl.delta_prev = deltas[j].data_ptr()
                 if j in injs:
                     bl.inj = injs[j].data_ptr()

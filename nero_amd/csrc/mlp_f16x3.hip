@@ -281,6 +281,21 @@ __global__ __launch_bounds__(512, 1) void fwd_f16_kernel(nero_fwd_chain ch, int 
                 acc_to_global(scr, val[0], sblock, lane);
                 acc_to_global(scr, val[1], sblock + (size_t)32 * NERO_HID, lane);
             }
+            if (L.relu_mask) {                              // sign bits of this lane's 2 x 16 outputs -> one word per (row, tile)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    unsigned bits = 0u;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        bits |= (val[r][g].x > 0.f ? 1u : 0u) << (4 * g);
+                        bits |= (val[r][g].y > 0.f ? 1u : 0u) << (4 * g + 1);
+                        bits |= (val[r][g].z > 0.f ? 1u : 0u) << (4 * g + 2);
+                        bits |= (val[r][g].w > 0.f ? 1u : 0u) << (4 * g + 3);
+                    }
+                    const unsigned other = __shfl_xor(bits, 32);
+                    if (h == 0) L.relu_mask[(size_t)(row0 + 32 * r + i) * 8 + wave] = bits | (other << 16);
+                }
+            }
         }
         publish_rowmax(S.rmax, m[0], m[1], wave, i, h);
         __syncthreads();                                   // row maxima visible; every wave is done reading the input planes
@@ -491,10 +506,21 @@ __global__ __launch_bounds__(512, 1) void bwd_f16_kernel(nero_bwd_chain ch, int 
         float4 pa[2][4];                                   // saved activations of this lane's outputs, requested before the GEMM
         const bool has_inj = !first && L.inj != nullptr;
         if (!first && live_wave) {
+            if (L.mask_prev && L.act_prev == NERO_ACT_RELU) {   // 4 bytes per (row, tile) instead of 128: only the sign is needed
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
+                for (int r = 0; r < 2; ++r) {
+                    const unsigned bits = L.mask_prev[(size_t)(row0 + 32 * r + i) * 8 + wave] >> (16 * h);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) pa[r][g] = *reinterpret_cast<const float4*>(L.a_prev + goff + (size_t)r * 32 * NERO_HID + 8 * g);
+                    for (int g = 0; g < 4; ++g)
+                        pa[r][g] = make_float4((bits >> (4 * g)) & 1u ? 1.f : 0.f, (bits >> (4 * g + 1)) & 1u ? 1.f : 0.f,
+                                               (bits >> (4 * g + 2)) & 1u ? 1.f : 0.f, (bits >> (4 * g + 3)) & 1u ? 1.f : 0.f);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) pa[r][g] = *reinterpret_cast<const float4*>(L.a_prev + goff + (size_t)r * 32 * NERO_HID + 8 * g);
+            }
         }
         float4 gq[2][4];                                   // incoming gradient of this lane's outputs, true units
         const float rs0 = S.rs_main[i], rs1 = S.rs_main[32 + i];

@@ -175,7 +175,7 @@ __device__ __forceinline__ nero_fwd_layer fwd_layer_copy(CFwdLayer& s) {
     nero_fwd_layer L;
     L.w_main = s.w_main; L.w_aux = s.w_aux; L.bias = s.bias; L.save = s.save; L.head_w = s.head_w; L.head_b = s.head_b;
     L.head_out = s.head_out; L.k_main = s.k_main; L.k_aux = s.k_aux; L.n_tiles = s.n_tiles; L.n_head = s.n_head; L.act = s.act;
-    L.head_k = s.head_k;
+    L.head_k = s.head_k; L.relu_mask = nullptr;
     return L;
 }
 

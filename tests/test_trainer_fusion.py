@@ -10,7 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 CFG = {'n_samples': 16, 'n_importance': 16, 'n_bg_samples': 8, 'freeze_inv_s_step': 15000, 'perturb': 0.0, 'apply_occ_loss': True,
-       'occ_loss_step': 20000, 'shader_config': {'human_light': True}}
+       'occ_loss_step': 20000}
 
 
 def test_weight_norm_kernels_vs_torch():
