@@ -45,6 +45,9 @@ struct WF { uint4 wh, wl; };
 struct XF { uint4 xh0, xl0, xh1, xl1; };
 
 __device__ __forceinline__ void load_w(WF& o, const uint4* wp, int c) {
+#ifdef F16_NO_WSTREAM                               // (timing experiments, scripts/f16_variants.sh: every k-step re-reads step 0)
+    c = 0;
+#endif
     const uint4* w = wp + (size_t)c * 128;
     o.wh = w[0];
     o.wl = w[64];
@@ -60,6 +63,11 @@ __device__ __forceinline__ void load_x(XF& o, const char* xp, int half_bytes, in
 #define NERO_MFH(ACC, A, B) \
     ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), ACC, 0, 0, 0)
 __device__ __forceinline__ void ops_compute(f32x16 (&aH)[2], f32x16 (&aL)[2], const WF& w, const XF& x) {
+#ifdef F16_NO_MFMA
+    aH[0][0] += __uint_as_float(w.wh.x ^ x.xh0.x); aL[0][0] += __uint_as_float(w.wl.x ^ x.xl0.x);
+    aH[1][0] += __uint_as_float(w.wh.y ^ x.xh1.x); aL[1][0] += __uint_as_float(w.wl.y ^ x.xl1.x);
+    return;
+#endif
     NERO_MFH(aL[0], w.wl, x.xh0); NERO_MFH(aL[1], w.wl, x.xh1);
     NERO_MFH(aH[0], w.wh, x.xh0); NERO_MFH(aH[1], w.wh, x.xh1);
     NERO_MFH(aL[0], w.wh, x.xl0); NERO_MFH(aL[1], w.wh, x.xl1);
@@ -272,6 +280,11 @@ __global__ __launch_bounds__(512, 1) void fwd_f16_kernel(nero_fwd_chain ch, int 
         float4 val[2][4];
         float m[2] = {0.f, 0.f};
         if (live_wave) {
+#ifdef F16_NO_EPI
+            for (int r = 0; r < 2; ++r) for (int g = 0; g < 4; ++g) val[r][g] = make_float4(aH[r][4 * g], aL[r][4 * g], 0.f, 0.f);
+            m[0] = m[1] = 1.f;
+            if (false)
+#endif
             if (L.act == NERO_ACT_RELU) fwd_values<NERO_ACT_RELU>(aH, aL, bq, U, val, m);
             else if (L.act == NERO_ACT_SOFTPLUS100) fwd_values<NERO_ACT_SOFTPLUS100>(aH, aL, bq, U, val, m);
             else fwd_values<NERO_ACT_NONE>(aH, aL, bq, U, val, m);
