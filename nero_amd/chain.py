@@ -332,10 +332,12 @@ class Chain:
         return {'deltas': deltas, 'd_init': d_init, 'd_aux': d_aux}
 
     # ------------------------------------------------------------------------------------------------------------
-    def weight_grads(self, fwd, bwd, n_rows, init, aux, head_dys=None, workspace=None, second=None, head_extra=None):
+    def weight_grads(self, fwd, bwd, n_rows, init, aux, head_dys=None, workspace=None, second=None, head_extra=None, outs=None):
         """-> list per entry of dict(dW, db, dWh, dbh) (torch tensors shaped like the effective weights).
         second: optional {dense entry: (D1 [rows,256], B1_main [rows,256] or init-like, B1_aux)} extra operand pair
-        accumulated into the same dW (SDF double-backward)."""
+        accumulated into the same dW (SDF double-backward).
+        outs: optional {dense entry: (dW_out [n_out, k_total], db_out [n_out])} -- caller-owned destinations (e.g. views of a flat
+        gradient bucket) the GEMM writes straight into instead of fresh tensors."""
         head_dys = head_dys or {}
         second = second or {}
         head_extra = head_extra or {}
@@ -358,8 +360,12 @@ class Chain:
                 g['dbh'] = g['dbh'][:h.n_head]
             if d is not None:
                 delta = bwd['deltas'][i]
-                dW = torch.empty_like(d.W.detach())
-                db = torch.empty(d.n_out, dtype=torch.float32, device=self.device)
+                if outs is not None and i in outs:
+                    dW, db = outs[i]
+                    assert dW.shape == d.W.shape and dW.stride(1) == 1 and db.numel() == d.n_out
+                else:
+                    dW = torch.empty_like(d.W.detach())
+                    db = torch.empty(d.n_out, dtype=torch.float32, device=self.device)
                 main_in = init if prev is None else fwd['saves'][prev]
                 sec = second.get(i)
                 parts = []

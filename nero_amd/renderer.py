@@ -290,7 +290,7 @@ class NeROShapeRenderer(nn.Module):
                               self.deviation_network.variance.detach(), rand1, rand_bg, trace)
 
     def render(self, rays_o, rays_d, near, far, human_poses, perturb_overwrite=-1, cos_anneal_ratio=0.0, is_train=True,
-               step=None, rand1=None, rand_bg=None, z_vals=None, occ_keys=None, _kern=None):
+               step=None, rand1=None, rand_bg=None, z_vals=None, occ_keys=None, _kern=None, _grad_views=None):
         """same contract as the reference (network/renderer.py:445-463); extra keyword-only style arguments rand1 / rand_bg /
         z_vals allow tests to inject the random draws or teacher-force the sample positions."""
         perturb = self.cfg['perturb']
@@ -300,16 +300,16 @@ class NeROShapeRenderer(nn.Module):
         if z_vals is None:
             z_vals = self.sample_ray(rays_o, rays_d, near, far, perturb, rand1, rand_bg, K)
         return self.render_core(rays_o, rays_d, z_vals, human_poses, cos_anneal_ratio=cos_anneal_ratio, step=step,
-                                is_train=is_train, _kern=(names, eff, K), occ_keys=occ_keys)
+                                is_train=is_train, _kern=(names, eff, K), occ_keys=occ_keys, _grad_views=_grad_views)
 
     def render_core(self, rays_o, rays_d, z_vals, human_poses, cos_anneal_ratio=0.0, step=None, is_train=True, _kern=None,
-                    occ_keys=None):
+                    occ_keys=None, _grad_views=None):
         from .shape_step import RenderCore, SDFValue, occ_loss, validation_info
         names, eff, Kpre = _kern if _kern is not None else self._kernels()
         c = self.cfg
         meta = {'names': names, 'shapes': [tuple(t.shape) for t in eff], 'shader_cfg': self.color_network.cfg, 'K': Kpre,
                 'anneal': float(cos_anneal_ratio), 'exp_max': float(self.color_network.cfg['light_exp_max']),
-                'freeze_inv_s': c['freeze_inv_s_step'] is not None and step < c['freeze_inv_s_step']}
+                'freeze_inv_s': c['freeze_inv_s_step'] is not None and step < c['freeze_inv_s_step'], 'grad_views': _grad_views}
         var = self.deviation_network.variance
         poses = None
         if self.color_network.cfg['human_light']:

@@ -86,7 +86,7 @@ class SDFField:
                 'normal': normal}
 
     # -- reverse of (sdf, feat, normal) w.r.t. the weights -----------------------------------------------------------
-    def backward(self, ctx, d_sdf4, d_feat, d_normal, workspace=None):
+    def backward(self, ctx, d_sdf4, d_feat, d_normal, workspace=None, outs=None):
         """d_sdf4 [rows_pad,4] (col 0 used), d_feat [rows_pad,256], d_normal [n,3] or None.
         -> list of 9 (dW [n_out,k], db [n_out]) for lin0..lin8 (lin8 with all 257 rows)."""
         n, x, pe, fwd, gbar = ctx['n'], ctx['x'], ctx['pe'], ctx['fwd'], ctx['gbar']
@@ -120,7 +120,7 @@ class SDFField:
                 second[l] = (gbar[l], ehat if l == 0 else tbuf[0, l - 1], ehat)
             head_extra[8] = tbuf[0, 7]
         bwd = ch.backward(fwd, n, dy=d_feat, head_dys={8: d_sdf4}, injs=injs)
-        gr = ch.weight_grads(fwd, bwd, n, pe, pe, head_dys={8: d_sdf4}, workspace=workspace, second=second, head_extra=head_extra)
+        gr = ch.weight_grads(fwd, bwd, n, pe, pe, head_dys={8: d_sdf4}, workspace=workspace, second=second, head_extra=head_extra, outs=outs)
         out = []
         for l in range(9):
             if l == 8:

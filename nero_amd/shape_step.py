@@ -268,6 +268,12 @@ class RenderCore(torch.autograd.Function):
         L.check(lib.nero_composite_bwd(_p(S['alphaRT']), _p(S['colorRT']), _p(S['weights']), _p(d_rgb), R, T, _p(d_aRT), _p(d_cRT), st))
         ws = torch.empty(L.lib.nero_dw_workspace_floats(max(n_in + row_pad(n_in), n_out, 1)), **f32)
         G = {}                                   # name -> gradient
+        # fused trainer: destinations inside the flat gradient bucket -- the weight-gradient GEMMs write there directly and the
+        # corresponding autograd outputs are None (no AccumulateGrad add kernel, no temporary)
+        gv = meta.get('grad_views') or {}
+
+        def outs_of(prefix, idxs):
+            return {i: (gv[f'{prefix}.{i}.weight'], gv[f'{prefix}.{i}.bias']) for i in idxs if f'{prefix}.{i}.weight' in gv}
 
         def put_pred(prefix, gr):
             for i in range(3):
@@ -283,12 +289,13 @@ class RenderCore(torch.autograd.Function):
             L.check(lib.nero_nerf_head_bwd(_p(trunk['heads'][8]), _p(head['heads'][2]), _p(S['dist_o']), n_out, _p(d_ao), _p(d_co),
                                            _p(d_sig4), _p(d_rgb4), st))
             hb = K.nerf_head.backward(head, n_out, head_dys={2: d_rgb4}, need_dinit=True)
-            hg = K.nerf_head.weight_grads(head, hb, n_out, trunk['saves'][7], S['pev32'], head_dys={2: d_rgb4}, workspace=ws)
+            hg = K.nerf_head.weight_grads(head, hb, n_out, trunk['saves'][7], S['pev32'], head_dys={2: d_rgb4}, workspace=ws,
+                                          outs={i: (gv[f'nerf.{n}.weight'], gv[f'nerf.{n}.bias']) for i, n in ((0, 'feature'), (1, 'views')) if f'nerf.{n}.weight' in gv})
             G['nerf.feature.weight'], G['nerf.feature.bias'] = hg[0]['dW'], hg[0]['db']
             G['nerf.views.weight'], G['nerf.views.bias'] = hg[1]['dW'], hg[1]['db']
             G['nerf.rgb.weight'], G['nerf.rgb.bias'] = hg[2]['dWh'], hg[2]['dbh']
             tb = K.nerf_trunk.backward(trunk, n_out, dy=hb['d_init'], head_dys={8: d_sig4})
-            tg = K.nerf_trunk.weight_grads(trunk, tb, n_out, S['pe88'], S['pe88'], head_dys={8: d_sig4}, workspace=ws)
+            tg = K.nerf_trunk.weight_grads(trunk, tb, n_out, S['pe88'], S['pe88'], head_dys={8: d_sig4}, workspace=ws, outs=outs_of('nerf.pts', range(8)))
             for i in range(8):
                 G[f'nerf.pts.{i}.weight'], G[f'nerf.pts.{i}.bias'] = tg[i]['dW'], tg[i]['db']
             G['nerf.alpha.weight'], G['nerf.alpha.bias'] = tg[8]['dWh'], tg[8]['dbh']
@@ -312,15 +319,16 @@ class RenderCore(torch.autograd.Function):
                                                _p(f_h['heads'][3] if f_h else None), _p(S['hmask']), _p(dLhum), st))
             n2 = rpi + n_in
             ob = K.outer_light.backward(f_out, n2, head_dys={3: dLh}, need_dinit=True)
-            put_pred('outer_light', K.outer_light.weight_grads(f_out, ob, n2, S['Xo2'], None, head_dys={3: dLh}, workspace=ws))
+            put_pred('outer_light', K.outer_light.weight_grads(f_out, ob, n2, S['Xo2'], None, head_dys={3: dLh}, workspace=ws, outs=outs_of('outer_light', range(3))))
             ib = K.inner_light.backward(f_in, n_in, head_dys={3: dLi}, need_dinit=True)
-            put_pred('inner_light', K.inner_light.weight_grads(f_in, ib, n_in, S['Xi'], None, head_dys={3: dLi}, workspace=ws))
+            put_pred('inner_light', K.inner_light.weight_grads(f_in, ib, n_in, S['Xi'], None, head_dys={3: dLi}, workspace=ws, outs=outs_of('inner_light', range(3))))
             wb = K.inner_weight.backward(f_w, n_in, head_dys={3: dLo})
-            put_pred('inner_weight', K.inner_weight.weight_grads(f_w, wb, n_in, S['Xo'], None, head_dys={3: dLo}, workspace=ws))
+            put_pred('inner_weight', K.inner_weight.weight_grads(f_w, wb, n_in, S['Xo'], None, head_dys={3: dLo}, workspace=ws, outs=outs_of('inner_weight', range(3))))
             extra = None
             if f_h:
                 hb = K.human_light.backward(f_h, n_in, head_dys={3: dLhum}, need_dinit=True)
-                put_pred('human_light_predictor', K.human_light.weight_grads(f_h, hb, n_in, S['Xh'], None, head_dys={3: dLhum}, workspace=ws))
+                put_pred('human_light_predictor', K.human_light.weight_grads(f_h, hb, n_in, S['Xh'], None, head_dys={3: dLhum}, workspace=ws,
+                                                                         outs=outs_of('human_light_predictor', range(3))))
                 extra = torch.empty((rpi, 4), **f32)
                 L.check(lib.nero_human_encode_bwd(_p(S['x4']), _p(geo), _p(mat), _p(S['inner_idx']), T, _p(S['poses']), n_in,
                                                   _p(hb['d_init']), _p(extra), st))
@@ -332,13 +340,13 @@ class RenderCore(torch.autograd.Function):
             feat = S['sctx']['feat']
             for j, (c, name, dh) in enumerate(zip(K.mat, ('metallic_predictor', 'roughness_predictor', 'albedo_predictor'), (dmr, drr, dar))):
                 mb = c.backward(S['mats'][j], n_in, head_dys={3: dh}, need_dinit=True, dinit_out=d_feat, accumulate_dinit=(j > 0))
-                put_pred(name, c.weight_grads(S['mats'][j], mb, n_in, feat, S['x8'], head_dys={3: dh}, workspace=ws))
+                put_pred(name, c.weight_grads(S['mats'][j], mb, n_in, feat, S['x8'], head_dys={3: dh}, workspace=ws, outs=outs_of(name, range(3))))
             d_sdf4, d_grad, dinv = torch.empty((rpi, 4), **f32), torch.empty((rpi, 3), **f32), torch.empty(rpi, **f32)
             d_gerr_c = d_gerr.contiguous() if d_gerr is not None else None
             L.check(lib.nero_sdf_alpha_bwd(_p(S['sctx']['sdf4']), _p(S['sctx']['normal']), _p(S['x4']), _p(S['inner_idx']), _p(S['d']), T,
                                            _p(S['variance']), C.c_float(meta['anneal']), n_in, _p(d_ai), _p(d_gerr_c), _p(d_geo),
                                            _p(d_sdf4), _p(d_grad), _p(dinv), st))
-            sg = K.sdf.backward(S['sctx'], d_sdf4, d_feat, d_grad, workspace=ws)
+            sg = K.sdf.backward(S['sctx'], d_sdf4, d_feat, d_grad, workspace=ws, outs=outs_of('sdf', range(8)))
             for l in range(9):
                 G[f'sdf.{l}.weight'], G[f'sdf.{l}.bias'] = sg[l]
             if not meta['freeze_inv_s']:
@@ -348,8 +356,11 @@ class RenderCore(torch.autograd.Function):
                 d_var = dinv[:n_in].sum() * 10.0 * inv_s * live
         grads = []
         for name, shape in zip(meta['names'], meta['shapes']):
-            g = G.get(name)
-            grads.append(g if g is not None else torch.zeros(shape, **f32))
+            g, v = G.get(name), gv.get(name)
+            if v is not None and (g is None or g.data_ptr() == v.data_ptr()):
+                grads.append(None)               # written in place (or no gradient this step: the bucket was zeroed)
+            else:
+                grads.append(g if g is not None else torch.zeros(shape, **f32))
         ctx.S = None
         return (None, None, None, None, d_var, None, None) + tuple(grads)
 

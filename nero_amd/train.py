@@ -108,6 +108,7 @@ class FusedShapeOptimizer:
             off += p_.numel()
         self.reparametrise()
         self.K = ShapeKernels(unflatten_effective(self.names, [t.detach() for t in self.eff]), net.color_network.cfg, device)
+        self.grad_views = {n: t.grad for n, t in zip(self.names, self.eff)}     # where the weight-gradient GEMMs write
 
     @staticmethod
     def _linears(net):
@@ -229,7 +230,7 @@ class ShapeTrainStep:
         o, d, gt = self._batch()
         near, far = net.near_far_from_sphere(o, d)
         out = net.render(o, d, near, far, None, -1, net.get_anneal_val(step), is_train=True, step=step,
-                         _kern=self.fopt.kernels() if self.fused else None)
+                         _kern=self.fopt.kernels() if self.fused else None, _grad_views=self.fopt.grad_views if self.fused else None)
         # data parallel: the eikonal mean runs over each rank's own inner samples and the occlusion loss over its own candidate
         # set -> weight both by their global counts so that N ranks reproduce the single-process means
         w_eik, w_occ = global_count_weights([out['_state']['n_in'], out.get('_occ_count', 0)], self.world, self.device)
