@@ -49,7 +49,7 @@ def hbm_traffic_per_launch(kernel):
         try:
             for line in open(os.path.join(ROOT, 'profiles', name)):
                 f = line.strip().split(',')
-                if len(f) == 5 and f[0] == kernel:
+                if len(f) in (5, 6) and f[0] == kernel:      # kernel, launches, fetch_kb_raw, fetch_kb (x2 corrected), write_kb[, gb_per_step]
                     return int((float(f[3]) + float(f[4])) * 1024), name
         except OSError:
             pass

@@ -14,7 +14,7 @@ for tag, cn in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
     a = collections.defaultdict(float); n = collections.Counter()
     for r in csv.DictReader(open(f[0])):
         if r['Counter_Name'] != cn: continue
-        k = r['Kernel_Name'].split('(')[0].replace('void ', '').replace('(anonymous namespace)::', '')
+        k = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0].split('<')[0]
         a[k] += float(r['Counter_Value']); n[k] += 1
     tot[tag] = (a, n)
 ks = sorted(tot['fetch'][0], key=lambda k: -(tot['fetch'][0][k] + tot['write'][0].get(k, 0)))[:14]
