@@ -35,10 +35,11 @@ PEAK_F32_MFMA = 157.3e12                                 # MI355X dense fp32 MFM
 PEAK_BF16_MFMA = 2500e12                                 # MI355X dense bf16 / fp16 MFMA peak (same guide)
 # fp32-equivalent ceilings of the arithmetic the dense layers run on (nero_amd/chain.py GEMM_MODE): the f32-input MFMA itself,
 # the bf16 matrix pipe issuing 6 plane products per fp32 multiply-add (mlp_split.hip), the fp16 pipe issuing 3 (mlp_f16x3.hip)
-PEAK_OF_MODE = {0: PEAK_F32_MFMA, 1: PEAK_BF16_MFMA / 6, 2: PEAK_BF16_MFMA / 3}
+PEAK_OF_MODE = {0: PEAK_F32_MFMA, 1: PEAK_BF16_MFMA / 6, 2: PEAK_BF16_MFMA / 3, 3: PEAK_BF16_MFMA / 3}
 MFMA_OF_MODE = {0: 'v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain)',
                 1: 'v_mfma_f32_32x32x16_bf16, 3 exact bf16 planes per operand, 6 plane products per fp32 multiply-add: peak = 2500 / 6',
                 2: 'v_mfma_f32_32x32x16_f16, 2 block-scaled fp16 planes per operand, 3 plane products per fp32 multiply-add: peak = 2500 / 3'}
+MFMA_OF_MODE[3] = MFMA_OF_MODE[2]
 BELL = {'freeze_inv_s_step': 15000, 'apply_occ_loss': True, 'occ_loss_step': 20000}      # configs/shape/syn/bell.yaml
 VARIANCE = 0.5
 
@@ -355,8 +356,10 @@ def main():
         L.lib.nero_prof_enable(0)
         rep = (C.c_double * 12)()
         L.lib.nero_prof_report(rep)
-        kname = {'fwd': ('mlp_fwd_kernel', 'fwd_split_kernel', 'fwd_f16_kernel'), 'tan': ('mlp_tan_kernel', 'tan_split_kernel', 'tan_f16_kernel'),
-                 'bwd': ('mlp_bwd_kernel', 'bwd_split_kernel', 'bwd_f16_kernel'), 'dw': ('dw_gemm_kernel', 'dw_split_kernel', 'dw_split_kernel')}
+        kname = {'fwd': ('mlp_fwd_kernel', 'fwd_split_kernel', 'fwd_f16_kernel', 'fwd_p_kernel'),
+                 'tan': ('mlp_tan_kernel', 'tan_split_kernel', 'tan_f16_kernel', 'tan_p_kernel'),
+                 'bwd': ('mlp_bwd_kernel', 'bwd_split_kernel', 'bwd_f16_kernel', 'bwd_p_kernel'),
+                 'dw': ('dw_gemm_kernel', 'dw_split_kernel', 'dw_f16_kernel', 'dw_f16_kernel')}
         passes = ('fwd', 'tan', 'bwd', 'dw')
         kinds = [kname[m][CH.GEMM_MODE[m]] for m in passes]
         peaks = [PEAK_OF_MODE[CH.GEMM_MODE[m]] for m in passes]
@@ -379,7 +382,7 @@ def main():
 
     if rank == 0:
         split = CH.GEMM_MODE['fwd'] != L.GEMM_F32
-        modes = {k: {0: 'f32', 1: 'bf16x6', 2: 'f16x3'}[v] for k, v in CH.GEMM_MODE.items()}
+        modes = {k: {0: 'f32', 1: 'bf16x6', 2: 'f16x3', 3: 'f16x3p'}[v] for k, v in CH.GEMM_MODE.items()}
         # whole-step algorithmic FLOPs with the measured inner/outer split of this rank
         sampler_evals = args.rays * (64 + 3 * 16)
         flop_step = (n_in / args.steps) * 2 * (6 * C_SDF + 3 * C_APP) + (n_out / args.steps) * 2 * 3 * C_NERF + sampler_evals * 2 * C_SDF

@@ -33,10 +33,10 @@ enum { NERO_ACT_NONE = 0, NERO_ACT_RELU = 1, NERO_ACT_SOFTPLUS100 = 2 };
 /* F16X3: operands as two fp16 planes (h, l*2^11) of their block-scaled value (per activation row / per weight matrix, exact
  * powers of two), three plane products in two accumulator sets -- half the MFMA count of BF16X6 at the same error class
  * (representation error <= 2^-24 of the block maximum, dropped term <= 2^-24 of the product). */
-/* F16X3R: the F16X3 arithmetic and packed images, "row-owner" kernels (mlp_ro.hip): a wave keeps its 32 rows' operand fragments in
- * registers for the whole chain, the weights stream through an LDS ring shared by the 4 waves of a 128-row workgroup, heads run on
- * the matrix pipe (nero_fwd_layer.head_w is then a packed kind-3 image of the [n_head, head_k] matrix, head_k a multiple of 16). */
-enum { NERO_GEMM_F32 = 0, NERO_GEMM_BF16X6 = 1, NERO_GEMM_F16X3 = 2, NERO_GEMM_F16X3R = 3 };
+/* F16X3P: the F16X3 arithmetic, packed images and results (bit for bit) on 256-thread workgroups, two resident per CU
+ * (mlp_f16p.hip): a wave computes two feature tiles one after the other, the aux operand is converted from global memory, so that
+ * one workgroup's epilogue / barriers / HBM waits are covered by the other's MFMAs. */
+enum { NERO_GEMM_F32 = 0, NERO_GEMM_BF16X6 = 1, NERO_GEMM_F16X3 = 2, NERO_GEMM_F16X3P = 3 };
 enum { NERO_OK = 0, NERO_ERR_ARG = -1, NERO_ERR_LAUNCH = -2, NERO_ERR_UNSUPPORTED = -3 };
 
 const char* nero_last_error(void);

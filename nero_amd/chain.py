@@ -14,19 +14,19 @@ from . import _lib as L
 
 # arithmetic of the dense layers (include/nero_hip.h NERO_GEMM_*), all fp32-grade (tests/test_mlp_engine.py runs every test in
 # every mode against the same fp64 reference and tolerance):
-#   'f16x3'  (default for the forward / tangent / reverse chain kernels) two block-scaled fp16 planes, 3 MFMA products
-#   'bf16x6' (default for the weight-gradient GEMM; f16x3 does not fit its 64 accumulator tiles) three bf16 planes, 6 products
-#   'f16x3r' the f16x3 arithmetic and operand images on the row-owner kernels (mlp_ro.hip): activations in registers, weights
-#            streamed through LDS, heads on the matrix pipe
+#   'f16x3'  (default) two block-scaled fp16 planes, 3 MFMA products: per activation row / weight matrix in the chain kernels
+#            (mlp_f16x3.hip), per 16-row chunk with a running accumulator unit in the weight-gradient GEMM (mlp_f16dw.hip)
+#   'bf16x6' three bf16 planes, 6 products (mlp_split.hip)
+#   'f16x3p' the f16x3 arithmetic, operand images and results on 256-thread workgroups, two resident per CU (mlp_f16p.hip)
 #   'f32'    the f32-input MFMA, an exact fmaf chain
 # NERO_GEMM=<mode> selects all passes, NERO_GEMM_FWD / _TAN / _BWD / _DW one pass.
-_MODE_NAMES = {'f32': L.GEMM_F32, 'bf16x6': L.GEMM_BF16X6, 'f16x3': L.GEMM_F16X3, 'f16x3r': L.GEMM_F16X3R}
-_F16 = (L.GEMM_F16X3, L.GEMM_F16X3R)          # the two engines that share the kind-3 packed images
-_DEFAULT = {'fwd': 'f16x3', 'tan': 'f16x3', 'bwd': 'f16x3', 'dw': 'bf16x6'}
+_MODE_NAMES = {'f32': L.GEMM_F32, 'bf16x6': L.GEMM_BF16X6, 'f16x3': L.GEMM_F16X3, 'f16x3p': L.GEMM_F16X3P}
+_F16 = (L.GEMM_F16X3, L.GEMM_F16X3P)          # the two engines that share the kind-3 packed images
+_DEFAULT = {'fwd': 'f16x3', 'tan': 'f16x3', 'bwd': 'f16x3', 'dw': 'f16x3'}
 
 
 def _resolve(mode, k):
-    return _MODE_NAMES['bf16x6' if (mode in ('f16x3', 'f16x3r') and k == 'dw') else mode]
+    return _MODE_NAMES['f16x3' if (mode == 'f16x3p' and k == 'dw') else mode]      # (one fp16 weight-gradient kernel)
 
 
 GEMM_MODE = {k: _resolve(os.environ.get('NERO_GEMM_' + k.upper(), os.environ.get('NERO_GEMM', _DEFAULT[k])), k)
@@ -123,8 +123,6 @@ class Chain:
             if h is not None:
                 e['hw'] = 4 * L.HID
                 e['hb'] = 4
-                if GEMM_MODE['fwd'] == L.GEMM_F16X3R:                             # head as one 32-row MFMA tile over the input
-                    e['hwp'] = 64 + (_r16(h.k) // 16) * 512
             sizes.append(e)
         return sizes
 
@@ -185,8 +183,6 @@ class Chain:
                 Wh = h.W.detach()
                 assert Wh.stride(1) == 1
                 job(2, Wh, p['hw'], h.n_head, Wh.stride(0), 0, h.k, 0, L.HID, 0)
-                if 'hwp' in p:
-                    job(3, Wh, p['hwp'], h.n_head, Wh.stride(0), 0, h.k, 0, _r16(h.k), 1)
                 if h.b is not None:
                     job(2, h.b.detach(), p['hb'], 1, h.n_head, 0, h.n_head, 0, 4, 0)
             packed.append(p)
@@ -206,7 +202,7 @@ class Chain:
         ch.aux, ch.ld_aux, ch.k_aux = L.ptr(aux), (aux.stride(0) if aux is not None else 0), self.k_aux
         ch.n_layers, ch.aux_wide = len(self.entries), int(self.aux_wide)
         split = GEMM_MODE['fwd'] != L.GEMM_F32
-        fkeys = {L.GEMM_F32: ('fm', 'fa'), L.GEMM_BF16X6: ('sfm', 'sfa'), L.GEMM_F16X3: ('hfm', 'hfa'), L.GEMM_F16X3R: ('hfm', 'hfa')}[GEMM_MODE['fwd']]
+        fkeys = {L.GEMM_F32: ('fm', 'fa'), L.GEMM_BF16X6: ('sfm', 'sfa'), L.GEMM_F16X3: ('hfm', 'hfa'), L.GEMM_F16X3P: ('hfm', 'hfa')}[GEMM_MODE['fwd']]
         ch.gemm_mode = GEMM_MODE['fwd']
         ch.macs_per_row = float(sum(d.n_out * (d.k_main + d.k_aux) for d, _ in self.entries if d is not None))
         if init is not None:
@@ -222,7 +218,7 @@ class Chain:
         # ReLU sign masks (32 B per row and layer) for the reverse pass of the fp16 tile engine: it then skips the 1 KiB/row read of
         # the saved activation (the weight-gradient GEMM still reads it)
         masks = [None] * len(self.entries)
-        relu_idx = [i for i in self.dense_idx if save and self.entries[i][0].act == L.ACT_RELU] if GEMM_MODE['fwd'] == L.GEMM_F16X3 else []
+        relu_idx = [i for i in self.dense_idx if save and self.entries[i][0].act == L.ACT_RELU] if GEMM_MODE['fwd'] in _F16 else []
         mbuf = torch.empty((len(relu_idx), rp, 8), dtype=torch.int32, device=self.device) if relu_idx else None
         for k, i in enumerate(relu_idx):
             masks[i] = mbuf[k]
@@ -233,8 +229,6 @@ class Chain:
                 heads[i] = ho
                 fl.head_w, fl.head_b, fl.head_out = p['hw'].data_ptr(), p['hb'].data_ptr(), ho.data_ptr()
                 fl.n_head, fl.head_k = h.n_head, (h.k + 3) // 4 * 4
-                if GEMM_MODE['fwd'] == L.GEMM_F16X3R:
-                    fl.head_w, fl.head_k = p['hwp'].data_ptr(), _r16(h.k)
             if d is not None:
                 rk = _r16 if split else _r8
                 fl.w_main = L.ptr(p.get(fkeys[0]))
@@ -264,7 +258,7 @@ class Chain:
         ch = L.BwdChain()
         ch.n_layers, ch.aux_wide = len(self.entries), 0
         split = GEMM_MODE['bwd'] != L.GEMM_F32
-        bkeys = {L.GEMM_F32: ('bm', 'ba'), L.GEMM_BF16X6: ('sbm', 'sba'), L.GEMM_F16X3: ('hbm', 'hba'), L.GEMM_F16X3R: ('hbm', 'hba')}[GEMM_MODE['bwd']]
+        bkeys = {L.GEMM_F32: ('bm', 'ba'), L.GEMM_BF16X6: ('sbm', 'sba'), L.GEMM_F16X3: ('hbm', 'hba'), L.GEMM_F16X3P: ('hbm', 'hba')}[GEMM_MODE['bwd']]
         ch.gemm_mode = GEMM_MODE['bwd']
         rk = _r16 if split else _r8
         last = len(self.entries) - 1
@@ -309,7 +303,7 @@ class Chain:
                 bl.a_prev = saves[j].data_ptr()
                 bl.act_prev = self.entries[j][0].act
                 mk = fwd.get('masks')
-                if mk is not None and mk[j] is not None and GEMM_MODE['bwd'] == L.GEMM_F16X3:
+                if mk is not None and mk[j] is not None and GEMM_MODE['bwd'] in _F16:
                     bl.mask_prev = mk[j].data_ptr()
                 bl.delta_prev = deltas[j].data_ptr()
                 if j in injs:

@@ -1,7 +1,23 @@
-// mlp_f16_util.h -- device helpers shared by the two fp16 two-plane engines (mlp_f16x3.hip: activations in LDS, 64-row tiles;
-// mlp_ro.hip: activations in registers, weights streamed through LDS): block scaling, fp32 <-> fp16 plane pairs, the softplus
-// (beta = 100) family.  Include inside an anonymous namespace.
+// mlp_f16_util.h -- device helpers shared by the fp16 two-plane chain kernels (mlp_f16x3.hip: one 512-thread workgroup per CU;
+// mlp_f16p.hip: two 256-thread workgroups per CU): block scaling, fp32 <-> fp16 plane pairs, the softplus (beta = 100) family,
+// the three-product GEMM core.  Include inside an anonymous namespace.
 #pragma once
+
+// ---- phase timing (scripts/f16_variants.sh, -DF16_PHASE_TIMING): shader-clock cycles of wave 0 of every workgroup per phase ----
+#ifdef F16_PHASE_TIMING
+__device__ unsigned long long g_phase[16];
+#define PH_DECL long long ph_t = clock64(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PH(k) do { __builtin_amdgcn_sched_barrier(0); const long long t_ = clock64(); ph_acc[k] += t_ - ph_t; ph_t = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PH_PARAM , long long& ph_t, long long (&ph_acc)[8]
+#define PH_ARG , ph_t, ph_acc
+#define PH_END do { if (threadIdx.x == 0) for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&g_phase[k_], (unsigned long long)ph_acc[k_]); } while (0)
+#else
+#define PH_PARAM
+#define PH_ARG
+#define PH_DECL
+#define PH(k)
+#define PH_END
+#endif
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -98,4 +114,165 @@ __device__ __forceinline__ void tan_elem(float a, float zd, float gb, bool live,
 }
 __device__ __forceinline__ float amax4(float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
 __device__ __forceinline__ float4 scale4(float4 v, float s) { return make_float4(v.x * s, v.y * s, v.z * s, v.w * s); }
+
+
+// ---- GEMM core ------------------------------------------------------------------------------------------------------------
+// accH[r] += wh xh,  accL[r] += wh xl + wl xh  over `n` k-steps of 16 (r = 32-row half).  Weight planes three steps ahead in a
+// ring of four register sets (L2 stream), activation planes one step ahead in a double buffer (LDS).
+struct WF { uint4 wh, wl; };
+struct XF { uint4 xh0, xl0, xh1, xl1; };
+
+__device__ __forceinline__ void load_w(WF& o, const uint4* wp, int c) {
+#ifdef F16_NO_WSTREAM                               // (timing experiments, scripts/f16_variants.sh: every k-step re-reads step 0)
+    c = 0;
+#endif
+    const uint4* w = wp + (size_t)c * 128;
+    o.wh = w[0];
+    o.wl = w[64];
+}
+__device__ __forceinline__ void load_x(XF& o, const char* xp, int half_bytes, int plane_bytes, int c) {
+    const char* x = xp + c * 32;
+    o.xh0 = *reinterpret_cast<const uint4*>(x);
+    o.xl0 = *reinterpret_cast<const uint4*>(x + plane_bytes);
+    x += half_bytes;
+    o.xh1 = *reinterpret_cast<const uint4*>(x);
+    o.xl1 = *reinterpret_cast<const uint4*>(x + plane_bytes);
+}
+#define NERO_MFH(ACC, A, B) \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), ACC, 0, 0, 0)
+__device__ __forceinline__ void ops_compute(f32x16 (&aH)[2], f32x16 (&aL)[2], const WF& w, const XF& x) {
+#ifdef F16_NO_MFMA
+    aH[0][0] += __uint_as_float(w.wh.x ^ x.xh0.x); aL[0][0] += __uint_as_float(w.wl.x ^ x.xl0.x);
+    aH[1][0] += __uint_as_float(w.wh.y ^ x.xh1.x); aL[1][0] += __uint_as_float(w.wl.y ^ x.xl1.x);
+    return;
+#endif
+#ifdef GEMM_ORDER2
+    NERO_MFH(aL[0], w.wh, x.xl0); NERO_MFH(aH[0], w.wh, x.xh0); NERO_MFH(aL[1], w.wh, x.xl1);
+    NERO_MFH(aH[1], w.wh, x.xh1); NERO_MFH(aL[0], w.wl, x.xh0); NERO_MFH(aL[1], w.wl, x.xh1);
+#else
+    NERO_MFH(aL[0], w.wl, x.xh0); NERO_MFH(aL[1], w.wl, x.xh1);
+    NERO_MFH(aH[0], w.wh, x.xh0); NERO_MFH(aH[1], w.wh, x.xh1);
+    NERO_MFH(aL[0], w.wh, x.xl0); NERO_MFH(aL[1], w.wh, x.xl1);
+#endif
+}
+#ifdef GEMM_NOFENCE
+#define NERO_FENCE()
+#else
+#define NERO_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
+__device__ __forceinline__ void gemm_f16x3_loop(f32x16 (&aH)[2], f32x16 (&aL)[2], const uint4* wp, const char* xp, int half_bytes,
+                                           int plane_bytes, int n) {
+    if (n <= 0) return;
+    WF wa, wb, wc, wd;
+    XF xa, xb;
+    const int last = n - 1;
+#define NERO_CL(c) ((c) < last ? (c) : last)
+    load_w(wa, wp, 0);
+    load_w(wb, wp, NERO_CL(1));
+    load_w(wc, wp, NERO_CL(2));
+    load_x(xa, xp, half_bytes, plane_bytes, 0);
+    NERO_FENCE();
+    for (int c = 0; c < n; c += 4) {
+        load_w(wd, wp, NERO_CL(c + 3)); load_x(xb, xp, half_bytes, plane_bytes, NERO_CL(c + 1)); NERO_FENCE();
+        ops_compute(aH, aL, wa, xa); NERO_FENCE();
+        if (c + 1 < n) {
+            load_w(wa, wp, NERO_CL(c + 4)); load_x(xa, xp, half_bytes, plane_bytes, NERO_CL(c + 2)); NERO_FENCE();
+            ops_compute(aH, aL, wb, xb); NERO_FENCE();
+        }
+        if (c + 2 < n) {
+            load_w(wb, wp, NERO_CL(c + 5)); load_x(xb, xp, half_bytes, plane_bytes, NERO_CL(c + 3)); NERO_FENCE();
+            ops_compute(aH, aL, wc, xa); NERO_FENCE();
+        }
+        if (c + 3 < n) {
+            load_w(wc, wp, NERO_CL(c + 6)); load_x(xa, xp, half_bytes, plane_bytes, NERO_CL(c + 4)); NERO_FENCE();
+            ops_compute(aH, aL, wd, xb); NERO_FENCE();
+        }
+    }
+#undef NERO_CL
+}
+
+
+// compile-time step count (the 256-wide layers: 16 steps), fully unrolled: no clamps, no branches, every ring slot a fixed register
+// set.  XD = how many steps ahead the activation fragments are requested (ring of XD + 1 sets), weights three steps ahead.
+template <int V> struct IC { static constexpr int value = V; };
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(IC<I>{}); static_for<I + 1, N>(f); }
+}
+#ifndef GEMM_XD
+#define GEMM_XD 1
+#endif
+#ifndef GEMM_WD
+#define GEMM_WD 3
+#endif
+template <int N>
+__device__ __forceinline__ void gemm_f16x3_fixed(f32x16 (&aH)[2], f32x16 (&aL)[2], const uint4* wp, const char* xp, int half_bytes,
+                                                 int plane_bytes) {
+    constexpr int XD = GEMM_XD, XN = XD + 1, WD = GEMM_WD, WN = WD + 1;
+    WF w[WN];
+    XF x[XN];
+    static_for<0, WD>([&](auto c) { if (c.value < N) load_w(w[c.value], wp, c.value); });
+    static_for<0, XD>([&](auto c) { if (c.value < N) load_x(x[c.value], xp, half_bytes, plane_bytes, c.value); });
+    NERO_FENCE();
+    static_for<0, N>([&](auto cc) {
+        constexpr int c = cc.value;
+        if (c + WD < N) load_w(w[(c + WD) % WN], wp, c + WD);
+        if (c + XD < N) load_x(x[(c + XD) % XN], xp, half_bytes, plane_bytes, c + XD);
+        NERO_FENCE();
+        ops_compute(aH, aL, w[c % WN], x[c % XN]);
+        NERO_FENCE();
+    });
+}
+
+// run-time step count n <= 16 on the same unrolled body: every step guarded by a wave-uniform branch (no clamps, no ring rotation)
+__device__ __forceinline__ void gemm_f16x3_masked(f32x16 (&aH)[2], f32x16 (&aL)[2], const uint4* wp, const char* xp, int half_bytes,
+                                                  int plane_bytes, int n) {
+    constexpr int XD = GEMM_XD, XN = XD + 1, WD = GEMM_WD, WN = WD + 1;
+    WF w[WN];
+    XF x[XN];
+    static_for<0, WD>([&](auto c) { if (c.value < n) load_w(w[c.value], wp, c.value); });
+    static_for<0, XD>([&](auto c) { if (c.value < n) load_x(x[c.value], xp, half_bytes, plane_bytes, c.value); });
+    NERO_FENCE();
+    static_for<0, 16>([&](auto cc) {
+        constexpr int c = cc.value;
+        if (c + WD < n) load_w(w[(c + WD) % WN], wp, c + WD);
+        if (c + XD < n) load_x(x[(c + XD) % XN], xp, half_bytes, plane_bytes, c + XD);
+        NERO_FENCE();
+        if (c < n) ops_compute(aH, aL, w[c % WN], x[c % XN]);
+        NERO_FENCE();
+    });
+}
+
+__device__ __forceinline__ void gemm_f16x3(f32x16 (&aH)[2], f32x16 (&aL)[2], const uint4* wp, const char* xp, int half_bytes,
+                                           int plane_bytes, int n) {
+#ifdef GEMM_MASKED
+    gemm_f16x3_masked(aH, aL, wp, xp, half_bytes, plane_bytes, n); return;
+#endif
+#ifdef GEMM_ASSUME16                                   // (timing experiments on all-256-wide chains only: wrong for any other K)
+    gemm_f16x3_fixed<16>(aH, aL, wp, xp, half_bytes, plane_bytes); return;
+#endif
+#ifdef GEMM_FIXED16
+    if (n == 16) { gemm_f16x3_fixed<16>(aH, aL, wp, xp, half_bytes, plane_bytes); return; }
+#endif
+    gemm_f16x3_loop(aH, aL, wp, xp, half_bytes, plane_bytes, n);
+}
+
+__device__ __forceinline__ void zero2(f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[r][v] = 0.f;
+}
+
+// row maxima of this wave's 64x32 block (two rows per lane) -> rmax[row][wave]
+__device__ __forceinline__ void publish_rowmax(float* rmax, float m0, float m1, int wave, int i, int h) {
+    m0 = fmaxf(m0, __shfl_xor(m0, 32));
+    m1 = fmaxf(m1, __shfl_xor(m1, 32));
+    if (h == 0) { rmax[i * 8 + wave] = m0; rmax[(32 + i) * 8 + wave] = m1; }
+}
+__device__ __forceinline__ float row_max8(const float* rmax, int row) {
+    const float4 a = *reinterpret_cast<const float4*>(rmax + row * 8);
+    const float4 b = *reinterpret_cast<const float4*>(rmax + row * 8 + 4);
+    return fmaxf(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)));
+}
 

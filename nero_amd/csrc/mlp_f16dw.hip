@@ -1,0 +1,328 @@
+// mlp_f16dw.hip -- the weight-gradient GEMM on the fp16 matrix pipe with THREE plane products per fp32 multiply-add
+// (nero_dw_job.gemm_mode NERO_GEMM_F16X3; the bf16x6 kernel of mlp_split.hip needs six).
+//
+//   C[n][k] = sum_r D[r][n] B[r][k]        (contraction over the batch rows, split over row slices; dw_reduce_kernel adds the slices)
+//
+// Same staging as dw_split_kernel: a chunk of 16 batch rows per step, thread (col, rh) loads rows 8rh..8rh+7 of its column of D
+// and of B, converts them and writes one 16-byte LDS entry per plane in fragment order; chunks double buffered.
+//
+// Arithmetic.  The contraction runs over the rows, so the block scale of an operand must be uniform over the 16 rows of a chunk:
+// every chunk of D and of B is scaled by an exact power of two that puts its largest magnitude into [2^14, 2^15) -- the top of
+// fp16's range -- and split as  xs = h + l,  h = fp16(xs),  l = fp16(xs - h)  (the TRUE remainder: at this scale it stays a normal
+// fp16 number for every element within 2^-2 of the chunk maximum and has an absolute error <= 2^-25 below that, i.e. the pair
+// represents xs to 2^-39 of the chunk maximum or better).  hD hB + hD lB + lD hB go into ONE fp32 accumulator (dropped:
+// lD lB <= 2^-24 of the product).  Chunks have different scales; the accumulator keeps a running unit 2^(E-30), E = the largest
+// eD + eB seen so far: a chunk whose eD + eB is smaller by s is shifted down by s binary places, split between the two operands
+// (each absorbs 15 places without leaving fp32 grade, 29 before its maximum stops being representable; beyond s = 58 the chunk
+// is below 2^-58 of the largest one and contributes nothing to an fp32 sum); a chunk that raises E rescales the accumulators
+// (exact, rare: the running maximum settles after the first chunks).  Chunk maxima are exchanged through LDS one pipeline stage
+// ahead, so the exchange adds no barrier.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/nero_hip.h"
+#include "common.h"
+#include "mlp_split.h"
+
+namespace {
+
+#ifdef DW_PHASE_TIMING
+__device__ unsigned long long g_dw_phase[8];
+#define DPH_DECL long long ph_t = clock64(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define DPH(k) do { __builtin_amdgcn_sched_barrier(0); const long long t_ = clock64(); ph_acc[k] += t_ - ph_t; ph_t = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define DPH_END do { if (threadIdx.x == 0) for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&g_dw_phase[k_], (unsigned long long)ph_acc[k_]); } while (0)
+#else
+#define DPH_DECL
+#define DPH(k)
+#define DPH_END
+#endif
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int DWH_PLANE = 2 * 256 * 16;              // one plane of one matrix: [2][256] x 16 B = 8 KB
+constexpr int DWH_MAT = 2 * DWH_PLANE;               // h + l = 16 KB
+constexpr int DWH_STAGE = 2 * DWH_MAT;               // D + B = 32 KB
+constexpr int DWH_SMAX = 2 * DWH_STAGE;              // float smax[2 slots][8 waves][2]
+constexpr int DWH_LDS = DWH_SMAX + 2 * 8 * 2 * 4;
+
+__device__ __forceinline__ int exp_of(float m) {     // e with m * 2^-e in [0.5, 1) (0 for m == 0 / denormal), clamped
+    const int eb = (__float_as_uint(m) >> 23) & 0xff;
+    int e = eb ? eb - 126 : -60;
+    return e < -60 ? -60 : (e > 60 ? 60 : e);
+}
+__device__ __forceinline__ float p2(int e) {         // 2^e, e in [-126, 127]
+    e = e < -126 ? -126 : (e > 127 ? 127 : e);
+    return __uint_as_float((unsigned)(127 + e) << 23);
+}
+__device__ __forceinline__ unsigned pk_f16(float a, float b) {
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
+__device__ __forceinline__ void split_true(float a, float b, unsigned& h, unsigned& l) {
+    h = pk_f16(a, b);
+    const f16x2 hh = __builtin_bit_cast(f16x2, h);
+    l = pk_f16(a - (float)hh[0], b - (float)hh[1]);
+}
+
+// Operand loads through a buffer resource rebased to the chunk's first row (SALU): per-thread byte offset `off` (constant for the
+// whole kernel) + j rows; rows past the slice end and columns past the matrix width fall outside num_records and read as 0 --
+// no address arithmetic, clamps or masks in the VALU stream.
+__device__ __forceinline__ void dwh_fetch(float (&v)[8], const float* __restrict__ src, int ld, int r0, int r1, int off) {
+    const int left = r1 - r0;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)r0 * ld), 0, (left > 0 ? left : 0) * ld * 4, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off + j * ld * 4, 0, 0));
+}
+__device__ __forceinline__ float amax8(const float (&v)[8]) {
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[j]));
+    return m;
+}
+// maximum of a non-negative value over the wave on the DPP network (no LDS traffic): xor 1, xor 2, half-row mirror, row mirror,
+// then lane 15 -> next row, lane 31 -> upper half; lane 63 holds the result
+__device__ __forceinline__ float wave_max(float m) {
+#define NERO_DPPMAX(CTRL, ROWS) m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), CTRL, ROWS, 0xf, true)))
+    NERO_DPPMAX(0xB1, 0xf);
+    NERO_DPPMAX(0x4E, 0xf);
+    NERO_DPPMAX(0x141, 0xf);
+    NERO_DPPMAX(0x140, 0xf);
+    NERO_DPPMAX(0x142, 0xa);
+    NERO_DPPMAX(0x143, 0xc);
+#undef NERO_DPPMAX
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63));
+}
+__device__ __forceinline__ void dwh_put(char* mat, const float (&v)[8], float sc, int col, int rh) {
+    unsigned hp[4], lp[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split_true(v[2 * j] * sc, v[2 * j + 1] * sc, hp[j], lp[j]);
+    char* dst = mat + (rh * 256 + col) * 16;
+    *reinterpret_cast<uint4*>(dst) = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+    *reinterpret_cast<uint4*>(dst + DWH_PLANE) = make_uint4(lp[0], lp[1], lp[2], lp[3]);
+}
+struct Fr2 { uint4 h, l; };
+__device__ __forceinline__ Fr2 dwh_frag(const char* mat, int tile, int i, int h) {
+    const char* s = mat + (h * 256 + 32 * tile + i) * 16;
+    Fr2 f;
+    f.h = *reinterpret_cast<const uint4*>(s);
+    f.l = *reinterpret_cast<const uint4*>(s + DWH_PLANE);
+    return f;
+}
+#define NERO_MFH(ACC, A, B) \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), ACC, 0, 0, 0)
+__device__ __forceinline__ void mf3(f32x16& acc, const Fr2& a, const Fr2& b) {
+    NERO_MFH(acc, a.l, b.h);
+    NERO_MFH(acc, a.h, b.l);
+    NERO_MFH(acc, a.h, b.h);
+}
+
+// operand shifts of a chunk that lies s >= 0 binary places below the accumulator unit
+__device__ __forceinline__ void split_shift(int s, int& a, int& b) {
+    a = (s + 1) >> 1;
+    a = a > 29 ? 29 : a;
+    b = s - a;
+    b = b > 29 ? 29 : b;
+}
+
+#ifndef DW_SGB_V
+#define DW_SGB_V 4
+#endif
+template <bool NARROW>
+__global__ __launch_bounds__(512, 1) void dw_f16_kernel(nero_dw_job job, int n_rows, int rows_per_slice, float* __restrict__ partials,
+                                                        int n_pad, int k_pad) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* smax = reinterpret_cast<float*>(smem + DWH_SMAX);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int col = tid & 255, rh = tid >> 8;
+    const int r_begin = blockIdx.x * rows_per_slice;
+    int r_end = r_begin + rows_per_slice;
+    r_end = r_end < n_rows ? r_end : n_rows;
+    const int n_tiles = n_pad >> 5, k_tiles = k_pad >> 5;
+    constexpr int NA = NARROW ? 1 : 2;                   // n-tiles per wave
+    const int nt0 = NARROW ? wave : 2 * (wave >> 1), kt0 = NARROW ? 0 : 4 * (wave & 1);
+    f32x16 acc[NA][4];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
+    float bsum = 0.f;                                    // bias gradient partial of column `col` (rows of this thread's half)
+    const int nch = r_end > r_begin ? (r_end - r_begin + 15) / 16 : 0;
+    const int total = nch * (job.d1 ? 2 : 1);
+    constexpr int OOB = 0x40000000;                      // byte offset beyond any num_records: the load returns 0
+    const int offD0 = col < job.n_out ? (8 * rh * job.ldd0 + col) * 4 : OOB, offB0 = col < job.k_cols ? (8 * rh * job.ldb0 + col) * 4 : OOB;
+    const int offD1 = col < job.n_out ? (8 * rh * job.ldd1 + col) * 4 : OOB, offB1 = col < job.k_cols ? (8 * rh * job.ldb1 + col) * 4 : OOB;
+    auto fetch = [&](float (&vd)[8], float (&vb)[8], int q) {
+        const bool second = q >= nch;
+#ifdef DW_NOSTREAM                                       // (timing experiment: every chunk re-reads the slice's first rows, L2 hits)
+        const int r0 = r_begin;
+#else
+        const int r0 = r_begin + (second ? q - nch : q) * 16;
+#endif
+        dwh_fetch(vd, second ? job.d1 : job.d0, second ? job.ldd1 : job.ldd0, r0, r_end, second ? offD1 : offD0);
+        dwh_fetch(vb, second ? job.b1 : job.b0, second ? job.ldb1 : job.ldb0, r0, r_end, second ? offB1 : offB0);
+    };
+    // chunk maxima of the chunk held in (vd, vb) -> smax[slot][wave]
+    auto publish = [&](const float (&vd)[8], const float (&vb)[8], int slot) {
+        const float md = wave_max(amax8(vd)), mb = wave_max(amax8(vb));
+        if (lane == 0) { smax[(slot * 8 + wave) * 2] = md; smax[(slot * 8 + wave) * 2 + 1] = mb; }
+    };
+    // exponents (eD, eB) of the chunk whose maxima sit in smax[slot]
+    auto chunk_exp = [&](int slot, int& eD, int& eB) {
+        const float4* p = reinterpret_cast<const float4*>(smax + slot * 16);
+        const float4 a = p[0], b = p[1], c = p[2], d = p[3];
+        eD = exp_of(fmaxf(fmaxf(fmaxf(a.x, a.z), fmaxf(b.x, b.z)), fmaxf(fmaxf(c.x, c.z), fmaxf(d.x, d.z))));
+        eB = exp_of(fmaxf(fmaxf(fmaxf(a.y, a.w), fmaxf(b.y, b.w)), fmaxf(fmaxf(c.y, c.w), fmaxf(d.y, d.w))));
+    };
+    int E = -1000;                                       // accumulator unit = 2^(E - 30); -1000 = nothing accumulated yet
+    float resc = 1.f;                                    // factor the accumulators take before the next chunk's products are added
+    // store chunk (vd, vb), whose maxima are in smax[slot], into stage `st`; updates E / resc (selects only: `live` = false makes
+    // the call a harmless store into a stage nobody reads any more)
+    auto put = [&](const float (&vd)[8], const float (&vb)[8], int slot, char* st, bool live) {
+        int eD, eB;
+        chunk_exp(slot, eD, eB);
+        const int ec = eD + eB;
+        const bool raise = live && ec > E;
+        const float r_up = E <= -1000 ? 1.f : p2(E - ec);
+        resc = raise ? r_up : 1.f;
+        E = raise ? ec : E;
+        const int s = E - ec;                            // >= 0 for live chunks
+        int sa, sb;
+        split_shift(s < 0 ? 0 : s, sa, sb);
+        const float dead = s > 58 ? 0.f : 1.f;           // (below 2^-58 of the running maximum: nothing reaches an fp32 sum)
+        dwh_put(st, vd, p2(15 - eD - sa) * dead, col, rh);
+        dwh_put(st + DWH_MAT, vb, p2(15 - eB - sb), col, rh);
+    };
+    float ad[8], ab[8], cd[8], cb[8];                    // chunk q+1 (landed) and chunk q+2 (in flight)
+    float resc_next = 1.f;
+    if (total > 0) {
+        fetch(ad, ab, 0);
+        publish(ad, ab, 0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsum += ad[j];
+        if (total > 1) fetch(cd, cb, 1);
+    }
+    __syncthreads();                                     // maxima of chunk 0 visible
+    if (total > 0) {
+        put(ad, ab, 0, smem, true);
+        if (total > 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { ad[j] = cd[j]; ab[j] = cb[j]; }
+            publish(ad, ab, 1);
+        }
+        resc = 1.f;                                      // (chunk 0 defines the first unit: the accumulators are still zero)
+    }
+    __syncthreads();                                     // stage 0 and the maxima of chunk 1 visible
+    DPH_DECL;
+    for (int q = 0; q < total; ++q) {
+        const char* sD = smem + (q & 1) * DWH_STAGE;
+        const char* sB = sD + DWH_MAT;
+        // (indices past the end are clamped: the extra fetch / store is harmless -- nobody reads that stage any more)
+        fetch(cd, cb, q + 2 < total ? q + 2 : total - 1);
+        __builtin_amdgcn_sched_barrier(0);               // (the loads of chunk q+2 stay at the top: they are consumed at the bottom)
+        DPH(0);
+        // Program order inside the ONE basic block of the loop body: operand fragments of chunk q first (LDS reads of the current
+        // stage -- issued before the stores into the other stage, which the compiler cannot prove disjoint), then the conversion
+        // of chunk q+1 (VALU + LDS stores), then the products; the schedule-group pattern below spreads the MFMAs over the VALU
+        // stream instead of leaving them in one clump behind it.
+        auto convert_next = [&]() {
+            const float keep = (q + 1 < nch) ? 1.f : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bsum = fmaf(keep, ad[j], bsum);
+            // chunk q+1 -> the other stage, in the unit it leaves E at
+            put(ad, ab, (q + 1) & 1, smem + ((q + 1) & 1) * DWH_STAGE, q + 1 < total);
+            resc_next = resc;
+        };
+        if (NARROW) {
+            convert_next();
+            if (nt0 < n_tiles) {
+                const Fr2 fa = dwh_frag(sD, nt0, i, h);
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (b < k_tiles) mf3(acc[0][b], fa, dwh_frag(sB, b, i, h));
+            }
+        } else {
+            Fr2 fa[NA], fb[4];
+#pragma unroll
+            for (int a = 0; a < NA; ++a) fa[a] = dwh_frag(sD, nt0 + a, i, h);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) fb[b] = dwh_frag(sB, kt0 + b, i, h);
+            DPH(1);
+            convert_next();
+            DPH(2);
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int a = 0; a < NA; ++a) mf3(acc[a][b], fa[a], fb[b]);
+            DPH(3);
+#if DW_SGB_V > 0
+#pragma unroll
+            for (int k = 0; k < 24; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, DW_SGB_V, 0);   // DW_SGB_V VALU
+            }
+#endif
+        }
+        // the products of chunk q are in; bring the accumulators to the unit of chunk q+1 (rare)
+        if (resc_next != 1.f) {
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) acc[a][b][v] *= resc_next;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ad[j] = cd[j]; ab[j] = cb[j]; }
+        publish(ad, ab, q & 1);                          // chunk q+2's maxima -> the slot chunk q's just left
+        DPH(4);
+        __syncthreads();
+        DPH(5);
+    }
+    DPH_END;
+    // this slice's partial C (row-major [n_pad][k_pad]) and bias partial, in the layout dw_reduce_kernel expects
+    const float unit = E <= -1000 ? 0.f : p2(E - 30);
+    float* __restrict__ P = partials + (size_t)blockIdx.x * ((size_t)n_pad * k_pad + n_pad);
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int nt = nt0 + a, kt = kt0 + b;
+            if (nt < n_tiles && kt < k_tiles) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int row = 32 * nt + (v & 3) + 8 * (v >> 2) + 4 * h;
+                    P[(size_t)row * k_pad + 32 * kt + i] = acc[a][b][v] * unit;
+                }
+            }
+        }
+    float* red = reinterpret_cast<float*>(smem);
+    if (rh == 1) red[col] = bsum;
+    __syncthreads();
+    if (rh == 0 && col < n_pad) P[(size_t)n_pad * k_pad + col] = bsum + red[col];
+}
+
+}  // namespace
+
+#ifdef DW_PHASE_TIMING
+extern "C" int nero_debug_phases_dw(unsigned long long* out8, int reset) {
+    hipDeviceSynchronize();
+    if (out8) hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_dw_phase), sizeof(unsigned long long) * 8);
+    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_dw_phase), z, sizeof(z)); }
+    return 0;
+}
+#endif
+int nero_f16_dw(const nero_dw_job* job, int n_rows, int rows_per_slice, int slices, float* partials, int n_pad, int k_pad, hipStream_t stream) {
+    NERO_ONCE(hipFuncSetAttribute((const void*)dw_f16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DWH_LDS));
+    NERO_ONCE(hipFuncSetAttribute((const void*)dw_f16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DWH_LDS));
+    if (k_pad <= 128)
+        hipLaunchKernelGGL(dw_f16_kernel<true>, dim3(slices), dim3(512), DWH_LDS, stream, *job, n_rows, rows_per_slice, partials, n_pad, k_pad);
+    else
+        hipLaunchKernelGGL(dw_f16_kernel<false>, dim3(slices), dim3(512), DWH_LDS, stream, *job, n_rows, rows_per_slice, partials, n_pad, k_pad);
+    return NERO_OK;
+}

@@ -25,6 +25,7 @@ namespace {
 
 #include "mlp_f16_util.h"
 
+
 // ---- accumulator-layout -> row-major global store through a wave-private LDS scratch (as mlp_split.hip) -----------------
 __device__ __forceinline__ void acc_to_global(float* scr, const float4 (&q)[4], float* __restrict__ gblock, int lane) {
     const int i = lane & 31, h = lane >> 5;
@@ -36,80 +37,6 @@ __device__ __forceinline__ void acc_to_global(float* scr, const float4 (&q)[4], 
         *reinterpret_cast<float4*>(gblock + (size_t)(8 * p + (lane >> 3)) * NERO_HID + 4 * (lane & 7)) =
             *reinterpret_cast<const float4*>(scr + (8 * p + (lane >> 3)) * SCR_LD + 4 * (lane & 7));
     __builtin_amdgcn_wave_barrier();
-}
-
-// ---- GEMM core ------------------------------------------------------------------------------------------------------------
-// accH[r] += wh xh,  accL[r] += wh xl + wl xh  over `n` k-steps of 16 (r = 32-row half).  Weight planes three steps ahead in a
-// ring of four register sets (L2 stream), activation planes one step ahead in a double buffer (LDS).
-struct WF { uint4 wh, wl; };
-struct XF { uint4 xh0, xl0, xh1, xl1; };
-
-__device__ __forceinline__ void load_w(WF& o, const uint4* wp, int c) {
-#ifdef F16_NO_WSTREAM                               // (timing experiments, scripts/f16_variants.sh: every k-step re-reads step 0)
-    c = 0;
-#endif
-    const uint4* w = wp + (size_t)c * 128;
-    o.wh = w[0];
-    o.wl = w[64];
-}
-__device__ __forceinline__ void load_x(XF& o, const char* xp, int half_bytes, int plane_bytes, int c) {
-    const char* x = xp + c * 32;
-    o.xh0 = *reinterpret_cast<const uint4*>(x);
-    o.xl0 = *reinterpret_cast<const uint4*>(x + plane_bytes);
-    x += half_bytes;
-    o.xh1 = *reinterpret_cast<const uint4*>(x);
-    o.xl1 = *reinterpret_cast<const uint4*>(x + plane_bytes);
-}
-#define NERO_MFH(ACC, A, B) \
-    ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), ACC, 0, 0, 0)
-__device__ __forceinline__ void ops_compute(f32x16 (&aH)[2], f32x16 (&aL)[2], const WF& w, const XF& x) {
-#ifdef F16_NO_MFMA
-    aH[0][0] += __uint_as_float(w.wh.x ^ x.xh0.x); aL[0][0] += __uint_as_float(w.wl.x ^ x.xl0.x);
-    aH[1][0] += __uint_as_float(w.wh.y ^ x.xh1.x); aL[1][0] += __uint_as_float(w.wl.y ^ x.xl1.x);
-    return;
-#endif
-    NERO_MFH(aL[0], w.wl, x.xh0); NERO_MFH(aL[1], w.wl, x.xh1);
-    NERO_MFH(aH[0], w.wh, x.xh0); NERO_MFH(aH[1], w.wh, x.xh1);
-    NERO_MFH(aL[0], w.wh, x.xl0); NERO_MFH(aL[1], w.wh, x.xl1);
-}
-#define NERO_FENCE() __builtin_amdgcn_sched_barrier(0)
-
-__device__ __forceinline__ void gemm_f16x3(f32x16 (&aH)[2], f32x16 (&aL)[2], const uint4* wp, const char* xp, int half_bytes,
-                                           int plane_bytes, int n) {
-    if (n <= 0) return;
-    WF wa, wb, wc, wd;
-    XF xa, xb;
-    const int last = n - 1;
-#define NERO_CL(c) ((c) < last ? (c) : last)
-    load_w(wa, wp, 0);
-    load_w(wb, wp, NERO_CL(1));
-    load_w(wc, wp, NERO_CL(2));
-    load_x(xa, xp, half_bytes, plane_bytes, 0);
-    NERO_FENCE();
-    for (int c = 0; c < n; c += 4) {
-        load_w(wd, wp, NERO_CL(c + 3)); load_x(xb, xp, half_bytes, plane_bytes, NERO_CL(c + 1)); NERO_FENCE();
-        ops_compute(aH, aL, wa, xa); NERO_FENCE();
-        if (c + 1 < n) {
-            load_w(wa, wp, NERO_CL(c + 4)); load_x(xa, xp, half_bytes, plane_bytes, NERO_CL(c + 2)); NERO_FENCE();
-            ops_compute(aH, aL, wb, xb); NERO_FENCE();
-        }
-        if (c + 2 < n) {
-            load_w(wb, wp, NERO_CL(c + 5)); load_x(xb, xp, half_bytes, plane_bytes, NERO_CL(c + 3)); NERO_FENCE();
-            ops_compute(aH, aL, wc, xa); NERO_FENCE();
-        }
-        if (c + 3 < n) {
-            load_w(wc, wp, NERO_CL(c + 6)); load_x(xa, xp, half_bytes, plane_bytes, NERO_CL(c + 4)); NERO_FENCE();
-            ops_compute(aH, aL, wd, xb); NERO_FENCE();
-        }
-    }
-#undef NERO_CL
-}
-
-__device__ __forceinline__ void zero2(f32x16 (&acc)[2]) {
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) acc[r][v] = 0.f;
 }
 
 // rows [row0, row0+64) x first k columns (k multiple of 4, <= 256) of a row-major fp32 matrix -> scaled plane pairs + the per-row
@@ -192,18 +119,6 @@ __device__ __forceinline__ Lds carve(char* smem) {
 }
 inline int f16_lds_bytes(int wide) { return 2 * PLANE_A + 2 * 64 * (wide ? SX_W : SX_N) + (64 + 64 + 512) * 4 + 8 * SCR_BYTES; }
 
-// row maxima of this wave's 64x32 block (two rows per lane) -> rmax[row][wave]
-__device__ __forceinline__ void publish_rowmax(float* rmax, float m0, float m1, int wave, int i, int h) {
-    m0 = fmaxf(m0, __shfl_xor(m0, 32));
-    m1 = fmaxf(m1, __shfl_xor(m1, 32));
-    if (h == 0) { rmax[i * 8 + wave] = m0; rmax[(32 + i) * 8 + wave] = m1; }
-}
-__device__ __forceinline__ float row_max8(const float* rmax, int row) {
-    const float4 a = *reinterpret_cast<const float4*>(rmax + row * 8);
-    const float4 b = *reinterpret_cast<const float4*>(rmax + row * 8 + 4);
-    return fmaxf(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)));
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 // forward chain
 // ---------------------------------------------------------------------------------------------------------------------
@@ -236,9 +151,11 @@ __global__ __launch_bounds__(512, 1) void fwd_f16_kernel(nero_fwd_chain ch, int 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
     const int row0 = blockIdx.x * 64;
+    PH_DECL;
     if (ch.init) load_planes_scaled(S.actp, SA, PLANE_A, S.rs_main, ch.init, ch.ld_init, ch.k_init, row0, n_rows, tid);
     if (ch.aux) load_planes_scaled(S.auxp, SX, PLANE_X, S.rs_aux, ch.aux, ch.ld_aux, ch.k_aux, row0, n_rows, tid);
     __syncthreads();
+    PH(0);
     for (int l = 0; l < ch.n_layers; ++l) {
         const nero_fwd_layer& L = ch.layer[l];
         if (L.n_head > 0) eval_head_f16(S.actp, S.rs_main, L.head_w, L.head_b, L.head_out, L.n_head, L.head_k, row0, tid);
@@ -252,6 +169,7 @@ __global__ __launch_bounds__(512, 1) void fwd_f16_kernel(nero_fwd_chain ch, int 
         for (int g = 0; g < 4; ++g)
             bq[g] = (live_wave && L.bias) ? *reinterpret_cast<const float4*>(L.bias + 32 * wave + 8 * g + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
         float U[2] = {1.f, 1.f};                           // result unit of the accumulators, per 32-row half (this lane's rows i, 32+i)
+        PH(1);
         if (live_wave) {
             const int sm = L.k_main >> 4, sx = L.k_aux >> 4;
             if (sx > 0) {
@@ -279,6 +197,7 @@ __global__ __launch_bounds__(512, 1) void fwd_f16_kernel(nero_fwd_chain ch, int 
         // values, optional saves, row maxima
         float4 val[2][4];
         float m[2] = {0.f, 0.f};
+        PH(2);
         if (live_wave) {
 #ifdef F16_NO_EPI
             for (int r = 0; r < 2; ++r) for (int g = 0; g < 4; ++g) val[r][g] = make_float4(aH[r][4 * g], aL[r][4 * g], 0.f, 0.f);
@@ -288,6 +207,7 @@ __global__ __launch_bounds__(512, 1) void fwd_f16_kernel(nero_fwd_chain ch, int 
             if (L.act == NERO_ACT_RELU) fwd_values<NERO_ACT_RELU>(aH, aL, bq, U, val, m);
             else if (L.act == NERO_ACT_SOFTPLUS100) fwd_values<NERO_ACT_SOFTPLUS100>(aH, aL, bq, U, val, m);
             else fwd_values<NERO_ACT_NONE>(aH, aL, bq, U, val, m);
+            PH(3);
             if (L.save) {
                 float* scr = reinterpret_cast<float*>(S.scr + wave * SCR_BYTES);
                 float* sblock = L.save + (size_t)row0 * NERO_HID + 32 * wave;
@@ -310,8 +230,10 @@ __global__ __launch_bounds__(512, 1) void fwd_f16_kernel(nero_fwd_chain ch, int 
                 }
             }
         }
+        PH(4);
         publish_rowmax(S.rmax, m[0], m[1], wave, i, h);
         __syncthreads();                                   // row maxima visible; every wave is done reading the input planes
+        PH(5);
         {
             const int e0 = scale_exp(row_max8(S.rmax, i)), e1 = scale_exp(row_max8(S.rmax, 32 + i));
             if (live_wave) {
@@ -327,8 +249,11 @@ __global__ __launch_bounds__(512, 1) void fwd_f16_kernel(nero_fwd_chain ch, int 
             // (nobody reads rs_main between the barrier above and the one below: the units U were taken before the GEMM)
             if (wave == 0 && h == 0) { S.rs_main[i] = pow2i(e0); S.rs_main[32 + i] = pow2i(e1); }
         }
+        PH(6);
         __syncthreads();
+        PH(7);
     }
+    PH_END;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -506,6 +431,7 @@ __global__ __launch_bounds__(512, 1) void bwd_f16_kernel(nero_bwd_chain ch, int 
         if (tid < 64) S.rs_main[tid] = 1.f;
     }
     __syncthreads();
+    PH_DECL;
     for (int l = ch.n_layers - 1; l >= 0; --l) {
         const nero_bwd_layer& L = ch.layer[l];
         const bool first = (L.a_prev == nullptr);
@@ -537,6 +463,7 @@ __global__ __launch_bounds__(512, 1) void bwd_f16_kernel(nero_bwd_chain ch, int 
         }
         float4 gq[2][4];                                   // incoming gradient of this lane's outputs, true units
         const float rs0 = S.rs_main[i], rs1 = S.rs_main[32 + i];
+        PH(1);
         if (L.n_out > 0) {
             f32x16 aH[2], aL[2];
             if (ch.d_aux && L.w_aux_t) {
@@ -569,6 +496,7 @@ __global__ __launch_bounds__(512, 1) void bwd_f16_kernel(nero_bwd_chain ch, int 
                 u[0] = wsc * rs0;
                 u[1] = wsc * rs1;
             }
+            PH(2);
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -606,18 +534,23 @@ __global__ __launch_bounds__(512, 1) void bwd_f16_kernel(nero_bwd_chain ch, int 
         }
         float4 val[2][4];
         float m[2] = {0.f, 0.f};
+        PH(3);
         if (live_wave) {
             if (L.act_prev == NERO_ACT_RELU) bwd_values_h<NERO_ACT_RELU>(gq, pa, goff, has_inj, L, row0, i, fbase, n_rows, val, m);
             else if (L.act_prev == NERO_ACT_SOFTPLUS100) bwd_values_h<NERO_ACT_SOFTPLUS100>(gq, pa, goff, has_inj, L, row0, i, fbase, n_rows, val, m);
             else bwd_values_h<NERO_ACT_NONE>(gq, pa, goff, has_inj, L, row0, i, fbase, n_rows, val, m);
+            PH(4);
             if (L.delta_prev) {
                 float* scr = reinterpret_cast<float*>(S.scr + wave * SCR_BYTES);
                 acc_to_global(scr, val[0], L.delta_prev + boff, lane);
                 acc_to_global(scr, val[1], L.delta_prev + boff + (size_t)32 * NERO_HID, lane);
             }
         }
+        PH(5);
         commit_planes(S, val, m[0], m[1], live_wave, wave, i, h);
+        PH(6);
     }
+    PH_END;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -675,6 +608,14 @@ __global__ __launch_bounds__(256) void pack_f16_kernel(PackBatchH B) {
 }  // namespace
 
 // ---- host side (dispatched from mlp_engine.hip / mlp_split.hip) --------------------------------------------------------------
+#ifdef F16_PHASE_TIMING
+extern "C" int nero_debug_phases(unsigned long long* out16, int reset) {
+    hipDeviceSynchronize();
+    if (out16) hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)); }
+    return 0;
+}
+#endif
 int nero_f16_pack_batch(const nero_pack_job* jobs, int n_jobs, hipStream_t stream) {
     PackBatchH B;
     int max_work = 1, any = 0;

@@ -17,5 +17,9 @@ int nero_f16_pack_batch(const nero_pack_job* jobs, int n_jobs, hipStream_t strea
 int nero_f16_forward(const nero_fwd_chain* ch, int n_rows, hipStream_t stream);
 int nero_f16_tangent(const nero_tan_chain* ch, int n_rows, hipStream_t stream);
 int nero_f16_backward(const nero_bwd_chain* ch, int n_rows, hipStream_t stream);
-// fp16 two-plane engine, row-owner organisation (mlp_ro.hip)
-int nero_ro_forward(const nero_fwd_chain* ch, int n_rows, hipStream_t stream);
+int nero_f16_dw(const nero_dw_job* job, int n_rows, int rows_per_slice, int slices, float* partials, int n_pad, int k_pad,
+                hipStream_t stream);                                                    // mlp_f16dw.hip
+// fp16 two-plane engine, two workgroups per CU (mlp_f16p.hip)
+int nero_f16p_forward(const nero_fwd_chain* ch, int n_rows, hipStream_t stream);
+int nero_f16p_tangent(const nero_tan_chain* ch, int n_rows, hipStream_t stream);
+int nero_f16p_backward(const nero_bwd_chain* ch, int n_rows, hipStream_t stream);

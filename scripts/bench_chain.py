@@ -1,6 +1,6 @@
-"""Row-owner engine (f16x3r) vs the 64-row-tile f16x3 engine on the shapes of the training step (run on the GPU box):
-8x(256->256) chains with / without saves, the value-only SDF chain of the sampler, a 4-layer predictor with a head.
-Prints times, fp32-equivalent TFLOP/s and the agreement of the outputs with the exact-f32 MFMA engine."""
+"""Chain-kernel engines side by side on the shapes of the training step (run on the GPU box): 8x(256->256) chains with / without
+saves, the value-only SDF chain of the sampler, the full SDF forward, a 4-layer predictor with a head.  Prints times, fp32-equivalent
+TFLOP/s and the agreement of the outputs with the exact-f32 MFMA engine.  python scripts/bench_chain.py [rows] [modes]"""
 import math, sys, time
 import torch
 sys.path.insert(0, '.')
@@ -11,7 +11,7 @@ from nero_amd.sdf import SDFField, encode_pe
 
 g = torch.Generator().manual_seed(0)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 524288
-modes = sys.argv[2].split(',') if len(sys.argv) > 2 else ['f32', 'f16x3', 'f16x3r']
+modes = sys.argv[2].split(',') if len(sys.argv) > 2 else ['f32', 'f16x3', 'f16x3p']
 rp = row_pad(N)
 x = torch.randn(rp, 256, device='cuda') * 0.1
 def mk(n_out, n_in, s=1.0): return ((torch.randn(n_out, n_in, generator=g) * s / math.sqrt(n_in)).cuda(), (torch.randn(n_out, generator=g) * 0.01).cuda())
