@@ -44,8 +44,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int DWH_PLANE = 2 * 256 * 16;              // one plane of one matrix: [2][256] x 16 B = 8 KB
 constexpr int DWH_MAT = 2 * DWH_PLANE;               // h + l = 16 KB
 constexpr int DWH_STAGE = 2 * DWH_MAT;               // D + B = 32 KB
-constexpr int DWH_SMAX = 2 * DWH_STAGE;              // float smax[2 slots][8 waves][2]
-constexpr int DWH_LDS = DWH_SMAX + 2 * 8 * 2 * 4;
+constexpr int DWH_SMAX = 2 * DWH_STAGE;              // float smax[2 slots][8 waves]
+constexpr int DWH_LDS = DWH_SMAX + 2 * 8 * 4;
 
 __device__ __forceinline__ int exp_of(float m) {     // e with m * 2^-e in [0.5, 1) (0 for m == 0 / denormal), clamped
     const int eb = (__float_as_uint(m) >> 23) & 0xff;
@@ -66,20 +66,18 @@ __device__ __forceinline__ void split_true(float a, float b, unsigned& h, unsign
     l = pk_f16(a - (float)hh[0], b - (float)hh[1]);
 }
 
-// Operand loads through a buffer resource rebased to the chunk's first row (SALU): per-thread byte offset `off` (constant for the
-// whole kernel) + j rows; rows past the slice end and columns past the matrix width fall outside num_records and read as 0 --
-// no address arithmetic, clamps or masks in the VALU stream.
-__device__ __forceinline__ void dwh_fetch(float (&v)[8], const float* __restrict__ src, int ld, int r0, int r1, int off) {
+// ---- staging --------------------------------------------------------------------------------------------------------------
+// Waves 0-3 stage D, waves 4-7 stage B.  Inside a group thread (cq = tid & 63, rq = wave & 3) owns columns 4cq..4cq+3 of the
+// chunk rows 4rq..4rq+3: FOUR buffer_load_dwordx4 per chunk (a wave instruction = one full 1 KB row; the dword-per-lane form
+// needs 4x the wave instructions and the texture-address path, ~38 cycles of issue per instruction beside 8 waves, was the
+// pole of the first version).  The buffer resource is rebased to the chunk's first row (SALU); rows past the slice end and
+// column quads past the matrix width fall outside num_records and read as 0; a ragged last quad is masked by multiplies.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void dwh_fetch(f32x4 (&v)[4], const float* __restrict__ src, int ld, int r0, int r1, int off) {
     const int left = r1 - r0;
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)r0 * ld), 0, (left > 0 ? left : 0) * ld * 4, 0x00020000);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off + j * ld * 4, 0, 0));
-}
-__device__ __forceinline__ float amax8(const float (&v)[8]) {
-    float m = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[j]));
-    return m;
+    for (int j = 0; j < 4; ++j) v[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + j * ld * 4, 0, 0));
 }
 // maximum of a non-negative value over the wave on the DPP network (no LDS traffic): xor 1, xor 2, half-row mirror, row mirror,
 // then lane 15 -> next row, lane 31 -> upper half; lane 63 holds the result
@@ -94,25 +92,22 @@ __device__ __forceinline__ float wave_max(float m) {
 #undef NERO_DPPMAX
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63));
 }
-__device__ __forceinline__ void dwh_put(char* mat, const float (&v)[8], float sc, int col, int rh) {
-    unsigned hp[4], lp[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) split_true(v[2 * j] * sc, v[2 * j + 1] * sc, hp[j], lp[j]);
-    char* dst = mat + (rh * 256 + col) * 16;
-    *reinterpret_cast<uint4*>(dst) = make_uint4(hp[0], hp[1], hp[2], hp[3]);
-    *reinterpret_cast<uint4*>(dst + DWH_PLANE) = make_uint4(lp[0], lp[1], lp[2], lp[3]);
-}
+// LDS image of one plane: [rh = row octet][entry e(col)] x 16 B, e(col) = 64 (col & 3) + ((col >> 2) + 4 (col & 3)) mod 64.
+// The four columns of a thread land 64 entries apart, so that for each of them the 64 lanes of a wave write CONSECUTIVE entries
+// (ds_write_b64: 2-way at worst), and the rotation by 4 (col & 3) keeps the fragment reads (lane i <-> column 32 t + i,
+// ds_read_b128, lane groups {0-3,12-15,20-27} ...) on 16 distinct 16-byte slots.
+__device__ __forceinline__ int dwh_entry(int col) { return 64 * (col & 3) + (((col >> 2) + 4 * (col & 3)) & 63); }
+
 struct Fr2 { uint4 h, l; };
-__device__ __forceinline__ Fr2 dwh_frag(const char* mat, int tile, int i, int h) {
-    const char* s = mat + (h * 256 + 32 * tile + i) * 16;
+__device__ __forceinline__ Fr2 dwh_frag(const char* mat, int byte_off) {
     Fr2 f;
-    f.h = *reinterpret_cast<const uint4*>(s);
-    f.l = *reinterpret_cast<const uint4*>(s + DWH_PLANE);
+    f.h = *reinterpret_cast<const uint4*>(mat + byte_off);
+    f.l = *reinterpret_cast<const uint4*>(mat + byte_off + DWH_PLANE);
     return f;
 }
 #define NERO_MFH(ACC, A, B) \
     ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), ACC, 0, 0, 0)
-__device__ __forceinline__ void mf3(f32x16& acc, const Fr2& a, const Fr2& b) {
+__device__ __forceinline__ void mf3(f32x16& acc, const Fr2& a, const Fr2& b) {       // (back-to-back accumulation forwards at full rate)
     NERO_MFH(acc, a.l, b.h);
     NERO_MFH(acc, a.h, b.l);
     NERO_MFH(acc, a.h, b.h);
@@ -133,11 +128,12 @@ template <bool NARROW>
 __global__ __launch_bounds__(512, 1) void dw_f16_kernel(nero_dw_job job, int n_rows, int rows_per_slice, float* __restrict__ partials,
                                                         int n_pad, int k_pad) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* smax = reinterpret_cast<float*>(smem + DWH_SMAX);
+    float* smax = reinterpret_cast<float*>(smem + DWH_SMAX);         // [2 slots][8 waves]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
-    const int col = tid & 255, rh = tid >> 8;
+    const bool isB = wave >= 4;                          // staging role of this wave
+    const int cq = lane, rq = wave & 3;
     const int r_begin = blockIdx.x * rows_per_slice;
     int r_end = r_begin + rows_per_slice;
     r_end = r_end < n_rows ? r_end : n_rows;
@@ -151,41 +147,54 @@ __global__ __launch_bounds__(512, 1) void dw_f16_kernel(nero_dw_job job, int n_r
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
-    float bsum = 0.f;                                    // bias gradient partial of column `col` (rows of this thread's half)
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};                   // bias gradient partials of this thread's 4 columns (D group)
     const int nch = r_end > r_begin ? (r_end - r_begin + 15) / 16 : 0;
     const int total = nch * (job.d1 ? 2 : 1);
     constexpr int OOB = 0x40000000;                      // byte offset beyond any num_records: the load returns 0
-    const int offD0 = col < job.n_out ? (8 * rh * job.ldd0 + col) * 4 : OOB, offB0 = col < job.k_cols ? (8 * rh * job.ldb0 + col) * 4 : OOB;
-    const int offD1 = col < job.n_out ? (8 * rh * job.ldd1 + col) * 4 : OOB, offB1 = col < job.k_cols ? (8 * rh * job.ldb1 + col) * 4 : OOB;
-    auto fetch = [&](float (&vd)[8], float (&vb)[8], int q) {
+    const int cols = isB ? job.k_cols : job.n_out;
+    const int ld0 = isB ? job.ldb0 : job.ldd0, ld1 = isB ? job.ldb1 : job.ldd1;
+    const float* src0 = isB ? job.b0 : job.d0;
+    const float* src1 = isB ? job.b1 : job.d1;
+    const int off0 = 4 * cq < cols ? (4 * rq * ld0 + 4 * cq) * 4 : OOB, off1 = 4 * cq < cols ? (4 * rq * ld1 + 4 * cq) * 4 : OOB;
+    f32x4 cmask;                                         // ragged last quad: columns >= cols hold foreign data
+#pragma unroll
+    for (int c = 0; c < 4; ++c) cmask[c] = 4 * cq + c < cols ? 1.f : 0.f;
+    // byte offsets inside a plane: this thread's four 8-byte store slots, and the fragment entries of this wave's tiles
+    int st_off[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) st_off[c] = (rq >> 1) * 4096 + dwh_entry(4 * cq + c) * 16 + (rq & 1) * 8;
+    int fa_off[NA], fb_off[4];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) fa_off[a] = h * 4096 + dwh_entry(32 * (nt0 + a) + i) * 16;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) fb_off[b] = h * 4096 + dwh_entry(32 * (kt0 + b) + i) * 16;
+    auto fetch = [&](f32x4 (&v)[4], int q) {
         const bool second = q >= nch;
 #ifdef DW_NOSTREAM                                       // (timing experiment: every chunk re-reads the slice's first rows, L2 hits)
         const int r0 = r_begin;
 #else
         const int r0 = r_begin + (second ? q - nch : q) * 16;
 #endif
-        dwh_fetch(vd, second ? job.d1 : job.d0, second ? job.ldd1 : job.ldd0, r0, r_end, second ? offD1 : offD0);
-        dwh_fetch(vb, second ? job.b1 : job.b0, second ? job.ldb1 : job.ldb0, r0, r_end, second ? offB1 : offB0);
+        dwh_fetch(v, second ? src1 : src0, second ? ld1 : ld0, r0, r_end, second ? off1 : off0);
     };
-    // chunk maxima of the chunk held in (vd, vb) -> smax[slot][wave]
-    auto publish = [&](const float (&vd)[8], const float (&vb)[8], int slot) {
-        const float md = wave_max(amax8(vd)), mb = wave_max(amax8(vb));
-        if (lane == 0) { smax[(slot * 8 + wave) * 2] = md; smax[(slot * 8 + wave) * 2 + 1] = mb; }
-    };
-    // exponents (eD, eB) of the chunk whose maxima sit in smax[slot]
-    auto chunk_exp = [&](int slot, int& eD, int& eB) {
-        const float4* p = reinterpret_cast<const float4*>(smax + slot * 16);
-        const float4 a = p[0], b = p[1], c = p[2], d = p[3];
-        eD = exp_of(fmaxf(fmaxf(fmaxf(a.x, a.z), fmaxf(b.x, b.z)), fmaxf(fmaxf(c.x, c.z), fmaxf(d.x, d.z))));
-        eB = exp_of(fmaxf(fmaxf(fmaxf(a.y, a.w), fmaxf(b.y, b.w)), fmaxf(fmaxf(c.y, c.w), fmaxf(d.y, d.w))));
+    // mask the ragged quad, publish this wave's maximum of the chunk part held in v -> smax[slot][wave]
+    auto publish = [&](f32x4 (&v)[4], int slot) {
+        float m = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] *= cmask;
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v[j][0]), fabsf(v[j][1])), fmaxf(fabsf(v[j][2]), fabsf(v[j][3]))));
+        }
+        m = wave_max(m);
+        if (lane == 0) smax[slot * 8 + wave] = m;
     };
     int E = -1000;                                       // accumulator unit = 2^(E - 30); -1000 = nothing accumulated yet
     float resc = 1.f;                                    // factor the accumulators take before the next chunk's products are added
-    // store chunk (vd, vb), whose maxima are in smax[slot], into stage `st`; updates E / resc (selects only: `live` = false makes
-    // the call a harmless store into a stage nobody reads any more)
-    auto put = [&](const float (&vd)[8], const float (&vb)[8], int slot, char* st, bool live) {
-        int eD, eB;
-        chunk_exp(slot, eD, eB);
+    // convert the chunk part in v (maxima of the whole chunk in smax[slot]) into stage `st`; updates E / resc (selects only:
+    // `live` = false makes the call a harmless store into a stage nobody reads any more)
+    auto put = [&](const f32x4 (&v)[4], int slot, char* st, bool live) {
+        const float4 ma = *reinterpret_cast<const float4*>(smax + slot * 8), mb = *reinterpret_cast<const float4*>(smax + slot * 8 + 4);
+        const int eD = exp_of(fmaxf(fmaxf(ma.x, ma.y), fmaxf(ma.z, ma.w))), eB = exp_of(fmaxf(fmaxf(mb.x, mb.y), fmaxf(mb.z, mb.w)));
         const int ec = eD + eB;
         const bool raise = live && ec > E;
         const float r_up = E <= -1000 ? 1.f : p2(E - ec);
@@ -195,25 +204,33 @@ __global__ __launch_bounds__(512, 1) void dw_f16_kernel(nero_dw_job job, int n_r
         int sa, sb;
         split_shift(s < 0 ? 0 : s, sa, sb);
         const float dead = s > 58 ? 0.f : 1.f;           // (below 2^-58 of the running maximum: nothing reaches an fp32 sum)
-        dwh_put(st, vd, p2(15 - eD - sa) * dead, col, rh);
-        dwh_put(st + DWH_MAT, vb, p2(15 - eB - sb), col, rh);
+        const float sc = isB ? p2(15 - eB - sb) : p2(15 - eD - sa) * dead;
+        char* mat = st + (isB ? DWH_MAT : 0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            unsigned h01, l01, h23, l23;
+            split_true(v[0][c] * sc, v[1][c] * sc, h01, l01);
+            split_true(v[2][c] * sc, v[3][c] * sc, h23, l23);
+            *reinterpret_cast<uint2*>(mat + st_off[c]) = make_uint2(h01, h23);
+            *reinterpret_cast<uint2*>(mat + DWH_PLANE + st_off[c]) = make_uint2(l01, l23);
+        }
     };
-    float ad[8], ab[8], cd[8], cb[8];                    // chunk q+1 (landed) and chunk q+2 (in flight)
+    f32x4 av[4], cv[4];                                  // chunk q+1 (landed) and chunk q+2 (in flight)
     float resc_next = 1.f;
     if (total > 0) {
-        fetch(ad, ab, 0);
-        publish(ad, ab, 0);
+        fetch(av, 0);
+        publish(av, 0);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bsum += ad[j];
-        if (total > 1) fetch(cd, cb, 1);
+        for (int j = 0; j < 4; ++j) bsum += av[j];
+        if (total > 1) fetch(cv, 1);
     }
     __syncthreads();                                     // maxima of chunk 0 visible
     if (total > 0) {
-        put(ad, ab, 0, smem, true);
+        put(av, 0, smem, true);
         if (total > 1) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { ad[j] = cd[j]; ab[j] = cb[j]; }
-            publish(ad, ab, 1);
+            for (int j = 0; j < 4; ++j) av[j] = cv[j];
+            publish(av, 1);
         }
         resc = 1.f;                                      // (chunk 0 defines the first unit: the accumulators are still zero)
     }
@@ -223,35 +240,35 @@ __global__ __launch_bounds__(512, 1) void dw_f16_kernel(nero_dw_job job, int n_r
         const char* sD = smem + (q & 1) * DWH_STAGE;
         const char* sB = sD + DWH_MAT;
         // (indices past the end are clamped: the extra fetch / store is harmless -- nobody reads that stage any more)
-        fetch(cd, cb, q + 2 < total ? q + 2 : total - 1);
-        __builtin_amdgcn_sched_barrier(0);               // (the loads of chunk q+2 stay at the top: they are consumed at the bottom)
+        fetch(cv, q + 2 < total ? q + 2 : total - 1);
+        __builtin_amdgcn_sched_barrier(0);               // (the loads of chunk q+2 stay at the top: they are consumed at the bottom;
+                                                         //  issuing them one step earlier, before the barrier, measured 5-10 % slower)
         DPH(0);
         // Program order inside the ONE basic block of the loop body: operand fragments of chunk q first (LDS reads of the current
         // stage -- issued before the stores into the other stage, which the compiler cannot prove disjoint), then the conversion
-        // of chunk q+1 (VALU + LDS stores), then the products; the schedule-group pattern below spreads the MFMAs over the VALU
-        // stream instead of leaving them in one clump behind it.
+        // of chunk q+1 (VALU + LDS stores), then the products; the schedule-group pattern spreads the MFMAs over the VALU stream.
         auto convert_next = [&]() {
             const float keep = (q + 1 < nch) ? 1.f : 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) bsum = fmaf(keep, ad[j], bsum);
+            for (int j = 0; j < 4; ++j) bsum += av[j] * keep;
             // chunk q+1 -> the other stage, in the unit it leaves E at
-            put(ad, ab, (q + 1) & 1, smem + ((q + 1) & 1) * DWH_STAGE, q + 1 < total);
+            put(av, (q + 1) & 1, smem + ((q + 1) & 1) * DWH_STAGE, q + 1 < total);
             resc_next = resc;
         };
         if (NARROW) {
             convert_next();
             if (nt0 < n_tiles) {
-                const Fr2 fa = dwh_frag(sD, nt0, i, h);
+                const Fr2 fa = dwh_frag(sD, fa_off[0]);
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
-                    if (b < k_tiles) mf3(acc[0][b], fa, dwh_frag(sB, b, i, h));
+                    if (b < k_tiles) mf3(acc[0][b], fa, dwh_frag(sB, fb_off[b]));
             }
         } else {
             Fr2 fa[NA], fb[4];
 #pragma unroll
-            for (int a = 0; a < NA; ++a) fa[a] = dwh_frag(sD, nt0 + a, i, h);
+            for (int a = 0; a < NA; ++a) fa[a] = dwh_frag(sD, fa_off[a]);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) fb[b] = dwh_frag(sB, kt0 + b, i, h);
+            for (int b = 0; b < 4; ++b) fb[b] = dwh_frag(sB, fb_off[b]);
             DPH(1);
             convert_next();
             DPH(2);
@@ -260,7 +277,7 @@ __global__ __launch_bounds__(512, 1) void dw_f16_kernel(nero_dw_job job, int n_r
 #pragma unroll
                 for (int a = 0; a < NA; ++a) mf3(acc[a][b], fa[a], fb[b]);
             DPH(3);
-#if DW_SGB_V > 0
+#if DW_SGB_V > 0 && !defined(DW_PHASE_TIMING)
 #pragma unroll
             for (int k = 0; k < 24; ++k) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one MFMA
@@ -278,8 +295,8 @@ __global__ __launch_bounds__(512, 1) void dw_f16_kernel(nero_dw_job job, int n_r
                     for (int v = 0; v < 16; ++v) acc[a][b][v] *= resc_next;
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { ad[j] = cd[j]; ab[j] = cb[j]; }
-        publish(ad, ab, q & 1);                          // chunk q+2's maxima -> the slot chunk q's just left
+        for (int j = 0; j < 4; ++j) av[j] = cv[j];
+        publish(av, q & 1);                              // chunk q+2's maxima -> the slot chunk q's just left
         DPH(4);
         __syncthreads();
         DPH(5);
@@ -301,10 +318,14 @@ __global__ __launch_bounds__(512, 1) void dw_f16_kernel(nero_dw_job job, int n_r
                 }
             }
         }
-    float* red = reinterpret_cast<float*>(smem);
-    if (rh == 1) red[col] = bsum;
+    // bias: the four row quads of a column quad live in waves 0..3
+    f32x4* red = reinterpret_cast<f32x4*>(smem);
+    if (!isB) red[rq * 64 + cq] = bsum;
     __syncthreads();
-    if (rh == 0 && col < n_pad) P[(size_t)n_pad * k_pad + col] = bsum + red[col];
+    if (tid < n_pad) {
+        const float* r = reinterpret_cast<const float*>(smem);
+        P[(size_t)n_pad * k_pad + tid] = (r[tid] + r[256 + tid]) + (r[512 + tid] + r[768 + tid]);
+    }
 }
 
 }  // namespace
