@@ -32,6 +32,39 @@ constexpr float LO = 2048.f, LO_INV = 1.f / 2048.f;
 constexpr int HDR_BYTES = 256;          // packed-image header: float[0] = 2^ew (the factor results are multiplied by), uint[1] = max bits
 constexpr int SCR_LD = 36, SCR_BYTES = 32 * SCR_LD * 4;
 
+constexpr int SCRP_ROWS = 16;
+constexpr int SCRP_BYTES = SCRP_ROWS * SCR_LD * 4;     // 2304 B per wave: store-transposition scratch, 16 rows at a time
+
+// accumulator-layout 32x32 block -> row-major global store, 16 rows at a time through the wave-private scratch
+__device__ __forceinline__ void acc_to_global16(float* scr, const float4 (&q)[4], float* __restrict__ gblock, int lane) {
+    const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        if ((i >> 4) == p) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(scr + (i & 15) * SCR_LD + 8 * g + 4 * h) = q[g];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int idx = lane + 64 * k, row = idx >> 3, c4 = 4 * (idx & 7);
+            *reinterpret_cast<float4*>(gblock + (size_t)(16 * p + row) * NERO_HID + c4) = *reinterpret_cast<const float4*>(scr + row * SCR_LD + c4);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- LDS-DMA ----------------------------------------------------------------------------------------------------------------
+// global_load_lds_dwordx4: lane l's 16 bytes at `gptr` land at LDS byte address `lds_addr` + 16 l, no VGPRs in between.  Issued
+// through inline asm on purpose: the compiler's wait-count pass otherwise puts a vmcnt(0) in front of EVERY later LDS access
+// (it cannot prove the rest of the dynamic LDS array disjoint from the DMA target), which turns the prefetch into a stall.  Its
+// vmcnt bookkeeping stays conservative (an untracked older load only makes counted waits longer); the reader must issue its own
+// s_waitcnt vmcnt(0) before touching the target.
+__device__ __forceinline__ void lds_dma16(const void* gptr, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gptr), "s"(lds_addr) : "memory", "m0");
+}
+__device__ __forceinline__ unsigned lds_offset_of(const void* p) { return (unsigned)(size_t)p; }      // generic -> LDS byte offset
+
 // ---- scaling -----------------------------------------------------------------------------------------------------------
 // exponent e with m * 2^-e in [0.5, 1) for normal m > 0 (0 for m == 0 / denormal), clamped to [-40, 40]
 __device__ __forceinline__ int scale_exp(float m) {

@@ -21,8 +21,6 @@ namespace {
 #include "mlp_f16_util.h"
 
 constexpr int PW = 4;                                  // waves per workgroup
-constexpr int SCRP_ROWS = 16;
-constexpr int SCRP_BYTES = SCRP_ROWS * SCR_LD * 4;     // 2304 B per wave
 
 struct LdsP { char* actp; float* rs_main; float* rs_aux; float* rmax; char* scr; };
 __device__ __forceinline__ LdsP carve_p(char* smem) {
@@ -37,25 +35,6 @@ __device__ __forceinline__ LdsP carve_p(char* smem) {
 inline int p_lds_bytes() { return 2 * PLANE_A + (64 + 64 + 512) * 4 + PW * SCRP_BYTES; }      // 79360
 
 struct Ctx { LdsP S; int wave, lane, i, h, row0, n_rows; };
-
-// accumulator-layout 32x32 block -> row-major global store, 16 rows at a time through the wave-private scratch
-__device__ __forceinline__ void acc_to_global16(float* scr, const float4 (&q)[4], float* __restrict__ gblock, int lane) {
-    const int i = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        if ((i >> 4) == p) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(scr + (i & 15) * SCR_LD + 8 * g + 4 * h) = q[g];
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int idx = lane + 64 * k, row = idx >> 3, c4 = 4 * (idx & 7);
-            *reinterpret_cast<float4*>(gblock + (size_t)(16 * p + row) * NERO_HID + c4) = *reinterpret_cast<const float4*>(scr + row * SCR_LD + c4);
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
 
 // rows [row0, row0+64) x first k columns of a row-major fp32 matrix -> scaled plane pairs + per-row scale (4 threads per row)
 __device__ __forceinline__ void load_planes_scaled_p(char* planes, float* rs, const float* __restrict__ src, int ld, int k, int row0,

@@ -418,13 +418,46 @@ __device__ __forceinline__ void bwd_values_h(const float4 (&gq)[2][4], const flo
     else bwd_values<ACT, false>(gq, pa, goff, has_inj, L, row0, i, fbase, n_rows, val, m);
 }
 
+// LDS of the reverse kernel: planes | row scales, row maxima | PA: the saved activations of the layer the walk reaches NEXT,
+// 8 KB per wave in this lane's fragment order [r][g][lane] x 16 B, brought in by LDS-DMA (global_load_lds_dwordx4) while the
+// current layer computes; between its read-out and the next request the same 8 KB serve as the wave's store-transposition scratch.  Without it the 64 KB per tile and layer were requested in front of
+// the k-loop, every CU at once, and the weight stream queued behind them (vmcnt retires in order): 14.9k instead of 8.3k cycles
+// per softplus layer (profiles/r02_phase_timing.txt); it also frees 32 VGPRs through the GEMM.
+constexpr int BWD_PA_BYTES = 8 * 8192;
+inline int bwd_lds_bytes() { return 2 * PLANE_A + (64 + 64 + 512) * 4 + BWD_PA_BYTES; }      // 135680
+
 __global__ __launch_bounds__(512, 1) void bwd_f16_kernel(nero_bwd_chain ch, int n_rows) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const Lds S = carve<SX_N>(smem);                   // (the aux planes are unused by the reverse walk)
+    Lds S;
+    S.actp = smem;
+    S.auxp = nullptr;                                  // (the aux planes are unused by the reverse walk)
+    S.rs_main = reinterpret_cast<float*>(smem + 2 * PLANE_A);
+    S.rs_aux = S.rs_main + 64;
+    S.rmax = S.rs_aux + 64;
+    S.scr = nullptr;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
     const int row0 = blockIdx.x * 64;
+    char* pa_lds = reinterpret_cast<char*>(S.rmax + 64 * 8) + wave * 8192;
+    const unsigned pa_addr = __builtin_amdgcn_readfirstlane(lds_offset_of(pa_lds));
+    const size_t goff = (size_t)(row0 + i) * NERO_HID + 32 * wave + 4 * h;
+    unsigned mbits[2] = {0u, 0u};                      // ReLU sign masks of the layer being processed
+    // request what the epilogue of layer `Ln` needs of its input activation: the sign words (registers) or the fp32 tile (LDS-DMA)
+    auto prefetch_act = [&](const nero_bwd_layer& Ln) {
+        if (Ln.a_prev == nullptr || wave >= Ln.k_main_tiles) return;
+        if (Ln.mask_prev && Ln.act_prev == NERO_ACT_RELU) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) mbits[r] = Ln.mask_prev[(size_t)(row0 + 32 * r + i) * 8 + wave];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    lds_dma16(Ln.a_prev + goff + (size_t)r * 32 * NERO_HID + 8 * g, pa_addr + (r * 4 + g) * 1024);
+        }
+    };
+    prefetch_act(ch.layer[ch.n_layers - 1]);
     if (ch.dy) load_planes_scaled(S.actp, SA, PLANE_A, S.rs_main, ch.dy, ch.ld_dy, ch.k_dy, row0, n_rows, tid);
     else {
         for (int idx = tid; idx < 2 * PLANE_A / 16; idx += 512) reinterpret_cast<uint4*>(S.actp)[idx] = make_uint4(0u, 0u, 0u, 0u);
@@ -439,28 +472,9 @@ __global__ __launch_bounds__(512, 1) void bwd_f16_kernel(nero_bwd_chain ch, int 
         const int nt = L.k_main_tiles;
         const bool live_wave = wave < nt;
         const int fbase = 32 * wave + 4 * h;
-        const size_t goff = (size_t)(row0 + i) * NERO_HID + fbase;
         const size_t boff = (size_t)row0 * NERO_HID + 32 * wave;
         const int steps = L.n_out >> 4;
-        float4 pa[2][4];                                   // saved activations of this lane's outputs, requested before the GEMM
         const bool has_inj = !first && L.inj != nullptr;
-        if (!first && live_wave) {
-            if (L.mask_prev && L.act_prev == NERO_ACT_RELU) {   // 4 bytes per (row, tile) instead of 128: only the sign is needed
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const unsigned bits = L.mask_prev[(size_t)(row0 + 32 * r + i) * 8 + wave] >> (16 * h);
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        pa[r][g] = make_float4((bits >> (4 * g)) & 1u ? 1.f : 0.f, (bits >> (4 * g + 1)) & 1u ? 1.f : 0.f,
-                                               (bits >> (4 * g + 2)) & 1u ? 1.f : 0.f, (bits >> (4 * g + 3)) & 1u ? 1.f : 0.f);
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 2; ++r)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) pa[r][g] = *reinterpret_cast<const float4*>(L.a_prev + goff + (size_t)r * 32 * NERO_HID + 8 * g);
-            }
-        }
         float4 gq[2][4];                                   // incoming gradient of this lane's outputs, true units
         const float rs0 = S.rs_main[i], rs1 = S.rs_main[32 + i];
         PH(1);
@@ -536,15 +550,36 @@ __global__ __launch_bounds__(512, 1) void bwd_f16_kernel(nero_bwd_chain ch, int 
         float m[2] = {0.f, 0.f};
         PH(3);
         if (live_wave) {
+            float4 pa[2][4];                               // saved activations of this lane's outputs (ReLU: 1 / 0 from the sign mask)
+            if (L.mask_prev && L.act_prev == NERO_ACT_RELU) {   // 4 bytes per (row, tile) instead of 128: only the sign is needed
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const unsigned bits = mbits[r] >> (16 * h);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        pa[r][g] = make_float4((bits >> (4 * g)) & 1u ? 1.f : 0.f, (bits >> (4 * g + 1)) & 1u ? 1.f : 0.f,
+                                               (bits >> (4 * g + 2)) & 1u ? 1.f : 0.f, (bits >> (4 * g + 3)) & 1u ? 1.f : 0.f);
+                }
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's LDS-DMA of the tile has landed
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) pa[r][g] = *reinterpret_cast<const float4*>(pa_lds + (r * 4 + g) * 1024 + lane * 16);
+            }
             if (L.act_prev == NERO_ACT_RELU) bwd_values_h<NERO_ACT_RELU>(gq, pa, goff, has_inj, L, row0, i, fbase, n_rows, val, m);
             else if (L.act_prev == NERO_ACT_SOFTPLUS100) bwd_values_h<NERO_ACT_SOFTPLUS100>(gq, pa, goff, has_inj, L, row0, i, fbase, n_rows, val, m);
             else bwd_values_h<NERO_ACT_NONE>(gq, pa, goff, has_inj, L, row0, i, fbase, n_rows, val, m);
             PH(4);
-            if (L.delta_prev) {
-                float* scr = reinterpret_cast<float*>(S.scr + wave * SCR_BYTES);
-                acc_to_global(scr, val[0], L.delta_prev + boff, lane);
-                acc_to_global(scr, val[1], L.delta_prev + boff + (size_t)32 * NERO_HID, lane);
-            }
+        }
+        if (live_wave && L.delta_prev) {                   // (the PA buffer has been read out: it is the transposition scratch now)
+            float* scr = reinterpret_cast<float*>(pa_lds);
+            acc_to_global(scr, val[0], L.delta_prev + boff, lane);
+            acc_to_global(scr, val[1], L.delta_prev + boff + (size_t)32 * NERO_HID, lane);
+        }
+        if (l > 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the scratch reads are done before the DMA may land
+            prefetch_act(ch.layer[l - 1]);
         }
         PH(5);
         commit_planes(S, val, m[0], m[1], live_wave, wave, i, h);
@@ -667,7 +702,7 @@ int nero_f16_backward(const nero_bwd_chain* ch, int n_rows, hipStream_t stream) 
         if (ch->layer[l].n_out & 15) return nero_fail(NERO_ERR_ARG, "nero_mlp_backward(f16x3): n_out must be a multiple of 16");
     if (ch->d_aux && (ch->ld_daux & 3)) return nero_fail(NERO_ERR_ARG, "nero_mlp_backward(f16x3): ld_daux must be a multiple of 4");
     if (ch->d_init && (ch->ld_dinit & 3)) return nero_fail(NERO_ERR_ARG, "nero_mlp_backward(f16x3): ld_dinit must be a multiple of 4");
-    NERO_ONCE(hipFuncSetAttribute((const void*)bwd_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, f16_lds_bytes(0)));
-    hipLaunchKernelGGL(bwd_f16_kernel, grid, block, f16_lds_bytes(0), stream, *ch, n_rows);
+    NERO_ONCE(hipFuncSetAttribute((const void*)bwd_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bwd_lds_bytes()));
+    hipLaunchKernelGGL(bwd_f16_kernel, grid, block, bwd_lds_bytes(), stream, *ch, n_rows);
     return NERO_OK;
 }
