@@ -200,7 +200,11 @@ __device__ __forceinline__ void gemm_f16x3_loop(f32x16 (&aH)[2], f32x16 (&aL)[2]
     WF wa, wb, wc, wd;
     XF xa, xb;
     const int last = n - 1;
+#ifdef GEMM_NOCLAMP
+#define NERO_CL(c) (c)
+#else
 #define NERO_CL(c) ((c) < last ? (c) : last)
+#endif
     load_w(wa, wp, 0);
     load_w(wb, wp, NERO_CL(1));
     load_w(wc, wp, NERO_CL(2));
