@@ -17,12 +17,14 @@ from . import _lib as L
 #   'f16x3'  (default) two block-scaled fp16 planes, 3 MFMA products: per activation row / weight matrix in the chain kernels
 #            (mlp_f16x3.hip), per 16-row chunk with a running accumulator unit in the weight-gradient GEMM (mlp_f16dw.hip)
 #   'bf16x6' three bf16 planes, 6 products (mlp_split.hip)
-#   'f16x3p' the f16x3 arithmetic, operand images and results on 256-thread workgroups, two resident per CU (mlp_f16p.hip)
+#   'f16x3p' the f16x3 arithmetic, operand images and results on 256-thread workgroups, two resident per CU (mlp_f16p.hip):
+#            default for the forward chains (3-9 % faster: one workgroup's input load / epilogue under the other's MFMAs); the
+#            tangent / reverse chains keep the 512-thread kernels (their 2-per-CU versions spill)
 #   'f32'    the f32-input MFMA, an exact fmaf chain
 # NERO_GEMM=<mode> selects all passes, NERO_GEMM_FWD / _TAN / _BWD / _DW one pass.
 _MODE_NAMES = {'f32': L.GEMM_F32, 'bf16x6': L.GEMM_BF16X6, 'f16x3': L.GEMM_F16X3, 'f16x3p': L.GEMM_F16X3P}
 _F16 = (L.GEMM_F16X3, L.GEMM_F16X3P)          # the two engines that share the kind-3 packed images
-_DEFAULT = {'fwd': 'f16x3', 'tan': 'f16x3', 'bwd': 'f16x3', 'dw': 'f16x3'}
+_DEFAULT = {'fwd': 'f16x3p', 'tan': 'f16x3', 'bwd': 'f16x3', 'dw': 'f16x3'}
 
 
 def _resolve(mode, k):

@@ -118,6 +118,7 @@ __device__ __forceinline__ Lds carve(char* smem) {
     return l;
 }
 inline int f16_lds_bytes(int wide) { return 2 * PLANE_A + 2 * 64 * (wide ? SX_W : SX_N) + (64 + 64 + 512) * 4 + 8 * SCR_BYTES; }
+inline int tan_lds_bytes() { return 2 * PLANE_A + 2 * 64 * SX_N + (64 + 64 + 512) * 4 + 8 * 8192; }      // 150016
 
 // ---------------------------------------------------------------------------------------------------------------------
 // forward chain
@@ -313,23 +314,32 @@ __global__ __launch_bounds__(512, 1) void tan_f16_kernel(nero_tan_chain ch, int 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
     const int row0 = blockIdx.x * 64;
+    // the saved activations of the NEXT layer arrive by LDS-DMA in this lane's fragment order (as in the reverse kernel: 8 KB per
+    // wave in place of the store scratch, which they double as once read out); the first-order signal gbar stays a register load
+    char* pa_lds = S.scr + wave * 8192;
+    const unsigned pa_addr = __builtin_amdgcn_readfirstlane(lds_offset_of(pa_lds));
+    const size_t goff = (size_t)(row0 + i) * NERO_HID + 32 * wave + 4 * h;     // + r*32*HID + 8g
+    auto prefetch_act = [&](const nero_tan_layer& Ln) {
+        if (wave >= Ln.n_tiles) return;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) lds_dma16(Ln.a_saved + goff + (size_t)r * 32 * NERO_HID + 8 * g, pa_addr + (r * 4 + g) * 1024);
+    };
+    prefetch_act(ch.layer[0]);
     if (ch.init) load_planes_scaled(S.actp, SA, PLANE_A, S.rs_main, ch.init, ch.ld_init, ch.k_init, row0, n_rows, tid);
     if (ch.aux) load_planes_scaled(S.auxp, SX, PLANE_X, S.rs_aux, ch.aux, ch.ld_aux, ch.k_aux, row0, n_rows, tid);
     __syncthreads();
     for (int l = 0; l < ch.n_layers; ++l) {
         const nero_tan_layer& L = ch.layer[l];
         const bool live_wave = wave < L.n_tiles;
-        const size_t goff = (size_t)(row0 + i) * NERO_HID + 32 * wave + 4 * h;     // + r*32*HID + 8g
         const size_t boff = (size_t)row0 * NERO_HID + 32 * wave;
-        float4 pa[2][4], pg[2][4];
+        float4 pg[2][4];
         if (live_wave) {
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    pa[r][g] = *reinterpret_cast<const float4*>(L.a_saved + goff + (size_t)r * 32 * NERO_HID + 8 * g);
-                    pg[r][g] = *reinterpret_cast<const float4*>(L.gbar + goff + (size_t)r * 32 * NERO_HID + 8 * g);
-                }
+                for (int g = 0; g < 4; ++g) pg[r][g] = *reinterpret_cast<const float4*>(L.gbar + goff + (size_t)r * 32 * NERO_HID + 8 * g);
         }
         f32x16 aH[2], aL[2];
         zero2(aH);
@@ -339,7 +349,14 @@ __global__ __launch_bounds__(512, 1) void tan_f16_kernel(nero_tan_chain ch, int 
         float4 val[2][4];
         float m[2] = {0.f, 0.f};
         if (live_wave) {
-            float* scr = reinterpret_cast<float*>(S.scr + wave * SCR_BYTES);
+            float4 pa[2][4];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's LDS-DMA of the tile has landed
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) pa[r][g] = *reinterpret_cast<const float4*>(pa_lds + (r * 4 + g) * 1024 + lane * 16);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // read out: the buffer is the store scratch from here on
+            float* scr = reinterpret_cast<float*>(pa_lds);
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const bool live = (row0 + 32 * r + i) < n_rows;
@@ -360,6 +377,10 @@ __global__ __launch_bounds__(512, 1) void tan_f16_kernel(nero_tan_chain ch, int 
                 acc_to_global(scr, adq, L.adot + boff + (size_t)r * 32 * NERO_HID, lane);
                 acc_to_global(scr, ijq, L.inj + boff + (size_t)r * 32 * NERO_HID, lane);
             }
+        }
+        if (l + 1 < ch.n_layers) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the scratch reads are done before the DMA may land
+            prefetch_act(ch.layer[l + 1]);
         }
         commit_planes(S, val, m[0], m[1], live_wave, wave, i, h);
     }
@@ -696,8 +717,8 @@ int nero_f16_tangent(const nero_tan_chain* ch, int n_rows, hipStream_t stream) {
         if ((ch->layer[l].k_main | ch->layer[l].k_aux) & 15)
             return nero_fail(NERO_ERR_ARG, "nero_mlp_tangent(f16x3): k_main / k_aux must be multiples of 16");
     if (ch->aux_wide) return nero_fail(NERO_ERR_UNSUPPORTED, "nero_mlp_tangent(f16x3): aux_wide chains are not supported");
-    NERO_ONCE(hipFuncSetAttribute((const void*)tan_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, f16_lds_bytes(0)));
-    hipLaunchKernelGGL(tan_f16_kernel, grid, block, f16_lds_bytes(0), stream, *ch, n_rows);
+    NERO_ONCE(hipFuncSetAttribute((const void*)tan_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tan_lds_bytes()));
+    hipLaunchKernelGGL(tan_f16_kernel, grid, block, tan_lds_bytes(), stream, *ch, n_rows);
     return NERO_OK;
 }
 

