@@ -159,6 +159,9 @@ __device__ __forceinline__ void load_w(WF& o, const uint4* wp, int c) {
 #ifdef F16_NO_WSTREAM                               // (timing experiments, scripts/f16_variants.sh: every k-step re-reads step 0)
     c = 0;
 #endif
+#ifdef F16_NO_WLOAD                                 // (timing experiment: no weight loads at all past the first fragment)
+    if (c > 0) { o.wh = make_uint4(c, c, c, c); o.wl = o.wh; return; }
+#endif
     const uint4* w = wp + (size_t)c * 128;
     o.wh = w[0];
     o.wl = w[64];
