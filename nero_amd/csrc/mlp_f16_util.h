@@ -159,9 +159,6 @@ __device__ __forceinline__ void load_w(WF& o, const uint4* wp, int c) {
 #ifdef F16_NO_WSTREAM                               // (timing experiments, scripts/f16_variants.sh: every k-step re-reads step 0)
     c = 0;
 #endif
-#ifdef F16_NO_WLOAD                                 // (timing experiment: no weight loads at all past the first fragment)
-    if (c > 0) { o.wh = make_uint4(c, c, c, c); o.wl = o.wh; return; }
-#endif
     const uint4* w = wp + (size_t)c * 128;
     o.wh = w[0];
     o.wl = w[64];
@@ -182,20 +179,11 @@ __device__ __forceinline__ void ops_compute(f32x16 (&aH)[2], f32x16 (&aL)[2], co
     aH[1][0] += __uint_as_float(w.wh.y ^ x.xh1.x); aL[1][0] += __uint_as_float(w.wl.y ^ x.xl1.x);
     return;
 #endif
-#ifdef GEMM_ORDER2
-    NERO_MFH(aL[0], w.wh, x.xl0); NERO_MFH(aH[0], w.wh, x.xh0); NERO_MFH(aL[1], w.wh, x.xl1);
-    NERO_MFH(aH[1], w.wh, x.xh1); NERO_MFH(aL[0], w.wl, x.xh0); NERO_MFH(aL[1], w.wl, x.xh1);
-#else
     NERO_MFH(aL[0], w.wl, x.xh0); NERO_MFH(aL[1], w.wl, x.xh1);
     NERO_MFH(aH[0], w.wh, x.xh0); NERO_MFH(aH[1], w.wh, x.xh1);
     NERO_MFH(aL[0], w.wh, x.xl0); NERO_MFH(aL[1], w.wh, x.xl1);
-#endif
 }
-#ifdef GEMM_NOFENCE
-#define NERO_FENCE()
-#else
-#define NERO_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
+#define NERO_FENCE() __builtin_amdgcn_sched_barrier(0)      // (without the fences hipcc sinks the prefetches: the kernels run 40 % slower)
 
 __device__ __forceinline__ void gemm_f16x3_loop(f32x16 (&aH)[2], f32x16 (&aL)[2], const uint4* wp, const char* xp, int half_bytes,
                                            int plane_bytes, int n) {
@@ -203,11 +191,7 @@ __device__ __forceinline__ void gemm_f16x3_loop(f32x16 (&aH)[2], f32x16 (&aL)[2]
     WF wa, wb, wc, wd;
     XF xa, xb;
     const int last = n - 1;
-#ifdef GEMM_NOCLAMP
-#define NERO_CL(c) (c)
-#else
 #define NERO_CL(c) ((c) < last ? (c) : last)
-#endif
     load_w(wa, wp, 0);
     load_w(wb, wp, NERO_CL(1));
     load_w(wc, wp, NERO_CL(2));
@@ -264,35 +248,10 @@ __device__ __forceinline__ void gemm_f16x3_fixed(f32x16 (&aH)[2], f32x16 (&aL)[2
     });
 }
 
-// run-time step count n <= 16 on the same unrolled body: every step guarded by a wave-uniform branch (no clamps, no ring rotation)
-__device__ __forceinline__ void gemm_f16x3_masked(f32x16 (&aH)[2], f32x16 (&aL)[2], const uint4* wp, const char* xp, int half_bytes,
-                                                  int plane_bytes, int n) {
-    constexpr int XD = GEMM_XD, XN = XD + 1, WD = GEMM_WD, WN = WD + 1;
-    WF w[WN];
-    XF x[XN];
-    static_for<0, WD>([&](auto c) { if (c.value < n) load_w(w[c.value], wp, c.value); });
-    static_for<0, XD>([&](auto c) { if (c.value < n) load_x(x[c.value], xp, half_bytes, plane_bytes, c.value); });
-    NERO_FENCE();
-    static_for<0, 16>([&](auto cc) {
-        constexpr int c = cc.value;
-        if (c + WD < n) load_w(w[(c + WD) % WN], wp, c + WD);
-        if (c + XD < n) load_x(x[(c + XD) % XN], xp, half_bytes, plane_bytes, c + XD);
-        NERO_FENCE();
-        if (c < n) ops_compute(aH, aL, w[c % WN], x[c % XN]);
-        NERO_FENCE();
-    });
-}
-
 __device__ __forceinline__ void gemm_f16x3(f32x16 (&aH)[2], f32x16 (&aL)[2], const uint4* wp, const char* xp, int half_bytes,
                                            int plane_bytes, int n) {
-#ifdef GEMM_MASKED
-    gemm_f16x3_masked(aH, aL, wp, xp, half_bytes, plane_bytes, n); return;
-#endif
 #ifdef GEMM_ASSUME16                                   // (timing experiments on all-256-wide chains only: wrong for any other K)
     gemm_f16x3_fixed<16>(aH, aL, wp, xp, half_bytes, plane_bytes); return;
-#endif
-#ifdef GEMM_FIXED16
-    if (n == 16) { gemm_f16x3_fixed<16>(aH, aL, wp, xp, half_bytes, plane_bytes); return; }
 #endif
     gemm_f16x3_loop(aH, aL, wp, xp, half_bytes, plane_bytes, n);
 }

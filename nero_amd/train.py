@@ -150,7 +150,7 @@ class ShapeTrainStep:
     (rank-strided); gradients are summed with ONE flat all-reduce per step and divided by world size."""
 
     def __init__(self, cfg, rays_per_rank=4096, pool_rays=262144, device='cuda', seed=6033, variance=None, eikonal_weight=0.1,
-                 rank=0, world=1, prime_fraction=0.35, fused=None, prime_passes=2):
+                 rank=0, world=1, prime_fraction=0.35, fused=None, prime_passes=4):
         self.device, self.rank, self.world, self.R = device, rank, world, rays_per_rank
         torch.manual_seed(seed)
         if world > 1:                  # global occlusion-loss candidate budget = the single-process cap (SURVEY.md 8e)
@@ -179,9 +179,10 @@ class ShapeTrainStep:
             if prime_fraction > 0:
                 self.prime_allocator(prime_fraction)
             self._lazy_init()
-            # size the caching allocator for the real batch: `prime_passes` full-size forward + backward passes (no optimiser step,
-            # the weights and Adam moments are untouched; the pool cursor is rewound).  The per-step workspaces are ~30 GB of
-            # variously sized blocks; without this the first optimisation steps pay hipMalloc / block-splitting for them.
+            # size the caching allocator for the real batches: `prime_passes` full-size forward + backward passes over the first
+            # batches of the pool (no optimiser step: the weights and Adam moments are untouched; the pool cursor is rewound).
+            # The per-step workspaces are ~30 GB of variously sized blocks whose sizes follow the per-batch sample counts; without
+            # this the first optimisation steps pay hipMalloc / block-splitting for them.
             if prime_passes > 0 and pool_rays >= rays_per_rank * world:
                 for i in range(prime_passes):
                     self.forward_backward(25000 + i)
