@@ -1,0 +1,119 @@
+"""GPU tier: properties of the round-2 kernels that the per-mode engine tests do not state on their own.
+* the paired-workgroup forward engine (NERO_GEMM_F16X3P, mlp_f16p.hip) reproduces the 512-thread fp16 engine BIT FOR BIT
+  (same packed images, same per-row scales, same MFMA order): chains with a skip / aux input, heads, saves and ReLU masks;
+* the fp16 three-product weight-gradient GEMM (mlp_f16dw.hip) against an fp64 matmul on operands built to stress its block
+  scaling: row magnitudes spread over 2^40, an outlier block at the start (the running accumulator unit is set high first),
+  ReLU-sparse operands, two operand pairs, ragged shapes."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(n_out, n_in, g, s=1.4):
+    return (torch.randn(n_out, n_in, generator=g) * s / math.sqrt(n_in)).cuda(), (torch.randn(n_out, generator=g) * 0.05).cuda()
+
+
+@pytest.mark.parametrize('n_rows', [777, 20000])
+def test_paired_forward_engine_is_bit_identical_to_the_512_thread_engine(n_rows):
+    from nero_amd import _lib as L
+    from nero_amd import chain as CH
+    from nero_amd.chain import Chain, Dense, Head, row_pad
+    g = torch.Generator().manual_seed(1)
+    rp = row_pad(n_rows)
+    pe = torch.zeros(rp, 40, device='cuda')
+    pe[:n_rows, :39] = torch.randn(n_rows, 39, generator=g).cuda()
+    # an SDF-shaped chain: narrow first layer, skip layer with an aux part, softplus, head + dense at the end
+    ws = [_mk(256, 39, g), _mk(256, 256, g), _mk(217, 256, g), _mk(256, 256, g), _mk(257, 256, g, 1.0)]
+    x8 = torch.zeros(rp, 8, device='cuda')
+    x8[:n_rows, :3] = torch.randn(n_rows, 3, generator=g).cuda()
+    feat = torch.randn(rp, 256, generator=g).cuda() * 0.3
+    pw = [_mk(256, 259, g), _mk(256, 256, g), _mk(3, 256, g)]
+    old = dict(CH.GEMM_MODE)
+    outs = {}
+    try:
+        for mode in ('f16x3', 'f16x3p'):
+            CH.set_gemm_mode(mode)
+            sdf = Chain([(Dense(*ws[0], L.ACT_SOFTPLUS100, 39), None), (Dense(*ws[1], L.ACT_SOFTPLUS100, 256), None),
+                         (Dense(*ws[2], L.ACT_SOFTPLUS100, 256), None),
+                         (Dense(*ws[3], L.ACT_SOFTPLUS100, 217, 0, 39, 217, 1.0 / math.sqrt(2)), None),
+                         (Dense(ws[4][0][1:], ws[4][1][1:], L.ACT_NONE, 256), Head(ws[4][0][0:1], ws[4][1][0:1]))],
+                        k_init=40, k_aux=40).pack()
+            f = sdf.forward(pe, pe, n_rows, save=True)
+            pred = Chain([(Dense(*pw[0], L.ACT_RELU, 256, 0, 3, 256), None), (Dense(*pw[1], L.ACT_RELU, 256), None),
+                          (None, Head(*pw[2]))], k_init=256, k_aux=8).pack()
+            p = pred.forward(feat, x8, n_rows, save=True)
+            outs[mode] = [s[:n_rows].clone() for s in f['saves'] if s is not None] + [f['heads'][4][:n_rows, :1].clone()] + \
+                         [s[:n_rows].clone() for s in p['saves'] if s is not None] + [p['heads'][2][:n_rows, :3].clone()] + \
+                         [m[:n_rows].clone() for m in p['masks'] if m is not None]
+    finally:
+        CH.GEMM_MODE.update(old)
+    assert len(outs['f16x3']) == len(outs['f16x3p']) >= 9
+    for a, b in zip(outs['f16x3'], outs['f16x3p']):
+        assert torch.equal(a, b)
+
+
+def _dw(mode, D, B, n, D1=None, B1=None, n_out=256, k=256):
+    from nero_amd import _lib as L
+    ws = torch.empty(L.lib.nero_dw_workspace_floats(n), dtype=torch.float32, device='cuda')
+    dW = torch.empty(n_out, k, device='cuda')
+    db = torch.empty(n_out, device='cuda')
+    job = L.DwJob()
+    job.d0, job.ldd0, job.b0, job.ldb0 = D.data_ptr(), D.stride(0), B.data_ptr(), B.stride(0)
+    if D1 is not None:
+        job.d1, job.ldd1, job.b1, job.ldb1 = D1.data_ptr(), D1.stride(0), B1.data_ptr(), B1.stride(0)
+    job.n_out, job.k_cols, job.dW, job.ldw, job.col0, job.db = n_out, k, dW.data_ptr(), dW.stride(0), 0, db.data_ptr()
+    job.scale, job.accumulate, job.gemm_mode = 1.0, 0, mode
+    L.check(L.lib.nero_dw_gemm(C.byref(job), n, C.c_void_p(ws.data_ptr()), L.stream_ptr()))
+    torch.cuda.synchronize()
+    return dW, db
+
+
+def _rel(a, b):
+    return float((a.double() - b).abs().max() / b.abs().max())
+
+
+@pytest.mark.parametrize('kind', ['plain', 'tails', 'outlier-first', 'relu', 'zero-chunks'])
+def test_fp16_weight_gradient_gemm_vs_fp64(kind):
+    from nero_amd import _lib as L
+    n = 70001                                           # ragged: the last slice ends inside a 16-row chunk
+    g = torch.Generator(device='cuda').manual_seed(3)
+    D = torch.randn(n, 256, device='cuda', generator=g)
+    B = torch.randn(n, 256, device='cuda', generator=g)
+    if kind == 'tails':
+        D *= torch.exp(torch.randn(n, 1, device='cuda', generator=g) * 4.0) * 1e-4
+        B *= torch.exp(torch.randn(n, 1, device='cuda', generator=g) * 2.0)
+    elif kind == 'outlier-first':
+        D *= 1e-6
+        D[:16] *= 1e9
+    elif kind == 'relu':
+        B = torch.relu(B)
+        D *= (torch.rand(n, 1, device='cuda', generator=g) < 0.3)
+    elif kind == 'zero-chunks':
+        D[1000:40000] = 0
+        B[30000:50000] = 0
+    ref, refb = D.double().t() @ B.double(), D.double().sum(0)
+    dW, db = _dw(L.GEMM_F16X3, D, B, n)
+    dW6, _ = _dw(L.GEMM_BF16X6, D, B, n)
+    e3, e6, e32 = _rel(dW, ref), _rel(dW6, ref), _rel(D.t() @ B, ref)
+    assert e3 < 2e-6 and e3 < 3 * max(e6, 3e-7), (e3, e6, e32)          # fp32 grade, and in the class of the six-product kernel
+    assert _rel(db, refb) < 2e-6
+
+
+@pytest.mark.parametrize('n_out,k', [(217, 256), (256, 48), (3, 256), (256, 96), (256, 39)])
+def test_fp16_weight_gradient_gemm_ragged_shapes_and_two_pairs(n_out, k):
+    from nero_amd import _lib as L
+    n = 33333
+    g = torch.Generator(device='cuda').manual_seed(5)
+    D = torch.randn(n, 256, device='cuda', generator=g) * torch.exp(torch.randn(n, 1, device='cuda', generator=g) * 3.0)
+    B = torch.randn(n, 256, device='cuda', generator=g)
+    D1 = torch.randn(n, 256, device='cuda', generator=g) * 1e-3
+    B1 = torch.randn(n, 256, device='cuda', generator=g) * 10
+    # columns beyond the logical widths hold foreign data (the chain kernels write whole 32-column tiles): they must not leak
+    ref = D[:, :n_out].double().t() @ B[:, :k].double() + D1[:, :n_out].double().t() @ B1[:, :k].double()
+    dW, db = _dw(L.GEMM_F16X3, D, B, n, D1, B1, n_out=n_out, k=k)
+    assert _rel(dW, ref) < 2e-6
+    assert _rel(db, D[:, :n_out].double().sum(0)) < 2e-6
