@@ -34,8 +34,8 @@ __device__ __forceinline__ void acc_to_global(float* scr, const float4 (&q)[4], 
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int p = 0; p < 4; ++p)
-        *reinterpret_cast<float4*>(gblock + (size_t)(8 * p + (lane >> 3)) * NERO_HID + 4 * (lane & 7)) =
-            *reinterpret_cast<const float4*>(scr + (8 * p + (lane >> 3)) * SCR_LD + 4 * (lane & 7));
+        store_ws4(gblock + (size_t)(8 * p + (lane >> 3)) * NERO_HID + 4 * (lane & 7),
+                  *reinterpret_cast<const float4*>(scr + (8 * p + (lane >> 3)) * SCR_LD + 4 * (lane & 7)));
     __builtin_amdgcn_wave_barrier();
 }
 
