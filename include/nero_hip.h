@@ -181,7 +181,9 @@ typedef struct {
     float* db;                          /* [n_out] or NULL                    */
     float scale;
     int accumulate;                     /* 0: overwrite, 1: add into dW/db    */
-    int gemm_mode, pad_;                /* NERO_GEMM_* (operands are plain fp32 matrices in either mode) */
+    int gemm_mode, pad_;                /* NERO_GEMM_* (operands are plain fp32 matrices in every mode).  F16X3 / F16X3P: three fp16
+                                           plane products, each 16-row chunk block-scaled to the top of fp16's range, one fp32
+                                           accumulator with a running unit (mlp_f16dw.hip); BF16X6: six bf16 products */
 } nero_dw_job;
 
 int nero_dw_workspace_floats(int n_rows);
