@@ -7,6 +7,10 @@
                                Stage II NeROMaterialRenderer._construct_ray_batch (network/renderer.py:756-802) behind the brute-force
                                tracer oracle (the third-party tracer is absent), + get_human_coordinate_poses of both classes
   tests/golden/ref_state.json  state_dict keys / shapes / dtypes of the reference constructors for the four shipped config families
+  tests/golden/bell_noclip_l1.npz, bell_l2.npz, bell_smoothl1.npz
+                               three more Stage-I render cases (oracle/gen_golden.py::run_case) for branches round 1 left unpinned:
+                               clip_sample_variance = False (network/renderer.py:434-438) and the rgb_loss kinds l1 / l2 / smooth_l1
+                               (network/renderer.py:332-344)
 
 TEST INFRASTRUCTURE ONLY: /root/reference does not exist on the GPU box; the committed fixtures are what travels.
 """
@@ -107,6 +111,15 @@ def state_manifest():
     print('state manifest ok:', {k: len(v) for k, v in out.items()})
 
 
+def extra_render_cases():
+    from oracle.gen_golden import run_case
+    small = dict(n_samples=16, n_importance=16, n_bg_samples=8, up_sample_steps=4)
+    run_case('bell_noclip_l1', dict(small, clip_sample_variance=False, rgb_loss='l1'), R=48, step=25000, variance=0.45)
+    run_case('bell_l2', dict(small, rgb_loss='l2'), R=48, step=25000, variance=0.3)
+    run_case('bell_smoothl1', dict(small, rgb_loss='smooth_l1'), R=48, step=25000, variance=0.35)
+
+
 if __name__ == '__main__':
     pools()
     state_manifest()
+    extra_render_cases()

@@ -10,7 +10,7 @@ from tests.helpers import T, assert_grads_fp32_grade, build_case_model, load_gol
 
 pytestmark = pytest.mark.gpu
 
-CASES = ['bell_s25000', 'bell_s5000_sharp', 'bell_c1', 'bear_s25000', 'bell_sphdir']
+CASES = ['bell_s25000', 'bell_s5000_sharp', 'bell_c1', 'bear_s25000', 'bell_sphdir', 'bell_noclip_l1', 'bell_l2', 'bell_smoothl1']
 
 
 def rel(a, b):
@@ -121,7 +121,7 @@ def test_render_core_outputs_and_grads(name):
     assert_grads_fp32_grade(named_grads(net), named_grads(ref), g64, where=name)
 
 
-@pytest.mark.parametrize('name', ['bell_s25000', 'bell_occcap', 'bell_s500', 'bear_s25000', 'bell_sphdir'])
+@pytest.mark.parametrize('name', ['bell_s25000', 'bell_occcap', 'bell_s500', 'bear_s25000', 'bell_sphdir', 'bell_noclip_l1', 'bell_l2', 'bell_smoothl1'])
 def test_full_training_loss_with_occ_and_init_reg(name):
     """trainer loss incl. the occlusion loss (step >= 20000, with and without the random cap) and the InitSDFRegLoss inputs
     (step < 1000), teacher-forced on the golden z_vals; loss, loss_occ and gradients vs the oracle"""
