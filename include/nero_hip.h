@@ -208,7 +208,10 @@ typedef struct {
     float* m_v; float* v_v; float* m_g; float* v_g;
     int rows, cols;
 } nero_wn_job;
-typedef struct { float* p; const float* grad; float* m; float* v; int n; int pad_; } nero_adam_job;
+/* step: 0 = this job uses the call's `step` argument; > 0 = the job's own 1-based Adam step (bias correction); < 0 = the tensor has no
+ * gradient this step: skipped entirely -- torch.optim.Adam skips parameters whose .grad is None, their step counter and moments do not
+ * advance (deviation_network.variance while step < freeze_inv_s_step, network/renderer.py:494-495). */
+typedef struct { float* p; const float* grad; float* m; float* v; int n; int step; } nero_adam_job;
 int nero_wn_forward_batch(const nero_wn_job* jobs /*host*/, int n_jobs, void* stream);
 int nero_wn_adam_batch(const nero_wn_job* wn /*host*/, int n_wn, const nero_adam_job* plain /*host*/, int n_plain, float lr, float beta1,
                        float beta2, float eps, int step /*1-based*/, void* stream);

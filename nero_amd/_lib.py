@@ -73,7 +73,7 @@ class WnJob(C.Structure):
 
 
 class AdamJob(C.Structure):
-    _fields_ = [('p', _fp), ('grad', _fp), ('m', _fp), ('v', _fp), ('n', C.c_int), ('pad_', C.c_int)]
+    _fields_ = [('p', _fp), ('grad', _fp), ('m', _fp), ('v', _fp), ('n', C.c_int), ('step', C.c_int)]
 
 
 MAX_WN_JOBS, MAX_ADAM_JOBS = 40, 96

@@ -76,7 +76,10 @@ __device__ __forceinline__ void acc_to_global16(float* scr, const float4 (&q)[4]
 // vmcnt bookkeeping stays conservative (an untracked older load only makes counted waits longer); the reader must issue its own
 // s_waitcnt vmcnt(0) before touching the target.
 __device__ __forceinline__ void lds_dma16(const void* gptr, unsigned lds_addr) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gptr), "s"(lds_addr) : "memory", "m0");
+    // M0 = LDS base of the transfer.  It is handed over as a "{m0}"-constrained INPUT, so the compiler materialises the s_mov_b32 m0
+    // itself and knows the register is live here (a clobber of m0 is ignored by hipcc: "reserved register").  The s_nop covers the
+    // S_MOV-to-M0 -> LDS-DMA wait state, which hipcc's hazard recogniser cannot insert for an instruction inside an asm block.
+    asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gptr), "{m0}"(lds_addr) : "memory");
 }
 __device__ __forceinline__ unsigned lds_offset_of(const void* p) { return (unsigned)(size_t)p; }      // generic -> LDS byte offset
 

@@ -40,7 +40,15 @@ __global__ __launch_bounds__(256) void wn_forward_kernel(WnBatch B) {
     if (lane == 0) J.inv_norm[row] = 1.f / n;
 }
 
-struct AdamHyper { float lr_over_bc1, inv_sqrt_bc2, beta1, beta2, eps; };
+struct AdamHyper { float lr_over_bc1, inv_sqrt_bc2, beta1, beta2, eps, lr; };
+
+// bias corrections of a job that keeps its own step counter (nero_adam_job.step > 0)
+__device__ __forceinline__ AdamHyper hyper_for_step(AdamHyper H, int step) {
+    const double bc1 = 1.0 - pow((double)H.beta1, (double)step), bc2 = 1.0 - pow((double)H.beta2, (double)step);
+    H.lr_over_bc1 = (float)((double)H.lr / bc1);
+    H.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    return H;
+}
 
 __device__ __forceinline__ void adam_one(float& p, float& m, float& v, float g, const AdamHyper& H) {
     m = m + (g - m) * (1.f - H.beta1);
@@ -79,6 +87,8 @@ __global__ __launch_bounds__(256) void wn_adam_kernel(WnBatch B, AdamHyper H) {
 // plain Adam: grid (blocks, n_jobs), grid-stride
 __global__ __launch_bounds__(256) void adam_kernel(AdamBatch B, AdamHyper H) {
     const nero_adam_job& J = B.job[blockIdx.y];
+    if (J.step < 0) return;                                   // no gradient this step: parameter, moments and step count untouched
+    if (J.step > 0) H = hyper_for_step(H, J.step);
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < J.n; idx += gridDim.x * 256) {
         float p = J.p[idx], m = J.m[idx], q = J.v[idx];
         adam_one(p, m, q, J.grad[idx], H);
@@ -112,7 +122,7 @@ int nero_wn_adam_batch(const nero_wn_job* wn, int n_wn, const nero_adam_job* pla
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     H.lr_over_bc1 = (float)(lr / bc1);
     H.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-    H.beta1 = beta1; H.beta2 = beta2; H.eps = eps;
+    H.beta1 = beta1; H.beta2 = beta2; H.eps = eps; H.lr = lr;
     if (n_wn > 0) {
         WnBatch B;
         int max_rows = 1;

@@ -44,9 +44,22 @@ class MaterialKernels:
         self.tab_d, self.tab_s = table(dn), table(sn)
 
     def pack(self):
-        for c in [self.feats, self.outer_light, self.inner_light, self.human_light] + self.mat:
-            if c is not None:
-                c.pack()
+        """(re)pack the operand images of all networks into ONE zero-filled flat buffer (kept while its size fits) with the pack jobs
+        of every chain batched (as ShapeKernels.pack)"""
+        from .chain import run_pack_jobs
+        parts = [c for c in [self.feats, self.outer_light, self.inner_light, self.human_light] + self.mat if c is not None]
+        sizes = [(c.pack_floats() + 63) // 64 * 64 for c in parts]
+        total = sum(sizes)
+        flat = getattr(self, '_flat', None)
+        if flat is None or flat.numel() != total:
+            flat = self._flat = torch.zeros(total, dtype=torch.float32, device=self.device)
+        else:
+            flat.zero_()
+        jobs, off = [], 0
+        for c, n in zip(parts, sizes):
+            jobs += c.pack(flat[off:off + n], run=False)
+            off += n
+        run_pack_jobs(jobs)
         return self
 
 
@@ -87,7 +100,8 @@ class PredictMaterials(torch.autograd.Function):
     """raw (pre-sigmoid) metallic / roughness / albedo heads for points x [n,3] -> [n,5]   (predict_materials, field.py:915-922)"""
 
     @staticmethod
-    def forward(ctx, K, names, x, *params):
+    def forward(ctx, K, names, gv, x, *params):
+        """gv: optional {name: destination view} (fused trainer: slices of the flat gradient bucket the GEMMs write in place)"""
         dev = x.device
         n = x.shape[0]
         rp = row_pad(n)
@@ -100,7 +114,7 @@ class PredictMaterials(torch.autograd.Function):
         ff = K.feats.forward(pe, pe, n)
         feats = ff['saves'][7]
         mf = [c.forward(feats, x8, n) for c in K.mat]
-        ctx.K, ctx.names, ctx.n, ctx.pe, ctx.x8, ctx.ff, ctx.mf = K, names, n, pe, x8, ff, mf
+        ctx.K, ctx.names, ctx.n, ctx.pe, ctx.x8, ctx.ff, ctx.mf, ctx.gv = K, names, n, pe, x8, ff, mf, (gv or {})
         ctx.shapes = [tuple(p.shape) for p in params]
         return torch.cat([mf[0]['heads'][3][:n, :1], mf[1]['heads'][3][:n, :1], mf[2]['heads'][3][:n, :3]], -1)
 
@@ -112,6 +126,12 @@ class PredictMaterials(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         ws = torch.empty(L.lib.nero_dw_workspace_floats(max(n, 1)), **f32)
         G = {}
+        gv, inplace = ctx.gv, set()
+
+        def outs_of(prefix, idxs):
+            o = {i: (gv[f'{prefix}.{i}.weight'], gv[f'{prefix}.{i}.bias']) for i in idxs if f'{prefix}.{i}.weight' in gv}
+            inplace.update(f'{prefix}.{i}.{k}' for i in o for k in ('weight', 'bias'))
+            return o
         d_feats = torch.empty((rp, 256), **f32)
         feats = ff['saves'][7]
         cols = ((0, 1), (1, 2), (2, 5))
@@ -119,17 +139,22 @@ class PredictMaterials(torch.autograd.Function):
             dh = torch.zeros((rp, 4), **f32)
             dh[:n, :cols[j][1] - cols[j][0]] = d_raw[:, cols[j][0]:cols[j][1]]
             mb = c.backward(mf[j], n, head_dys={3: dh}, need_dinit=True, dinit_out=d_feats, accumulate_dinit=(j > 0))
-            gr = c.weight_grads(mf[j], mb, n, feats, x8, head_dys={3: dh}, workspace=ws)
+            gr = c.weight_grads(mf[j], mb, n, feats, x8, head_dys={3: dh}, workspace=ws, outs=outs_of(name, range(3)))
             for i in range(3):
                 G[f'{name}.{i}.weight'], G[f'{name}.{i}.bias'] = gr[i]['dW'], gr[i]['db']
             G[f'{name}.3.weight'], G[f'{name}.3.bias'] = gr[3]['dWh'], gr[3]['dbh']
         fb = K.feats.backward(ff, n, dy=d_feats)
-        fg = K.feats.weight_grads(ff, fb, n, pe, pe, workspace=ws)
+        fg = K.feats.weight_grads(ff, fb, n, pe, pe, workspace=ws, outs=outs_of('feats', range(8)))
         for i in range(8):
             G[f'feats.{i}.weight'], G[f'feats.{i}.bias'] = fg[i]['dW'], fg[i]['db']
-        grads = [G.get(nm) for nm in ctx.names[:len(ctx.shapes)]]
-        grads = [g if g is not None else torch.zeros(s, **f32) for g, s in zip(grads, ctx.shapes)]
-        return (None, None, None) + tuple(grads)
+        grads = []
+        for nm, shape in zip(ctx.names[:len(ctx.shapes)], ctx.shapes):
+            if nm in inplace:
+                grads.append(None)                    # written straight into the flat bucket by the weight-gradient GEMM
+            else:
+                g = G.get(nm)
+                grads.append(g if g is not None else (None if nm in gv else torch.zeros(shape, **f32)))
+        return (None, None, None, None) + tuple(grads)
 
 
 class MCShade(torch.autograd.Function):
@@ -137,7 +162,7 @@ class MCShade(torch.autograd.Function):
     weighted specular light [P,3] (no grad).  Gradients: mat5 and the outer / inner light MLP weights."""
 
     @staticmethod
-    def forward(ctx, K, tracer, names, pts, view, normals, mat5, rand_d, rand_s, poses, *params):
+    def forward(ctx, K, tracer, names, gv, pts, view, normals, mat5, rand_d, rand_s, poses, *params):
         dev = pts.device
         lib, st = L.lib, _st()
         f32 = dict(dtype=torch.float32, device=dev)
@@ -185,7 +210,7 @@ class MCShade(torch.autograd.Function):
                                         C.c_float(cfg['light_exp_max']), C.c_float(cfg['inner_light_exp_max']), Pn, Dd, Ds,
                                         GEOMETRY_TYPES[cfg['geometry_type']], _p(rgb), _p(dl), _p(sl), _p(sp), st))
         ctx.S = dict(K=K, names=names, P=Pn, pt=pt, dirs=dirs, depth=depth, fnrm=fnrm, slot=slot, Xm=Xm, Xh=Xh, fo=fo, fi=fi,
-                     fh=fh, Xhum=Xhum, hmask=hmask, poses=poses,
+                     fh=fh, Xhum=Xhum, hmask=hmask, poses=poses, gv=(gv or {}),
                      n_miss=n_miss, n_hit=n_hit, shapes=[tuple(p.shape) for p in params])
         ctx.mark_non_differentiable(sl, sp)
         return rgb, dl, sl, sp
@@ -214,6 +239,12 @@ class MCShade(torch.autograd.Function):
                                         _p(d_or), _p(d_ir), _p(d_hr), _p(d_mat5), _p(d_w), st))
         ws = torch.empty(L.lib.nero_dw_workspace_floats(max(n_miss, n_hit, 1)), **f32)
         G = {}
+        gv, inplace = S['gv'], set()
+
+        def outs_of(prefix):
+            o = {i: (gv[f'{prefix}.{i}.weight'], gv[f'{prefix}.{i}.bias']) for i in range(3) if f'{prefix}.{i}.weight' in gv}
+            inplace.update(f'{prefix}.{i}.{k}' for i in o for k in ('weight', 'bias'))
+            return o
 
         def put(prefix, gr):
             for i in range(3):
@@ -222,21 +253,26 @@ class MCShade(torch.autograd.Function):
         dXm = dXh = dXhum = None
         if n_miss > 0:
             ob = K.outer_light.backward(fo, n_miss, head_dys={3: d_or}, need_dinit=True)
-            put('outer_light', K.outer_light.weight_grads(fo, ob, n_miss, S['Xm'], None, head_dys={3: d_or}, workspace=ws))
+            put('outer_light', K.outer_light.weight_grads(fo, ob, n_miss, S['Xm'], None, head_dys={3: d_or}, workspace=ws, outs=outs_of('outer_light')))
             dXm = ob['d_init']
             if fh:
                 hb = K.human_light.backward(fh, n_miss, head_dys={3: d_hr}, need_dinit=True)
-                put('human_light', K.human_light.weight_grads(fh, hb, n_miss, S['Xhum'], None, head_dys={3: d_hr}, workspace=ws))
+                put('human_light', K.human_light.weight_grads(fh, hb, n_miss, S['Xhum'], None, head_dys={3: d_hr}, workspace=ws, outs=outs_of('human_light')))
                 dXhum = hb['d_init']
         if n_hit > 0:
             ib = K.inner_light.backward(fi, n_hit, head_dys={3: d_ir}, need_dinit=True)
-            put('inner_light', K.inner_light.weight_grads(fi, ib, n_hit, S['Xh'], None, head_dys={3: d_ir}, workspace=ws))
+            put('inner_light', K.inner_light.weight_grads(fi, ib, n_hit, S['Xh'], None, head_dys={3: d_ir}, workspace=ws, outs=outs_of('inner_light')))
             dXh = ib['d_init']
         L.check(lib.nero_mc_dir_bwd(_p(S['pt']), _p(S['dirs']), _p(S['fnrm']), _p(S['slot']), _p(K.tab_s), _p(dXm), _p(dXh), _p(d_w),
                                     Pn, Dd, Ds, _p(d_mat5), K.sphere, _p(dXhum), _p(S['poses']), st))
         grads = []
         for nm, shape in zip(S['names'], S['shapes']):
-            g = G.get(nm)
-            grads.append(g if g is not None else torch.zeros(shape, **f32))
+            if nm in inplace:
+                grads.append(None)                    # written straight into the flat bucket by the weight-gradient GEMM
+            else:
+                g = G.get(nm)
+                # (no gradient this step, e.g. no light ray hit the mesh: zeros -- or nothing at all when the leaf's .grad is a
+                # view of the pre-zeroed bucket)
+                grads.append(g if g is not None else (None if nm in gv else torch.zeros(shape, **f32)))
         ctx.S = None
-        return (None, None, None, None, None, None, d_mat5, None, None, None) + tuple(grads)
+        return (None, None, None, None, None, None, None, d_mat5, None, None, None) + tuple(grads)

@@ -40,10 +40,27 @@ class GradBucket:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
 
+    def reattach(self):
+        """make every p.grad a view of the flat buffer again.  Something outside may have severed one (module.zero_grad() /
+        optimizer.zero_grad() default to set_to_none=True; `p.grad = fresh` re-binds): a severed .grad would silently drop out of
+        the collective and of the fused Adam kernel.  A gradient found in a foreign tensor is copied into its slice first."""
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            g = p.grad
+            if g is None or g.data_ptr() != self.flat.data_ptr() + 4 * off:
+                view = self.flat[off:off + n].view_as(p)
+                if g is not None:
+                    view.copy_(g)
+                p.grad = view
+            off += n
+
     def zero(self):
+        self.reattach()
         self.flat.zero_()
 
     def all_reduce_mean(self, world, group=None):
+        self.reattach()
         if world <= 1:
             return
         _all_reduce_sum(self.flat, group)

@@ -213,7 +213,9 @@ class NeROShapeRenderer(nn.Module):
         out['ray_rgb'] = out['ray_rgb'].reshape(h, w, 3)
         if gt_depth is not None:
             out['gt_depth'], out['gt_mask'] = gt_depth.unsqueeze(-1), gt_mask.unsqueeze(-1)
-        self.zero_grad()
+        # (the reference calls zero_grad() here, network/renderer.py:316; set_to_none=False keeps the .grad tensors -- under
+        # nero_amd.parallel.GradBucket they are views of the persistent flat all-reduce buffer and must not be severed)
+        self.zero_grad(set_to_none=False)
         return out
 
     def forward(self, data):
@@ -261,7 +263,10 @@ class NeROShapeRenderer(nn.Module):
         from .chain import GEMM_MODE
         key = None
         if not torch.is_grad_enabled():
-            key = (tuple((p.data_ptr(), p._version) for p in self.parameters()), tuple(sorted(GEMM_MODE.items())))
+            # (_param_epoch: bumped by optimisers that update the parameters with raw kernels, which torch's version counters
+            # cannot see -- nero_amd.train.FusedShapeOptimizer)
+            key = (tuple((p.data_ptr(), p._version) for p in self.parameters()), tuple(sorted(GEMM_MODE.items())),
+                   getattr(self, '_param_epoch', 0))
             cached = getattr(self, '_kern_cache', None)
             if cached is not None and cached[0] == key:
                 return cached[1]
@@ -361,6 +366,14 @@ def linear_to_srgb(x):
     return torch.where(x <= 0.0031308, 323 / 25 * x, (211 * torch.clamp(x, min=eps) ** (5 / 12) - 11) / 200)
 
 
+def material_hinge(shader_cfg, rough, metallic, step):
+    """the saturation hinge of the first 2000 steps, a SUM over the batch's points (network/field.py:1079-1084); None when inactive"""
+    if not (shader_cfg['reg_min_max'] and step is not None and step < 2000):
+        return None
+    return (torch.sum(torch.clamp(rough - 0.98 ** 2, min=0)) + torch.sum(torch.clamp(0.02 ** 2 - rough, min=0))
+            + torch.sum(torch.clamp(metallic - 0.98, min=0)) + torch.sum(torch.clamp(0.02 - metallic, min=0)))
+
+
 class NeROMaterialRenderer(nn.Module):
     """Stage II: fixed mesh, Monte-Carlo microfacet shading of surface points (network/renderer.py:649-915).  `mesh` may be given
     as (vertices [nV,3], triangles [nT,3]); otherwise cfg['mesh'] is read with trimesh (not a dependency of the hot path)."""
@@ -404,13 +417,13 @@ class NeROMaterialRenderer(nn.Module):
         """-> metallic [n,1], roughness [n,1] (affine to [0.04^2, 1]), albedo [n,3]   (network/field.py:915-922)"""
         from .material_step import PredictMaterials
         names, eff, K = _kern if _kern is not None else self._kernels()
-        raw = PredictMaterials.apply(K, names[:40], pts, *eff[:40])
+        raw = PredictMaterials.apply(K, names[:40], getattr(self, '_grad_views', None), pts, *eff[:40])
         rmin = 0.04 ** 2
         return torch.sigmoid(raw[:, 0:1]), torch.sigmoid(raw[:, 1:2]) * (1.0 - rmin) + rmin, torch.sigmoid(raw[:, 2:5])
 
     def shade(self, pts, view_dirs, normals, human_poses, is_train, step=None, rand_d=None, rand_s=None, _reg_pts=None):
         from .material_step import MCShade
-        kern = self._kernels()
+        kern = self._kern_override if getattr(self, '_kern_override', None) is not None else self._kernels()
         names, eff, K = kern
         scfg = self.shader_network.cfg
         Pn = pts.shape[0]
@@ -424,8 +437,8 @@ class NeROMaterialRenderer(nn.Module):
         else:
             rand_d = rand_s = None
         mat5 = torch.cat([metallic, rough, albedo], -1)
-        rgb_lin, dl, sl, sp = MCShade.apply(K, self.ray_tracer, names[40:], pts, view_dirs, normals, mat5, rand_d, rand_s, human_poses,
-                                            *eff[40:])
+        rgb_lin, dl, sl, sp = MCShade.apply(K, self.ray_tracer, names[40:], getattr(self, '_grad_views', None), pts, view_dirs, normals,
+                                            mat5, rand_d, rand_s, human_poses, *eff[40:])
         kd = 1 - metallic
         outputs = {
             'rgb_pr': linear_to_srgb(rgb_lin), 'albedo': albedo, 'roughness': rough, 'metallic': metallic,
@@ -445,10 +458,13 @@ class NeROMaterialRenderer(nn.Module):
         reg = 0
         if scfg['reg_change']:
             reg = reg + torch.mean((torch.abs(m2[0] - metallic) + torch.abs(m2[1] - rough) + torch.abs(m2[2] - albedo)) * scfg['reg_lambda1'], dim=1)
-        if scfg['reg_min_max'] and step is not None and step < 2000:
-            reg = reg + torch.sum(torch.clamp(rough - 0.98 ** 2, min=0)) + torch.sum(torch.clamp(0.02 ** 2 - rough, min=0))
-            reg = reg + torch.sum(torch.clamp(metallic - 0.98, min=0)) + torch.sum(torch.clamp(0.02 - metallic, min=0))
+        hinge = self.material_hinge(rough, metallic, step)
+        if hinge is not None:
+            reg = reg + hinge
         return reg
+
+    def material_hinge(self, rough, metallic, step):
+        return material_hinge(self.shader_network.cfg, rough, metallic, step)
 
     def regularization_points(self, pts, normals, reg_ang=None, reg_eps=None):
         """tangent-plane perturbation of the surface points (network/field.py:1066-1076)"""

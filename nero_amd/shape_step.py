@@ -271,9 +271,12 @@ class RenderCore(torch.autograd.Function):
         # fused trainer: destinations inside the flat gradient bucket -- the weight-gradient GEMMs write there directly and the
         # corresponding autograd outputs are None (no AccumulateGrad add kernel, no temporary)
         gv = meta.get('grad_views') or {}
+        inplace = set()                          # names whose gradient a GEMM wrote straight into its bucket view (explicit, not inferred)
 
         def outs_of(prefix, idxs):
-            return {i: (gv[f'{prefix}.{i}.weight'], gv[f'{prefix}.{i}.bias']) for i in idxs if f'{prefix}.{i}.weight' in gv}
+            o = {i: (gv[f'{prefix}.{i}.weight'], gv[f'{prefix}.{i}.bias']) for i in idxs if f'{prefix}.{i}.weight' in gv}
+            inplace.update(f'{prefix}.{i}.{k}' for i in o for k in ('weight', 'bias'))
+            return o
 
         def put_pred(prefix, gr):
             for i in range(3):
@@ -289,8 +292,9 @@ class RenderCore(torch.autograd.Function):
             L.check(lib.nero_nerf_head_bwd(_p(trunk['heads'][8]), _p(head['heads'][2]), _p(S['dist_o']), n_out, _p(d_ao), _p(d_co),
                                            _p(d_sig4), _p(d_rgb4), st))
             hb = K.nerf_head.backward(head, n_out, head_dys={2: d_rgb4}, need_dinit=True)
-            hg = K.nerf_head.weight_grads(head, hb, n_out, trunk['saves'][7], S['pev32'], head_dys={2: d_rgb4}, workspace=ws,
-                                          outs={i: (gv[f'nerf.{n}.weight'], gv[f'nerf.{n}.bias']) for i, n in ((0, 'feature'), (1, 'views')) if f'nerf.{n}.weight' in gv})
+            head_outs = {i: (gv[f'nerf.{n}.weight'], gv[f'nerf.{n}.bias']) for i, n in ((0, 'feature'), (1, 'views')) if f'nerf.{n}.weight' in gv}
+            inplace.update(f'nerf.{n}.{k}' for i, n in ((0, 'feature'), (1, 'views')) if i in head_outs for k in ('weight', 'bias'))
+            hg = K.nerf_head.weight_grads(head, hb, n_out, trunk['saves'][7], S['pev32'], head_dys={2: d_rgb4}, workspace=ws, outs=head_outs)
             G['nerf.feature.weight'], G['nerf.feature.bias'] = hg[0]['dW'], hg[0]['db']
             G['nerf.views.weight'], G['nerf.views.bias'] = hg[1]['dW'], hg[1]['db']
             G['nerf.rgb.weight'], G['nerf.rgb.bias'] = hg[2]['dWh'], hg[2]['dbh']
@@ -357,8 +361,12 @@ class RenderCore(torch.autograd.Function):
         grads = []
         for name, shape in zip(meta['names'], meta['shapes']):
             g, v = G.get(name), gv.get(name)
-            if v is not None and (g is None or g.data_ptr() == v.data_ptr()):
-                grads.append(None)               # written in place (or no gradient this step: the bucket was zeroed)
+            if name in inplace:
+                # the GEMM OVERWROTE the bucket view: handing a tensor to autograd as well would add it on top
+                assert g is None or g.data_ptr() == v.data_ptr(), f'{name}: written in place AND returned'
+                grads.append(None)
+            elif g is None and v is not None:
+                grads.append(None)               # no gradient this step: the bucket was zeroed
             else:
                 grads.append(g if g is not None else torch.zeros(shape, **f32))
         ctx.S = None

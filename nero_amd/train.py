@@ -46,23 +46,25 @@ def shape_training_loss(net, out, gt, step, eikonal_weight=0.1, eikonal_rank_wei
     return loss
 
 
-class FusedShapeOptimizer:
-    """Trainer-loop fusion for the Stage-I model.  Replaces, per step, ~40 torch._weight_norm launches, their
-    ~35 backward launches, the per-parameter gradient fills and torch's multi-tensor Adam by
+class FusedOptimizer:
+    """Trainer-loop fusion for a model given as a list of Linear modules.  Replaces, per step, the
+    torch._weight_norm launches, their backward launches, the per-parameter gradient fills and torch's multi-tensor Adam by
         nero_wn_forward_batch   (1 launch: every effective weight W = g v / ||v|| into persistent buffers the packed operand images
                                  are built from -- the chain descriptors are built ONCE, the pointers never change)
-        nero_wn_adam_batch      (2 launches: weight-norm backward fused with Adam for (g, v); plain Adam for biases, the NeRF++
-                                 Linear weights and the variance)
+        nero_wn_adam_batch      (2 launches: weight-norm backward fused with Adam for (g, v); plain Adam for biases, plain Linear
+                                 weights and extra scalars)
     The render step's autograd node hands dL/dW_eff to leaf tensors whose .grad are views of ONE flat bucket, which is also the
-    all-reduce payload (dg, dv are linear in dW_eff, so reducing dW_eff is equivalent to reducing the parameter gradients)."""
+    all-reduce payload (dg, dv are linear in dW_eff, so reducing dW_eff is equivalent to reducing the parameter gradients).
 
-    def __init__(self, net, device, betas=(0.9, 0.999), eps=1e-8):
+    Adam follows torch.optim.Adam per PARAMETER: a tensor without a gradient in some step (`absent` in step(): the variance while
+    step < freeze_inv_s_step) is skipped -- value, moments and its own step counter stay put -- exactly like a `.grad is None`
+    parameter under torch (train/trainer.py:105-170 runs torch.optim.Adam)."""
+
+    def __init__(self, lins, extra_plain, device, betas=(0.9, 0.999), eps=1e-8):
         import ctypes as C
         from . import _lib as L
-        from .shape_step import ShapeKernels, unflatten_effective
-        self.L, self.C, self.net, self.device = L, C, net, device
+        self.L, self.C, self.device = L, C, device
         self.betas, self.eps, self.t = betas, eps, 0
-        lins = self._linears(net)                     # [(name prefix in flatten_effective order, nn.Linear)]
         f32 = dict(dtype=torch.float32, device=device)
         self.names, self.eff, leaves = [], [], []
         self._wn, self._plain = [], []                # (lin, w_eff, inv_norm) / plain parameters
@@ -80,11 +82,10 @@ class FusedShapeOptimizer:
             self.names += [name + '.weight', name + '.bias']
             self.eff += [w, lin.bias]
         assert len(self._wn) <= L.MAX_WN_JOBS
-        self.variance = net.deviation_network.variance
-        self._plain.append(self.variance)
-        leaves.append(self.variance)
-        # the sdf last layer is consumed as [Dense(W[1:]) | Head(W[0:1])] by the kernels: views of the same leaf
-        from .parallel import GradBucket
+        for p_ in extra_plain:
+            self._plain.append(p_)
+            leaves.append(p_)
+        self._plain_steps = [0] * len(self._plain)    # torch.optim.Adam keeps one step counter per parameter
         self.bucket = GradBucket(leaves)              # .grad of every leaf = view of one flat buffer
         # Adam moments: (m, v) for weight_v / weight_g of every weight-normed Linear and for every plain tensor
         n_state = sum(l.weight_v.numel() + l.weight_g.numel() for l, _, _ in self._wn) + sum(p.numel() for p in self._plain)
@@ -107,8 +108,52 @@ class FusedShapeOptimizer:
             j.p, j.grad, j.m, j.v, j.n = p_.data_ptr(), p_.grad.data_ptr(), self.m[off:].data_ptr(), self.v[off:].data_ptr(), p_.numel()
             off += p_.numel()
         self.reparametrise()
-        self.K = ShapeKernels(unflatten_effective(self.names, [t.detach() for t in self.eff]), net.color_network.cfg, device)
         self.grad_views = {n: t.grad for n, t in zip(self.names, self.eff)}     # where the weight-gradient GEMMs write
+
+    def reparametrise(self):
+        """effective weights of every weight-normed Linear from the current (g, v): one launch"""
+        L = self.L
+        L.check(L.lib.nero_wn_forward_batch(self._wn_jobs, len(self._wn), L.stream_ptr()))
+
+    def kernels(self):
+        """(names, effective leaves, packed chains), repacked from the current parameters"""
+        self.reparametrise()
+        return self.names, self.eff, self.K.pack()
+
+    def zero_grad(self):
+        self.bucket.zero()
+
+    def step(self, lr, world=1, absent=()):
+        """all-reduce (mean) of the flat dL/dW_eff bucket, then weight-norm backward + Adam.  `absent`: parameters that received NO
+        gradient this step (torch: .grad is None) -- skipped, their Adam step counters do not advance."""
+        L, C = self.L, self.C
+        self.bucket.all_reduce_mean(world)
+        self.t += 1
+        skip = {id(p_) for p_ in absent}
+        for i, (j, p_) in enumerate(zip(self._plain_jobs, self._plain)):
+            if id(p_) in skip:
+                j.step = -1
+            else:
+                self._plain_steps[i] += 1
+                j.step = self._plain_steps[i]
+        L.check(L.lib.nero_wn_adam_batch(self._wn_jobs, len(self._wn), self._plain_jobs, len(self._plain), C.c_float(lr),
+                                         C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps), self.t, L.stream_ptr()))
+        self._after_step()
+
+    def _after_step(self):
+        pass
+
+
+class FusedShapeOptimizer(FusedOptimizer):
+    """FusedOptimizer over the ten networks of NeROShapeRenderer (+ deviation_network.variance) with their packed chains."""
+
+    def __init__(self, net, device, betas=(0.9, 0.999), eps=1e-8):
+        from .shape_step import ShapeKernels, unflatten_effective
+        self.net = net
+        self.variance = net.deviation_network.variance
+        super().__init__(self._linears(net), [self.variance], device, betas, eps)
+        # the sdf last layer is consumed as [Dense(W[1:]) | Head(W[0:1])] by the kernels: views of the same leaf
+        self.K = ShapeKernels(unflatten_effective(self.names, [t.detach() for t in self.eff]), net.color_network.cfg, device)
 
     @staticmethod
     def _linears(net):
@@ -124,25 +169,33 @@ class FusedShapeOptimizer:
             out += [(f'{pn}.{i}', getattr(cn, pn)[k]) for i, k in enumerate((0, 2, 4, 6))]
         return out
 
-    def reparametrise(self):
-        """effective weights of every weight-normed Linear from the current (g, v): one launch"""
-        L, C = self.L, self.C
-        L.check(L.lib.nero_wn_forward_batch(self._wn_jobs, len(self._wn), L.stream_ptr()))
+    def _after_step(self):
+        # the parameters were updated by raw kernels: torch's version counters did not move, so the renderer's no-grad cache of
+        # packed operand images (NeROShapeRenderer._kernels) must be dropped explicitly
+        self.net._param_epoch = getattr(self.net, '_param_epoch', 0) + 1
+        self.net._kern_cache = None
 
-    def kernels(self):
-        """(names, effective leaves, packed chains) for NeROShapeRenderer.render(_kern=...), repacked from the current parameters"""
-        self.reparametrise()
-        return self.names, self.eff, self.K.pack()
 
-    def zero_grad(self):
-        self.bucket.zero()
+class FusedMaterialOptimizer(FusedOptimizer):
+    """FusedOptimizer over MCShadingNetwork (feats network, three material predictors, outer / inner / human light MLPs):
+    Stage II's ~500 torch weight-norm launches and its multi-tensor Adam become 3 launches (profiles/r02_stage2_kernel_stats.csv)."""
 
-    def step(self, lr, world=1):
-        L, C = self.L, self.C
-        self.bucket.all_reduce_mean(world)
-        self.t += 1
-        L.check(L.lib.nero_wn_adam_batch(self._wn_jobs, len(self._wn), self._plain_jobs, len(self._plain), C.c_float(lr),
-                                         C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps), self.t, L.stream_ptr()))
+    def __init__(self, net, device, betas=(0.9, 0.999), eps=1e-8):
+        from .material_step import MaterialKernels, unflatten_material_effective
+        self.net = net
+        super().__init__(self._linears(net.shader_network), [], device, betas, eps)
+        self.K = MaterialKernels(unflatten_material_effective(self.names, [t.detach() for t in self.eff]), net.shader_network.cfg, device)
+
+    @staticmethod
+    def _linears(sn):
+        out = [(f'feats.{i}', sn.feats_network.module0[k]) for i, k in enumerate((0, 2, 4, 6))]
+        out += [(f'feats.{4 + i}', sn.feats_network.module1[k]) for i, k in enumerate((0, 2, 4, 6))]
+        preds = ['metallic_predictor', 'roughness_predictor', 'albedo_predictor', 'outer_light', 'inner_light']
+        if sn.cfg['human_lights']:
+            preds.append('human_light')
+        for pn in preds:
+            out += [(f'{pn}.{i}', getattr(sn, pn)[k]) for i, k in enumerate((0, 2, 4, 6))]
+        return out
 
 
 class ShapeTrainStep:
@@ -252,8 +305,134 @@ class ShapeTrainStep:
     def step(self, step):
         lr = warm_up_cos_lr(step)
         info = self.forward_backward(step)
+        # deviation_network.variance receives no gradient while inv_s is frozen (network/renderer.py:494-495): torch.optim.Adam in the
+        # reference skips it (.grad is None) -- value, moments and its step counter stay put until the unfreeze step
+        c = self.net.cfg
+        var = self.net.deviation_network.variance
+        frozen = c['freeze_inv_s_step'] is not None and step < c['freeze_inv_s_step']
         if self.fused:
-            self.fopt.step(lr, self.world)            # all-reduce of the flat dL/dW_eff bucket + weight-norm backward + Adam
+            self.fopt.step(lr, self.world, absent=[var] if frozen else ())     # flat all-reduce + weight-norm backward + Adam
+        else:
+            for g in self.opt.param_groups:
+                g['lr'] = lr
+            self.bucket.all_reduce_mean(self.world)
+            keep = var.grad
+            if frozen:
+                var.grad = None
+            self.opt.step()
+            var.grad = keep
+        return info
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Stage II: material estimation (NeROMaterialRenderer.train_step, network/renderer.py:829-844; MaterialRegLoss, network/loss.py:45-55)
+# ----------------------------------------------------------------------------------------------------------------------
+def material_lr(step, total_step=100000, warm_up_end=1000, learning_rate=5e-4, learning_rate_alpha=0.05):
+    """WarmUpCosLR with the material YAMLs' lr_cfg (configs/material/*/ *.yaml: end_warm 1000, end_iter 100000)"""
+    return warm_up_cos_lr(step, total_step, warm_up_end, learning_rate, learning_rate_alpha)
+
+
+def material_training_loss(shader_cfg, out, step, world=1):
+    """sum of the means of the `loss*` entries (train/trainer.py:134-137): loss_rgb, loss_mat_reg, loss_diffuse_light.
+    Data parallel: all three are means over a rank's P surface points -- equal shards, so the rank average of the
+    gradients IS the big-batch gradient -- except the `reg_min_max` hinge of the first 2000 steps, which the reference adds as a SUM
+    over the batch's points (network/field.py:1079-1084): a rank's share of that sum is weighted by `world` so that the average over
+    ranks restores the global sum."""
+    loss = out['loss_rgb'].mean()
+    if 'loss_mat_reg' in out:
+        loss = loss + out['loss_mat_reg'].mean()
+    if 'loss_diffuse_light' in out:
+        loss = loss + out['loss_diffuse_light'].mean()
+    if world > 1 and 'loss_mat_reg' in out:
+        from .renderer import material_hinge
+        hinge = material_hinge(shader_cfg, out['roughness'], out['metallic'], step)
+        if hinge is not None:
+            loss = loss + (world - 1) * hinge
+    return loss
+
+
+def synthetic_surface_pool(net, n_points, device, seed=5, window=110, n_images=8):
+    """Stage-II pool stand-in (no dataset in the container): camera rays of the synthetic rig traced through the renderer's mesh with
+    the product tracer, hits kept -- what NeROMaterialRenderer.set_ray_pool builds from a database (network/renderer.py:756-802).
+    -> dict(pts, view, normals, rgb [n,3], img_idx [n]) on `device`, poses_img [n_images,3,4]"""
+    pts, view, nrm, rgb, idx = [], [], [], [], []
+    got, off = 0, 0
+    while got < n_points:
+        o, d, poses, gt = synthetic_rays(4 * n_points, seed=seed, window=window, offset=off, n_images=n_images)
+        off += 4 * n_points
+        o, d = o.to(device), d.to(device)
+        inters, normals, depth, hit = net.trace(o, d)
+        sel = torch.nonzero(hit)[:, 0]
+        pts.append(inters[sel]); view.append(-d[sel]); nrm.append(normals[sel]); rgb.append(gt.to(device)[sel])
+        idx.append((torch.arange(o.shape[0], device=device) % n_images)[sel])
+        got += sel.numel()
+        if off > 64 * n_points:
+            raise RuntimeError('synthetic_surface_pool: the camera rig hardly hits the mesh')
+    _, _, poses, _ = synthetic_rays(n_images, seed=seed, n_images=n_images)
+    cat = lambda xs: torch.cat(xs, 0)[:n_points].contiguous()
+    return {'pts': cat(pts), 'view': cat(view), 'normals': cat(nrm), 'rgb': cat(rgb), 'img_idx': cat(idx)}, poses.to(device)
+
+
+class MaterialTrainStep:
+    """Stage-II data parallelism (BASELINE configs[4]): one process = one GPU; every rank holds the same weights, the
+    same BVH and the same (identically shuffled) pool of surface points and takes the rank-strided slice of each global batch;
+    gradients of all 104 / 112 tensors travel as ONE flat all-reduce (5.6 / 6.3 MB), then the fused weight-norm + Adam kernels."""
+
+    def __init__(self, cfg, mesh, points_per_rank=4096, pool_points=None, device='cuda', seed=6033, rank=0, world=1, fused=None,
+                 pool=None):
+        from .renderer import NeROMaterialRenderer
+        self.device, self.rank, self.world, self.P = device, rank, world, points_per_rank
+        torch.manual_seed(seed)
+        self.net = NeROMaterialRenderer(cfg, mesh=mesh)
+        perturb_state(self.net, None)
+        self.net = self.net.to(device)
+        self.params = [p for p in self.net.parameters()]
+        self.fused = (device != 'cpu') if fused is None else fused
+        if self.fused:
+            self.fopt = FusedMaterialOptimizer(self.net, device)
+            self.bucket = self.fopt.bucket
+        else:
+            self.bucket = GradBucket(self.params)
+            self.opt = torch.optim.Adam(self.params, lr=1e-3, fused=(device != 'cpu'))
+        pool_points = pool_points or 4 * points_per_rank * world
+        if pool is None:
+            pool, poses_img = synthetic_surface_pool(self.net, pool_points, device)
+        else:
+            pool, poses_img = pool
+        self.pool, self.pool_n = pool, pool['pts'].shape[0]
+        self.human_img = self.net.get_human_coordinate_poses(poses_img)
+        self.cursor = 0
+
+    def _batch(self):
+        G = self.P * self.world
+        if self.cursor + G > self.pool_n:
+            self.cursor = 0
+        s = rank_slice(self.cursor, self.P, self.rank)
+        self.cursor += G
+        return {k: v[s] for k, v in self.pool.items()}
+
+    def forward_backward(self, step, rands=None):
+        """shade + losses + backward of this rank's slice of the next global batch; gradients land in the flat bucket.
+        rands: optional dict(rand_d, rand_s, reg_ang, reg_eps) for this slice (tests); default: drawn on the device"""
+        net = self.net
+        self.bucket.zero()
+        b = self._batch()
+        hp = self.human_img[b['img_idx']] if net.shader_network.cfg['human_lights'] else None
+        if self.fused:                                # effective-weight leaves + packed chains of the fused optimiser, and the
+            net._kern_override, net._grad_views = self.fopt.kernels(), self.fopt.grad_views      # bucket views the GEMMs write into
+        try:
+            out = net.shade_train(b['pts'], b['view'], b['normals'], hp, b['rgb'], step, **(rands or {}))
+        finally:
+            net._kern_override = net._grad_views = None
+        loss = material_training_loss(net.shader_network.cfg, out, step, self.world)
+        loss.backward()
+        return {'loss': loss.detach(), 'out': out}
+
+    def step(self, step):
+        lr = material_lr(step)
+        info = self.forward_backward(step)
+        if self.fused:
+            self.fopt.step(lr, self.world)
         else:
             for g in self.opt.param_groups:
                 g['lr'] = lr

@@ -533,8 +533,8 @@ def render_core(P, cfg, o, d, z_vals, poses, cos_anneal, step, occ_keys=None):
         out['gradient_error'] = (torch.linalg.norm(grad, dim=-1) - 1.0) ** 2
         out['std'] = torch.mean(1.0 / inv_s.expand(ii.numel()))
     else:
-        out['gradient_error'] = torch.zeros(1)
-        out['std'] = torch.zeros(1)
+        out['gradient_error'] = torch.zeros(1, dtype=z_vals.dtype, device=z_vals.device)
+        out['std'] = torch.zeros(1, dtype=z_vals.dtype, device=z_vals.device)
 
     alpha = alpha.reshape(R, T)
     # compositing uses torch.cumprod over float32 here too (renderer.py:578); differentiable, so use torch.cumprod
@@ -549,7 +549,7 @@ def render_core(P, cfg, o, d, z_vals, poses, cos_anneal, step, occ_keys=None):
         out['sdf_vals'] = sdf_network(P, pts[m])[:, 0]
 
     if cfg['apply_occ_loss']:                                               # renderer.py:522-548, 596-601
-        out['loss_occ'] = torch.zeros(1)
+        out['loss_occ'] = torch.zeros(1, dtype=z_vals.dtype, device=z_vals.device)
         if ii.numel() > 0 and step >= cfg['occ_loss_step']:
             m = (torch.norm(pi, dim=-1) < 0.999) & (torch.abs(sdf) < cfg['occ_sdf_thresh']) & ((grad * di).sum(-1) < 0)
             cand = torch.nonzero(m)[:, 0]

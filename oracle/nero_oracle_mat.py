@@ -162,15 +162,15 @@ def get_lights(P, cfg, trace_fn, pts, dirs, poses):
     pf, df = pts.reshape(-1, 3), dirs.reshape(-1, 3)
     inters, normals, depth, hit = trace_fn((pf + df * 1e-5).detach(), df.detach())
     miss = ~hit
-    lights = torch.zeros(pf.shape[0], 3, dtype=pts.dtype)
-    hl_out = torch.zeros(1, 3)
+    lights = torch.zeros(pf.shape[0], 3, dtype=pts.dtype, device=pts.device)
+    hl_out = torch.zeros(1, 3, dtype=pts.dtype, device=pts.device)
     if int(miss.sum()) > 0:
         mi = torch.nonzero(miss)[:, 0]
         outer = outer_lights(P, cfg, pf[mi], df[mi])
         if cfg['human_lights']:
             hl, hw = human_light_mc(P, pf[mi], df[mi], poses.reshape(-1, 3, 4)[mi])
         else:
-            hl, hw = torch.zeros_like(outer), torch.zeros(outer.shape[0], 1)
+            hl, hw = torch.zeros_like(outer), torch.zeros(outer.shape[0], 1, dtype=outer.dtype, device=outer.device)
         lights = lights.index_put((mi,), outer * (1 - hw) + hl * hw)
         hl_out = hl * hw
     if int(hit.sum()) > 0:
