@@ -126,3 +126,102 @@ def test_fused_training_steps_match_the_torch_path():
         assert float(d.mean()) <= 5e-3 * upd + 1e-9, (k, float(d.mean()), upd)
         assert float((d > 0.02 * upd + 1e-9).float().mean()) <= 0.02, (k, float((d > 0.02 * upd).float().mean()))
     assert upd > 0
+
+
+def test_adam_job_without_gradient_is_skipped_like_torch():
+    """nero_adam_job.step: a tensor with no gradient for the first steps (torch: .grad is None -> skipped, its step counter does not
+    advance) must, once it has one, take torch.optim.Adam's FIRST-step update (bias corrections of step 1), while the other jobs keep
+    counting.  ADVICE r2: deviation_network.variance across freeze_inv_s_step."""
+    from nero_amd import _lib as L
+    g0 = torch.Generator().manual_seed(1)
+    p_a, p_b = torch.randn(5, generator=g0).cuda(), torch.randn(300, generator=g0).cuda()
+    grads_a = [torch.randn(5, generator=g0).cuda() * 1e-2 for _ in range(5)]
+    grads_b = [torch.randn(300, generator=g0).cuda() * 1e-2 for _ in range(5)]
+    # torch: parameter a has no gradient during the first three steps
+    ra, rb = p_a.clone().requires_grad_(True), p_b.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ra, rb], lr=3e-4)
+    for it in range(5):
+        ra.grad = None if it < 3 else grads_a[it].clone()
+        rb.grad = grads_b[it].clone()
+        opt.step()
+    # kernels
+    a, b = p_a.clone(), p_b.clone()
+    z = torch.zeros_like
+    ma, va, mb, vb = z(a), z(a), z(b), z(b)
+    ga, gb = z(a), z(b)
+    jobs = (L.AdamJob * 2)()
+    jobs[0].p, jobs[0].grad, jobs[0].m, jobs[0].v, jobs[0].n = a.data_ptr(), ga.data_ptr(), ma.data_ptr(), va.data_ptr(), 5
+    jobs[1].p, jobs[1].grad, jobs[1].m, jobs[1].v, jobs[1].n = b.data_ptr(), gb.data_ptr(), mb.data_ptr(), vb.data_ptr(), 300
+    wn = (L.WnJob * 1)()
+    own = 0
+    for it in range(5):
+        gb.copy_(grads_b[it])
+        if it < 3:
+            jobs[0].step = -1
+        else:
+            ga.copy_(grads_a[it])
+            own += 1
+            jobs[0].step = own
+        jobs[1].step = it + 1
+        L.check(L.lib.nero_wn_adam_batch(wn, 0, jobs, 2, C.c_float(3e-4), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-8), it + 1, L.stream_ptr()))
+        if it == 2:
+            torch.cuda.synchronize()
+            assert torch.equal(a, p_a) and float(ma.abs().max()) == 0.0 and float(va.abs().max()) == 0.0      # untouched while absent
+    torch.cuda.synchronize()
+    for got, want, p0 in ((a, ra, p_a), (b, rb, p_b)):
+        upd = float((want.detach() - p0).abs().max())
+        assert upd > 0 and float((got - want.detach()).abs().max()) <= 2e-3 * upd + 1e-9
+    # and a job with step 0 follows the call's global step (the round-2 ABI)
+    c1, c2 = p_b.clone(), p_b.clone()
+    m1, v1, m2, v2 = z(c1), z(c1), z(c2), z(c2)
+    j = (L.AdamJob * 2)()
+    j[0].p, j[0].grad, j[0].m, j[0].v, j[0].n, j[0].step = c1.data_ptr(), gb.data_ptr(), m1.data_ptr(), v1.data_ptr(), 300, 0
+    j[1].p, j[1].grad, j[1].m, j[1].v, j[1].n, j[1].step = c2.data_ptr(), gb.data_ptr(), m2.data_ptr(), v2.data_ptr(), 300, 7
+    L.check(L.lib.nero_wn_adam_batch(wn, 0, j, 2, C.c_float(3e-4), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-8), 7, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert float((c1 - c2).abs().max()) <= 1e-9
+
+
+def test_variance_crosses_the_freeze_boundary_like_the_torch_path():
+    """freeze_inv_s_step inside the run: two frozen steps, then three live ones.  The fused optimiser must leave the variance alone
+    while frozen and then move it like torch.optim.Adam does from ITS first step (a global step counter made the first
+    live updates 3-6x too large)."""
+    from nero_amd.train import ShapeTrainStep
+    cfg = {**CFG, 'freeze_inv_s_step': 25002}
+    traj = {}
+    for fused in (False, True):
+        ts = ShapeTrainStep(cfg, rays_per_rank=192, pool_rays=768, device='cuda:0', variance=0.4, prime_fraction=0.0, fused=fused, prime_passes=0)
+        v = []
+        for i in range(5):
+            ts.step(25000 + i)
+            v.append(float(ts.net.deviation_network.variance))
+        traj[fused] = v
+    tu, tf = traj[False], traj[True]
+    assert abs(tu[0] - 0.4) < 1e-7 and abs(tu[1] - 0.4) < 1e-7                       # torch path: .grad is None while frozen
+    assert abs(tf[0] - 0.4) < 1e-7 and abs(tf[1] - 0.4) < 1e-7                       # frozen: untouched
+    first_u, first_f = tu[2] - tu[1], tf[2] - tf[1]
+    assert abs(first_u) > 1e-6
+    # Adam's first update is lr * sign(g) (bias-corrected m / sqrt(v) = 1): both paths move by the learning rate of that step
+    assert abs(first_f - first_u) <= 0.02 * abs(first_u), (first_u, first_f)
+    assert abs((tf[4] - tf[1]) - (tu[4] - tu[1])) <= 0.05 * abs(tu[4] - tu[1]), (tu, tf)
+
+
+def test_inference_cache_sees_fused_updates():
+    """the no-grad cache of packed operand images is keyed on torch's version counters, which the fused Adam kernels do
+    not bump -- forward_only / render_image / extract_fields after fused steps must use the NEW weights"""
+    from nero_amd.train import ShapeTrainStep
+    ts = ShapeTrainStep(CFG, rays_per_rank=128, pool_rays=256, device='cuda:0', variance=0.4, prime_fraction=0.0, fused=True, prime_passes=0)
+    ts.cursor = 0
+    a = ts.forward_only(25000).clone()
+    ts.cursor = 0
+    a2 = ts.forward_only(25000).clone()
+    assert torch.equal(a, a2)                                   # cache hit, same weights
+    for i in range(3):
+        ts.step(25000 + i)
+    ts.cursor = 0
+    b = ts.forward_only(25000).clone()
+    assert float((a - b).abs().max()) > 1e-6                    # three Adam steps later the render must have moved
+    ts.net._kern_cache = None                                   # a freshly packed render of the same batch is the ground truth
+    ts.cursor = 0
+    c = ts.forward_only(25000)
+    assert torch.equal(b, c)
