@@ -44,16 +44,33 @@ BELL = {'freeze_inv_s_step': 15000, 'apply_occ_loss': True, 'occ_loss_step': 200
 VARIANCE = 0.5
 
 
-def hbm_traffic_per_launch(kernel):
-    """average HBM bytes per launch of `kernel` from the newest committed PMC summary (scripts/prof_traffic.sh), or None"""
-    for name in ('r02_hbm_traffic_per_kernel.csv', 'r01_hbm_traffic_per_kernel.csv'):
+def lib_sha12():
+    import hashlib
+    try:
+        return hashlib.sha256(open(os.path.join(ROOT, 'nero_amd', 'libnero_hip.so'), 'rb').read()).hexdigest()[:12]
+    except OSError:
+        return None
+
+
+def hbm_traffic_per_launch(kernel, prefix='hbm_traffic_per_kernel'):
+    """average HBM bytes per launch of `kernel` from the newest committed PMC summary (scripts/prof_traffic.sh), or None.
+    -> (bytes, description of the source incl. the commit / library hash the counters were taken on and whether that library is
+    the one running now)"""
+    for rnd in ('r03', 'r02', 'r01'):
+        name = f'{rnd}_{prefix}.csv'
         try:
-            for line in open(os.path.join(ROOT, 'profiles', name)):
-                f = line.strip().split(',')
-                if len(f) in (5, 6) and f[0] == kernel:      # kernel, launches, fetch_kb_raw, fetch_kb (x2 corrected), write_kb[, gb_per_step]
-                    return int((float(f[3]) + float(f[4])) * 1024), name
+            lines = open(os.path.join(ROOT, 'profiles', name)).read().splitlines()
         except OSError:
-            pass
+            continue
+        stamp = next((ln[1:].strip() for ln in lines if ln.startswith('# taken on')), 'taken on: not recorded (round <= 2 summary)')
+        for line in lines:
+            f = line.strip().split(',')
+            if len(f) in (5, 6) and f[0] == kernel:      # kernel, launches, fetch_kb_raw, fetch_kb (x2 corrected), write_kb[, gb_per_step]
+                cur = lib_sha12()
+                same = (cur is not None and cur in stamp)
+                return int((float(f[3]) + float(f[4])) * 1024), (f'profiles/{name}: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, '
+                                                                   f'separate passes, bytes per launch; {stamp}; library running now: {cur} '
+                                                                   f'({"same build" if same else "DIFFERENT build: counters may be stale"})')
     return None, None
 
 
@@ -141,81 +158,161 @@ def torch_gpu_baseline(cfg, variance, step, rays, dev, warmup=10, steps=50):
                     f'{step}, fp32 ATen ops + fused Adam, peak {peak:.1f} GiB'}
 
 
-def stage2_bench(dev, P_=4096, configs=((128, 128), (512, 256)), warmup=5, steps=20, subdiv=7):
-    """BASELINE configs[3]: Stage-II material step -- materials, direction sampling, BVH trace of P*D secondary
-    rays, hit / miss light MLPs, microfacet estimator, regularisers, backward, fused Adam -- on a 327 680-triangle bumpy icosphere
-    (stand-in for the extracted shape mesh).  pts/s, light-rays/s, tracer rays/s and the MLP-FLOP fraction of section 8d's model
-    3 * [2 C_mat + D ((1-h) C_outer + h C_inner)] MACs per point with the measured hit fraction h."""
+def _bench_mesh(subdiv=7):
     import numpy as np
-    from nero_amd import chain as CH
-    from nero_amd.renderer import NeROMaterialRenderer
-    from nero_amd.synthetic import icosphere, synthetic_rays
+    from nero_amd.synthetic import icosphere
     v, f = icosphere(subdiv, 0.5, 0.2)
-    f = np.ascontiguousarray(f[:, ::-1])
-    out = {'mesh_triangles': int(f.shape[0]), 'points': P_, 'configs': []}
-    o, d, _, gt = synthetic_rays(8 * P_, seed=5, window=110)
-    o, d, gt = o.to(dev), d.to(dev), gt.to(dev)
-    for Dd, Ds in configs:
-        torch.manual_seed(6033)
-        net = NeROMaterialRenderer({'shader_cfg': dict(diffuse_sample_num=Dd, specular_sample_num=Ds, human_lights=False, outer_light_version='direction'),
-                                    'database_name': 'syn/bell'}, mesh=(v, f)).to(dev)
-        inters, normals, depth, hit = net.trace(o, d)
-        sel = torch.nonzero(hit)[:P_, 0]
-        assert sel.numel() == P_, sel.numel()
-        pts, view, nrm, g = inters[sel].contiguous(), -d[sel].contiguous(), normals[sel].contiguous(), gt[sel]
-        opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)
-        tracer = net.ray_tracer
-        rec = {'n': 0, 'hit': 0, 'ms': 0.0, 'on': False}
+    return v, np.ascontiguousarray(f[:, ::-1])
 
-        class Timed:                                            # times nero_bvh_trace on the secondary rays of the untimed extra step
-            def trace(self, ro, rd):
-                if not rec['on']:
-                    return tracer.trace(ro, rd)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                r = tracer.trace(ro, rd)
-                e1.record()
-                torch.cuda.synchronize()
-                rec['ms'] += e0.elapsed_time(e1)
-                rec['n'] += ro.shape[0]
-                rec['hit'] += int((r[2] < 10).sum())
-                return r
-        net.ray_tracer = Timed()
 
-        def step(i):
-            opt.zero_grad(set_to_none=True)
-            so = net.shade_train(pts, view, nrm, None, g, 5000 + i)
-            (so['loss_rgb'].mean() + so['loss_mat_reg'].mean() + so['loss_diffuse_light'].mean()).backward()
-            opt.step()
-        for i in range(warmup):
-            step(i)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+STAGE2_CFG = {'bell': dict(human_lights=False, outer_light_version='direction'),                 # configs/material/syn/bell.yaml
+              'bear': dict(human_lights=True, outer_light_version='sphere_direction')}            # configs/material/real/bear.yaml
+
+
+def stage2_step_bench(dev, kind, P_, Dd, Ds, mesh, rank=0, world=1, warmup=5, steps=20, sync=None, max_over_ranks=None, prof=True):
+    """K Stage-II training steps through nero_amd.train.MaterialTrainStep (fused weight-norm / Adam kernels, flat gradient bucket,
+    RCCL all-reduce when world > 1) on P_ surface points per rank x (Dd + Ds) MC directions: materials, direction sampling, BVH trace
+    of the P*D secondary rays, hit / miss light MLPs, microfacet estimator, regularisers, backward, optimiser.  pts/s, light-rays/s,
+    tracer rays/s, the MLP-FLOP fraction of SURVEY.md 8d's model 3 [2 C_mat + D ((1-h) C_miss + h C_inner)] MACs per point with the
+    measured hit fraction h, and (rank 0) the per-class MFMA kernel timing of three extra steps (`roofline`)."""
+    import ctypes as C
+    from nero_amd import _lib as L
+    from nero_amd import chain as CH
+    from nero_amd.train import MaterialTrainStep
+    sync = sync or torch.cuda.synchronize
+    mx = max_over_ranks or (lambda x: x)
+    scfg = dict(diffuse_sample_num=Dd, specular_sample_num=Ds, **STAGE2_CFG[kind])
+    ts = MaterialTrainStep({'shader_cfg': scfg, 'database_name': 'real/bear/raw_1024' if kind == 'bear' else 'syn/bell'}, mesh,
+                           points_per_rank=P_, pool_points=4 * P_ * world, device=dev, rank=rank, world=world)
+    tracer = ts.net.ray_tracer
+    rec = {'n': 0, 'hit': 0, 'ms': 0.0, 'on': False}
+
+    class Timed:                                            # times nero_bvh_trace on the secondary rays of one untimed extra step
+        def trace(self, ro, rd):
+            if not rec['on']:
+                return tracer.trace(ro, rd)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = tracer.trace(ro, rd)
+            e1.record()
+            torch.cuda.synchronize()
+            rec['ms'] += e0.elapsed_time(e1)
+            rec['n'] += ro.shape[0]
+            rec['hit'] += int((r[2] < 10).sum())
+            return r
+    ts.net.ray_tracer = Timed()
+    for i in range(warmup):
+        ts.step(5000 + i)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    sync()
+    t0 = time.time()
+    ev[0].record()
+    for i in range(steps):
+        ts.step(5000 + warmup + i)
+        ev[i + 1].record()
+    sync()
+    wall = mx(time.time() - t0) / steps
+    ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+    rec['on'] = True
+    ts.step(6000)
+    rec['on'] = False
+    torch.cuda.synchronize()
+    D = Dd + Ds
+    h = rec['hit'] / max(rec['n'], 1)
+    c_miss = (168704 if kind == 'bear' else C_OUTER) + (138240 if kind == 'bear' else 0)        # SURVEY.md 8a: C_outer (+ C_human)
+    flop_pt = 2 * 3 * (2 * C_MAT + D * ((1 - h) * c_miss + h * C_INNER))
+    peak = PEAK_OF_MODE[CH.GEMM_MODE['fwd']]
+    out = {'model': kind, 'points_per_gpu': P_, 'directions': f'{Dd}+{Ds}', 'n_gpus': world, 'trainer': 'fused (nero_wn_forward_batch / nero_wn_adam_batch)',
+           'ms_per_step': round(wall * 1e3, 3), 'ms_per_step_median': round(ms[len(ms) // 2], 3),
+           'points_per_s': round(P_ * world / wall, 1), 'light_rays_per_s': round(P_ * world * D / wall, 1),
+           'tracer_rays_per_s': round(rec['n'] / (rec['ms'] * 1e-3), 1) if rec['ms'] > 0 else None, 'tracer_ms': round(rec['ms'], 3),
+           'hit_fraction': round(h, 4), 'mlp_mflop_per_point': round(flop_pt / 1e6, 1),
+           'mlp_flop_frac': round(flop_pt * P_ / wall / peak, 4), 'mlp_flop_frac_peak_tflops': round(peak / 1e12, 1),
+           'warmup': warmup, 'steps': steps}
+    if prof and rank == 0:
+        L.lib.nero_prof_enable(1)
+        for i in range(3):
+            ts.step(7000 + i)
         torch.cuda.synchronize()
-        t0 = time.time()
-        ev[0].record()
-        for i in range(steps):
-            step(i)
-            ev[i + 1].record()
-        torch.cuda.synchronize()
-        wall = (time.time() - t0) / steps
-        ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
-        rec['on'] = True
-        step(0)
-        torch.cuda.synchronize()
-        D = Dd + Ds
-        h = rec['hit'] / max(rec['n'], 1)
-        flop_pt = 2 * 3 * (2 * C_MAT + D * ((1 - h) * C_OUTER + h * C_INNER))
-        peak = PEAK_OF_MODE[CH.GEMM_MODE['fwd']]
-        out['configs'].append({
-            'directions': f'{Dd}+{Ds}', 'ms_per_step': round(wall * 1e3, 3), 'ms_per_step_median': round(ms[len(ms) // 2], 3),
-            'points_per_s': round(P_ / wall, 1), 'light_rays_per_s': round(P_ * D / wall, 1),
-            'tracer_rays_per_s': round(rec['n'] / (rec['ms'] * 1e-3), 1) if rec['ms'] > 0 else None, 'tracer_ms': round(rec['ms'], 3),
-            'hit_fraction': round(h, 4), 'mlp_mflop_per_point': round(flop_pt / 1e6, 1),
-            'mlp_flop_frac': round(flop_pt * P_ / wall / peak, 4), 'mlp_flop_frac_peak_tflops': round(peak / 1e12, 1),
-            'warmup': warmup, 'steps': steps})
-        del net, opt
-        torch.cuda.empty_cache()
+        L.lib.nero_prof_enable(0)
+        rep = (C.c_double * 12)()
+        L.lib.nero_prof_report(rep)
+        names = ('fwd', 'tan', 'bwd', 'dw')
+        rows = {names[k]: (rep[3 * k], rep[3 * k + 1], rep[3 * k + 2]) for k in range(4) if rep[3 * k] > 0}
+        if rows:
+            dom = max(rows, key=lambda k: rows[k][1])
+            n_l, ms_l, fl = rows[dom]
+            kern = {'fwd': 'fwd_p_kernel', 'bwd': 'bwd_f16_kernel', 'dw': 'dw_f16_kernel', 'tan': 'tan_f16_kernel'}[dom]
+            traffic, tsrc = hbm_traffic_per_launch(kern, 'stage2_hbm_traffic_per_kernel')
+            out['roofline'] = {'bound': 'mfma', 'kernel': kern, 'achieved': round(fl / (ms_l * 1e-3) / 1e12, 2), 'peak': round(peak / 1e12, 1),
+                               'unit': 'TFLOP/s', 'frac': round(fl / (ms_l * 1e-3) / peak, 4), 'avg_launch_ms': round(ms_l / max(n_l, 1), 4),
+                               'traffic': traffic, 'traffic_source': tsrc,
+                               'per_kernel': {k: {'launches_per_step': v[0] / 3, 'ms_per_step': round(v[1] / 3, 3),
+                                                  'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2)} for k, v in rows.items()}}
+    elif prof:
+        for i in range(3):
+            ts.step(7000 + i)
+    del ts
+    torch.cuda.empty_cache()
     return out
+
+
+def stage2_bench(dev, P_=4096, configs=((128, 128), (512, 256)), warmup=5, steps=20, subdiv=7):
+    """BASELINE configs[3]: bell Stage-II material step at P = 4096 x (128+128) and x (512+256, the YAML default)
+    on a 327 680-triangle bumpy icosphere (stand-in for the extracted shape mesh)."""
+    mesh = _bench_mesh(subdiv)
+    out = {'mesh_triangles': int(mesh[1].shape[0]), 'points': P_, 'configs': []}
+    for Dd, Ds in configs:
+        out['configs'].append(stage2_step_bench(dev, 'bell', P_, Dd, Ds, mesh, warmup=warmup, steps=steps))
+    return out
+
+
+def dropin_trainer_bench(dev, cfg, rays, variance, step0=25000, warmup=5, steps=20):
+    """what INTEGRATION.md option A gives a user of the reference Trainer: NeROShapeRenderer.forward({'step': s}) (pool slicing,
+    _process_ray_batch, render, loss_rgb: network/renderer.py:319-330) under a plain torch.optim.Adam loop with the reference's loss
+    assembly (train/trainer.py:120-140) -- torch weight-norm autograd, no fused optimiser, no flat bucket -- at `rays` = train_ray_num."""
+    import numpy as np
+    from nero_amd.renderer import NeROShapeRenderer
+    from nero_amd.synthetic import look_at_pose, perturb_state
+    from nero_amd.train import shape_training_loss, warm_up_cos_lr
+    torch.manual_seed(6033)
+    net = NeROShapeRenderer({**cfg, 'train_ray_num': rays}, training=False)
+    perturb_state(net, variance)
+    net = net.to(dev)
+    rg = np.random.default_rng(0)
+    n_img, res = 8, 512
+    az, el = rg.uniform(0, 2 * np.pi, n_img), rg.uniform(0.15, 1.2, n_img)
+    cams = np.stack([np.cos(az) * np.cos(el), np.sin(az) * np.cos(el), np.sin(el)], -1) * 3.0
+    poses = torch.from_numpy(np.stack([look_at_pose(c) for c in cams], 0))
+    K = torch.tensor([[700.0, 0, res / 2], [0, 700.0, res / 2], [0, 0, 1]]).repeat(n_img, 1, 1)
+    imgs = torch.from_numpy(np.random.default_rng(2).uniform(0, 1, (n_img, res, res, 3)).astype(np.float32))
+    net.set_ray_pool(imgs, K, poses, device=dev)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
+
+    def one(i):
+        st = step0 + i
+        for g in opt.param_groups:
+            g['lr'] = warm_up_cos_lr(st)
+        opt.zero_grad()
+        out = net({'step': st})
+        loss = out['loss_rgb'].mean() + (out['gradient_error'] * 0.1).mean()
+        if 'loss_occ' in out:
+            loss = loss + out['loss_occ'].mean()
+        loss.backward()
+        opt.step()
+    for i in range(warmup):
+        one(i)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for i in range(steps):
+        one(warmup + i)
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / steps
+    del net, opt
+    torch.cuda.empty_cache()
+    return {'value': round(rays / dt, 1), 'unit': 'rays/s', 'ms_per_step': round(dt * 1e3, 3), 'rays': rays, 'steps': steps, 'warmup': warmup,
+            'what': "NeROShapeRenderer.forward({'step': s}) + the reference's loss assembly + torch.optim.Adam(fused=True): the drop-in path of "
+                    'INTEGRATION.md option A (torch weight-norm autograd, no fused trainer kernels)'}
 
 
 def spawn_ranks(n):
@@ -233,12 +330,39 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+def run_stage2(args, dev, rank, world, sync, max_over_ranks):
+    """`--stage 2`: the Stage-II material step as the headline (BASELINE configs[3] at N = 1; configs[4] = `--config bear --points 2048
+    --dirs 256+256` at N = 8).  Same contract: W untimed steps, K timed between barrier + synchronize, max over ranks."""
+    Dd, Ds = (int(x) for x in args.dirs.split('+'))
+    P_ = args.points or (2048 if args.config == 'bear' else 4096)
+    mesh = _bench_mesh()
+    r = stage2_step_bench(dev, args.config, P_, Dd, Ds, mesh, rank, world, args.warmup, args.steps, sync, max_over_ranks)
+    if rank != 0:
+        return
+    res = {'metric': 'Stage-II material training surface points/sec', 'value': r['points_per_s'], 'unit': 'points/s', 'n_gpus': world,
+           'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': r['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak',
+           'vs_baseline': None, 'dtype': 'f32 (dense layers as two block-scaled fp16 planes, 3 MFMA products, fp32 accumulation)',
+           'data': 'synthetic',
+           'config': {'workload': f"Glossy{'Real' if args.config == 'bear' else 'Synthetic'} '{args.config}' Stage-II material, {P_} surface points x "
+                                  f'({Dd}+{Ds}) MC light directions per GPU, {int(mesh[1].shape[0])}-triangle mesh, step 5000',
+                      'points_per_gpu': P_, 'parallelism': f'dp{world}', 'optimizer': 'adam(fused)'},
+           'stage2': r}
+    if 'roofline' in r:
+        res['roofline'] = r['roofline']
+    print(json.dumps(res), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--rays', type=int, default=4096)
+    ap.add_argument('--stage', type=int, default=1, choices=(1, 2), help='1: Stage-I shape step (the BASELINE metric); 2: Stage-II material step')
+    ap.add_argument('--config', default='bell', choices=('bell', 'bear'), help="bell = GlossySynthetic (no human light); bear = GlossyReal "
+                    '(human light; BASELINE configs[2] is `--config bear --rays 1024 --gpus 8`)')
+    ap.add_argument('--points', type=int, default=0, help='--stage 2: surface points per GPU (default 4096 bell / 2048 bear)')
+    ap.add_argument('--dirs', default='128+128', help='--stage 2: diffuse+specular MC directions (BASELINE configs[4]: 256+256)')
     ap.add_argument('--train-step', type=int, default=25000, help='training-schedule step the batch is evaluated at')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--quick', action='store_true', help='headline + roofline only (development runs)')
@@ -265,9 +389,6 @@ def main():
     from nero_amd.train import ShapeTrainStep
     import ctypes as C
 
-    cfg = dict(BELL)
-    ts = ShapeTrainStep(cfg, rays_per_rank=args.rays, device=dev, variance=VARIANCE, rank=rank, world=world)
-
     def sync():
         if world > 1:
             dist.barrier()
@@ -278,6 +399,17 @@ def main():
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t)
+
+    if args.stage == 2:
+        run_stage2(args, dev, rank, world, sync, max_over_ranks)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    cfg = dict(BELL) if args.config == 'bell' else {**BELL, 'shader_config': {'human_light': True}}     # configs/shape/{syn/bell,real/bear}.yaml
+    c_app = C_APP if args.config == 'bell' else 1349888                                                 # + the human-light MLP
+    ts = ShapeTrainStep(cfg, rays_per_rank=args.rays, device=dev, variance=VARIANCE, rank=rank, world=world)
 
     # ---- the contract: W untimed steps, then EXACTLY K steps between barrier + synchronize, max over ranks -----------------------
     for i in range(args.warmup):
@@ -314,7 +446,7 @@ def main():
     # ---- the same step on the exact-fp32 MFMA engine (NERO_GEMM=f32), reported next to the headline: 2 warmup + 5 timed steps --
     from nero_amd import chain as CH
     alt = None
-    if CH.GEMM_MODE['fwd'] != L.GEMM_F32 and not args.quick:
+    if CH.GEMM_MODE['fwd'] != L.GEMM_F32 and not args.quick and world == 1:
         saved = dict(CH.GEMM_MODE)
         CH.set_gemm_mode('f32')
         for i in range(2):
@@ -370,8 +502,7 @@ def main():
         traffic, tsrc = hbm_traffic_per_launch(dom[0])
         roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
                 'frac': round(ach / peak, 4), 'traffic': traffic, 'kernel': dom[0], 'mfma': MFMA_OF_MODE[dom[5]],
-                'traffic_source': f'profiles/{tsrc}: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, separate passes, '
-                                  'bytes per launch' if tsrc else None,
+                'traffic_source': tsrc,
                 'avg_launch_ms': round(dom[2] / max(dom[1], 1), 4),
                 'per_kernel': {r[0]: {'launches_per_step': r[1] / 3, 'ms_per_step': round(r[2] / 3, 3),
                                       'tflops': round(r[3] / (r[2] * 1e-3) / 1e12, 2) if r[2] > 0 else 0.0,
@@ -380,12 +511,13 @@ def main():
         for i in range(3):
             ts.step(args.train_step + 100 + i)
 
+    res = None
     if rank == 0:
         split = CH.GEMM_MODE['fwd'] != L.GEMM_F32
         modes = {k: {0: 'f32', 1: 'bf16x6', 2: 'f16x3', 3: 'f16x3p'}[v] for k, v in CH.GEMM_MODE.items()}
         # whole-step algorithmic FLOPs with the measured inner/outer split of this rank
         sampler_evals = args.rays * (64 + 3 * 16)
-        flop_step = (n_in / args.steps) * 2 * (6 * C_SDF + 3 * C_APP) + (n_out / args.steps) * 2 * 3 * C_NERF + sampler_evals * 2 * C_SDF
+        flop_step = (n_in / args.steps) * 2 * (6 * C_SDF + 3 * c_app) + (n_out / args.steps) * 2 * 3 * C_NERF + sampler_evals * 2 * C_SDF
         res = {
             'metric': 'training rays/sec (Stage-I shape, 128 samples/ray)', 'value': round(value, 1), 'unit': 'rays/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
@@ -393,8 +525,8 @@ def main():
             'dtype': ('f32 (dense layers: fp32 operands carried as exact / block-scaled 16-bit plane pairs or triples on the bf16/fp16 '
                       f'matrix pipe with fp32 accumulation, fp32-grade error; modes {modes})') if split else 'f32',
             'data': 'synthetic',
-            'config': {'workload': "GlossySynthetic 'bell' Stage-I shape, 4096 rays x (64+64+32) samples per GPU, "
-                                   f'training-schedule step {args.train_step}', 'rays_per_gpu': args.rays,
+            'config': {'workload': f"Glossy{'Synthetic' if args.config == 'bell' else 'Real'} '{args.config}' Stage-I shape, {args.rays} rays x "
+                                   f'(64+64+32) samples per GPU, training-schedule step {args.train_step}', 'rays_per_gpu': args.rays,
                        'parallelism': f'dp{world}', 'optimizer': 'adam(fused)', 'inv_s': 'exp(10*0.5)'},
             'step_mlp_flop_frac': round(flop_step / (dt / args.steps) / PEAK_OF_MODE[CH.GEMM_MODE['fwd']], 4),
             'step_mlp_flop_frac_of_f32_mfma_peak': round(flop_step / (dt / args.steps) / PEAK_F32_MFMA, 4),
@@ -403,14 +535,63 @@ def main():
         }
         if alt is not None:
             res['f32_mfma_engine'] = alt
-        if world == 1 and not args.quick:          # (baselines and the Stage-II leg: rank 0 at N = 1 only)
-            del ts
-            import gc
-            gc.unfreeze()
-            gc.collect()
-            torch.cuda.empty_cache()
-            res['stage2'] = stage2_bench(dev)
-            torch.cuda.empty_cache()
+    del ts
+    import gc
+    gc.unfreeze()
+    gc.collect()
+    torch.cuda.empty_cache()
+
+    def leg(name, fn):
+        """an extra measurement must never cost the headline line"""
+        try:
+            v = fn()
+        except Exception as e:                                                # noqa: BLE001
+            v = {'error': f'{type(e).__name__}: {e}'[:300]}
+        if rank == 0 and v is not None:
+            res[name] = v
+        gc.collect()
+        torch.cuda.empty_cache()
+
+    if world > 1 and not args.quick:
+        # BASELINE configs[2] and configs[4] as data-parallel jobs of THIS world size (every rank takes part; rank 0 reports):
+        # bear Stage I with 8192 rays per global batch, bear Stage II with 16384 surface points x (256+256) directions
+        def c2():
+            r_ = max(64, 8192 // world)
+            t2 = ShapeTrainStep({**BELL, 'shader_config': {'human_light': True}}, rays_per_rank=r_, device=dev, variance=VARIANCE, rank=rank,
+                                world=world, prime_fraction=0.0)
+            for i in range(5):
+                t2.step(args.train_step + i)
+            sync()
+            t0_ = time.time()
+            for i in range(20):
+                t2.step(args.train_step + 5 + i)
+            sync()
+            d_ = max_over_ranks(time.time() - t0_) / 20
+            return {'workload': f"GlossyReal 'bear' Stage-I shape, {r_ * world} rays per global batch = {r_} per GPU x {world} GPUs, RCCL flat "
+                                'gradient all-reduce (BASELINE configs[2])', 'value': round(r_ * world / d_, 1), 'unit': 'rays/s',
+                    'ms_per_step': round(d_ * 1e3, 3), 'rays_per_gpu': r_, 'n_gpus': world, 'steps': 20, 'warmup': 5}
+        leg('configs2_bear_8192_rays_dp', c2)
+        leg('configs4_bear_stage2_16384_points_dp',
+            lambda: stage2_step_bench(dev, 'bear', max(64, 16384 // world), 256, 256, _bench_mesh(), rank, world, 5, 20, sync, max_over_ranks, prof=False))
+    if rank == 0:
+        if world == 1 and not args.quick:          # (baselines, the small-batch / drop-in legs and the Stage-II legs: rank 0 at N = 1 only)
+            def r512():
+                t5 = ShapeTrainStep(cfg, rays_per_rank=512, device=dev, variance=VARIANCE, prime_fraction=0.0)
+                for i in range(5):
+                    t5.step(args.train_step + i)
+                torch.cuda.synchronize()
+                t0_ = time.time()
+                for i in range(20):
+                    t5.step(args.train_step + 5 + i)
+                torch.cuda.synchronize()
+                d_ = (time.time() - t0_) / 20
+                return {'value': round(512 / d_, 1), 'unit': 'rays/s', 'ms_per_step': round(d_ * 1e3, 3), 'rays': 512, 'steps': 20, 'warmup': 5,
+                        'what': "the reference's own train_ray_num = 512 (configs/shape/syn/bell.yaml:31) on the fused training step"}
+            leg('r512', r512)
+            leg('dropin_trainer', lambda: {'r4096': dropin_trainer_bench(dev, cfg, args.rays, VARIANCE, args.train_step),
+                                           'r512': dropin_trainer_bench(dev, cfg, 512, VARIANCE, args.train_step)})
+            leg('stage2', lambda: stage2_bench(dev))
+            leg('stage2_bear_2048x512', lambda: stage2_step_bench(dev, 'bear', 2048, 256, 256, _bench_mesh()))
             tg = torch_gpu_baseline(cfg, VARIANCE, args.train_step, args.rays, dev)
             res['torch_gpu_baseline'] = tg
             res['x_torch_gpu_baseline'] = round(res['protocol_8d']['rays_per_s_at_median'] / tg['value'], 2)

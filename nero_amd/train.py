@@ -226,6 +226,9 @@ class ShapeTrainStep:
         self.eik_w = eikonal_weight
         o, d, poses, gt = synthetic_rays(pool_rays, seed=1)
         self.pool = {'o': o.to(device), 'd': d.to(device), 'gt': gt.to(device)}
+        self.human = bool(self.net.color_network.cfg['human_light'])
+        if self.human:                 # per-ray human frame of the ray's image (get_human_coordinate_poses, network/renderer.py:240-256)
+            self.pool['hp'] = self.net.get_human_coordinate_poses(poses.to(device))
         self.pool_n = pool_rays
         self.cursor = 0
         if device != 'cpu':
@@ -252,7 +255,7 @@ class ShapeTrainStep:
         are paid at construction, not inside the first training step"""
         o, d = self.pool['o'][:64], self.pool['d'][:64]
         near, far = self.net.near_far_from_sphere(o, d)
-        out = self.net.render(o, d, near, far, None, -1, 0.5, is_train=True, step=25000, _kern=self.fopt.kernels() if self.fused else None)
+        out = self.net.render(o, d, near, far, self.pool['hp'][:64] if self.human else None, -1, 0.5, is_train=True, step=25000, _kern=self.fopt.kernels() if self.fused else None)
         shape_training_loss(self.net, out, self.pool['gt'][:64], 25000).backward()
         self.bucket.zero()
         torch.cuda.synchronize()
@@ -272,6 +275,7 @@ class ShapeTrainStep:
             self.cursor = 0
         s = rank_slice(self.cursor, self.R, self.rank)
         self.cursor += G
+        self._hp = self.pool['hp'][s] if self.human else None
         return self.pool['o'][s], self.pool['d'][s], self.pool['gt'][s]
 
     def forward_only(self, step):
@@ -282,7 +286,7 @@ class ShapeTrainStep:
         near, far = net.near_far_from_sphere(o, d)
         with torch.no_grad():
             # (a schedule step below occ_loss_step: inference does not evaluate the occlusion loss)
-            out = net.render(o, d, near, far, None, 0, net.get_anneal_val(step), is_train=False,
+            out = net.render(o, d, near, far, self._hp, 0, net.get_anneal_val(step), is_train=False,
                              step=min(step, net.cfg['occ_loss_step'] - 1))
         return out['ray_rgb']
 
@@ -292,7 +296,7 @@ class ShapeTrainStep:
         self.bucket.zero()
         o, d, gt = self._batch()
         near, far = net.near_far_from_sphere(o, d)
-        out = net.render(o, d, near, far, None, -1, net.get_anneal_val(step), is_train=True, step=step,
+        out = net.render(o, d, near, far, self._hp, -1, net.get_anneal_val(step), is_train=True, step=step,
                          _kern=self.fopt.kernels() if self.fused else None, _grad_views=self.fopt.grad_views if self.fused else None)
         # data parallel: the eikonal mean runs over each rank's own inner samples and the occlusion loss over its own candidate
         # set -> weight both by their global counts so that N ranks reproduce the single-process means

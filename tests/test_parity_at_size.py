@@ -39,8 +39,9 @@ ODEV = 'cuda'                    # where the oracle's ATen ops execute (see the 
 
 # bounds on the escape clauses of assert_grads_fp32_grade, from the measured counts (gpurun_out/parity_at_size.json of the round-3
 # runs) plus margin: (b) is reserved for first-layer predictor tensors with |g| ~ 1e-6 of their MLP's scale, (a) for ReLU-tie flips
-MAX_CLAUSE_B = 8
-MAX_CLAUSE_A = 40
+# measured (MI355X, round 3): clause (b) 0 tensors in every case; clause (a) 10-27 of 84-124 tensors (light / NeRF++ MLPs: ReLU ties)
+MAX_CLAUSE_B = 2
+MAX_CLAUSE_A = 32
 
 
 def _free():
@@ -57,7 +58,7 @@ def _shape_case(cfg, variance, dtype=torch.float32, device='cpu', seed=6033):
     return net.to(dtype).to(device)
 
 
-def _oracle_step(net, cfg, o, d, z_vals, hp, gt, step, keys, dtype):
+def _oracle_step(net, cfg, o, d, z_vals, hp, gt, step, keys, dtype, ODEV=ODEV):
     """one oracle forward + loss + backward in `dtype` on ODEV.  -> (small outputs on the CPU, loss, named grads)"""
     f = lambda a: a.to(ODEV).to(dtype)
     sd = {k: v for k, v in net.named_parameters()}
@@ -77,7 +78,7 @@ def _oracle_step(net, cfg, o, d, z_vals, hp, gt, step, keys, dtype):
     return small, loss, g
 
 
-def _run_shape(test_id, cfg, variance, R, step, with_f64, fallback_lut=False, monkeypatch=None, tmp_path=None):
+def _run_shape(test_id, cfg, variance, R, step, with_f64, fallback_lut=False, monkeypatch=None, tmp_path=None, cpu_floor=False):
     from nero_amd.synthetic import synthetic_rays
     from nero_amd.train import shape_training_loss
     if fallback_lut:                                             # construct with NO reference asset in reach: computed table
@@ -126,9 +127,15 @@ def _run_shape(test_id, cfg, variance, R, step, with_f64, fallback_lut=False, mo
     _, _, g64 = _oracle_step(ref64, cfg, o, d, z_vals, hp, gt, step, keys, torch.float64)
     del ref64
     _free()
+    g32s = [g32]
+    if cpu_floor:
+        # a second fp32 evaluation of the oracle, on ATen's CPU backend: which ReLU ties an fp32 run resolves differently from fp64
+        # depends on its GEMM summation order, so "how far is fp32 torch from fp64" is the spread over both backends
+        ref_cpu = _shape_case(cfg, variance)
+        g32s.append(_oracle_step(ref_cpu, cfg, o, d, z_vals, hp, gt, step, keys, torch.float32, 'cpu')[2])
     info = {}
-    assert_grads_fp32_grade(g_hip, g32, g64, where=f'{test_id} R={R}', info=info)
-    rec.update(info)
+    assert_grads_fp32_grade(g_hip, g32s, g64, where=f'{test_id} R={R}', info=info)
+    rec.update(info, fp32_floor_backends=['cuda', 'cpu'] if cpu_floor else ['cuda'])
     parity_report(test_id, **rec)
     assert info['n_clause_b'] <= MAX_CLAUSE_B and info['n_clause_a'] <= MAX_CLAUSE_A, info
 
@@ -149,7 +156,9 @@ def test_c2_bell_4096_rays_product_default_fg_table(monkeypatch, tmp_path):
 
 def test_c3_bear_1024_rays_per_gpu():
     cfg = {**BELL, 'shader_config': {'human_light': True}}                                   # configs/shape/real/bear.yaml
-    _run_shape('c3_bear_1024', cfg, 0.5, 1024, 25000, with_f64=True)
+    # (the human-light MLP is driven by the few rays that hit the camera plane: one flipped ReLU tie there is a 1e-4-sized share of its
+    # whole gradient, so this case takes its fp32-torch floor over both ATen backends)
+    _run_shape('c3_bear_1024', cfg, 0.5, 1024, 25000, with_f64=True, cpu_floor=True)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -341,5 +350,7 @@ def test_c4_shaped_stage2_hip_tracer_with_explicit_edge_exclusion():
     assert worst < STAGE2_BVH_BOUNDS['max_worst_kept_point'], worst
 
 
-# round-2 bounds (0.6 / 0.97 / 1e-2) until the first round-3 GPU run reported the measured values; tightened from them afterwards
-STAGE2_BVH_BOUNDS = {'min_fraction_points_kept': 0.6, 'min_fraction_within_1e4': 0.97, 'max_worst_kept_point': 1e-2}
+# measured on MI355X for this deterministic case (gpurun_out/parity_at_size.json, round 3): 120 razor-edge rays of 131 072 (2 answered
+# differently), 117 of 512 points excluded (0.7715 kept), 99.24 % of the kept points within 1e-4, worst kept point 2.19e-3.
+# (round 2 asserted 0.6 / 0.97 / 1e-2.)
+STAGE2_BVH_BOUNDS = {'min_fraction_points_kept': 0.75, 'min_fraction_within_1e4': 0.985, 'max_worst_kept_point': 4e-3}
