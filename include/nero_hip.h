@@ -15,6 +15,7 @@
 #ifndef NERO_HIP_H
 #define NERO_HIP_H
 #include <stdint.h>
+#include <stddef.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -347,6 +348,68 @@ int nero_mc_combine_bwd(const float* pt, const float* dirs, const float* depth, 
 int nero_mc_dir_bwd(const float* pt, const float* dirs, const float* face_normals, const int* slot, const float* tab_s,
                     const float* dX_miss, const float* dX_hit, const float* d_wspec, int P, int Dd, int Ds, float* d_mat5, int sphere,
                     const float* dXh /*or NULL*/, const float* poses /*[P,3,4] or NULL*/, void* stream);
+
+/* ---- C-level driver of the Stage-I render step (nero_stage1_render_fwd / _bwd, nero_workspace_bytes) -------------------
+ * One call each for sample_ray (network/renderer.py:403-443), render / render_core (:445-463, 550-606: the drop-in boundary) and
+ * their backward incl. the second-order SDF term (autograd through SDFNetwork.gradient, network/field.py:155-167).  The calls
+ * sequence the entry points above exactly as nero_amd/shape_step.py does (tests/test_stage1_driver.py: bit-for-bit equal), so a host in
+ * any language runs the step without Python.  ALL memory is the caller's: one workspace (nero_stage1_workspace_bytes) from which every
+ * intermediate is carved, one buffer for the packed operand images (nero_stage1_pack_bytes).  The only host synchronisation is the
+ * read-back of the inner / outer sample counts inside nero_stage1_render_fwd (they size every later launch).
+ * The fp16 two-plane engines only (gemm_* in {NERO_GEMM_F16X3, NERO_GEMM_F16X3P}); NERO_ERR_UNSUPPORTED otherwise. */
+#define NERO_S1_LINEARS 49
+/* index of a Linear in nero_stage1_weights / _grads: sdf_network.lin0..8 = 0..8, outer_nerf.pts_linears.0..7 = 9..16, views_linears.0 = 17,
+ * feature_linear = 18, alpha_linear = 19, rgb_linear = 20, then the predictors' four Linears each: metallic 21.., roughness 25.., albedo
+ * 29.., outer_light 33.., inner_light 37.., inner_weight 41.., human_light_predictor 45.. (shader_config.human_light only). */
+typedef struct { const float* W; const float* b; } nero_linear;        /* EFFECTIVE weight [n_out, k] row-major contiguous, bias [n_out] */
+typedef struct { float* dW; float* db; } nero_linear_grad;              /* destinations shaped like W / b (overwritten)                   */
+typedef struct { nero_linear lin[NERO_S1_LINEARS]; } nero_stage1_weights;
+typedef struct { nero_linear_grad lin[NERO_S1_LINEARS]; } nero_stage1_grads;
+typedef struct {
+    int n_samples, n_importance, n_bg_samples, up_sample_steps, clip_sample_variance;   /* NeROShapeRenderer.default_cfg, renderer.py:84-95 */
+    int human_light, sphere_direction;                                                  /* shader_config, network/field.py:487-495          */
+    float light_exp_max;
+    int gemm_fwd, gemm_tan, gemm_bwd, gemm_dw;                                           /* NERO_GEMM_*                                      */
+} nero_stage1_cfg;
+/* device pointers into the workspace, valid from nero_stage1_render_fwd until the next one (what the losses and the validation path read:
+ * compute_occ_loss renderer.py:522-548 needs x4 / sdf4 / normal / geo / inner_idx, compute_validation_info :465-482 needs weights) */
+typedef struct {
+    int R, T, n_in, n_out;
+    float* pts4;            /* [R*T,4] mid points + section lengths                       */
+    int* ray_counts; int* ray_off; int* counts;
+    int* inner_idx; int* outer_idx;
+    float* x4;              /* [rows_pad(n_in),4] inner sample positions                  */
+    float* sdf4;            /* [rows_pad(n_in),4] column 0 = sdf                          */
+    float* feat;            /* [rows_pad(n_in),256]                                       */
+    float* normal;          /* [n_in,3] SDF gradient                                      */
+    float* geo;             /* [rows_pad(n_in),8] nhat, NoV, reflection, |grad|           */
+    float* weights;         /* [R,T] compositing weights                                  */
+} nero_stage1_state;
+typedef struct nero_stage1 nero_stage1;
+
+int nero_stage1_create(const nero_stage1_cfg* cfg, nero_stage1** out);
+void nero_stage1_destroy(nero_stage1* h);
+size_t nero_stage1_pack_bytes(nero_stage1* h);
+/* (re)build the packed operand images of all ten networks from the effective weights: once per optimisation step */
+int nero_stage1_pack(nero_stage1* h, const nero_stage1_weights* w, void* pack_buf, void* stream);
+/* worst case over the data-dependent inner / outer split for R rays (sampler + forward + backward) */
+size_t nero_stage1_workspace_bytes(nero_stage1* h, int R);
+size_t nero_stage1_workspace_bytes_for(nero_stage1* h, int R, int n_in, int n_out, int with_sampler);
+/* z_vals [R, n_samples + n_importance + n_bg_samples]; rand1 [R] / rand_bg [R, n_bg] uniform draws or NULL (no perturbation) */
+int nero_stage1_sample(nero_stage1* h, int R, const float* o, const float* d, const float* near, const float* far, const float* variance,
+                       const float* rand1, const float* rand_bg, float* z_vals, void* ws, size_t ws_bytes, void* stream);
+/* rgb [R,3]; gerr / occ_prob: capacity R*T floats, the first n_in entries are written (eikonal term, unclamped occ_prob);
+ * n_in_out / n_out_out: host ints.  poses [R,3,4] human frames or NULL.  Keeps its state in `ws` for nero_stage1_render_bwd. */
+int nero_stage1_render_fwd(nero_stage1* h, int R, const float* o, const float* d, const float* z_vals, const float* variance,
+                           const float* lut, const float* poses, float anneal, float* rgb, float* gerr, float* occ_prob,
+                           int* n_in_out, int* n_out_out, void* ws, size_t ws_bytes, void* stream);
+/* d_rgb [R,3], d_gerr [n_in] or NULL, d_occ [n_in] or NULL -> every dW / db of `grads` (NULL entries are skipped);
+ * d_inv_s_sum: device float receiving sum_k d L / d inv_s (the caller applies d inv_s / d variance), or NULL */
+int nero_stage1_render_bwd(nero_stage1* h, const float* d_rgb, const float* d_gerr, const float* d_occ, const nero_stage1_grads* grads,
+                           float* d_inv_s_sum, void* stream);
+int nero_stage1_get_state(nero_stage1* h, nero_stage1_state* out);
+/* no-grad SDF values of PE-6 rows [rows_pad(n),40] -> out4 [rows_pad(n),4], column 0 = sdf (sampler / occlusion march / mesh grid) */
+int nero_stage1_sdf_from_pe(nero_stage1* h, const float* pe, int n, float* out4, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -584,7 +584,7 @@ static void report_occupancy(const void* f, const char* name) {      // NERO_DEB
         fprintf(stderr, "[nero] %s: dynamic LDS %d -> %d workgroups per CU (err %d)\n", name, lds, nb, (int)e);
     }
     int nb = -1;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f, 256, p_lds_bytes());
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f, 256, p_lds_bytes());
     fprintf(stderr, "[nero] %s: dynamic LDS %d -> %d workgroups per CU\n", name, p_lds_bytes(), nb);
 }
 int nero_f16p_forward(const nero_fwd_chain* ch, int n_rows, hipStream_t stream) {

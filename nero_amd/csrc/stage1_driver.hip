@@ -1,0 +1,922 @@
+// stage1_driver.hip -- the C-level driver of the Stage-I render step (nero_stage1_render_fwd / _bwd,
+// nero_stage1_workspace_bytes).  Host code only, plus four trivial kernels: it sequences the library's own entry points (chain
+// kernels, sampler, shader algebra, compositing, weight-gradient GEMMs) exactly as nero_amd/shape_step.py does, so that a host in
+// ANY language can run sample_ray + render_core + their backward (network/renderer.py:403-443, 445-463, 550-606 and autograd's
+// double backward through SDFNetwork.gradient, network/field.py:155-167) with one call each and no Python in between.
+//
+// Memory: the caller hands over ONE workspace (size from nero_stage1_workspace_bytes); every intermediate -- saved activations,
+// deltas, encodings, partial sums -- is carved from it by a bump allocator with stack-style release, nothing is hipMalloc'ed.  The
+// forward keeps its state there for the backward; nero_stage1_get_state exposes the pieces the loss needs (occlusion-loss march,
+// validation extras).  The only host synchronisation is the read-back of the inner / outer sample counts after render_prep
+// (they size every later launch), as in the Python driver.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+#include <vector>
+#include "../../include/nero_hip.h"
+#include "common.h"
+
+namespace {
+
+constexpr int MAXL = NERO_MAX_LAYERS;
+inline int r8(int x) { return (x + 7) / 8 * 8; }
+inline int r16(int x) { return (x + 15) / 16 * 16; }
+inline int tiles(int x) { return (x + 31) / 32; }
+inline int rpad(int n) { return NERO_ROW_PAD(n); }
+inline bool is_f16(int m) { return m == NERO_GEMM_F16X3 || m == NERO_GEMM_F16X3P; }
+
+// ---- workspace arena -------------------------------------------------------------------------------------------------------
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, off = 0, peak = 0;
+    bool dry = false;                                  // size query: no memory behind it, nothing is launched
+    bool failed = false;
+    void* take(size_t bytes) {
+        const size_t a = (off + 255) & ~(size_t)255;
+        off = a + bytes;
+        peak = off > peak ? off : peak;
+        if (dry) return reinterpret_cast<void*>(0x1000 + a);       // a non-NULL token: descriptors are built, never dereferenced
+        if (off > cap) { failed = true; return nullptr; }
+        return base + a;
+    }
+    float* f32(size_t n) { return static_cast<float*>(take(n * 4)); }
+    int* i32(size_t n) { return static_cast<int*>(take(n * 4)); }
+    size_t mark() const { return off; }
+    void release(size_t m) { off = m; }
+};
+
+__global__ void x8_from_x4_kernel(const float* __restrict__ x4, float* __restrict__ x8, int n, int n_pad) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_pad) return;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < n) { v = reinterpret_cast<const float4*>(x4)[r]; v.w = 0.f; }      // (rows_pad rows, as x8[:, :3] = x4[:, :3] over the padded buffer)
+    else { v = reinterpret_cast<const float4*>(x4)[r]; v.w = 0.f; }
+    reinterpret_cast<float4*>(x8)[2 * r] = v;
+    reinterpret_cast<float4*>(x8)[2 * r + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__global__ void ones_col0_kernel(float* __restrict__ b, int n_pad) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_pad) reinterpret_cast<float4*>(b)[r] = make_float4(1.f, 0.f, 0.f, 0.f);
+}
+// dst[r*ldd + c] = src[r*lds + c]
+__global__ void copy2d_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, int rows, int cols) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * cols) return;
+    const int r = idx / cols, c = idx - r * cols;
+    dst[(size_t)r * ldd + c] = src[(size_t)r * lds + c];
+}
+// out[0] = sum_{i<n} v[i] in the order torch's sum would not promise either: one workgroup, fp32 tree over a grid-stride pass
+__global__ __launch_bounds__(1024) void sum_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
+    __shared__ float part[1024];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) s += v[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 512; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = part[0];
+}
+
+#define RC(expr) do { const int rc_ = (expr); if (rc_ != NERO_OK) return rc_; } while (0)
+#define LAUNCH(...) do { if (!A.dry) { RC(__VA_ARGS__); } } while (0)
+
+// ---- one network as a list of entries (nero_amd/chain.py::Chain) ------------------------------------------------------------------
+struct Dense {
+    bool has = false;
+    const float* W = nullptr; int ldw = 0; const float* b = nullptr;
+    int n_out = 0, act = 0, k_main = 0, main_c0 = 0, k_aux = 0, aux_c0 = 0;
+    float scale = 1.f;
+    float* dW = nullptr; int ld_dw = 0; float* db = nullptr;          // gradient destinations (row-major like W), set per backward
+};
+struct Head {
+    bool has = false;
+    const float* W = nullptr; int ldw = 0; const float* b = nullptr;
+    int n_head = 0, k = 0;
+    float* dW = nullptr; int ld_dw = 0; float* db = nullptr;
+};
+struct Entry {
+    Dense d; Head h;
+    float *bias = nullptr, *hfm = nullptr, *hfa = nullptr, *hbm = nullptr, *hba = nullptr, *hw = nullptr, *hb = nullptr;   // packed images
+};
+struct Fwd {
+    float* saves[MAXL]; uint32_t* masks[MAXL]; float* heads[MAXL];
+    Fwd() { for (int i = 0; i < MAXL; ++i) { saves[i] = nullptr; masks[i] = nullptr; heads[i] = nullptr; } }
+};
+struct Bwd {
+    const float* deltas[MAXL]; int ld_delta[MAXL];
+    float* d_init = nullptr; int ld_dinit = 0; float* d_aux = nullptr; int ld_daux = 0;
+    Bwd() { for (int i = 0; i < MAXL; ++i) { deltas[i] = nullptr; ld_delta[i] = NERO_HID; } }
+};
+struct Second { const float* D1 = nullptr; int ldd1 = 0; const float* B1m = nullptr; int ldb1m = 0; const float* B1a = nullptr; int ldb1a = 0; };
+
+struct Modes { int fwd, tan, bwd, dw; };
+
+struct Chain {
+    std::vector<Entry> e;
+    int k_init = 0, k_aux = 0, aux_wide = 0;
+    int n() const { return (int)e.size(); }
+    int last_dense() const { int l = -1; for (int i = 0; i < n(); ++i) if (e[i].d.has) l = i; return l; }
+
+    // floats of the packed operand images (fp16 two-plane engine: 64-float header + 512 floats per (tile, 16-k step))
+    size_t pack_floats() const {
+        size_t t = 0;
+        for (const Entry& x : e) {
+            if (x.d.has) {
+                const Dense& d = x.d;
+                const int nt = tiles(d.n_out);
+                t += 32 * nt;
+                if (d.k_main) t += 64 + (size_t)(r16(d.k_main) / 16) * nt * 512 + 64 + (size_t)(r16(d.n_out) / 16) * tiles(d.k_main) * 512;
+                if (d.k_aux) t += 64 + (size_t)(r16(d.k_aux) / 16) * nt * 512 + 64 + (size_t)(r16(d.n_out) / 16) * tiles(d.k_aux) * 512;
+            }
+            if (x.h.has) t += 4 * NERO_HID + 4;
+        }
+        return t;
+    }
+    // carve the images from `buf` (zero-filled by the caller) and append the pack jobs
+    void pack(float*& buf, std::vector<nero_pack_job>& jobs) {
+        auto job = [&](int kind, const float* W, float* out, int nrows, int ld, int col0, int ncols, int transpose, int kpad, int nt_count, float scale) {
+            nero_pack_job j;
+            j.W = W; j.out = out; j.kind = kind; j.nrows = nrows; j.ld = ld; j.col0 = col0; j.ncols = ncols; j.transpose = transpose;
+            j.kpad = kpad; j.nt_count = nt_count; j.scale = scale; j.pad_ = 0;
+            jobs.push_back(j);
+        };
+        for (Entry& x : e) {
+            if (x.d.has) {
+                const Dense& d = x.d;
+                const int nt = tiles(d.n_out);
+                x.bias = buf; buf += 32 * nt;
+                x.hfm = x.hfa = x.hbm = x.hba = nullptr;
+                if (d.k_main) {
+                    x.hfm = buf; buf += 64 + (size_t)(r16(d.k_main) / 16) * nt * 512;
+                    x.hbm = buf; buf += 64 + (size_t)(r16(d.n_out) / 16) * tiles(d.k_main) * 512;
+                    job(3, d.W, x.hfm, d.n_out, d.ldw, d.main_c0, d.k_main, 0, r16(d.k_main), nt, d.scale);
+                    job(3, d.W, x.hbm, d.n_out, d.ldw, d.main_c0, d.k_main, 1, r16(d.n_out), tiles(d.k_main), d.scale);
+                }
+                if (d.k_aux) {
+                    x.hfa = buf; buf += 64 + (size_t)(r16(d.k_aux) / 16) * nt * 512;
+                    x.hba = buf; buf += 64 + (size_t)(r16(d.n_out) / 16) * tiles(d.k_aux) * 512;
+                    job(3, d.W, x.hfa, d.n_out, d.ldw, d.aux_c0, d.k_aux, 0, r16(d.k_aux), nt, d.scale);
+                    job(3, d.W, x.hba, d.n_out, d.ldw, d.aux_c0, d.k_aux, 1, r16(d.n_out), tiles(d.k_aux), d.scale);
+                }
+                if (d.b) job(2, d.b, x.bias, 1, d.n_out, 0, d.n_out, 0, 32 * nt, 0, 1.f);
+            }
+            if (x.h.has) {
+                x.hw = buf; buf += 4 * NERO_HID;
+                x.hb = buf; buf += 4;
+                job(2, x.h.W, x.hw, x.h.n_head, x.h.ldw, 0, x.h.k, 0, NERO_HID, 0, 1.f);
+                if (x.h.b) job(2, x.h.b, x.hb, 1, x.h.n_head, 0, x.h.n_head, 0, 4, 0, 1.f);
+            }
+        }
+    }
+
+    // nero_amd/chain.py::Chain.forward
+    int forward(Arena& A, const Modes& M, const float* init, int ld_init, const float* aux, int ld_aux, int n_rows, bool save, Fwd& F,
+                void* stream) const {
+        const int rp = rpad(n_rows);
+        nero_fwd_chain ch;
+        memset(&ch, 0, sizeof(ch));
+        ch.init = init; ch.ld_init = init ? ld_init : 0; ch.k_init = k_init;
+        ch.aux = aux; ch.ld_aux = aux ? ld_aux : 0; ch.k_aux = k_aux;
+        ch.n_layers = n(); ch.aux_wide = aux_wide;
+        ch.gemm_mode = M.fwd;
+        if (ch.gemm_mode == NERO_GEMM_F16X3P && aux_wide) ch.gemm_mode = NERO_GEMM_F16X3;     // (chain.py: the wide-aux trunk stays on the 512-thread kernel)
+        double macs = 0.0;
+        for (const Entry& x : e) if (x.d.has) macs += (double)x.d.n_out * (x.d.k_main + x.d.k_aux);
+        ch.macs_per_row = macs;
+        const int ld = last_dense();
+        for (int i = 0; i < n(); ++i) {
+            const Entry& x = e[i];
+            nero_fwd_layer& fl = ch.layer[i];
+            if (x.h.has) {
+                F.heads[i] = A.f32((size_t)rp * 4);
+                fl.head_w = x.hw; fl.head_b = x.hb; fl.head_out = F.heads[i];
+                fl.n_head = x.h.n_head; fl.head_k = (x.h.k + 3) / 4 * 4;
+            }
+            if (x.d.has) {
+                const Dense& d = x.d;
+                fl.w_main = x.hfm; fl.w_aux = x.hfa; fl.bias = x.bias;
+                fl.k_main = d.k_main ? r16(d.k_main) : 0; fl.k_aux = d.k_aux ? r16(d.k_aux) : 0;
+                fl.n_tiles = tiles(d.n_out); fl.act = d.act;
+                if (save || i == ld) { F.saves[i] = A.f32((size_t)rp * NERO_HID); fl.save = F.saves[i]; }
+                if (save && d.act == NERO_ACT_RELU) { F.masks[i] = reinterpret_cast<uint32_t*>(A.i32((size_t)rp * 8)); fl.relu_mask = F.masks[i]; }
+            }
+        }
+        if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1: workspace too small");
+        LAUNCH(nero_mlp_forward(&ch, n_rows, stream));
+        return NERO_OK;
+    }
+
+    // nero_amd/chain.py::Chain.backward
+    int backward(Arena& A, const Modes& M, const Fwd& F, int n_rows, const float* dy, int ld_dy, const float* const* head_dys /*[MAXL] or NULL*/,
+                 bool need_dinit, bool need_daux, const float* const* injs /*[MAXL] or NULL*/, float* dinit_out, int ld_dinit_out,
+                 bool accumulate_dinit, bool skip_last_dense, Bwd& B, void* stream) const {
+        const int rp = rpad(n_rows), last = n() - 1;
+        nero_bwd_chain ch;
+        memset(&ch, 0, sizeof(ch));
+        ch.n_layers = n(); ch.aux_wide = 0; ch.gemm_mode = M.bwd;
+        if (dy) {
+            ch.dy = dy; ch.ld_dy = ld_dy;
+            ch.k_dy = e[last].d.has ? r8(e[last].d.n_out) : NERO_HID;
+        }
+        if (need_dinit) {
+            if (dinit_out) { B.d_init = dinit_out; B.ld_dinit = ld_dinit_out; }
+            else { B.d_init = A.f32((size_t)rp * k_init); B.ld_dinit = k_init; }
+            ch.d_init = B.d_init; ch.ld_dinit = B.ld_dinit; ch.accumulate_dinit = accumulate_dinit ? 1 : 0;
+        }
+        if (need_daux) {
+            B.d_aux = A.f32((size_t)rp * k_aux); B.ld_daux = k_aux;
+            if (!A.dry && !A.failed) (void)hipMemsetAsync(B.d_aux, 0, (size_t)rp * k_aux * 4, (hipStream_t)stream);
+            ch.d_aux = B.d_aux; ch.ld_daux = k_aux;
+        }
+        int prev_dense[MAXL];
+        int pd = -1;
+        for (int i = 0; i < n(); ++i) { prev_dense[i] = pd; if (e[i].d.has) pd = i; }
+        float* dw[MAXL];
+        for (int i = 0; i < n(); ++i) {
+            dw[i] = nullptr;
+            if (e[i].d.has) { dw[i] = A.f32((size_t)rp * NERO_HID); B.deltas[i] = dw[i]; B.ld_delta[i] = NERO_HID; }
+        }
+        double macs = 0.0;
+        for (int i = 0; i < n(); ++i) {
+            const Entry& x = e[i];
+            nero_bwd_layer& bl = ch.layer[i];
+            const int j = prev_dense[i];
+            if (x.d.has && !(skip_last_dense && i == last)) {
+                const Dense& d = x.d;
+                bl.w_main_t = x.hbm;
+                bl.w_aux_t = need_daux ? x.hba : nullptr;
+                bl.n_out = r16(d.n_out);
+                bl.k_main_tiles = d.k_main ? tiles(d.k_main) : 0;
+                bl.k_aux_tiles = d.k_aux ? tiles(d.k_aux) : 0;
+                const bool first = j < 0;
+                if (first && !need_dinit) macs += (need_daux && d.k_aux) ? (double)d.n_out * d.k_aux : 0.0;
+                else macs += (double)d.n_out * (d.k_main + (need_daux ? d.k_aux : 0));
+            } else {
+                bl.n_out = 0;
+                bl.k_main_tiles = j >= 0 ? tiles(e[j].d.n_out) : 0;
+            }
+            if (x.h.has && head_dys && head_dys[i]) { bl.head_w = x.hw; bl.head_dy = head_dys[i]; bl.n_head = x.h.n_head; }
+            if (j >= 0) {
+                bl.a_prev = F.saves[j];
+                bl.act_prev = e[j].d.act;
+                if (F.masks[j]) bl.mask_prev = F.masks[j];
+                bl.delta_prev = dw[j];
+                if (injs && injs[j]) bl.inj = injs[j];
+            }
+        }
+        if (e[last].d.has && !skip_last_dense) { B.deltas[last] = dy; B.ld_delta[last] = ld_dy; }   // (the delta of the last dense entry is dy itself)
+        ch.macs_per_row = macs;
+        if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1: workspace too small");
+        LAUNCH(nero_mlp_backward(&ch, n_rows, stream));
+        return NERO_OK;
+    }
+
+    // nero_amd/chain.py::Chain.weight_grads -- every result goes straight to the entry's dW / db destination
+    int weight_grads(Arena& A, const Modes& M, const Fwd& F, const Bwd& B, int n_rows, const float* init, int ld_init, const float* aux,
+                     int ld_aux, const float* const* head_dys, const Second* second /*[MAXL] or NULL*/, const float* const* head_extra,
+                     float* partials, void* stream) const {
+        int prev = -1;
+        for (int i = 0; i < n(); ++i) {
+            const Entry& x = e[i];
+            if (x.h.has && head_dys && head_dys[i] && x.h.dW) {
+                const size_t m = A.mark();
+                float* tW = A.f32(4 * NERO_HID);
+                float* tb = A.f32(4);
+                if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1: workspace too small");
+                LAUNCH(nero_head_dw(head_dys[i], F.saves[prev], head_extra ? head_extra[i] : nullptr, x.h.n_head, n_rows, tW, tb, partials, 0, stream));
+                if (!A.dry) {
+                    const int tot = x.h.n_head * x.h.k;
+                    hipLaunchKernelGGL(copy2d_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, tW, NERO_HID, x.h.dW, x.h.ld_dw, x.h.n_head, x.h.k);
+                    if (x.h.db) hipLaunchKernelGGL(copy2d_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, tb, 4, x.h.db, 4, 1, x.h.n_head);
+                }
+                A.release(m);       // (stream order: the copies above read tW / tb before any later kernel can overwrite them)
+            }
+            if (x.d.has) {
+                const Dense& d = x.d;
+                if (d.dW) {
+                    const float* main_in = prev < 0 ? init : F.saves[prev];
+                    const int ld_main = prev < 0 ? ld_init : NERO_HID;
+                    struct Part { const float* Bm; int ldb, kc, c0, which; } parts[2];
+                    int np = 0;
+                    if (d.k_main) parts[np++] = {main_in, ld_main, d.k_main, d.main_c0, 0};
+                    if (d.k_aux) parts[np++] = {aux, ld_aux, d.k_aux, d.aux_c0, 1};
+                    for (int pi = 0; pi < np; ++pi) {
+                        nero_dw_job job;
+                        memset(&job, 0, sizeof(job));
+                        job.d0 = B.deltas[i]; job.ldd0 = B.ld_delta[i]; job.b0 = parts[pi].Bm; job.ldb0 = parts[pi].ldb;
+                        if (second && second[i].D1) {
+                            job.d1 = second[i].D1; job.ldd1 = second[i].ldd1;
+                            job.b1 = parts[pi].which ? second[i].B1a : second[i].B1m;
+                            job.ldb1 = parts[pi].which ? second[i].ldb1a : second[i].ldb1m;
+                        }
+                        job.n_out = d.n_out; job.k_cols = parts[pi].kc;
+                        job.dW = d.dW; job.ldw = d.ld_dw; job.col0 = parts[pi].c0;
+                        job.db = pi == 0 ? d.db : nullptr;
+                        job.scale = d.scale; job.accumulate = 0; job.gemm_mode = M.dw;
+                        LAUNCH(nero_dw_gemm(&job, n_rows, partials, stream));
+                    }
+                }
+                prev = i;
+            }
+        }
+        return NERO_OK;
+    }
+};
+
+Entry dense(const nero_linear& L, int ldw, int n_out, int act, int k_main, int main_c0 = 0, int k_aux = 0, int aux_c0 = 0, float scale = 1.f) {
+    Entry x;
+    x.d.has = true; x.d.W = L.W; x.d.ldw = ldw; x.d.b = L.b; x.d.n_out = n_out; x.d.act = act;
+    x.d.k_main = k_main; x.d.main_c0 = main_c0; x.d.k_aux = k_aux; x.d.aux_c0 = aux_c0; x.d.scale = scale;
+    return x;
+}
+Entry head_only(const nero_linear& L, int ldw, int n_head, int k) {
+    Entry x;
+    x.h.has = true; x.h.W = L.W; x.h.ldw = ldw; x.h.b = L.b; x.h.n_head = n_head; x.h.k = k;
+    return x;
+}
+void set_dense_grad(Entry& x, const nero_linear_grad& g, int ld) { x.d.dW = g.dW; x.d.ld_dw = ld; x.d.db = g.db; }
+void set_head_grad(Entry& x, const nero_linear_grad& g, int ld) { x.h.dW = g.dW; x.h.ld_dw = ld; x.h.db = g.db; }
+
+// the four-layer predictors (make_predictor, network/field.py:310-346): layer 0 may take [main | aux] columns
+Chain predictor(const nero_linear* L, int k_main0, int k_aux0, int k_init, int k_aux, int n_head) {
+    Chain c;
+    const int k0 = k_main0 + k_aux0;
+    c.e.push_back(dense(L[0], k0, 256, NERO_ACT_RELU, k_main0, 0, k_aux0, k_main0));
+    c.e.push_back(dense(L[1], 256, 256, NERO_ACT_RELU, 256));
+    c.e.push_back(dense(L[2], 256, 256, NERO_ACT_RELU, 256));
+    c.e.push_back(head_only(L[3], 256, n_head, 256));
+    c.k_init = k_init; c.k_aux = k_aux;
+    return c;
+}
+void predictor_grads(Chain& c, const nero_linear_grad* g, int k0) {
+    set_dense_grad(c.e[0], g[0], k0);
+    set_dense_grad(c.e[1], g[1], 256);
+    set_dense_grad(c.e[2], g[2], 256);
+    set_head_grad(c.e[3], g[3], 256);
+}
+
+}  // namespace
+
+// ---- the handle -----------------------------------------------------------------------------------------------------------------
+enum { L_SDF = 0, L_NERF_PTS = 9, L_NERF_VIEWS = 17, L_NERF_FEATURE = 18, L_NERF_ALPHA = 19, L_NERF_RGB = 20, L_METALLIC = 21,
+       L_ROUGHNESS = 25, L_ALBEDO = 29, L_OUTER = 33, L_INNER = 37, L_WEIGHT = 41, L_HUMAN = 45 };
+constexpr int D_PE = 39, LD_PE = 40, N_FREQ = 6;
+
+struct nero_stage1 {
+    nero_stage1_cfg cfg;
+    Modes M;
+    int ld_outer = 72;
+    bool packed = false;
+    Chain sdf_full, sdf_value, nerf_trunk, nerf_head, mat[3], outer_light, inner_light, inner_weight, human_light;
+    // ---- state of the current step (pointers into the caller's workspace) ----
+    Arena A;
+    nero_stage1_state st;
+    size_t step_mark = 0;
+    // forward state kept for the backward
+    Fwd f_trunk, f_head, f_sdf, f_mat[3], f_out, f_in, f_w, f_h;
+    Bwd b_normal;
+    float *pe88 = nullptr, *pev32 = nullptr, *dist_o = nullptr, *pe40 = nullptr, *x8 = nullptr, *mat8 = nullptr, *Xo2 = nullptr, *Xi = nullptr,
+          *Xo = nullptr, *Xh = nullptr, *hmask = nullptr, *alphaRT = nullptr, *colorRT = nullptr;
+    const float *o = nullptr, *d = nullptr, *variance = nullptr, *lut = nullptr, *poses = nullptr;
+    float anneal = 0.f;
+};
+
+namespace {
+
+void build_chains(nero_stage1* h, const nero_stage1_weights* w) {
+    const nero_linear* L = w->lin;
+    // SDF (nero_amd/sdf.py::sdf_entries): PE-6 -> 9 layers, skip into layer 4 with 1/sqrt2 folded in, last layer = [head row 0 | dense rows 1..256]
+    Chain s;
+    for (int l = 0; l < 9; ++l) {
+        if (l == 0) s.e.push_back(dense(L[L_SDF], D_PE, 256, NERO_ACT_SOFTPLUS100, D_PE));
+        else if (l == 3) s.e.push_back(dense(L[L_SDF + 3], 256, 256 - D_PE, NERO_ACT_SOFTPLUS100, 256));
+        else if (l == 4) s.e.push_back(dense(L[L_SDF + 4], 256, 256, NERO_ACT_SOFTPLUS100, 256 - D_PE, 0, D_PE, 256 - D_PE, (float)(1.0 / sqrt(2.0))));
+        else if (l == 8) {
+            nero_linear rows1 = {L[L_SDF + 8].W + 256, L[L_SDF + 8].b + 1};
+            Entry x = dense(rows1, 256, 256, NERO_ACT_NONE, 256);
+            x.h.has = true; x.h.W = L[L_SDF + 8].W; x.h.ldw = 256; x.h.b = L[L_SDF + 8].b; x.h.n_head = 1; x.h.k = 256;
+            s.e.push_back(x);
+        } else s.e.push_back(dense(L[L_SDF + l], 256, 256, NERO_ACT_SOFTPLUS100, 256));
+    }
+    s.k_init = LD_PE; s.k_aux = LD_PE;
+    h->sdf_full = s;
+    // NeRF++ trunk: 8 ReLU layers, layer 5 takes [pe(84) | h(256)] (network/field.py:239-241, 265-269), sigma head on the trunk output
+    Chain t;
+    for (int i = 0; i < 8; ++i) {
+        if (i == 0) t.e.push_back(dense(L[L_NERF_PTS], 84, 256, NERO_ACT_RELU, 84));
+        else if (i == 5) t.e.push_back(dense(L[L_NERF_PTS + 5], 340, 256, NERO_ACT_RELU, 256, 84, 84, 0));
+        else t.e.push_back(dense(L[L_NERF_PTS + i], 256, 256, NERO_ACT_RELU, 256));
+    }
+    t.e.push_back(head_only(L[L_NERF_ALPHA], 256, 1, 256));
+    t.k_init = 88; t.k_aux = 88; t.aux_wide = 1;
+    h->nerf_trunk = t;
+    Chain hd;
+    hd.e.push_back(dense(L[L_NERF_FEATURE], 256, 256, NERO_ACT_NONE, 256));
+    hd.e.push_back(dense(L[L_NERF_VIEWS], 283, 128, NERO_ACT_RELU, 256, 0, 27, 256));
+    hd.e.push_back(head_only(L[L_NERF_RGB], 128, 3, 128));
+    hd.k_init = 256; hd.k_aux = 32;
+    h->nerf_head = hd;
+    h->mat[0] = predictor(L + L_METALLIC, 256, 3, 256, 8, 1);
+    h->mat[1] = predictor(L + L_ROUGHNESS, 256, 3, 256, 8, 1);
+    h->mat[2] = predictor(L + L_ALBEDO, 256, 3, 256, 8, 3);
+    h->ld_outer = h->cfg.sphere_direction ? 144 : 72;
+    h->outer_light = predictor(L + L_OUTER, h->ld_outer, 0, h->ld_outer, 0, 3);
+    h->inner_light = predictor(L + L_INNER, 123, 0, 128, 0, 3);
+    h->inner_weight = predictor(L + L_WEIGHT, 90, 0, 96, 0, 1);
+    if (h->cfg.human_light) h->human_light = predictor(L + L_HUMAN, 24, 0, 24, 0, 4);
+}
+
+// value-only SDF chain shares the images of the full one: entries 0..7 + the head of entry 8 as a pseudo layer
+void make_value_chain(nero_stage1* h) {
+    Chain v;
+    for (int l = 0; l < 8; ++l) v.e.push_back(h->sdf_full.e[l]);
+    Entry x;
+    x.h = h->sdf_full.e[8].h;
+    x.hw = h->sdf_full.e[8].hw; x.hb = h->sdf_full.e[8].hb;
+    v.e.push_back(x);
+    v.k_init = LD_PE; v.k_aux = LD_PE;
+    h->sdf_value = v;
+}
+
+std::vector<Chain*> all_chains(nero_stage1* h) {
+    std::vector<Chain*> v = {&h->sdf_full, &h->nerf_trunk, &h->nerf_head, &h->outer_light, &h->inner_light, &h->inner_weight};
+    if (h->cfg.human_light) v.push_back(&h->human_light);
+    v.push_back(&h->mat[0]); v.push_back(&h->mat[1]); v.push_back(&h->mat[2]);
+    return v;
+}
+
+size_t pack_floats_total(nero_stage1* h) {
+    size_t t = 0;
+    for (Chain* c : all_chains(h)) t += (c->pack_floats() + 63) / 64 * 64;
+    return t;
+}
+
+// no-grad SDF values of PE rows: -> heads [rows_pad, 4], column 0 = sdf   (SDFField.sdf_from_pe)
+int sdf_from_pe(nero_stage1* h, Arena& A, const float* pe, int n, float*& out4, void* stream) {
+    Fwd F;
+    RC(h->sdf_value.forward(A, h->M, pe, LD_PE, pe, LD_PE, n, false, F, stream));
+    out4 = F.heads[8];
+    return NERO_OK;
+}
+
+// ---- sample_ray (network/renderer.py:403-443; nero_amd/shape_step.py::sample_ray) ---------------------------------------------------
+int do_sample(nero_stage1* h, Arena& A, int R, const float* o, const float* d, const float* near, const float* far, const float* variance,
+              const float* rand1, const float* rand_bg, float* z, void* stream) {
+    const nero_stage1_cfg& c = h->cfg;
+    const int ns = c.n_samples, nb = c.n_bg_samples, up = c.up_sample_steps, m = c.n_importance / up;
+    const int n_in = ns + m * up, T = n_in + nb;
+    float* tab = A.f32((size_t)R * n_in);
+    LAUNCH(nero_coarse_z(near, far, rand1, R, ns, z, T, stream));
+    float* pe = A.f32((size_t)rpad(R * ns) * LD_PE);
+    if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1_sample: workspace too small");
+    LAUNCH(nero_ray_points_pe(o, d, z, T, 0, ns, R, pe, stream));
+    float* s4 = nullptr;
+    RC(sdf_from_pe(h, A, pe, R * ns, s4, stream));
+    LAUNCH(nero_scatter_sdf(s4, 4, R, ns, tab, n_in, stream));
+    int n = ns;
+    float* z_new = A.f32((size_t)R * m);
+    float* pe_new = A.f32((size_t)rpad(R * m) * LD_PE);
+    if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1_sample: workspace too small");
+    const float* var_ptr = c.clip_sample_variance ? variance : nullptr;
+    for (int i = 0; i < up; ++i) {
+        LAUNCH(nero_upsample(o, d, z, T, tab, n_in, n, var_ptr, 64.0f * (float)(1 << i), m, R, z_new, nullptr, nullptr, stream));
+        if (i + 1 < up) {
+            const size_t mk = A.mark();
+            LAUNCH(nero_ray_points_pe(o, d, z_new, m, 0, m, R, pe_new, stream));
+            RC(sdf_from_pe(h, A, pe_new, R * m, s4, stream));
+            LAUNCH(nero_merge_sorted(z, T, n, tab, n_in, z_new, m, s4, 4, R, nullptr, stream));
+            A.release(mk);
+        } else {
+            LAUNCH(nero_merge_sorted(z, T, n, nullptr, 0, z_new, m, nullptr, 0, R, nullptr, stream));
+        }
+        n += m;
+    }
+    LAUNCH(nero_background_z(far, rand_bg, R, nb, z, T, n_in, stream));
+    return NERO_OK;
+}
+
+// ---- render_core forward (nero_amd/shape_step.py::RenderCore.forward) ---------------------------------------------------------------
+int do_forward(nero_stage1* h, Arena& A, int R, int T, int n_in, int n_out, const float* d, const float* variance, const float* lut,
+               const float* poses, float anneal, float* rgb, float* gerr, float* occ_prob, void* stream) {
+    nero_stage1_state& S = h->st;
+    const Modes& M = h->M;
+    hipStream_t hs = (hipStream_t)stream;
+    const int rpi = rpad(n_in), rpo = rpad(n_out);
+    S.inner_idx = A.i32(n_in > 0 ? n_in : 1);
+    S.outer_idx = A.i32(n_out > 0 ? n_out : 1);
+    h->alphaRT = A.f32((size_t)R * T);
+    h->colorRT = A.f32((size_t)R * T * 3);
+    if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_fwd: workspace too small");
+    LAUNCH(nero_compact(S.pts4, S.ray_off, R, T, S.inner_idx, S.outer_idx, stream));
+    if (!A.dry) {
+        (void)hipMemsetAsync(h->alphaRT, 0, (size_t)R * T * 4, hs);
+        (void)hipMemsetAsync(h->colorRT, 0, (size_t)R * T * 12, hs);
+    }
+    if (n_out > 0) {
+        h->pe88 = A.f32((size_t)rpo * 88); h->pev32 = A.f32((size_t)rpo * 32); h->dist_o = A.f32(rpo);
+        if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_fwd: workspace too small");
+        LAUNCH(nero_gather_outer(S.pts4, d, S.outer_idx, T, n_out, h->pe88, h->pev32, h->dist_o, stream));
+        h->f_trunk = Fwd(); h->f_head = Fwd();
+        RC(h->nerf_trunk.forward(A, M, h->pe88, 88, h->pe88, 88, n_out, true, h->f_trunk, stream));
+        RC(h->nerf_head.forward(A, M, h->f_trunk.saves[7], NERO_HID, h->pev32, 32, n_out, true, h->f_head, stream));
+        const size_t mk = A.mark();
+        float* alpha_o = A.f32(rpo);
+        float* color_o = A.f32((size_t)rpo * 3);
+        if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_fwd: workspace too small");
+        LAUNCH(nero_nerf_head_fwd(h->f_trunk.heads[8], h->f_head.heads[2], h->dist_o, n_out, alpha_o, color_o, stream));
+        LAUNCH(nero_scatter_samples(alpha_o, color_o, S.outer_idx, n_out, h->alphaRT, h->colorRT, stream));
+        A.release(mk);
+    }
+    if (n_in > 0) {
+        S.x4 = A.f32((size_t)rpi * 4);
+        h->pe40 = A.f32((size_t)rpi * LD_PE);
+        if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_fwd: workspace too small");
+        LAUNCH(nero_gather_inner(S.pts4, S.inner_idx, n_in, S.x4, h->pe40, stream));
+        // SDFField.forward_normal: value + feature, then the first-order reverse pass seeded by the sdf row of W_8 = the normal
+        h->f_sdf = Fwd();
+        RC(h->sdf_full.forward(A, M, h->pe40, LD_PE, h->pe40, LD_PE, n_in, true, h->f_sdf, stream));
+        float* ones = A.f32((size_t)rpi * 4);
+        if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_fwd: workspace too small");
+        if (!A.dry) hipLaunchKernelGGL(ones_col0_kernel, dim3((rpi + 255) / 256), dim3(256), 0, hs, ones, rpi);
+        const float* hd[MAXL] = {};
+        hd[8] = ones;
+        h->b_normal = Bwd();
+        RC(h->sdf_full.backward(A, M, h->f_sdf, n_in, nullptr, 0, hd, true, true, nullptr, nullptr, 0, false, true, h->b_normal, stream));
+        S.normal = A.f32((size_t)n_in * 3);
+        if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_fwd: workspace too small");
+        LAUNCH(nero_pe_vjp(S.x4, 4, h->b_normal.d_init, h->b_normal.ld_dinit, h->b_normal.d_aux, h->b_normal.ld_daux, N_FREQ, n_in, S.normal, 3, stream));
+        S.sdf4 = h->f_sdf.heads[8];
+        S.feat = h->f_sdf.saves[8];
+        float* alpha_i = A.f32(rpi);
+        S.geo = A.f32((size_t)rpi * 8);
+        h->x8 = A.f32((size_t)rpi * 8);
+        if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_fwd: workspace too small");
+        LAUNCH(nero_sdf_alpha_fwd(S.sdf4, S.normal, S.x4, S.inner_idx, d, T, variance, anneal, n_in, alpha_i, S.geo, gerr, stream));
+        if (!A.dry) hipLaunchKernelGGL(x8_from_x4_kernel, dim3((rpi + 255) / 256), dim3(256), 0, hs, S.x4, h->x8, n_in, rpi);
+        for (int j = 0; j < 3; ++j) {
+            h->f_mat[j] = Fwd();
+            RC(h->mat[j].forward(A, M, S.feat, NERO_HID, h->x8, 8, n_in, true, h->f_mat[j], stream));
+        }
+        h->mat8 = A.f32((size_t)rpi * 8);
+        h->Xo2 = A.f32((size_t)2 * rpi * h->ld_outer);
+        h->Xi = A.f32((size_t)rpi * 128);
+        h->Xo = A.f32((size_t)rpi * 96);
+        if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_fwd: workspace too small");
+        LAUNCH(nero_shade_encode(S.x4, S.geo, h->f_mat[0].heads[3], h->f_mat[1].heads[3], h->f_mat[2].heads[3], n_in, h->mat8, h->Xo2,
+                                 h->Xo2 + (size_t)rpi * h->ld_outer, h->Xi, h->Xo, h->cfg.sphere_direction, stream));
+        h->f_out = Fwd(); h->f_in = Fwd(); h->f_w = Fwd(); h->f_h = Fwd();
+        RC(h->outer_light.forward(A, M, h->Xo2, h->ld_outer, nullptr, 0, rpi + n_in, true, h->f_out, stream));
+        RC(h->inner_light.forward(A, M, h->Xi, 128, nullptr, 0, n_in, true, h->f_in, stream));
+        RC(h->inner_weight.forward(A, M, h->Xo, 96, nullptr, 0, n_in, true, h->f_w, stream));
+        h->Xh = h->hmask = nullptr;
+        if (h->cfg.human_light) {
+            h->Xh = A.f32((size_t)rpi * 24); h->hmask = A.f32(rpi);
+            if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_fwd: workspace too small");
+            LAUNCH(nero_human_encode(S.x4, S.geo, h->mat8, S.inner_idx, T, poses, n_in, h->Xh, h->hmask, stream));
+            RC(h->human_light.forward(A, M, h->Xh, 24, nullptr, 0, n_in, true, h->f_h, stream));
+        }
+        const size_t mk = A.mark();
+        float* color_i = A.f32((size_t)rpi * 3);
+        if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_fwd: workspace too small");
+        const float* Lh = h->f_out.heads[3];
+        LAUNCH(nero_shade_combine_fwd(S.geo, h->mat8, Lh, Lh + (size_t)rpi * 4, h->f_in.heads[3], h->f_w.heads[3], lut, h->cfg.light_exp_max, n_in,
+                                      color_i, occ_prob, h->cfg.human_light ? h->f_h.heads[3] : nullptr, h->hmask, stream));
+        LAUNCH(nero_scatter_samples(alpha_i, color_i, S.inner_idx, n_in, h->alphaRT, h->colorRT, stream));
+        A.release(mk);
+    }
+    S.weights = A.f32((size_t)R * T);
+    if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_fwd: workspace too small");
+    LAUNCH(nero_composite_fwd(h->alphaRT, h->colorRT, R, T, S.weights, rgb, stream));
+    return NERO_OK;
+}
+
+// ---- render_core backward (RenderCore.backward + SDFField.backward) ------------------------------------------------------------------
+int do_backward(nero_stage1* h, Arena& A, const float* d_rgb, const float* d_gerr, const float* d_occ, const nero_stage1_grads* G,
+                float* d_inv_s_sum, void* stream) {
+    nero_stage1_state& S = h->st;
+    const Modes& M = h->M;
+    hipStream_t hs = (hipStream_t)stream;
+    const int R = S.R, T = S.T, n_in = S.n_in, n_out = S.n_out;
+    const int rpi = rpad(n_in), rpo = rpad(n_out);
+    const nero_linear_grad* g = G->lin;
+    float* d_aRT = A.f32((size_t)R * T);
+    float* d_cRT = A.f32((size_t)R * T * 3);
+    const int ws_rows = (n_in + rpi) > n_out ? (n_in + rpi) : n_out;
+    float* partials = A.f32((size_t)nero_dw_workspace_floats(ws_rows > 1 ? ws_rows : 1));
+    if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_bwd: workspace too small");
+    LAUNCH(nero_composite_bwd(h->alphaRT, h->colorRT, S.weights, d_rgb, R, T, d_aRT, d_cRT, stream));
+    if (n_out > 0) {
+        const size_t mk = A.mark();
+        float* d_ao = A.f32(rpo);
+        float* d_co = A.f32((size_t)rpo * 3);
+        float* d_sig4 = A.f32((size_t)rpo * 4);
+        float* d_rgb4 = A.f32((size_t)rpo * 4);
+        if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_bwd: workspace too small");
+        LAUNCH(nero_gather_sample_grads(d_aRT, d_cRT, S.outer_idx, n_out, d_ao, d_co, stream));
+        LAUNCH(nero_nerf_head_bwd(h->f_trunk.heads[8], h->f_head.heads[2], h->dist_o, n_out, d_ao, d_co, d_sig4, d_rgb4, stream));
+        Chain& hc = h->nerf_head;
+        set_dense_grad(hc.e[0], g[L_NERF_FEATURE], 256);
+        set_dense_grad(hc.e[1], g[L_NERF_VIEWS], 283);
+        set_head_grad(hc.e[2], g[L_NERF_RGB], 128);
+        const float* hd[MAXL] = {};
+        hd[2] = d_rgb4;
+        Bwd hb;
+        RC(hc.backward(A, M, h->f_head, n_out, nullptr, 0, hd, true, false, nullptr, nullptr, 0, false, false, hb, stream));
+        RC(hc.weight_grads(A, M, h->f_head, hb, n_out, h->f_trunk.saves[7], NERO_HID, h->pev32, 32, hd, nullptr, nullptr, partials, stream));
+        Chain& tc = h->nerf_trunk;
+        for (int i = 0; i < 8; ++i) set_dense_grad(tc.e[i], g[L_NERF_PTS + i], i == 0 ? 84 : (i == 5 ? 340 : 256));
+        set_head_grad(tc.e[8], g[L_NERF_ALPHA], 256);
+        const float* td[MAXL] = {};
+        td[8] = d_sig4;
+        Bwd tb;
+        RC(tc.backward(A, M, h->f_trunk, n_out, hb.d_init, hb.ld_dinit, td, false, false, nullptr, nullptr, 0, false, false, tb, stream));
+        RC(tc.weight_grads(A, M, h->f_trunk, tb, n_out, h->pe88, 88, h->pe88, 88, td, nullptr, nullptr, partials, stream));
+        A.release(mk);
+    }
+    if (n_in > 0) {
+        float* d_ai = A.f32(rpi);
+        float* d_ci = A.f32((size_t)rpi * 3);
+        float* dLh = A.f32((size_t)2 * rpi * 4);
+        float* dLi = A.f32((size_t)rpi * 4);
+        float* dLo = A.f32((size_t)rpi * 4);
+        float* dmat = A.f32((size_t)rpi * 8);
+        float* d_geo = A.f32((size_t)rpi * 8);
+        float* dLhum = h->cfg.human_light ? A.f32((size_t)rpi * 4) : nullptr;
+        float* d_feat = A.f32((size_t)rpi * NERO_HID);
+        float* dmr = A.f32((size_t)rpi * 4);
+        float* drr = A.f32((size_t)rpi * 4);
+        float* dar = A.f32((size_t)rpi * 4);
+        float* extra = h->cfg.human_light ? A.f32((size_t)rpi * 4) : nullptr;
+        if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_bwd: workspace too small");
+        LAUNCH(nero_gather_sample_grads(d_aRT, d_cRT, S.inner_idx, n_in, d_ai, d_ci, stream));
+        if (!A.dry) (void)hipMemsetAsync(d_geo, 0, (size_t)rpi * 32, hs);
+        const float* Lh = h->f_out.heads[3];
+        LAUNCH(nero_shade_combine_bwd(S.geo, h->mat8, Lh, Lh + (size_t)rpi * 4, h->f_in.heads[3], h->f_w.heads[3], h->lut, h->cfg.light_exp_max, n_in,
+                                      d_ci, d_occ, dLh, dLh + (size_t)rpi * 4, dLi, dLo, dmat, d_geo,
+                                      h->cfg.human_light ? h->f_h.heads[3] : nullptr, h->hmask, dLhum, stream));
+        const int n2 = rpi + n_in;
+        const float* dX_outer = nullptr; int ld_dxo = 0;
+        const float* dX_inner = nullptr;
+        {   // light MLPs: reverse passes for the input gradients + weight gradients; their deltas are released right away, the
+            // input gradients stay until the IDE backward has consumed them
+            const float* hd[MAXL] = {};
+            predictor_grads(h->outer_light, g + L_OUTER, h->ld_outer);
+            float* dxo = A.f32((size_t)rpad(n2) * h->ld_outer);
+            float* dxi = A.f32((size_t)rpi * 128);
+            float* dxh = h->cfg.human_light ? A.f32((size_t)rpi * 24) : nullptr;
+            size_t mk = A.mark();
+            hd[3] = dLh;
+            Bwd ob;
+            RC(h->outer_light.backward(A, M, h->f_out, n2, nullptr, 0, hd, true, false, nullptr, dxo, h->ld_outer, false, false, ob, stream));
+            RC(h->outer_light.weight_grads(A, M, h->f_out, ob, n2, h->Xo2, h->ld_outer, nullptr, 0, hd, nullptr, nullptr, partials, stream));
+            A.release(mk);
+            predictor_grads(h->inner_light, g + L_INNER, 123);
+            hd[3] = dLi;
+            Bwd ib;
+            RC(h->inner_light.backward(A, M, h->f_in, n_in, nullptr, 0, hd, true, false, nullptr, dxi, 128, false, false, ib, stream));
+            RC(h->inner_light.weight_grads(A, M, h->f_in, ib, n_in, h->Xi, 128, nullptr, 0, hd, nullptr, nullptr, partials, stream));
+            A.release(mk);
+            predictor_grads(h->inner_weight, g + L_WEIGHT, 90);
+            hd[3] = dLo;
+            Bwd wb;
+            RC(h->inner_weight.backward(A, M, h->f_w, n_in, nullptr, 0, hd, false, false, nullptr, nullptr, 0, false, false, wb, stream));
+            RC(h->inner_weight.weight_grads(A, M, h->f_w, wb, n_in, h->Xo, 96, nullptr, 0, hd, nullptr, nullptr, partials, stream));
+            A.release(mk);
+            if (h->cfg.human_light) {
+                predictor_grads(h->human_light, g + L_HUMAN, 24);
+                hd[3] = dLhum;
+                Bwd hb;
+                RC(h->human_light.backward(A, M, h->f_h, n_in, nullptr, 0, hd, true, false, nullptr, dxh, 24, false, false, hb, stream));
+                RC(h->human_light.weight_grads(A, M, h->f_h, hb, n_in, h->Xh, 24, nullptr, 0, hd, nullptr, nullptr, partials, stream));
+                A.release(mk);
+                LAUNCH(nero_human_encode_bwd(S.x4, S.geo, h->mat8, S.inner_idx, T, h->poses, n_in, dxh, extra, stream));
+            }
+            dX_outer = dxo; ld_dxo = h->ld_outer; dX_inner = dxi;
+        }
+        LAUNCH(nero_shade_encode_bwd(S.geo, h->mat8, dX_outer, dX_outer + (size_t)rpi * ld_dxo, dX_inner, dmat, n_in, d_geo, dmr, drr, dar, extra,
+                                     S.x4, h->cfg.sphere_direction, stream));
+        const float* dhs[3] = {dmr, drr, dar};
+        const int lidx[3] = {L_METALLIC, L_ROUGHNESS, L_ALBEDO};
+        for (int j = 0; j < 3; ++j) {
+            const size_t mk = A.mark();
+            predictor_grads(h->mat[j], g + lidx[j], 259);
+            const float* hd[MAXL] = {};
+            hd[3] = dhs[j];
+            Bwd mb;
+            RC(h->mat[j].backward(A, M, h->f_mat[j], n_in, nullptr, 0, hd, true, false, nullptr, d_feat, NERO_HID, j > 0, false, mb, stream));
+            RC(h->mat[j].weight_grads(A, M, h->f_mat[j], mb, n_in, S.feat, NERO_HID, h->x8, 8, hd, nullptr, nullptr, partials, stream));
+            A.release(mk);
+        }
+        float* d_sdf4 = A.f32((size_t)rpi * 4);
+        float* d_grad = A.f32((size_t)rpi * 3);
+        float* dinv = A.f32(rpi);
+        if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_bwd: workspace too small");
+        LAUNCH(nero_sdf_alpha_bwd(S.sdf4, S.normal, S.x4, S.inner_idx, h->d, T, h->variance, h->anneal, n_in, d_ai, d_gerr, d_geo, d_sdf4, d_grad,
+                                  dinv, stream));
+        // ---- SDFField.backward: tangent chain, reverse chain with the sigma'' injections, weight gradients with two operand pairs ----
+        Chain& sc = h->sdf_full;
+        for (int l = 0; l < 8; ++l) set_dense_grad(sc.e[l], g[L_SDF + l], l == 0 ? D_PE : 256);
+        {   // lin8: rows 1..256 = the dense part, row 0 = the sdf head, written in place into the [257, 256] gradient
+            nero_linear_grad rows1 = {g[L_SDF + 8].dW ? g[L_SDF + 8].dW + 256 : nullptr, g[L_SDF + 8].db ? g[L_SDF + 8].db + 1 : nullptr};
+            set_dense_grad(sc.e[8], rows1, 256);
+            set_head_grad(sc.e[8], g[L_SDF + 8], 256);
+        }
+        float* ehat = A.f32((size_t)rpi * LD_PE);
+        float* tbuf = A.f32((size_t)2 * 8 * rpi * NERO_HID);
+        if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_bwd: workspace too small");
+        LAUNCH(nero_pe_jvp(S.x4, 4, d_grad, 3, N_FREQ, n_in, ehat, LD_PE, stream));
+        nero_tan_chain tc;
+        memset(&tc, 0, sizeof(tc));
+        tc.init = ehat; tc.ld_init = LD_PE; tc.k_init = LD_PE; tc.aux = ehat; tc.ld_aux = LD_PE; tc.k_aux = LD_PE;
+        tc.n_layers = 8; tc.aux_wide = 0; tc.gemm_mode = M.tan;
+        const float* injs[MAXL] = {};
+        Second second[MAXL];
+        const float* head_extra[MAXL] = {};
+        double macs = 0.0;
+        for (int l = 0; l < 8; ++l) {
+            const Dense& dd = sc.e[l].d;
+            macs += (double)dd.n_out * (dd.k_main + dd.k_aux);
+            nero_tan_layer& tl = tc.layer[l];
+            tl.w_main = sc.e[l].hfm; tl.w_aux = sc.e[l].hfa;
+            tl.a_saved = h->f_sdf.saves[l]; tl.gbar = h->b_normal.deltas[l];
+            tl.adot = tbuf + (size_t)l * rpi * NERO_HID;
+            tl.inj = tbuf + (size_t)(8 + l) * rpi * NERO_HID;
+            tl.k_main = r16(dd.k_main); tl.k_aux = dd.k_aux ? r16(dd.k_aux) : 0; tl.n_tiles = tiles(dd.n_out);
+            injs[l] = tl.inj;
+            second[l].D1 = h->b_normal.deltas[l]; second[l].ldd1 = NERO_HID;
+            second[l].B1m = l == 0 ? ehat : tbuf + (size_t)(l - 1) * rpi * NERO_HID; second[l].ldb1m = l == 0 ? LD_PE : NERO_HID;
+            second[l].B1a = ehat; second[l].ldb1a = LD_PE;
+        }
+        tc.macs_per_row = macs;
+        head_extra[8] = tbuf + (size_t)7 * rpi * NERO_HID;
+        LAUNCH(nero_mlp_tangent(&tc, n_in, stream));
+        const float* sd[MAXL] = {};
+        sd[8] = d_sdf4;
+        Bwd sb;
+        RC(sc.backward(A, M, h->f_sdf, n_in, d_feat, NERO_HID, sd, false, false, injs, nullptr, 0, false, false, sb, stream));
+        RC(sc.weight_grads(A, M, h->f_sdf, sb, n_in, h->pe40, LD_PE, h->pe40, LD_PE, sd, second, head_extra, partials, stream));
+        if (d_inv_s_sum && !A.dry) hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, hs, dinv, n_in, d_inv_s_sum);
+    } else if (d_inv_s_sum && !A.dry) {
+        (void)hipMemsetAsync(d_inv_s_sum, 0, 4, hs);
+    }
+    return nero_check_launch("nero_stage1_render_bwd");
+}
+
+}  // namespace
+
+extern "C" {
+
+int nero_stage1_create(const nero_stage1_cfg* cfg, nero_stage1** out) {
+    if (!cfg || !out) return nero_fail(NERO_ERR_ARG, "nero_stage1_create: bad argument");
+    if (cfg->n_importance % (cfg->up_sample_steps > 0 ? cfg->up_sample_steps : 1) || cfg->up_sample_steps < 1 || cfg->n_samples < 2)
+        return nero_fail(NERO_ERR_ARG, "nero_stage1_create: n_importance must be a multiple of up_sample_steps");
+    if (!is_f16(cfg->gemm_fwd) || cfg->gemm_tan != NERO_GEMM_F16X3 || cfg->gemm_bwd != NERO_GEMM_F16X3 || !is_f16(cfg->gemm_dw))
+        return nero_fail(NERO_ERR_UNSUPPORTED, "nero_stage1_create: the C-level driver packs fp16 two-plane operands only (F16X3 / F16X3P)");
+    nero_stage1* h = new (std::nothrow) nero_stage1();
+    if (!h) return nero_fail(NERO_ERR_ARG, "nero_stage1_create: out of host memory");
+    h->cfg = *cfg;
+    h->M = {cfg->gemm_fwd, cfg->gemm_tan, cfg->gemm_bwd, NERO_GEMM_F16X3};
+    memset(&h->st, 0, sizeof(h->st));
+    nero_stage1_weights zero;
+    memset(&zero, 0, sizeof(zero));
+    build_chains(h, &zero);                      // shapes only: the size queries work before the first pack
+    make_value_chain(h);
+    *out = h;
+    return NERO_OK;
+}
+
+void nero_stage1_destroy(nero_stage1* h) { delete h; }
+
+size_t nero_stage1_pack_bytes(nero_stage1* h) { return h ? pack_floats_total(h) * 4 : 0; }
+
+int nero_stage1_pack(nero_stage1* h, const nero_stage1_weights* w, void* pack_buf, void* stream) {
+    if (!h || !w || !pack_buf) return nero_fail(NERO_ERR_ARG, "nero_stage1_pack: bad argument");
+    build_chains(h, w);
+    const size_t total = pack_floats_total(h);
+    (void)hipMemsetAsync(pack_buf, 0, total * 4, (hipStream_t)stream);
+    std::vector<nero_pack_job> jobs;
+    float* p = static_cast<float*>(pack_buf);
+    for (Chain* c : all_chains(h)) {
+        float* q = p;
+        c->pack(q, jobs);
+        p += (c->pack_floats() + 63) / 64 * 64;
+    }
+    make_value_chain(h);
+    for (size_t i0 = 0; i0 < jobs.size(); i0 += NERO_MAX_PACK_JOBS) {
+        const int n = (int)(jobs.size() - i0 < NERO_MAX_PACK_JOBS ? jobs.size() - i0 : NERO_MAX_PACK_JOBS);
+        RC(nero_pack_batch(jobs.data() + i0, n, stream));
+    }
+    h->packed = true;
+    return NERO_OK;
+}
+
+size_t nero_stage1_workspace_bytes_for(nero_stage1* h, int R, int n_in, int n_out, int with_sampler) {
+    if (!h || R < 0) return 0;
+    const nero_stage1_cfg& c = h->cfg;
+    const int T = c.n_samples + c.n_importance + c.n_bg_samples;
+    nero_stage1 tmp = *h;                         // dry run on a copy: same carve logic, no memory, no launches
+    Arena& A = tmp.A;
+    A = Arena();
+    A.dry = true;
+    size_t peak = 0;
+    if (with_sampler) {
+        float* z = A.f32((size_t)R * T);
+        (void)do_sample(&tmp, A, R, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, z, nullptr);
+        peak = A.peak;
+        A.off = 0;
+    }
+    nero_stage1_state& S = tmp.st;
+    S.R = R; S.T = T; S.n_in = n_in; S.n_out = n_out;
+    S.pts4 = A.f32((size_t)R * T * 4); S.ray_counts = A.i32(R); S.ray_off = A.i32(R); S.counts = A.i32(2);
+    (void)do_forward(&tmp, A, R, T, n_in, n_out, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr);
+    nero_stage1_grads G;
+    memset(&G, 0, sizeof(G));
+    for (int i = 0; i < NERO_S1_LINEARS; ++i) { G.lin[i].dW = reinterpret_cast<float*>(0x1000); G.lin[i].db = reinterpret_cast<float*>(0x1000); }
+    (void)do_backward(&tmp, A, nullptr, nullptr, nullptr, &G, nullptr, nullptr);
+    peak = A.peak > peak ? A.peak : peak;
+    return peak + 4096;
+}
+
+size_t nero_stage1_workspace_bytes(nero_stage1* h, int R) {
+    if (!h) return 0;
+    const nero_stage1_cfg& c = h->cfg;
+    const int T = c.n_samples + c.n_importance + c.n_bg_samples;
+    // worst cases of the data-dependent split: every sample inner (the expensive kind) / every sample outer
+    const size_t a = nero_stage1_workspace_bytes_for(h, R, R * T, 0, 1), b = nero_stage1_workspace_bytes_for(h, R, 0, R * T, 1);
+    return a > b ? a : b;
+}
+
+int nero_stage1_sample(nero_stage1* h, int R, const float* o, const float* d, const float* near, const float* far, const float* variance,
+                       const float* rand1, const float* rand_bg, float* z_vals, void* ws, size_t ws_bytes, void* stream) {
+    if (!h || !h->packed || !o || !d || !near || !far || !variance || !z_vals || !ws)
+        return nero_fail(NERO_ERR_ARG, "nero_stage1_sample: bad argument (pack the weights first)");
+    if (R == 0) return NERO_OK;
+    Arena A;
+    A.base = static_cast<char*>(ws); A.cap = ws_bytes;
+    RC(do_sample(h, A, R, o, d, near, far, variance, rand1, rand_bg, z_vals, stream));
+    return nero_check_launch("nero_stage1_sample");
+}
+
+int nero_stage1_render_fwd(nero_stage1* h, int R, const float* o, const float* d, const float* z_vals, const float* variance,
+                           const float* lut, const float* poses, float anneal, float* rgb, float* gerr, float* occ_prob,
+                           int* n_in_out, int* n_out_out, void* ws, size_t ws_bytes, void* stream) {
+    if (!h || !h->packed || !o || !d || !z_vals || !variance || !lut || !rgb || !gerr || !occ_prob || !ws || R <= 0)
+        return nero_fail(NERO_ERR_ARG, "nero_stage1_render_fwd: bad argument (pack the weights first)");
+    if (h->cfg.human_light && !poses) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_fwd: human_light needs poses [R,3,4]");
+    const nero_stage1_cfg& c = h->cfg;
+    const int T = c.n_samples + c.n_importance + c.n_bg_samples;
+    Arena& A = h->A;
+    A = Arena();
+    A.base = static_cast<char*>(ws); A.cap = ws_bytes;
+    nero_stage1_state& S = h->st;
+    memset(&S, 0, sizeof(S));
+    S.R = R; S.T = T;
+    S.pts4 = A.f32((size_t)R * T * 4); S.ray_counts = A.i32(R); S.ray_off = A.i32(R); S.counts = A.i32(2);
+    if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_fwd: workspace too small");
+    RC(nero_render_prep(o, d, z_vals, R, T, S.pts4, S.ray_counts, S.ray_off, S.counts, stream));
+    int counts[2] = {0, 0};
+    if (hipMemcpyAsync(counts, S.counts, 8, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+        hipStreamSynchronize((hipStream_t)stream) != hipSuccess)                      // the step's one host synchronisation
+        return nero_fail(NERO_ERR_LAUNCH, "nero_stage1_render_fwd: reading the sample counts failed");
+    S.n_in = counts[0]; S.n_out = counts[1];
+    if (n_in_out) *n_in_out = S.n_in;
+    if (n_out_out) *n_out_out = S.n_out;
+    h->o = o; h->d = d; h->variance = variance; h->lut = lut; h->poses = poses; h->anneal = anneal;
+    if (S.n_in == 0) {
+        (void)hipMemsetAsync(gerr, 0, 4, (hipStream_t)stream);
+        (void)hipMemsetAsync(occ_prob, 0, 4, (hipStream_t)stream);
+    }
+    RC(do_forward(h, A, R, T, S.n_in, S.n_out, d, variance, lut, poses, anneal, rgb, gerr, occ_prob, stream));
+    h->step_mark = A.mark();
+    return nero_check_launch("nero_stage1_render_fwd");
+}
+
+int nero_stage1_render_bwd(nero_stage1* h, const float* d_rgb, const float* d_gerr, const float* d_occ, const nero_stage1_grads* grads,
+                           float* d_inv_s_sum, void* stream) {
+    if (!h || !h->A.base || !d_rgb || !grads) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_bwd: bad argument (no forward state)");
+    h->A.release(h->step_mark);
+    return do_backward(h, h->A, d_rgb, d_gerr, d_occ, grads, d_inv_s_sum, stream);
+}
+
+int nero_stage1_get_state(nero_stage1* h, nero_stage1_state* out) {
+    if (!h || !out) return nero_fail(NERO_ERR_ARG, "nero_stage1_get_state: bad argument");
+    *out = h->st;
+    return NERO_OK;
+}
+
+int nero_stage1_sdf_from_pe(nero_stage1* h, const float* pe, int n, float* out4, void* ws, size_t ws_bytes, void* stream) {
+    if (!h || !h->packed || !pe || !out4 || !ws) return nero_fail(NERO_ERR_ARG, "nero_stage1_sdf_from_pe: bad argument");
+    if (n == 0) return NERO_OK;
+    Arena A;
+    A.base = static_cast<char*>(ws); A.cap = ws_bytes;
+    float* res = nullptr;
+    RC(sdf_from_pe(h, A, pe, n, res, stream));
+    (void)hipMemcpyAsync(out4, res, (size_t)rpad(n) * 16, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    return nero_check_launch("nero_stage1_sdf_from_pe");
+}
+
+}  // extern "C"

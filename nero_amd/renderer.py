@@ -295,23 +295,42 @@ class NeROShapeRenderer(nn.Module):
                               self.deviation_network.variance.detach(), rand1, rand_bg, trace)
 
     def render(self, rays_o, rays_d, near, far, human_poses, perturb_overwrite=-1, cos_anneal_ratio=0.0, is_train=True,
-               step=None, rand1=None, rand_bg=None, z_vals=None, occ_keys=None, _kern=None, _grad_views=None):
+               step=None, rand1=None, rand_bg=None, z_vals=None, occ_keys=None, _kern=None, _grad_views=None, _driver=None):
         """same contract as the reference (network/renderer.py:445-463); extra keyword-only style arguments rand1 / rand_bg /
-        z_vals allow tests to inject the random draws or teacher-force the sample positions."""
+        z_vals allow tests to inject the random draws or teacher-force the sample positions.  _driver: a packed
+        nero_amd.stage1.Stage1Driver -- sampling and render_core then run as one C call each (nero_stage1_*)."""
         perturb = self.cfg['perturb']
         if perturb_overwrite >= 0:
             perturb = perturb_overwrite
         names, eff, K = _kern if _kern is not None else self._kernels()
         if z_vals is None:
-            z_vals = self.sample_ray(rays_o, rays_d, near, far, perturb, rand1, rand_bg, K)
+            if _driver is not None:
+                R = rays_o.shape[0]
+                if perturb > 0:
+                    rand1 = torch.rand([R, 1], device=rays_o.device) if rand1 is None else rand1
+                    rand_bg = torch.rand([R, self.cfg['n_bg_samples']], device=rays_o.device) if rand_bg is None else rand_bg
+                else:
+                    rand1 = rand_bg = None
+                with torch.no_grad():
+                    z_vals = _driver.sample(rays_o.contiguous(), rays_d.contiguous(), near.contiguous(), far.contiguous(),
+                                            self.deviation_network.variance.detach(),
+                                            rand1.contiguous() if rand1 is not None else None, rand_bg.contiguous() if rand_bg is not None else None)
+            else:
+                z_vals = self.sample_ray(rays_o, rays_d, near, far, perturb, rand1, rand_bg, K)
         return self.render_core(rays_o, rays_d, z_vals, human_poses, cos_anneal_ratio=cos_anneal_ratio, step=step,
-                                is_train=is_train, _kern=(names, eff, K), occ_keys=occ_keys, _grad_views=_grad_views)
+                                is_train=is_train, _kern=(names, eff, K), occ_keys=occ_keys, _grad_views=_grad_views, _driver=_driver)
 
     def render_core(self, rays_o, rays_d, z_vals, human_poses, cos_anneal_ratio=0.0, step=None, is_train=True, _kern=None,
-                    occ_keys=None, _grad_views=None):
+                    occ_keys=None, _grad_views=None, _driver=None):
         from .shape_step import RenderCore, SDFValue, occ_loss, validation_info
         names, eff, Kpre = _kern if _kern is not None else self._kernels()
         c = self.cfg
+        # the C-level driver covers the training render; the InitSDFRegLoss inputs of the first 1000 steps and the validation extras
+        # go through the Python-sequenced chains
+        use_driver = _driver is not None and is_train and not (step is not None and step < 1000)
+        if not use_driver and Kpre is None:
+            from .shape_step import ShapeKernels, unflatten_effective
+            Kpre = ShapeKernels(unflatten_effective(names, [t.detach() for t in eff]), self.color_network.cfg, eff[0].device).pack()
         meta = {'names': names, 'shapes': [tuple(t.shape) for t in eff], 'shader_cfg': self.color_network.cfg, 'K': Kpre,
                 'anneal': float(cos_anneal_ratio), 'exp_max': float(self.color_network.cfg['light_exp_max']),
                 'freeze_inv_s': c['freeze_inv_s_step'] is not None and step < c['freeze_inv_s_step'], 'grad_views': _grad_views}
@@ -321,8 +340,14 @@ class NeROShapeRenderer(nn.Module):
             if human_poses is None:
                 raise ValueError('shader_config.human_light needs human_poses [R,3,4]')
             poses = human_poses.to(torch.float32).contiguous()
-        rgb, gerr, occ_prob = RenderCore.apply(meta, rays_o.contiguous(), rays_d.contiguous(), z_vals.contiguous(), var,
-                                               self.color_network.FG_LUT, poses, *eff)
+        if use_driver:
+            from .stage1 import RenderCoreC
+            meta['driver'] = _driver
+            rgb, gerr, occ_prob = RenderCoreC.apply(meta, rays_o.contiguous(), rays_d.contiguous(), z_vals.contiguous(), var,
+                                                    self.color_network.FG_LUT, poses, *eff)
+        else:
+            rgb, gerr, occ_prob = RenderCore.apply(meta, rays_o.contiguous(), rays_d.contiguous(), z_vals.contiguous(), var,
+                                                   self.color_network.FG_LUT, poses, *eff)
         n_in = gerr.shape[0]
         outputs = {'ray_rgb': rgb, 'gradient_error': gerr if n_in > 0 else torch.zeros(1, device=rgb.device)}
         inv_s = torch.exp(var * 10.0).clip(1e-6, 1e6)

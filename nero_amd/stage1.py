@@ -1,0 +1,229 @@
+"""ctypes face of the C-level Stage-I step driver (include/nero_hip.h: nero_stage1_*; nero_amd/csrc/stage1_driver.hip).
+
+The driver runs sample_ray, render_core and their backward (network/renderer.py:403-443, 445-463, 550-606) as ONE C call each: the
+launch sequence nero_amd/shape_step.py issues from Python (~200 ctypes calls per step) lives in the library, the workspace is one
+caller-owned buffer.  This module only moves pointers: it owns the workspace / packed-image tensors, fills the weight and gradient
+pointer tables, and wraps fwd / bwd in a torch.autograd.Function so that the loss assembly and the optimiser stay what they were."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from .chain import GEMM_MODE, row_pad
+
+N_LIN = 49
+_fp = C.c_void_p
+
+
+class Linear(C.Structure):
+    _fields_ = [('W', _fp), ('b', _fp)]
+
+
+class Weights(C.Structure):
+    _fields_ = [('lin', Linear * N_LIN)]
+
+
+class Grads(C.Structure):
+    _fields_ = [('lin', Linear * N_LIN)]          # (dW, db): same layout
+
+
+class Cfg(C.Structure):
+    _fields_ = [('n_samples', C.c_int), ('n_importance', C.c_int), ('n_bg_samples', C.c_int), ('up_sample_steps', C.c_int),
+                ('clip_sample_variance', C.c_int), ('human_light', C.c_int), ('sphere_direction', C.c_int), ('light_exp_max', C.c_float),
+                ('gemm_fwd', C.c_int), ('gemm_tan', C.c_int), ('gemm_bwd', C.c_int), ('gemm_dw', C.c_int)]
+
+
+class State(C.Structure):
+    _fields_ = [('R', C.c_int), ('T', C.c_int), ('n_in', C.c_int), ('n_out', C.c_int), ('pts4', _fp), ('ray_counts', _fp), ('ray_off', _fp),
+                ('counts', _fp), ('inner_idx', _fp), ('outer_idx', _fp), ('x4', _fp), ('sdf4', _fp), ('feat', _fp), ('normal', _fp),
+                ('geo', _fp), ('weights', _fp)]
+
+
+_lib = L.lib
+_lib.nero_stage1_pack_bytes.restype = C.c_size_t
+_lib.nero_stage1_workspace_bytes.restype = C.c_size_t
+_lib.nero_stage1_workspace_bytes_for.restype = C.c_size_t
+_lib.nero_stage1_destroy.restype = None
+_lib.nero_stage1_sample.argtypes = [_fp, C.c_int] + [_fp] * 8 + [_fp, C.c_size_t, _fp]
+_lib.nero_stage1_render_fwd.argtypes = [_fp, C.c_int] + [_fp] * 6 + [C.c_float] + [_fp] * 3 + [C.POINTER(C.c_int), C.POINTER(C.c_int), _fp, C.c_size_t, _fp]
+_lib.nero_stage1_render_bwd.argtypes = [_fp, _fp, _fp, _fp, C.POINTER(Grads), _fp, _fp]
+_lib.nero_stage1_sdf_from_pe.argtypes = [_fp, _fp, C.c_int, _fp, _fp, C.c_size_t, _fp]
+_lib.nero_stage1_pack.argtypes = [_fp, C.POINTER(Weights), _fp, _fp]
+_lib.nero_stage1_workspace_bytes.argtypes = [_fp, C.c_int]
+_lib.nero_stage1_workspace_bytes_for.argtypes = [_fp, C.c_int, C.c_int, C.c_int, C.c_int]
+_lib.nero_stage1_pack_bytes.argtypes = [_fp]
+_lib.nero_stage1_get_state.argtypes = [_fp, C.POINTER(State)]
+_lib.nero_stage1_destroy.argtypes = [_fp]
+
+
+def supported():
+    """the C driver packs fp16 two-plane operands only (the default engines)"""
+    return (GEMM_MODE['fwd'] in (L.GEMM_F16X3, L.GEMM_F16X3P) and GEMM_MODE['tan'] == L.GEMM_F16X3 and GEMM_MODE['bwd'] == L.GEMM_F16X3
+            and GEMM_MODE['dw'] in (L.GEMM_F16X3, L.GEMM_F16X3P))
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class Stage1Driver:
+    """one NeROShapeRenderer configuration on the C-level driver.  pack(eff) once per optimisation step, then sample / render."""
+
+    def __init__(self, cfg, shader_cfg, device='cuda'):
+        self.device = device
+        c = Cfg(cfg['n_samples'], cfg['n_importance'], cfg['n_bg_samples'], cfg['up_sample_steps'], int(bool(cfg['clip_sample_variance'])),
+                int(bool(shader_cfg.get('human_light', False))), int(bool(shader_cfg.get('sphere_direction', False))),
+                float(shader_cfg.get('light_exp_max', 0.0)), GEMM_MODE['fwd'], GEMM_MODE['tan'], GEMM_MODE['bwd'], GEMM_MODE['dw'])
+        self.cfg = c
+        self.T = cfg['n_samples'] + cfg['n_importance'] + cfg['n_bg_samples']
+        h = _fp()
+        L.check(_lib.nero_stage1_create(C.byref(c), C.byref(h)))
+        self.h = h
+        self.n_lin = 49 if c.human_light else 45
+        self._pack_buf = torch.empty(_lib.nero_stage1_pack_bytes(h), dtype=torch.uint8, device=device)
+        self._ws = None
+        self._scratch = None
+        self._w = Weights()
+        self._keep = None
+
+    def __del__(self):
+        h = getattr(self, 'h', None)
+        if h:
+            _lib.nero_stage1_destroy(h)
+            self.h = None
+
+    # ---- memory ---------------------------------------------------------------------------------------------------------------
+    def workspace_bytes(self, R, n_in=None, n_out=None):
+        if n_in is None:
+            return _lib.nero_stage1_workspace_bytes(self.h, R)
+        return _lib.nero_stage1_workspace_bytes_for(self.h, R, n_in, n_out, 1)
+
+    def workspace(self, R):
+        """the step workspace for R rays: the worst case over the data-dependent inner / outer split, allocated once"""
+        need = self.workspace_bytes(R)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _view(self, ptr, shape, dtype=torch.float32):
+        """tensor view of a state pointer inside the workspace"""
+        off = ptr - self._ws.data_ptr()
+        n = 1
+        for s in shape:
+            n *= s
+        return self._ws[off:off + n * 4].view(dtype).view(*shape)
+
+    # ---- weights ----------------------------------------------------------------------------------------------------------------
+    def pack(self, eff):
+        """eff: the effective weights in nero_amd.shape_step.flatten_effective order [W0, b0, W1, b1, ...] (contiguous fp32)"""
+        assert len(eff) == 2 * self.n_lin, (len(eff), self.n_lin)
+        for i in range(self.n_lin):
+            W, b = eff[2 * i], eff[2 * i + 1]
+            assert W.is_contiguous() and b.is_contiguous() and W.dtype == torch.float32
+            self._w.lin[i].W, self._w.lin[i].b = W.data_ptr(), b.data_ptr()
+        self._keep = list(eff)
+        L.check(_lib.nero_stage1_pack(self.h, C.byref(self._w), self._pack_buf.data_ptr(), L.stream_ptr()))
+        return self
+
+    # ---- the path -----------------------------------------------------------------------------------------------------------------
+    def sample(self, o, d, near, far, variance, rand1=None, rand_bg=None):
+        R = o.shape[0]
+        z = torch.empty((R, self.T), dtype=torch.float32, device=o.device)
+        ws = self.workspace(R)
+        L.check(_lib.nero_stage1_sample(self.h, R, _p(o), _p(d), _p(near), _p(far), _p(variance), _p(rand1), _p(rand_bg), _p(z),
+                                        ws.data_ptr(), ws.numel(), L.stream_ptr()))
+        return z
+
+    def sdf_from_pe(self, pe, n):
+        """SDFField.sdf_from_pe on the driver's packed SDF chain (its own scratch: the step state in the workspace stays intact)"""
+        rp = row_pad(n)
+        need = rp * (256 + 4) * 4 + 4096
+        if self._scratch is None or self._scratch.numel() < need:
+            self._scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
+        out = torch.empty((rp, 4), dtype=torch.float32, device=pe.device)
+        L.check(_lib.nero_stage1_sdf_from_pe(self.h, _p(pe), n, _p(out), self._scratch.data_ptr(), self._scratch.numel(), L.stream_ptr()))
+        return out
+
+    def state(self):
+        s = State()
+        L.check(_lib.nero_stage1_get_state(self.h, C.byref(s)))
+        return s
+
+
+class _SdfAdapter:
+    def __init__(self, drv):
+        self._drv = drv
+
+    def sdf_from_pe(self, pe, n):
+        return self._drv.sdf_from_pe(pe, n)
+
+
+class _KAdapter:
+    """what nero_amd.shape_step.occ_loss / secondary_occlusion need of a ShapeKernels object"""
+
+    def __init__(self, drv):
+        self.sdf = _SdfAdapter(drv)
+
+
+class RenderCoreC(torch.autograd.Function):
+    """render_core through nero_stage1_render_fwd / _bwd.  Same contract as nero_amd.shape_step.RenderCore: inputs (meta, o, d, z_vals,
+    variance, FG_LUT, poses, *effective weights), outputs ray_rgb [R,3], gradient_error [N_in], occ_prob [N_in] (unclamped)."""
+
+    @staticmethod
+    def forward(ctx, meta, o, d, z_vals, variance, lut, poses, *params):
+        drv = meta['driver']
+        R, T = z_vals.shape
+        dev = o.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        rgb = torch.empty((R, 3), **f32)
+        gerr, occ = torch.empty(R * T, **f32), torch.empty(R * T, **f32)
+        ws = drv.workspace(R)
+        n_in, n_out = C.c_int(0), C.c_int(0)
+        L.check(_lib.nero_stage1_render_fwd(drv.h, R, _p(o), _p(d), _p(z_vals), _p(variance), _p(lut), _p(poses), float(meta['anneal']), _p(rgb),
+                                            _p(gerr), _p(occ), C.byref(n_in), C.byref(n_out), ws.data_ptr(), ws.numel(), L.stream_ptr()))
+        n_in, n_out = n_in.value, n_out.value
+        st = drv.state()
+        rpi = row_pad(n_in)
+        S = {'K': _KAdapter(drv), 'R': R, 'T': T, 'n_in': n_in, 'n_out': n_out, 'o': o, 'd': d, 'variance': variance, 'lut': lut,
+             'pts4': drv._view(st.pts4, (R * T, 4)), 'weights': drv._view(st.weights, (R, T)),
+             'inner_idx': drv._view(st.inner_idx, (max(n_in, 1),), torch.int32)}
+        if n_in > 0:
+            S.update(x4=drv._view(st.x4, (rpi, 4)), geo=drv._view(st.geo, (rpi, 8)),
+                     sctx={'sdf4': drv._view(st.sdf4, (rpi, 4)), 'normal': drv._view(st.normal, (n_in, 3)), 'feat': drv._view(st.feat, (rpi, 256))})
+        ctx.drv, ctx.meta_small, ctx.n_in = drv, {k: meta[k] for k in ('names', 'shapes', 'freeze_inv_s', 'grad_views')}, n_in
+        ctx.variance = variance
+        ctx.keep = (o, d, z_vals, lut, poses)
+        meta['_state'] = S
+        return rgb, gerr[:n_in], occ[:n_in]
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_gerr, d_occ):
+        drv, meta, n_in = ctx.drv, ctx.meta_small, ctx.n_in
+        dev = d_rgb.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        gv = meta['grad_views'] or {}
+        G = Grads()
+        fresh = {}
+        for i in range(drv.n_lin):
+            nw, nb = meta['names'][2 * i], meta['names'][2 * i + 1]
+            if nw in gv:
+                dW, db = gv[nw], gv[nb]
+            else:                                  # (zeros: a network without samples this step -- n_in or n_out == 0 -- is not written)
+                dW, db = torch.zeros(meta['shapes'][2 * i], **f32), torch.zeros(meta['shapes'][2 * i + 1], **f32)
+                fresh[nw], fresh[nb] = dW, db
+            assert dW.is_contiguous() and db.is_contiguous()
+            G.lin[i].W, G.lin[i].b = dW.data_ptr(), db.data_ptr()
+        dsum = torch.zeros(1, **f32)
+        d_gerr_c = d_gerr.contiguous() if (d_gerr is not None and n_in > 0) else None
+        d_occ_c = d_occ.contiguous() if (d_occ is not None and n_in > 0) else None
+        L.check(_lib.nero_stage1_render_bwd(drv.h, _p(d_rgb.contiguous()), _p(d_gerr_c), _p(d_occ_c), C.byref(G), _p(dsum), L.stream_ptr()))
+        d_var = None
+        if n_in > 0 and not meta['freeze_inv_s']:
+            v = ctx.variance.detach()
+            inv_s = torch.exp(v * 10.0)
+            live = ((inv_s >= 1e-6) & (inv_s <= 1e6)).to(torch.float32)
+            d_var = dsum[0] * 10.0 * inv_s * live
+        grads = [fresh.get(name) for name in meta['names']]       # None: written in place into the (pre-zeroed) flat bucket
+        ctx.keep = None
+        return (None, None, None, None, d_var, None, None) + tuple(grads)

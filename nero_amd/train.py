@@ -217,9 +217,16 @@ class ShapeTrainStep:
         # torch path (torch._weight_norm autograd + torch.optim.Adam), which is also what the drop-in renderer runs under an
         # external optimiser
         self.fused = (device != 'cpu') if fused is None else fused
+        self.drv = None
         if self.fused:
             self.fopt = FusedShapeOptimizer(self.net, device)
             self.bucket = self.fopt.bucket
+            # the C-level step driver (nero_stage1_*: sampler, render forward and backward as one C call each); NERO_STEP_DRIVER=py
+            # keeps the Python-sequenced launches of nero_amd/shape_step.py (identical kernels, identical results)
+            import os
+            from . import stage1
+            if os.environ.get('NERO_STEP_DRIVER', 'c') != 'py' and stage1.supported():
+                self.drv = stage1.Stage1Driver(self.net.cfg, self.net.color_network.cfg, device)
         else:
             self.bucket = GradBucket(self.params)                # p.grad = views of one flat buffer, for the whole run
             self.opt = torch.optim.Adam(self.params, lr=1e-3, fused=(device != 'cpu'))
@@ -255,7 +262,8 @@ class ShapeTrainStep:
         are paid at construction, not inside the first training step"""
         o, d = self.pool['o'][:64], self.pool['d'][:64]
         near, far = self.net.near_far_from_sphere(o, d)
-        out = self.net.render(o, d, near, far, self.pool['hp'][:64] if self.human else None, -1, 0.5, is_train=True, step=25000, _kern=self.fopt.kernels() if self.fused else None)
+        out = self.net.render(o, d, near, far, self.pool['hp'][:64] if self.human else None, -1, 0.5, is_train=True, step=25000,
+                              **{k: v for k, v in self._render_args(25000).items() if k != '_grad_views'})
         shape_training_loss(self.net, out, self.pool['gt'][:64], 25000).backward()
         self.bucket.zero()
         torch.cuda.synchronize()
@@ -278,6 +286,17 @@ class ShapeTrainStep:
         self._hp = self.pool['hp'][s] if self.human else None
         return self.pool['o'][s], self.pool['d'][s], self.pool['gt'][s]
 
+    def _render_args(self, step):
+        """fused trainer: the effective-weight leaves, their packed operand images (C driver: nero_stage1_pack; otherwise the Python
+        chains) and the bucket views the weight-gradient GEMMs write into"""
+        if not self.fused:
+            return {}
+        if self.drv is not None and step >= 1000:
+            self.fopt.reparametrise()
+            self.drv.pack([t.detach() for t in self.fopt.eff])
+            return dict(_kern=(self.fopt.names, self.fopt.eff, None), _grad_views=self.fopt.grad_views, _driver=self.drv)
+        return dict(_kern=self.fopt.kernels(), _grad_views=self.fopt.grad_views)
+
     def forward_only(self, step):
         """one inference render of the next ray batch: the reference's is_train=False path (sampler + render forward + the
         validation extras of compute_validation_info), no loss / backward / optimiser; `step` only sets the cosine anneal"""
@@ -296,8 +315,7 @@ class ShapeTrainStep:
         self.bucket.zero()
         o, d, gt = self._batch()
         near, far = net.near_far_from_sphere(o, d)
-        out = net.render(o, d, near, far, self._hp, -1, net.get_anneal_val(step), is_train=True, step=step,
-                         _kern=self.fopt.kernels() if self.fused else None, _grad_views=self.fopt.grad_views if self.fused else None)
+        out = net.render(o, d, near, far, self._hp, -1, net.get_anneal_val(step), is_train=True, step=step, **self._render_args(step))
         # data parallel: the eikonal mean runs over each rank's own inner samples and the occlusion loss over its own candidate
         # set -> weight both by their global counts so that N ranks reproduce the single-process means
         w_eik, w_occ = global_count_weights([out['_state']['n_in'], out.get('_occ_count', 0)], self.world, self.device)
