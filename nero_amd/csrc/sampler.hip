@@ -55,26 +55,82 @@ __global__ void background_z_kernel(const float* __restrict__ far, const float* 
     z[(size_t)r * ldz + col0 + j] = far[r] / zo + 1.0f / (float)nb;
 }
 
-// PE-6 rows of the points o + d * z[r, col0 + j], row = r*ncols + j, zero padded to 40 columns / row_pad rows
-__global__ void ray_points_pe_kernel(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ z, int ldz,
-                                     int col0, int ncols, int R, int n_pad, float* __restrict__ pe) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= n_pad) return;
-    float* out = pe + (size_t)row * 40;
-    if (row >= R * ncols) { for (int c = 0; c < 40; ++c) out[c] = 0.f; return; }
-    const int r = row / ncols, j = row - r * ncols;
-    const float t = z[(size_t)r * ldz + col0 + j];
-    float p[3];
-    for (int c = 0; c < 3; ++c) { p[c] = o[r * 3 + c] + d[r * 3 + c] * t; out[c] = p[c]; }
-    float f = 1.f;
-    int q = 3;
-    for (int k = 0; k < 6; ++k) {
-        for (int c = 0; c < 3; ++c) out[q + c] = sinf(p[c] * f);
-        for (int c = 0; c < 3; ++c) out[q + 3 + c] = cosf(p[c] * f);
-        q += 6;
-        f *= 2.f;
+
+// column c of a positional-encoding row [x, sin(2^j x), cos(2^j x)]_{j < n_freq} (0 beyond the encoding): the encoders below give one
+// thread FOUR consecutive columns, so that a wave writes 1 KiB of consecutive floats (a thread per ROW wrote 160 / 352-byte records
+// with a 160 / 352-byte lane stride: every store instruction touched 64 cache lines)
+template <int DIM>
+__device__ __forceinline__ float pe_col(const float (&p)[DIM], int n_freq, int c) {
+    if (c < DIM) return p[c];
+    const int q = c - DIM, j = q / (2 * DIM), t = q - j * (2 * DIM);
+    if (j >= n_freq) return 0.f;
+    const float f = (float)(1 << j);
+    return t < DIM ? sinf(p[t] * f) : cosf(p[t - DIM] * f);
+}
+template <int DIM>
+__device__ __forceinline__ float4 pe_quad(const float (&p)[DIM], int n_freq, int c4) {
+    return make_float4(pe_col<DIM>(p, n_freq, c4), pe_col<DIM>(p, n_freq, c4 + 1), pe_col<DIM>(p, n_freq, c4 + 2), pe_col<DIM>(p, n_freq, c4 + 3));
+}
+
+// PE-6 rows of the points o + d * z[r, col0 + j]: thread <-> (row, column quad), 10 quads per 40-float row
+__global__ void ray_points_pe_q_kernel(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ z, int ldz,
+                                       int col0, int ncols, int R, int n_pad, float* __restrict__ pe) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_pad * 10) return;
+    const int row = idx / 10, q = idx - row * 10;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < R * ncols) {
+        const int r = row / ncols, j = row - r * ncols;
+        const float t = z[(size_t)r * ldz + col0 + j];
+        const float p[3] = {o[r * 3] + d[r * 3] * t, o[r * 3 + 1] + d[r * 3 + 1] * t, o[r * 3 + 2] + d[r * 3 + 2] * t};
+        v = pe_quad<3>(p, 6, 4 * q);
     }
-    out[39] = 0.f;
+    reinterpret_cast<float4*>(pe)[(size_t)row * 10 + q] = v;
+}
+
+// inner rows: unit 0 writes x4, units 0..9 the PE-6 quads
+__global__ void gather_inner_q_kernel(const float* __restrict__ pts4, const int* __restrict__ idx, int n, int n_pad,
+                                      float* __restrict__ x4, float* __restrict__ pe) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_pad * 10) return;
+    const int k = t / 10, q = t - k * 10;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f), x = v;
+    if (k < n) {
+        x = reinterpret_cast<const float4*>(pts4)[idx[k]];
+        const float p[3] = {x.x, x.y, x.z};
+        v = pe_quad<3>(p, 6, 4 * q);
+    }
+    if (q == 0) reinterpret_cast<float4*>(x4)[k] = x;
+    reinterpret_cast<float4*>(pe)[(size_t)k * 10 + q] = v;
+}
+
+// outer rows: units 0..21 = PE-10 of [p/|p|, 1/|p|] (84 + 4 pad), units 22..29 = PE-4 of the view direction (27 + 5 pad); unit 0 also dist
+__global__ void gather_outer_q_kernel(const float* __restrict__ pts4, const float* __restrict__ d, const int* __restrict__ idx, int T,
+                                      int n, int n_pad, float* __restrict__ pe88, float* __restrict__ pev32, float* __restrict__ dist) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_pad * 30) return;
+    const int k = t / 30, q = t - k * 30;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    float dd = 0.f;
+    if (k < n) {
+        const int s = idx[k];
+        const float4 x = reinterpret_cast<const float4*>(pts4)[s];
+        dd = x.w;
+        if (q < 22) {
+            const float nrm = sqrtf(x.x * x.x + x.y * x.y + x.z * x.z);
+            const float p[4] = {x.x / nrm, x.y / nrm, x.z / nrm, 1.0f / nrm};
+            v = pe_quad<4>(p, 10, 4 * q);
+        } else {
+            const int r = s / T;
+            const float dxr = d[r * 3], dyr = d[r * 3 + 1], dzr = d[r * 3 + 2];
+            const float dn = fmaxf(sqrtf(dxr * dxr + dyr * dyr + dzr * dzr), 1e-12f);
+            const float w[3] = {-(dxr / dn), -(dyr / dn), -(dzr / dn)};
+            v = pe_quad<3>(w, 4, 4 * (q - 22));
+        }
+    }
+    if (q < 22) reinterpret_cast<float4*>(pe88)[(size_t)k * 22 + q] = v;
+    else reinterpret_cast<float4*>(pev32)[(size_t)k * 8 + (q - 22)] = v;
+    if (q == 0) dist[k] = dd;
 }
 
 // Per-ray working arrays live in LDS as columns of a [index][64 lanes] table (lane-consecutive -> conflict-free): the scans
@@ -209,6 +265,249 @@ __global__ void merge_sorted_kernel(float* __restrict__ z, int ldz, int n, float
     }
 }
 
+
+// ---- wave-per-ray versions (one wavefront owns one ray; lane i holds samples i and i + 64) ------------------------------------------
+// The per-sample arithmetic runs lane-parallel with coalesced row loads; the two scans whose ORDER is part of the contract (the
+// float64 running transmittance / cumulative sums, rounded to float32 where stored) stay sequential: a wave-uniform loop reads the
+// i-th element with v_readlane and every lane advances the same running value, lane i keeping what the serial loop would have stored
+// -- the identical operation sequence, hence the identical bits (tests: teacher-forced `inds` / merge permutation torch.equal).
+// searchsorted and the merge ranks are ballot population counts.  4096 rays = 4096 waves (16 per CU) instead of 64.
+__device__ __forceinline__ float lane_elem(float e0, float e1, int i) {            // element i of the (i, i + 64) lane layout, wave-uniform
+    return i < 64 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e0), i)) : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e1), i - 64));
+}
+__device__ __forceinline__ int popc64(unsigned long long m) { return __popcll(m); }
+
+// cdf / inverse-CDF part shared by upsample and sample_pdf: w (n-1 weights in the lane layout) -> m samples.  zs / cs: wave-private
+// LDS rows of 128 floats holding z and (on return) the cdf.
+__device__ __forceinline__ void wave_sample_pdf(const float* zs, float* cs, float w0, float w1, int n, int m, int lane, float& out, int& ind) {
+    double acc = 0.0;
+    for (int i = 0; i < n - 1; ++i) acc += (double)(lane_elem(w0, w1, i) + 1e-5f);
+    const float norm = (float)acc;
+    const float p0 = (w0 + 1e-5f) / norm, p1 = (w1 + 1e-5f) / norm;
+    acc = 0.0;
+    float c0 = 0.f, c1 = 0.f;                          // cdf[lane], cdf[lane + 64]; cdf[0] = 0
+    for (int i = 0; i < n - 1; ++i) {
+        acc += (double)lane_elem(p0, p1, i);
+        const float v = (float)acc;
+        if (i + 1 == lane) c0 = v;
+        if (i + 1 == lane + 64) c1 = v;
+    }
+    cs[lane] = c0;
+    cs[lane + 64] = c1;
+    __builtin_amdgcn_wave_barrier();
+    const float u0 = 0.5f / (float)m, u1 = 1.0f - 0.5f / (float)m;
+    int idx = 0;
+    for (int j = 0; j < m; ++j) {                      // searchsorted(right=True) on the non-decreasing cdf = #{k < n: cdf[k] <= u}
+        const float u = linspace_f32(u0, u1, m, j);
+        const int cnt = popc64(__ballot(lane < n && c0 <= u)) + popc64(__ballot(lane + 64 < n && c1 <= u));
+        if (j == lane) idx = cnt;
+    }
+    out = 0.f;
+    ind = idx;
+    if (lane < m) {
+        const float u = linspace_f32(u0, u1, m, lane);
+        const int below = idx - 1 > 0 ? idx - 1 : 0;
+        const int above = idx < n - 1 ? idx : n - 1;
+        float denom = cs[above] - cs[below];
+        if (denom < 1e-5f) denom = 1.f;
+        const float t = (u - cs[below]) / denom;
+        out = zs[below] + t * (zs[above] - zs[below]);
+    }
+}
+
+// 4 rays per 256-thread workgroup
+__global__ __launch_bounds__(256) void upsample_wave_kernel(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ z, int ldz,
+                                                            const float* __restrict__ sdf, int lds, int n, const float* __restrict__ variance,
+                                                            float inv_s_cap, int m, int R, float* __restrict__ z_new, float* __restrict__ w_out,
+                                                            int* __restrict__ inds_out) {
+    __shared__ float sm[4][4][128];                    // per wave: z, sdf, radius / cdf, cos
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wv;
+    if (r >= R) return;
+    float* zs = sm[wv][0]; float* ss = sm[wv][1]; float* rs = sm[wv][2]; float* cs = sm[wv][3];
+    const float inv_s = variance ? fminf(expf(variance[0] * 10.0f), inv_s_cap) : inv_s_cap;
+    const float ox = o[r * 3], oy = o[r * 3 + 1], oz = o[r * 3 + 2];
+    const float dx = d[r * 3], dy = d[r * 3 + 1], dz_ = d[r * 3 + 2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int i = lane + 64 * e;
+        float zv = 0.f, sv = 0.f, rad = 0.f;
+        if (i < n) {
+            zv = z[(size_t)r * ldz + i];
+            sv = sdf[(size_t)r * lds + i];
+            const float px = ox + dx * zv, py = oy + dy * zv, pz = oz + dz_ * zv;
+            rad = sqrtf(px * px + py * py + pz * pz);
+        }
+        zs[i] = zv; ss[i] = sv; rs[i] = rad;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float alpha[2] = {0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {                      // section i: samples i, i + 1
+        const int i = lane + 64 * e;
+        float cosv = 0.f;
+        if (i < n - 1) cosv = (ss[i + 1] - ss[i]) / ((zs[i + 1] - zs[i]) + 1e-5f);
+        cs[i] = cosv;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int i = lane + 64 * e;
+        if (i < n - 1) {
+            const float inside = (rs[i] < 1.0f || rs[i + 1] < 1.0f) ? 1.f : 0.f;
+            const float dist = zs[i + 1] - zs[i];
+            const float mid = (ss[i] + ss[i + 1]) * 0.5f;
+            const float prev_cos = i > 0 ? cs[i - 1] : 0.f;
+            float c = fminf(prev_cos, cs[i]);
+            c = fminf(fmaxf(c, -1e3f), 0.f) * inside;
+            const float pe_ = mid - c * dist * 0.5f, ne_ = mid + c * dist * 0.5f;
+            const float pc = sigmoid_f(pe_ * inv_s), nc = sigmoid_f(ne_ * inv_s);
+            alpha[e] = (pc - nc + 1e-5f) / (pc + 1e-5f);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();                   // (cs is reused for the cdf below)
+    // w_i = alpha_i * (float)T_i,  T_{i+1} = T_i * (double)(1 - alpha_i + 1e-7f): the serial order, every lane in step
+    double Tr = 1.0;
+    float w0 = 0.f, w1 = 0.f;
+    for (int i = 0; i < n - 1; ++i) {
+        const float a = lane_elem(alpha[0], alpha[1], i);
+        const float w = a * (float)Tr;
+        if (i == lane) w0 = w;
+        if (i == lane + 64) w1 = w;
+        Tr *= (double)(1.0f - a + 1e-7f);
+    }
+    if (w_out) {
+        if (lane < n - 1) w_out[(size_t)r * (n - 1) + lane] = w0;
+        if (lane + 64 < n - 1) w_out[(size_t)r * (n - 1) + lane + 64] = w1;
+    }
+    float out; int ind;
+    wave_sample_pdf(zs, cs, w0, w1, n, m, lane, out, ind);
+    if (lane < m) {
+        z_new[(size_t)r * m + lane] = out;
+        if (inds_out) inds_out[(size_t)r * m + lane] = ind;
+    }
+}
+
+__global__ __launch_bounds__(256) void sample_pdf_wave_kernel(const float* __restrict__ bins, int ldb, const float* __restrict__ w, int ldw, int n, int m,
+                                                              int R, float* __restrict__ out, int* __restrict__ inds_out) {
+    __shared__ float sm[4][2][128];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wv;
+    if (r >= R) return;
+    float* zs = sm[wv][0]; float* cs = sm[wv][1];
+    zs[lane] = lane < n ? bins[(size_t)r * ldb + lane] : 0.f;
+    zs[lane + 64] = lane + 64 < n ? bins[(size_t)r * ldb + lane + 64] : 0.f;
+    const float w0 = lane < n - 1 ? w[(size_t)r * ldw + lane] : 0.f, w1 = lane + 64 < n - 1 ? w[(size_t)r * ldw + lane + 64] : 0.f;
+    __builtin_amdgcn_wave_barrier();
+    float v; int ind;
+    wave_sample_pdf(zs, cs, w0, w1, n, m, lane, v, ind);
+    if (lane < m) {
+        out[(size_t)r * m + lane] = v;
+        if (inds_out) inds_out[(size_t)r * m + lane] = ind;
+    }
+}
+
+// stable merge by ranks: an old element i lands at i + #{j: z_new[j] < z_i}, a new element j at j + #{i: z_i <= z_new[j]} (ties: old
+// first) -- for two sorted lists exactly the permutation the serial two-pointer merge produces
+__global__ __launch_bounds__(256) void merge_sorted_wave_kernel(float* __restrict__ z, int ldz, int n, float* __restrict__ sdf, int lds,
+                                                                const float* __restrict__ z_new, int m, const float* __restrict__ sdf_new, int ldsn,
+                                                                int R, int* __restrict__ index_out) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wv;
+    if (r >= R) return;
+    const bool hs = sdf != nullptr && sdf_new != nullptr;
+    float zo[2], so[2] = {0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int i = lane + 64 * e;
+        zo[e] = i < n ? z[(size_t)r * ldz + i] : 0.f;
+        if (hs && i < n) so[e] = sdf[(size_t)r * lds + i];
+    }
+    const float zn = lane < m ? z_new[(size_t)r * m + lane] : 0.f;
+    const float sn = (hs && lane < m) ? sdf_new[((size_t)r * m + lane) * ldsn] : 0.f;
+    int rank_old[2] = {0, 0}, rank_new = 0;
+    for (int j = 0; j < m; ++j) {
+        const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(zn), j));
+        rank_old[0] += v < zo[0] ? 1 : 0;
+        rank_old[1] += v < zo[1] ? 1 : 0;
+        const int cnt = popc64(__ballot(lane < n && zo[0] <= v)) + popc64(__ballot(lane + 64 < n && zo[1] <= v));
+        if (j == lane) rank_new = cnt;
+    }
+    // every load of this ray's row happened above; the stores below go to the same row (one wave owns it)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int i = lane + 64 * e;
+        if (i < n) {
+            const int k = i + rank_old[e];
+            z[(size_t)r * ldz + k] = zo[e];
+            if (hs) sdf[(size_t)r * lds + k] = so[e];
+            if (index_out) index_out[(size_t)r * (n + m) + k] = i;
+        }
+    }
+    if (lane < m) {
+        const int k = lane + rank_new;
+        z[(size_t)r * ldz + k] = zn;
+        if (hs) sdf[(size_t)r * lds + k] = sn;
+        if (index_out) index_out[(size_t)r * (n + m) + k] = n + lane;
+    }
+}
+
+// render_prep, one wave per ray, lane i <-> samples i, i + 64, i + 128 (T <= 192): coalesced z loads / float4 stores, the inner
+// count is a ballot population count
+__global__ __launch_bounds__(256) void render_prep_wave_kernel(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ z, int R,
+                                                               int T, float* __restrict__ pts4, int* __restrict__ ray_counts) {
+    __shared__ float sm[4][192];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wv;
+    if (r >= R) return;
+    float* zs = sm[wv];
+    for (int i = lane; i < T; i += 64) zs[i] = z[(size_t)r * T + i];
+    __builtin_amdgcn_wave_barrier();
+    const float ox = o[r * 3], oy = o[r * 3 + 1], oz = o[r * 3 + 2];
+    const float dx = d[r * 3], dy = d[r * 3 + 1], dz_ = d[r * 3 + 2];
+    int cnt = 0;
+    for (int i0 = 0; i0 < T; i0 += 64) {
+        const int i = i0 + lane;
+        bool in = false;
+        if (i < T) {
+            const int k = i < T - 1 ? i : T - 2;       // the last section repeats the previous length (renderer.py:554-558)
+            const float dist = zs[k + 1] - zs[k];
+            const float mid = zs[i] + dist * 0.5f;
+            const float x = ox + dx * mid, y = oy + dy * mid, zz = oz + dz_ * mid;
+            reinterpret_cast<float4*>(pts4)[(size_t)r * T + i] = make_float4(x, y, zz, dist);
+            in = sqrtf(x * x + y * y + zz * zz) <= 1.0f;
+        }
+        cnt += popc64(__ballot(in));
+    }
+    if (lane == 0) ray_counts[r] = cnt;
+}
+
+// ordered compaction with wave ballots: position inside the ray = population count of the lower lanes
+__global__ __launch_bounds__(256) void compact_wave_kernel(const float* __restrict__ pts4, const int* __restrict__ ray_off_in, int R, int T,
+                                                           int* __restrict__ inner_idx, int* __restrict__ outer_idx) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wv;
+    if (r >= R) return;
+    int ki = ray_off_in[r];
+    int ko = r * T - ki;
+    const unsigned long long lower = (1ull << lane) - 1ull;
+    for (int i0 = 0; i0 < T; i0 += 64) {
+        const int i = i0 + lane;
+        bool valid = i < T, in = false;
+        if (valid) {
+            const float4 v = reinterpret_cast<const float4*>(pts4)[(size_t)r * T + i];
+            in = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z) <= 1.0f;
+        }
+        const unsigned long long mi = __ballot(valid && in), mo = __ballot(valid && !in);
+        if (valid) {
+            if (in) inner_idx[ki + popc64(mi & lower)] = r * T + i;
+            else outer_idx[ko + popc64(mo & lower)] = r * T + i;
+        }
+        ki += popc64(mi);
+        ko += popc64(mo);
+    }
+}
+
 // copy a strided column (head output [rows,4] col 0) into the per-ray sdf table
 __global__ void scatter_sdf_kernel(const float* __restrict__ src, int lds_src, int R, int n, float* __restrict__ sdf, int lds) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -266,82 +565,6 @@ __global__ void ray_scan_kernel(const int* __restrict__ ray_counts, int R, int T
     if (tid == 1023) { counts[0] = part[1023]; counts[1] = R * T - part[1023]; }
 }
 
-// inner_idx / outer_idx: flat sample ids in (ray, sample) order; slot[s] = position of sample s in its list
-__global__ void compact_kernel(const float* __restrict__ pts4, const int* __restrict__ ray_off_in, int R, int T,
-                               int* __restrict__ inner_idx, int* __restrict__ outer_idx) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R) return;
-    int ki = ray_off_in[r];
-    int ko = r * T - ki;
-    for (int i = 0; i < T; ++i) {
-        const float4 v = reinterpret_cast<const float4*>(pts4)[(size_t)r * T + i];
-        const bool in = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z) <= 1.0f;
-        if (in) inner_idx[ki++] = r * T + i; else outer_idx[ko++] = r * T + i;
-    }
-}
-
-// inner rows: x4[k] = pts4[inner_idx[k]], pe[k] = PE-6(xyz)
-__global__ void gather_inner_kernel(const float* __restrict__ pts4, const int* __restrict__ idx, int n, int n_pad,
-                                    float* __restrict__ x4, float* __restrict__ pe) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_pad) return;
-    float* out = pe + (size_t)k * 40;
-    if (k >= n) { for (int c = 0; c < 40; ++c) out[c] = 0.f; reinterpret_cast<float4*>(x4)[k] = make_float4(0, 0, 0, 0); return; }
-    const float4 v = reinterpret_cast<const float4*>(pts4)[idx[k]];
-    reinterpret_cast<float4*>(x4)[k] = v;
-    const float p[3] = {v.x, v.y, v.z};
-    for (int c = 0; c < 3; ++c) out[c] = p[c];
-    float f = 1.f;
-    int q = 3;
-    for (int j = 0; j < 6; ++j) {
-        for (int c = 0; c < 3; ++c) out[q + c] = sinf(p[c] * f);
-        for (int c = 0; c < 3; ++c) out[q + 3 + c] = cosf(p[c] * f);
-        q += 6;
-        f *= 2.f;
-    }
-    out[39] = 0.f;
-}
-
-// outer rows (NeRF++ inverted-sphere parametrisation, renderer.py:514-517): pe88 = PE-10([p/|p|, 1/|p|]) (84 + 4 pad),
-// pev32 = PE-4(view = -normalize(d)) (27 + 5 pad), dist[k]
-__global__ void gather_outer_kernel(const float* __restrict__ pts4, const float* __restrict__ d, const int* __restrict__ idx, int T,
-                                    int n, int n_pad, float* __restrict__ pe88, float* __restrict__ pev32, float* __restrict__ dist) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_pad) return;
-    float* o1 = pe88 + (size_t)k * 88;
-    float* o2 = pev32 + (size_t)k * 32;
-    if (k >= n) { for (int c = 0; c < 88; ++c) o1[c] = 0.f; for (int c = 0; c < 32; ++c) o2[c] = 0.f; dist[k] = 0.f; return; }
-    const int s = idx[k];
-    const float4 v = reinterpret_cast<const float4*>(pts4)[s];
-    const int r = s / T;
-    const float nrm = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
-    const float p[4] = {v.x / nrm, v.y / nrm, v.z / nrm, 1.0f / nrm};
-    for (int c = 0; c < 4; ++c) o1[c] = p[c];
-    float f = 1.f;
-    int q = 4;
-    for (int j = 0; j < 10; ++j) {
-        for (int c = 0; c < 4; ++c) o1[q + c] = sinf(p[c] * f);
-        for (int c = 0; c < 4; ++c) o1[q + 4 + c] = cosf(p[c] * f);
-        q += 8;
-        f *= 2.f;
-    }
-    for (; q < 88; ++q) o1[q] = 0.f;
-    const float dxr = d[r * 3], dyr = d[r * 3 + 1], dzr = d[r * 3 + 2];
-    const float dn = fmaxf(sqrtf(dxr * dxr + dyr * dyr + dzr * dzr), 1e-12f);
-    const float w[3] = {-(dxr / dn), -(dyr / dn), -(dzr / dn)};
-    for (int c = 0; c < 3; ++c) o2[c] = w[c];
-    f = 1.f;
-    q = 3;
-    for (int j = 0; j < 4; ++j) {
-        for (int c = 0; c < 3; ++c) o2[q + c] = sinf(w[c] * f);
-        for (int c = 0; c < 3; ++c) o2[q + 3 + c] = cosf(w[c] * f);
-        q += 6;
-        f *= 2.f;
-    }
-    for (; q < 32; ++q) o2[q] = 0.f;
-    dist[k] = v.w;
-}
-
 }  // namespace
 
 #define GRID1D(n) dim3(((n) + 255) / 256), dim3(256), 0, (hipStream_t)stream
@@ -366,7 +589,7 @@ int nero_ray_points_pe(const float* o, const float* d, const float* z, int ldz, 
     if (!o || !d || !z || !pe) return nero_fail(NERO_ERR_ARG, "nero_ray_points_pe: bad argument");
     const int n_pad = NERO_ROW_PAD(R * ncols);
     if (n_pad == 0) return NERO_OK;
-    hipLaunchKernelGGL(ray_points_pe_kernel, GRID1D(n_pad), o, d, z, ldz, col0, ncols, R, n_pad, pe);
+    hipLaunchKernelGGL(ray_points_pe_q_kernel, GRID1D(n_pad * 10), o, d, z, ldz, col0, ncols, R, n_pad, pe);
     return nero_check_launch("nero_ray_points_pe");
 }
 
@@ -374,6 +597,10 @@ int nero_upsample(const float* o, const float* d, const float* z, int ldz, const
                   const float* variance, float inv_s_cap, int m, int R, float* z_new, float* w_out, int* inds_out, void* stream) {
     if (!o || !d || !z || !sdf || !z_new || n > MAXS || n < 2 || m > 32) return nero_fail(NERO_ERR_ARG, "nero_upsample: bad argument");
     if (R == 0) return NERO_OK;
+    if (n <= 128 && m <= 64) {                          // one wave per ray (lane i <-> samples i, i + 64)
+        hipLaunchKernelGGL(upsample_wave_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, o, d, z, ldz, sdf, lds, n, variance, inv_s_cap, m, R, z_new, w_out, inds_out);
+        return nero_check_launch("nero_upsample");
+    }
     NERO_ONCE(hipFuncSetAttribute((const void*)upsample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ray_tables_bytes(3, MAXS)));
     hipLaunchKernelGGL(upsample_kernel, dim3((R + 63) / 64), dim3(64), ray_tables_bytes(3, n), (hipStream_t)stream, o, d, z, ldz, sdf, lds, n, variance, inv_s_cap, m, R, z_new, w_out, inds_out);
     return nero_check_launch("nero_upsample");
@@ -382,6 +609,10 @@ int nero_upsample(const float* o, const float* d, const float* z, int ldz, const
 int nero_sample_pdf(const float* bins, int ldb, const float* w, int ldw, int n, int m, int R, float* out, int* inds_out, void* stream) {
     if (!bins || !w || !out || n > MAXS || n < 2 || m > 32) return nero_fail(NERO_ERR_ARG, "nero_sample_pdf: bad argument");
     if (R == 0) return NERO_OK;
+    if (n <= 128 && m <= 64) {
+        hipLaunchKernelGGL(sample_pdf_wave_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, bins, ldb, w, ldw, n, m, R, out, inds_out);
+        return nero_check_launch("nero_sample_pdf");
+    }
     NERO_ONCE(hipFuncSetAttribute((const void*)sample_pdf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ray_tables_bytes(3, MAXS)));
     hipLaunchKernelGGL(sample_pdf_kernel, dim3((R + 63) / 64), dim3(64), ray_tables_bytes(3, n), (hipStream_t)stream, bins, ldb, w, ldw, n, m, R, out, inds_out);
     return nero_check_launch("nero_sample_pdf");
@@ -391,6 +622,10 @@ int nero_merge_sorted(float* z, int ldz, int n, float* sdf, int lds, const float
                       int R, int* index_out, void* stream) {
     if (!z || !z_new || n + m > MAXS) return nero_fail(NERO_ERR_ARG, "nero_merge_sorted: bad argument");
     if (R == 0) return NERO_OK;
+    if (n <= 128 && m <= 64) {
+        hipLaunchKernelGGL(merge_sorted_wave_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, z, ldz, n, sdf, lds, z_new, m, sdf_new, ldsn, R, index_out);
+        return nero_check_launch("nero_merge_sorted");
+    }
     NERO_ONCE(hipFuncSetAttribute((const void*)merge_sorted_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ray_tables_bytes(2, MAXS)));
     hipLaunchKernelGGL(merge_sorted_kernel, dim3((R + 63) / 64), dim3(64), ray_tables_bytes(2, n), (hipStream_t)stream, z, ldz, n, sdf, lds, z_new, m, sdf_new, ldsn, R, index_out);
     return nero_check_launch("nero_merge_sorted");
@@ -407,7 +642,8 @@ int nero_render_prep(const float* o, const float* d, const float* z, int R, int 
                      int* counts, void* stream) {
     if (!o || !d || !z || !pts4 || !ray_counts || !ray_off || !counts) return nero_fail(NERO_ERR_ARG, "nero_render_prep: bad argument");
     if (R == 0) return NERO_OK;
-    hipLaunchKernelGGL(render_prep_kernel, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, o, d, z, R, T, pts4, ray_counts);
+    if (T >= 2 && T <= 192) hipLaunchKernelGGL(render_prep_wave_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, o, d, z, R, T, pts4, ray_counts);
+    else hipLaunchKernelGGL(render_prep_kernel, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, o, d, z, R, T, pts4, ray_counts);
     hipLaunchKernelGGL(ray_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ray_counts, R, T, ray_off, counts);
     return nero_check_launch("nero_render_prep");
 }
@@ -415,7 +651,7 @@ int nero_render_prep(const float* o, const float* d, const float* z, int R, int 
 int nero_compact(const float* pts4, const int* ray_off, int R, int T, int* inner_idx, int* outer_idx, void* stream) {
     if (!pts4 || !ray_off || !inner_idx || !outer_idx) return nero_fail(NERO_ERR_ARG, "nero_compact: bad argument");
     if (R == 0) return NERO_OK;
-    hipLaunchKernelGGL(compact_kernel, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, pts4, ray_off, R, T, inner_idx, outer_idx);
+    hipLaunchKernelGGL(compact_wave_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, pts4, ray_off, R, T, inner_idx, outer_idx);
     return nero_check_launch("nero_compact");
 }
 
@@ -423,7 +659,7 @@ int nero_gather_inner(const float* pts4, const int* idx, int n, float* x4, float
     const int n_pad = NERO_ROW_PAD(n);
     if (n_pad == 0) return NERO_OK;
     if (!pts4 || !idx || !x4 || !pe) return nero_fail(NERO_ERR_ARG, "nero_gather_inner: bad argument");
-    hipLaunchKernelGGL(gather_inner_kernel, GRID1D(n_pad), pts4, idx, n, n_pad, x4, pe);
+    hipLaunchKernelGGL(gather_inner_q_kernel, GRID1D(n_pad * 10), pts4, idx, n, n_pad, x4, pe);
     return nero_check_launch("nero_gather_inner");
 }
 
@@ -431,7 +667,7 @@ int nero_gather_outer(const float* pts4, const float* d, const int* idx, int T, 
     const int n_pad = NERO_ROW_PAD(n);
     if (n_pad == 0) return NERO_OK;
     if (!pts4 || !d || !idx || !pe88 || !pev32 || !dist) return nero_fail(NERO_ERR_ARG, "nero_gather_outer: bad argument");
-    hipLaunchKernelGGL(gather_outer_kernel, GRID1D(n_pad), pts4, d, idx, T, n, n_pad, pe88, pev32, dist);
+    hipLaunchKernelGGL(gather_outer_q_kernel, GRID1D(n_pad * 30), pts4, d, idx, T, n, n_pad, pe88, pev32, dist);
     return nero_check_launch("nero_gather_outer");
 }
 

@@ -722,6 +722,96 @@ __global__ void composite_bwd_kernel(const float* __restrict__ alphaRT, const fl
     }
 }
 
+// ---- compositing, one wave per ray (lane i <-> samples i, i + 64, ...): coalesced row loads / stores; the transmittance is a wave
+// prefix product and the backward's tail sum a wave suffix sum (fp32; the compositing outputs are floating point, so a different
+// association is within their 1e-4 tolerance -- the bit-exact contracts are the sampler's integer outputs, not these) --------------
+__device__ __forceinline__ float wave_incl_prod(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(v, o); if (lane >= o) v *= t; }
+    return v;
+}
+__device__ __forceinline__ float wave_incl_sum(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(v, o); if (lane >= o) v += t; }
+    return v;
+}
+__device__ __forceinline__ float wave_suffix_sum(float v, int lane) {       // inclusive: sum over lanes >= this one
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_down(v, o); if (lane + o < 64) v += t; }
+    return v;
+}
+__device__ __forceinline__ float wave_sum_all(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void composite_fwd_wave_kernel(const float* __restrict__ alphaRT, const float* __restrict__ colorRT, int R, int T,
+                                                                 float* __restrict__ weights, float* __restrict__ rgb) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    float carry = 1.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    for (int i0 = 0; i0 < T; i0 += 64) {
+        const int i = i0 + lane;
+        const bool ok = i < T;
+        const size_t s = (size_t)r * T + (ok ? i : 0);
+        const float a = ok ? alphaRT[s] : 0.f;
+        const float f = ok ? (1.0f - a + 1e-7f) : 1.f;
+        const float incl = wave_incl_prod(f, lane);
+        const float up = __shfl_up(incl, 1);
+        const float Tr = carry * (lane ? up : 1.f);    // exclusive product
+        const float w = a * Tr;
+        if (ok) {
+            weights[s] = w;
+            c0 += colorRT[s * 3] * w; c1 += colorRT[s * 3 + 1] * w; c2 += colorRT[s * 3 + 2] * w;
+        }
+        carry *= __shfl(incl, 63);
+    }
+    c0 = wave_sum_all(c0); c1 = wave_sum_all(c1); c2 = wave_sum_all(c2);
+    if (lane == 0) { rgb[r * 3] = c0; rgb[r * 3 + 1] = c1; rgb[r * 3 + 2] = c2; }
+}
+
+__global__ __launch_bounds__(256) void composite_bwd_wave_kernel(const float* __restrict__ alphaRT, const float* __restrict__ colorRT,
+                                                                 const float* __restrict__ weights, const float* __restrict__ d_rgb, int R, int T,
+                                                                 float* __restrict__ d_alphaRT, float* __restrict__ d_colorRT) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float g0 = d_rgb[r * 3], g1 = d_rgb[r * 3 + 1], g2 = d_rgb[r * 3 + 2];
+    // S_i = sum_{j > i} dw_j w_j as a SUFFIX scan (not total - prefix: behind an opaque sample the tail terms are ~1e-7 of the total and
+    // are divided by 1 - alpha ~ 1e-7 again)
+    float a[3], dw[3], q[3];
+    int nch = 0;
+    for (int i0 = 0; i0 < T && nch < 3; i0 += 64, ++nch) {
+        const int i = i0 + lane;
+        const bool ok = i < T;
+        const size_t s = (size_t)r * T + (ok ? i : 0);
+        a[nch] = ok ? alphaRT[s] : 0.f;
+        const float w = ok ? weights[s] : 0.f;
+        dw[nch] = ok ? (colorRT[s * 3] * g0 + colorRT[s * 3 + 1] * g1 + colorRT[s * 3 + 2] * g2) : 0.f;
+        q[nch] = dw[nch] * w;
+        if (ok) { d_colorRT[s * 3] = w * g0; d_colorRT[s * 3 + 1] = w * g1; d_colorRT[s * 3 + 2] = w * g2; }
+    }
+    float S[3];
+    float tail = 0.f;
+    for (int c = nch - 1; c >= 0; --c) {
+        const float incl = wave_suffix_sum(q[c], lane);
+        const float dn = __shfl_down(incl, 1);
+        S[c] = tail + (lane < 63 ? dn : 0.f);          // exclusive suffix + everything in the later chunks
+        tail += __shfl(incl, 0);
+    }
+    float carry_T = 1.f;
+    for (int c = 0; c < nch; ++c) {
+        const int i = c * 64 + lane;
+        const bool ok = i < T;
+        const float f = ok ? (1.0f - a[c] + 1e-7f) : 1.f;
+        const float ip = wave_incl_prod(f, lane);
+        const float up = __shfl_up(ip, 1);
+        const float Tr = carry_T * (lane ? up : 1.f);
+        if (ok) d_alphaRT[(size_t)r * T + i] = -S[c] / f + dw[c] * Tr;
+        carry_T *= __shfl(ip, 63);
+    }
+}
+
 __global__ void gather_sample_grads_kernel(const float* __restrict__ d_alphaRT, const float* __restrict__ d_colorRT,
                                            const int* __restrict__ idx, int n, float* __restrict__ d_a, float* __restrict__ d_c) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -837,14 +927,16 @@ int nero_scatter_samples(const float* a, const float* c, const int* idx, int n, 
 
 int nero_composite_fwd(const float* alphaRT, const float* colorRT, int R, int T, float* weights, float* rgb, void* stream) {
     if (R == 0) return NERO_OK;
-    hipLaunchKernelGGL(composite_fwd_kernel, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, alphaRT, colorRT, R, T, weights, rgb);
+    if (T <= 192) hipLaunchKernelGGL(composite_fwd_wave_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, alphaRT, colorRT, R, T, weights, rgb);
+    else hipLaunchKernelGGL(composite_fwd_kernel, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, alphaRT, colorRT, R, T, weights, rgb);
     return nero_check_launch("nero_composite_fwd");
 }
 
 int nero_composite_bwd(const float* alphaRT, const float* colorRT, const float* weights, const float* d_rgb, int R, int T,
                        float* d_alphaRT, float* d_colorRT, void* stream) {
     if (R == 0) return NERO_OK;
-    hipLaunchKernelGGL(composite_bwd_kernel, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, alphaRT, colorRT, weights, d_rgb, R, T, d_alphaRT, d_colorRT);
+    if (T <= 192) hipLaunchKernelGGL(composite_bwd_wave_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, alphaRT, colorRT, weights, d_rgb, R, T, d_alphaRT, d_colorRT);
+    else hipLaunchKernelGGL(composite_bwd_kernel, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, alphaRT, colorRT, weights, d_rgb, R, T, d_alphaRT, d_colorRT);
     return nero_check_launch("nero_composite_bwd");
 }
 

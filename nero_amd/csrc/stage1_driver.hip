@@ -67,18 +67,18 @@ __global__ void copy2d_kernel(const float* __restrict__ src, int lds, float* __r
     const int r = idx / cols, c = idx - r * cols;
     dst[(size_t)r * ldd + c] = src[(size_t)r * lds + c];
 }
-// out[0] = sum_{i<n} v[i] in the order torch's sum would not promise either: one workgroup, fp32 tree over a grid-stride pass
-__global__ __launch_bounds__(1024) void sum_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
-    __shared__ float part[1024];
+// out[b] = sum of block b's grid-stride share of v[0..n) (deterministic two-stage reduction: 128 partials, then one block over them)
+__global__ __launch_bounds__(256) void sum_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
+    __shared__ float part[256];
     float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += 1024) s += v[i];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) s += v[i];
     part[threadIdx.x] = s;
     __syncthreads();
-    for (int o = 512; o >= 1; o >>= 1) {
+    for (int o = 128; o >= 1; o >>= 1) {
         if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = part[0];
+    if (threadIdx.x == 0) out[blockIdx.x] = part[0];
 }
 
 #define RC(expr) do { const int rc_ = (expr); if (rc_ != NERO_OK) return rc_; } while (0)
@@ -759,7 +759,12 @@ int do_backward(nero_stage1* h, Arena& A, const float* d_rgb, const float* d_ger
         Bwd sb;
         RC(sc.backward(A, M, h->f_sdf, n_in, d_feat, NERO_HID, sd, false, false, injs, nullptr, 0, false, false, sb, stream));
         RC(sc.weight_grads(A, M, h->f_sdf, sb, n_in, h->pe40, LD_PE, h->pe40, LD_PE, sd, second, head_extra, partials, stream));
-        if (d_inv_s_sum && !A.dry) hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, hs, dinv, n_in, d_inv_s_sum);
+        float* part = A.f32(128);
+        if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_bwd: workspace too small");
+        if (d_inv_s_sum && !A.dry) {
+            hipLaunchKernelGGL(sum_kernel, dim3(128), dim3(256), 0, hs, dinv, n_in, part);
+            hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, hs, part, 128, d_inv_s_sum);
+        }
     } else if (d_inv_s_sum && !A.dry) {
         (void)hipMemsetAsync(d_inv_s_sum, 0, 4, hs);
     }
