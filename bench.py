@@ -366,6 +366,8 @@ def main():
     ap.add_argument('--train-step', type=int, default=25000, help='training-schedule step the batch is evaluated at')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--quick', action='store_true', help='headline + roofline only (development runs)')
+    ap.add_argument('--dp-configs', action='store_true', help='N > 1 only: after the headline, also run BASELINE configs[2] (bear Stage I, 8192 rays '
+                    'per global batch) and configs[4] (bear Stage II, 16384 points x 256+256) as data-parallel jobs of this world size')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -552,7 +554,9 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
 
-    if world > 1 and not args.quick:
+    if world > 1 and args.dp_configs and not args.quick:
+        # (opt-in: an exception on ONE rank inside an extra collective leg would leave the others waiting in an all-reduce, and the
+        # headline line of a scaling run must not depend on that)
         # BASELINE configs[2] and configs[4] as data-parallel jobs of THIS world size (every rank takes part; rank 0 reports):
         # bear Stage I with 8192 rays per global batch, bear Stage II with 16384 surface points x (256+256) directions
         def c2():

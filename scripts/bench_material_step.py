@@ -10,11 +10,12 @@ Dd = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 Ds = int(sys.argv[3]) if len(sys.argv) > 3 else 128
 sub = int(sys.argv[4]) if len(sys.argv) > 4 else 7
 kind = sys.argv[5] if len(sys.argv) > 5 else 'bell'
+only = sys.argv[6] if len(sys.argv) > 6 else 'both'          # 'fused' / 'torch' / 'both'
 v, f = icosphere(sub, 0.5, 0.2)
 f = np.ascontiguousarray(f[:, ::-1])
 scfg = dict(diffuse_sample_num=Dd, specular_sample_num=Ds, human_lights=(kind == 'bear'),
             outer_light_version='sphere_direction' if kind == 'bear' else 'direction')
-for fused in (False, True):
+for fused in {'both': (False, True), 'fused': (True,), 'torch': (False,)}[only]:
     ts = MaterialTrainStep({'shader_cfg': scfg, 'database_name': 'real/bear' if kind == 'bear' else 'syn/bell'}, (v, f), points_per_rank=P_,
                            pool_points=4 * P_, device='cuda:0', fused=fused)
     for i in range(4):
