@@ -62,6 +62,10 @@ def supported():
             and GEMM_MODE['dw'] in (L.GEMM_F16X3, L.GEMM_F16X3P))
 
 
+def current_modes():
+    return (GEMM_MODE['fwd'], GEMM_MODE['tan'], GEMM_MODE['bwd'], GEMM_MODE['dw'])
+
+
 def _p(t):
     return None if t is None else t.data_ptr()
 
@@ -75,6 +79,7 @@ class Stage1Driver:
                 int(bool(shader_cfg.get('human_light', False))), int(bool(shader_cfg.get('sphere_direction', False))),
                 float(shader_cfg.get('light_exp_max', 0.0)), GEMM_MODE['fwd'], GEMM_MODE['tan'], GEMM_MODE['bwd'], GEMM_MODE['dw'])
         self.cfg = c
+        self.modes = current_modes()                  # the engines this handle packs for (nero_amd.chain.GEMM_MODE at construction)
         self.T = cfg['n_samples'] + cfg['n_importance'] + cfg['n_bg_samples']
         h = _fp()
         L.check(_lib.nero_stage1_create(C.byref(c), C.byref(h)))
@@ -85,6 +90,10 @@ class Stage1Driver:
         self._scratch = None
         self._w = Weights()
         self._keep = None
+
+    def matches_current_modes(self):
+        """False after nero_amd.chain.set_gemm_mode() selected other engines: the caller then takes the Python-sequenced path"""
+        return self.modes == current_modes()
 
     def __del__(self):
         h = getattr(self, 'h', None)

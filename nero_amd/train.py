@@ -291,7 +291,7 @@ class ShapeTrainStep:
         chains) and the bucket views the weight-gradient GEMMs write into"""
         if not self.fused:
             return {}
-        if self.drv is not None and step >= 1000:
+        if self.drv is not None and step >= 1000 and self.drv.matches_current_modes():
             self.fopt.reparametrise()
             self.drv.pack([t.detach() for t in self.fopt.eff])
             return dict(_kern=(self.fopt.names, self.fopt.eff, None), _grad_views=self.fopt.grad_views, _driver=self.drv)

@@ -8,7 +8,7 @@ which = sys.argv[2] if len(sys.argv) > 2 else 'stage1'
 head = sys.argv[3] if len(sys.argv) > 3 else 'unknown'
 sha = sys.argv[4] if len(sys.argv) > 4 else 'unknown'
 suffix = '' if which == 'stage1' else '_stage2'
-marker = 'composite_bwd_kernel' if which == 'stage1' else 'mc_combine_bwd_kernel'       # one launch per training step
+marker = 'composite_bwd' if which == 'stage1' else 'mc_combine_bwd'       # one launch per training step
 first = 'wn_forward_kernel'
 def base(k):
     return k.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0].split('<')[0].strip()
