@@ -327,6 +327,11 @@ int nero_bvh_destroy(void* handle);
  *      slot[r] >= 0 -> miss row index, < 0 -> hit row index -(slot)-1. ---------------------------------------------------- */
 int nero_mc_point_setup(const float* pts, const float* view, const float* normals, const float* mat5, const float* rand_d,
                         const float* rand_s, int P, float* pt, void* stream);
+/* hit / miss split of the n = P*D secondary rays by `depth < 10` (NeROMaterialRenderer.trace, network/renderer.py:727; get_lights,
+ * network/field.py:861-877): miss_idx / hit_idx = the ray ids in ascending order (what torch.nonzero yields), slot as above, counts int32 [2]
+ * = (n_miss, n_hit) on the device; miss_idx / hit_idx need room for n entries each; tmp: nero_mc_split_tmp_ints(n) int32 of scratch. */
+int nero_mc_split_tmp_ints(int n);
+int nero_mc_split(const float* depth, int n, int* slot, int* miss_idx, int* hit_idx, int* counts, int* tmp, void* stream);
 int nero_mc_dirs(const float* pt, const float* tab_d, const float* tab_s, int P, int Dd, int Ds, float* dirs, float* origins, void* stream);
 /* sphere != 0 ('sphere_direction'): X [rows,144] = [IDE(w,0) | IDE(unit-sphere exit point,0)], else X [rows,72] */
 int nero_mc_encode_miss(const float* dirs, const int* idx, const float* pt, int D, int sphere, int n, float* X, void* stream);
@@ -410,6 +415,50 @@ int nero_stage1_render_bwd(nero_stage1* h, const float* d_rgb, const float* d_ge
 int nero_stage1_get_state(nero_stage1* h, nero_stage1_state* out);
 /* no-grad SDF values of PE-6 rows [rows_pad(n),40] -> out4 [rows_pad(n),4], column 0 = sdf (sampler / occlusion march / mesh grid) */
 int nero_stage1_sdf_from_pe(nero_stage1* h, const float* pe, int n, float* out4, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- C-level driver of the Stage-II (material) shading step (nero_mc_shade_fwd / _bwd) -----------------------------------
+ * predict_materials (network/field.py:915-922) and MCShadingNetwork.shade_mixed / get_lights (:856-880, 950-1012) with their backward, in
+ * the call order of NeROMaterialRenderer.shade (network/renderer.py:810-813):
+ *     nero_stage2_predict_fwd   raw material heads of the points (and of the regulariser's perturbed copies)
+ *     nero_stage2_rays          tangent frames, cosine-weighted + GGX directions, secondary-ray origins p + 1e-5 w
+ *     <the caller traces `origins, dirs` -- nero_bvh_trace, where the reference calls raytracing/raytracer.py:49 from field.py:860>
+ *     nero_stage2_shade_fwd     hit / miss split, light MLPs on the compacted rows, microfacet estimator
+ *     nero_stage2_shade_bwd, nero_stage2_predict_bwd   (autograd order: the shading first)
+ * One caller-owned workspace for the whole step (opened by predict_fwd), one buffer for the packed operand images; the only host
+ * synchronisation is the read-back of the (miss, hit) counts in shade_fwd.  fp16 two-plane engines only. */
+#define NERO_S2_LINEARS 32
+/* Linear index: feats_network.module0 / module1 Linears = 0..7, then the predictors' four each: metallic 8.., roughness 12.., albedo 16..,
+ * outer_light 20.., inner_light 24.., human_light 28.. (shader_cfg.human_lights only) */
+typedef struct { nero_linear lin[NERO_S2_LINEARS]; } nero_stage2_weights;
+typedef struct { nero_linear_grad lin[NERO_S2_LINEARS]; } nero_stage2_grads;
+typedef struct {
+    int diffuse_sample_num, specular_sample_num, human_lights, sphere_direction;    /* MCShadingNetwork.default_cfg, network/field.py:695-712 */
+    int geometry_type;                                                              /* 0 'schlick', 1 'ggx_smith'                             */
+    float light_exp_max, inner_light_exp_max;
+    int gemm_fwd, gemm_bwd, gemm_dw;
+} nero_stage2_cfg;
+typedef struct nero_stage2 nero_stage2;
+int nero_stage2_create(const nero_stage2_cfg* cfg, nero_stage2** out);
+void nero_stage2_destroy(nero_stage2* h);
+size_t nero_stage2_pack_bytes(nero_stage2* h);
+int nero_stage2_pack(nero_stage2* h, const nero_stage2_weights* w, void* pack_buf, void* stream);
+/* n_pred rows through predict_materials (P points + their P perturbed copies when the smoothness regulariser is on), P shaded points:
+ * worst case over the hit / miss split of the P * (Dd + Ds) light rays */
+size_t nero_stage2_workspace_bytes(nero_stage2* h, int n_pred, int P);
+/* x [n,3] -> raw5 [n,5] = pre-sigmoid (metallic, roughness, albedo rgb) */
+int nero_stage2_predict_fwd(nero_stage2* h, const float* x, int n, float* raw5, void* ws, size_t ws_bytes, void* stream);
+/* mat5 [P,5] = (metallic, roughness, albedo) after their activations; rand_d / rand_s [P] azimuth offsets or NULL; tab_d [Dd,2] / tab_s [Ds,2]
+ * the fixed (azimuth, elevation) tables (field.py:741-749) -> origins, dirs [P*(Dd+Ds),3] (caller-owned, kept alive until shade_bwd) */
+int nero_stage2_rays(nero_stage2* h, int P, const float* pts, const float* view, const float* normals, const float* mat5, const float* rand_d,
+                     const float* rand_s, const float* tab_d, const float* tab_s, float* origins, float* dirs, void* stream);
+/* pos / face_normals [P*D,3], depth [P*D] of the traced rays (depth >= 10 = miss; kept alive until shade_bwd); poses [P,3,4] or NULL
+ * -> rgb (linear), mean diffuse light, mean weighted specular light, specular part: [P,3] each */
+int nero_stage2_shade_fwd(nero_stage2* h, const float* pos, const float* face_normals, const float* depth, const float* poses, float* rgb,
+                          float* dl, float* sl, float* sp, int* n_miss_out, int* n_hit_out, void* stream);
+/* -> dW / db of the light MLPs (entries 20.. of `grads`), d_mat5 [P,5] */
+int nero_stage2_shade_bwd(nero_stage2* h, const float* d_rgb, const float* d_dl, const nero_stage2_grads* grads, float* d_mat5, void* stream);
+/* d_raw5 [n,5] -> dW / db of the feats network and the material predictors (entries 0..19) */
+int nero_stage2_predict_bwd(nero_stage2* h, const float* d_raw5, const nero_stage2_grads* grads, void* stream);
 
 #ifdef __cplusplus
 }

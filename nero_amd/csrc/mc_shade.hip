@@ -580,6 +580,70 @@ __global__ __launch_bounds__(64) void mc_dir_bwd_kernel(const float* __restrict_
     if (lane == 0) d_mat5[(size_t)p * 5 + 1] += dr;
 }
 
+
+// ---- hit / miss split of the P*D secondary rays (get_lights, network/field.py:861-877: lights[miss] = outer(...), lights[hit] =
+// inner(...)): ordered compaction of the ray ids by `depth < 10` into two index lists + the slot map the combine kernels read.
+// Three launches: per-block ballot counts, one-block exclusive scan, ordered scatter (position = block base + wave base + population
+// count of the lower lanes) -- the order torch.nonzero produces, without its host round trip for the sizes of intermediate tensors.
+constexpr int SPLIT_BLOCK = 1024;                  // rays per 256-thread block (4 per thread, wave-contiguous chunks of 64)
+__global__ __launch_bounds__(256) void mc_split_count_kernel(const float* __restrict__ depth, int n, int* __restrict__ block_hits) {
+    __shared__ int wsum[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = blockIdx.x * SPLIT_BLOCK + (wv * 4 + k) * 64 + lane;
+        c += __popcll(__ballot(i < n && depth[i] < 10.0f));
+    }
+    if (lane == 0) wsum[wv] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_hits[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+// exclusive scan of block_hits[0..nb) in place (one 1024-thread block, any nb); counts = (n_miss, n_hit)
+__global__ __launch_bounds__(1024) void mc_split_scan_kernel(int* __restrict__ block_hits, int nb, int n, int* __restrict__ counts) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (nb + 1023) / 1024;
+    int s = 0;
+    for (int k = 0; k < per; ++k) { const int b = tid * per + k; if (b < nb) s += block_hits[b]; }
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int base = part[tid] - s;
+    for (int k = 0; k < per; ++k) {
+        const int b = tid * per + k;
+        if (b < nb) { const int c = block_hits[b]; block_hits[b] = base; base += c; }
+    }
+    if (tid == 1023) { counts[0] = n - part[1023]; counts[1] = part[1023]; }
+}
+__global__ __launch_bounds__(256) void mc_split_scatter_kernel(const float* __restrict__ depth, int n, const int* __restrict__ block_base,
+                                                               int* __restrict__ slot, int* __restrict__ miss_idx, int* __restrict__ hit_idx) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long lower = (1ull << lane) - 1ull;
+    // hits before this wave's first chunk inside the block: the chunks are wave-contiguous, so count the earlier waves' chunks directly
+    int hits_before = block_base[blockIdx.x];
+    for (int c = 0; c < wv * 4; ++c) {
+        const int i = blockIdx.x * SPLIT_BLOCK + c * 64 + lane;
+        hits_before += __popcll(__ballot(i < n && depth[i] < 10.0f));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i0 = blockIdx.x * SPLIT_BLOCK + (wv * 4 + k) * 64;
+        const int i = i0 + lane;
+        const bool valid = i < n, hit = valid && depth[i] < 10.0f;
+        const unsigned long long mh = __ballot(hit);
+        if (valid) {
+            if (hit) { const int q = hits_before + __popcll(mh & lower); hit_idx[q] = i; slot[i] = -q - 1; }
+            else { const int q = (i0 - hits_before) + (lane - __popcll(mh & lower)); miss_idx[q] = i; slot[i] = q; }   // misses before i = i - hits before i
+        }
+        hits_before += __popcll(mh);
+    }
+}
 }  // namespace
 
 #define GRID1D(n) dim3(((n) + 127) / 128), dim3(128), 0, (hipStream_t)stream
@@ -655,6 +719,19 @@ int nero_mc_dir_bwd(const float* pt, const float* dirs, const float* face_normal
     hipLaunchKernelGGL(mc_dir_bwd_kernel, dim3(P), dim3(64), 0, (hipStream_t)stream, pt, dirs, face_normals, slot, tab_s, dX_miss, dX_hit,
                        d_wspec, P, Dd, Ds, d_mat5, sphere, dXh, poses);
     return nero_check_launch("nero_mc_dir_bwd");
+}
+
+
+int nero_mc_split_tmp_ints(int n) { return (n + SPLIT_BLOCK - 1) / SPLIT_BLOCK + 1; }
+
+int nero_mc_split(const float* depth, int n, int* slot, int* miss_idx, int* hit_idx, int* counts, int* tmp, void* stream) {
+    if (!depth || !slot || !miss_idx || !hit_idx || !counts || !tmp || n < 0) return nero_fail(NERO_ERR_ARG, "nero_mc_split: bad argument");
+    if (n == 0) { (void)hipMemsetAsync(counts, 0, 8, (hipStream_t)stream); return NERO_OK; }
+    const int nb = (n + SPLIT_BLOCK - 1) / SPLIT_BLOCK;
+    hipLaunchKernelGGL(mc_split_count_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, depth, n, tmp);
+    hipLaunchKernelGGL(mc_split_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, tmp, nb, n, counts);
+    hipLaunchKernelGGL(mc_split_scatter_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, depth, n, tmp, slot, miss_idx, hit_idx);
+    return nero_check_launch("nero_mc_split");
 }
 
 }  // extern "C"

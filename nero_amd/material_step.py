@@ -178,13 +178,14 @@ class MCShade(torch.autograd.Function):
         dirs, orig = torch.empty((Pn * D, 3), **f32), torch.empty((Pn * D, 3), **f32)
         L.check(lib.nero_mc_dirs(_p(pt), _p(K.tab_d), _p(K.tab_s), Pn, Dd, Ds, _p(dirs), _p(orig), st))
         pos, fnrm, depth = tracer.trace(orig, dirs)                       # closest hit, depth >= 10 <=> miss
-        hit = depth < 10
-        miss_idx = torch.nonzero(~hit)[:, 0].to(torch.int32)
-        hit_idx = torch.nonzero(hit)[:, 0].to(torch.int32)
-        n_miss, n_hit = miss_idx.numel(), hit_idx.numel()
-        slot = torch.empty(Pn * D, dtype=torch.int32, device=dev)
-        slot[miss_idx.long()] = torch.arange(n_miss, dtype=torch.int32, device=dev)
-        slot[hit_idx.long()] = -torch.arange(n_hit, dtype=torch.int32, device=dev) - 1
+        # hit / miss split on the device (ordered compaction, nero_mc_split): the index lists torch.nonzero would give + the slot map
+        N = Pn * D
+        depth = depth.contiguous().reshape(-1)
+        i32 = dict(dtype=torch.int32, device=dev)
+        slot, miss_idx, hit_idx, counts = torch.empty(N, **i32), torch.empty(N, **i32), torch.empty(N, **i32), torch.empty(2, **i32)
+        tmp = torch.empty(lib.nero_mc_split_tmp_ints(N), **i32)
+        L.check(lib.nero_mc_split(_p(depth), N, _p(slot), _p(miss_idx), _p(hit_idx), _p(counts), _p(tmp), st))
+        n_miss, n_hit = (int(v) for v in counts.cpu())               # the step's host synchronisation: sizes of the light-MLP launches
         rpm, rph = row_pad(n_miss), row_pad(n_hit)
         Xm, Xh = torch.empty((max(rpm, 64), 144 if K.sphere else 72), **f32), torch.empty((max(rph, 64), 128), **f32)
         fo = fi = fh = None

@@ -442,7 +442,12 @@ class NeROMaterialRenderer(nn.Module):
         """-> metallic [n,1], roughness [n,1] (affine to [0.04^2, 1]), albedo [n,3]   (network/field.py:915-922)"""
         from .material_step import PredictMaterials
         names, eff, K = _kern if _kern is not None else self._kernels()
-        raw = PredictMaterials.apply(K, names[:40], getattr(self, '_grad_views', None), pts, *eff[:40])
+        drv = getattr(self, '_driver', None)
+        if drv is not None:                           # C-level driver (nero_stage2_predict_fwd / _bwd): opens the step's workspace
+            from .stage2 import PredictMaterialsC
+            raw = PredictMaterialsC.apply(drv, names[:40], getattr(self, '_grad_views', None), getattr(self, '_n_shade', pts.shape[0]), pts, *eff[:40])
+        else:
+            raw = PredictMaterials.apply(K, names[:40], getattr(self, '_grad_views', None), pts, *eff[:40])
         rmin = 0.04 ** 2
         return torch.sigmoid(raw[:, 0:1]), torch.sigmoid(raw[:, 1:2]) * (1.0 - rmin) + rmin, torch.sigmoid(raw[:, 2:5])
 
@@ -453,6 +458,7 @@ class NeROMaterialRenderer(nn.Module):
         scfg = self.shader_network.cfg
         Pn = pts.shape[0]
         x = pts if _reg_pts is None else torch.cat([pts, _reg_pts], 0)
+        self._n_shade = Pn
         metallic, rough, albedo = self.predict_materials(x, kern)
         m2 = (metallic[Pn:], rough[Pn:], albedo[Pn:]) if _reg_pts is not None else None
         metallic, rough, albedo = metallic[:Pn], rough[:Pn], albedo[:Pn]
@@ -462,8 +468,14 @@ class NeROMaterialRenderer(nn.Module):
         else:
             rand_d = rand_s = None
         mat5 = torch.cat([metallic, rough, albedo], -1)
-        rgb_lin, dl, sl, sp = MCShade.apply(K, self.ray_tracer, names[40:], getattr(self, '_grad_views', None), pts, view_dirs, normals,
-                                            mat5, rand_d, rand_s, human_poses, *eff[40:])
+        drv = getattr(self, '_driver', None)
+        if drv is not None:
+            from .stage2 import MCShadeC
+            rgb_lin, dl, sl, sp = MCShadeC.apply(drv, self.ray_tracer, names[40:], getattr(self, '_grad_views', None), pts, view_dirs, normals,
+                                                 mat5, rand_d, rand_s, human_poses, *eff[40:])
+        else:
+            rgb_lin, dl, sl, sp = MCShade.apply(K, self.ray_tracer, names[40:], getattr(self, '_grad_views', None), pts, view_dirs, normals,
+                                                mat5, rand_d, rand_s, human_poses, *eff[40:])
         kd = 1 - metallic
         outputs = {
             'rgb_pr': linear_to_srgb(rgb_lin), 'albedo': albedo, 'roughness': rough, 'metallic': metallic,

@@ -410,9 +410,14 @@ class MaterialTrainStep:
         self.net = self.net.to(device)
         self.params = [p for p in self.net.parameters()]
         self.fused = (device != 'cpu') if fused is None else fused
+        self.drv = None
         if self.fused:
             self.fopt = FusedMaterialOptimizer(self.net, device)
             self.bucket = self.fopt.bucket
+            import os
+            from . import stage2
+            if os.environ.get('NERO_STEP_DRIVER', 'c') != 'py' and stage2.supported():      # the C-level shading driver (nero_stage2_*)
+                self.drv = stage2.Stage2Driver(self.net.shader_network.cfg, device)
         else:
             self.bucket = GradBucket(self.params)
             self.opt = torch.optim.Adam(self.params, lr=1e-3, fused=(device != 'cpu'))
@@ -441,11 +446,16 @@ class MaterialTrainStep:
         b = self._batch()
         hp = self.human_img[b['img_idx']] if net.shader_network.cfg['human_lights'] else None
         if self.fused:                                # effective-weight leaves + packed chains of the fused optimiser, and the
-            net._kern_override, net._grad_views = self.fopt.kernels(), self.fopt.grad_views      # bucket views the GEMMs write into
+            if self.drv is not None and self.drv.matches_current_modes():                        # bucket views the GEMMs write into
+                self.fopt.reparametrise()
+                self.drv.pack([t.detach() for t in self.fopt.eff])
+                net._kern_override, net._grad_views, net._driver = (self.fopt.names, self.fopt.eff, None), self.fopt.grad_views, self.drv
+            else:
+                net._kern_override, net._grad_views = self.fopt.kernels(), self.fopt.grad_views
         try:
             out = net.shade_train(b['pts'], b['view'], b['normals'], hp, b['rgb'], step, **(rands or {}))
         finally:
-            net._kern_override = net._grad_views = None
+            net._kern_override = net._grad_views = net._driver = None
         loss = material_training_loss(net.shader_network.cfg, out, step, self.world)
         loss.backward()
         return {'loss': loss.detach(), 'out': out}

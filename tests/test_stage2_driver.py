@@ -1,0 +1,113 @@
+"""The C-level Stage-II shading driver (include/nero_hip.h: nero_stage2_*; SURVEY.md 8b "nero_mc_shade_fwd/bwd").  CPU tier: struct
+layouts and the host-only workspace query.  GPU tier: the device-side hit / miss split against torch.nonzero, and one material training
+step sequenced by the C driver against the Python-sequenced step, bit for bit (reference boundary: NeROMaterialRenderer.shade,
+network/renderer.py:810-813)."""
+import ctypes as C
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_stage2_struct_layouts_match_header():
+    from nero_amd import stage2 as S2
+    src = ('#include <stdio.h>\n#include "nero_hip.h"\nint main(){printf("%zu %zu %zu\\n", sizeof(nero_stage2_cfg), sizeof(nero_stage2_weights), '
+           'sizeof(nero_stage2_grads));}')
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, 's.c')
+        open(c, 'w').write(src)
+        exe = os.path.join(td, 's')
+        subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), c, '-o', exe])
+        sizes = [int(x) for x in subprocess.check_output([exe]).split()]
+    assert sizes == [C.sizeof(S2.Cfg), C.sizeof(S2.Weights), C.sizeof(S2.Weights)], sizes
+
+
+def test_stage2_workspace_query_without_a_gpu():
+    from nero_amd import _lib as L
+    from nero_amd import stage2 as S2
+    lib = S2._lib
+    hs = []
+    for human in (0, 1):
+        c = S2.Cfg(128, 128, human, human, 0, 5.0, 5.0, 3, 2, 2)
+        h = C.c_void_p()
+        L.check(lib.nero_stage2_create(C.byref(c), C.byref(h)))
+        hs.append(h)
+    w_bell, w_bear = lib.nero_stage2_workspace_bytes(hs[0], 8192, 4096), lib.nero_stage2_workspace_bytes(hs[1], 8192, 4096)
+    # 1.05 M light rows x (3 saved layers + 3 deltas + encodings) ~ 10 GB; the human-light MLP adds its share
+    assert 4e9 < w_bell < 30e9 and w_bear > w_bell, (w_bell, w_bear)
+    assert lib.nero_stage2_workspace_bytes(hs[0], 1024, 512) < w_bell / 6
+    assert lib.nero_stage2_pack_bytes(hs[1]) > lib.nero_stage2_pack_bytes(hs[0]) > 8e6
+    bad = S2.Cfg(128, 128, 0, 0, 7, 5.0, 5.0, 3, 2, 2)
+    h = C.c_void_p()
+    assert lib.nero_stage2_create(C.byref(bad), C.byref(h)) == -3
+    for h in hs:
+        lib.nero_stage2_destroy(h)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n', [1, 63, 1024, 1025, 300001])
+def test_mc_split_matches_torch_nonzero(n):
+    from nero_amd import _lib as L
+    g = torch.Generator().manual_seed(n)
+    depth = torch.where(torch.rand(n, generator=g) < 0.3, torch.rand(n, generator=g) * 2.0, torch.full((n,), 10.0)).cuda()
+    i32 = dict(dtype=torch.int32, device='cuda')
+    slot, mi, hi, counts = torch.full((n,), 12345, **i32), torch.empty(n, **i32), torch.empty(n, **i32), torch.empty(2, **i32)
+    tmp = torch.empty(L.lib.nero_mc_split_tmp_ints(n), **i32)
+    L.check(L.lib.nero_mc_split(C.c_void_p(depth.data_ptr()), n, C.c_void_p(slot.data_ptr()), C.c_void_p(mi.data_ptr()), C.c_void_p(hi.data_ptr()),
+                                C.c_void_p(counts.data_ptr()), C.c_void_p(tmp.data_ptr()), L.stream_ptr()))
+    hit = depth < 10
+    want_m, want_h = torch.nonzero(~hit)[:, 0].int(), torch.nonzero(hit)[:, 0].int()
+    n_miss, n_hit = (int(v) for v in counts.cpu())
+    assert (n_miss, n_hit) == (want_m.numel(), want_h.numel())
+    assert torch.equal(mi[:n_miss], want_m) and torch.equal(hi[:n_hit], want_h)
+    want_slot = torch.empty(n, **i32)
+    want_slot[want_m.long()] = torch.arange(n_miss, **i32)
+    want_slot[want_h.long()] = -torch.arange(n_hit, **i32) - 1
+    assert torch.equal(slot, want_slot)
+
+
+SCFG = dict(diffuse_sample_num=32, specular_sample_num=32, human_lights=True, outer_light_version='sphere_direction')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('scfg', [SCFG, dict(diffuse_sample_num=64, specular_sample_num=32, human_lights=False, outer_light_version='direction',
+                                             geometry_type='ggx_smith')], ids=['bear', 'bell_smith'])
+def test_c_driven_material_step_equals_python_driven_step_bit_for_bit(scfg, monkeypatch):
+    from nero_amd.synthetic import icosphere
+    from nero_amd.train import MaterialTrainStep
+    v, f = icosphere(4, 0.5, 0.2)
+    mesh = (v, np.ascontiguousarray(f[:, ::-1]))
+    P = 160
+    g = torch.Generator().manual_seed(11)
+    rands = {'rand_d': torch.rand(P, 1, 1, generator=g).cuda(), 'rand_s': torch.rand(P, 1, 1, generator=g).cuda(),
+             'reg_ang': torch.rand(P, 1, generator=g).cuda(), 'reg_eps': torch.normal(mean=0.0, std=0.05, size=[P, 1], generator=g).cuda()}
+    res = {}
+    for drv in ('py', 'c'):
+        monkeypatch.setenv('NERO_STEP_DRIVER', drv)
+        ts = MaterialTrainStep({'shader_cfg': scfg, 'database_name': 'real/bear'}, mesh, points_per_rank=P, pool_points=4 * P, device='cuda:0')
+        assert (ts.drv is not None) == (drv == 'c')
+        info = ts.forward_backward(5000, rands)
+        torch.cuda.synchronize()
+        res[drv] = (float(info['loss']), info['out']['rgb_pr'].detach().clone(), ts.bucket.flat.clone())
+    (lp, rp, fp), (lc, rc, fc) = res['py'], res['c']
+    assert torch.equal(rp, rc)
+    assert lp == lc
+    assert torch.equal(fp, fc), float((fp - fc).abs().max())
+    assert float(fp.abs().max()) > 0
+
+
+@pytest.mark.gpu
+def test_c_driven_material_training_steps(monkeypatch):
+    from nero_amd.synthetic import icosphere
+    from nero_amd.train import MaterialTrainStep
+    monkeypatch.setenv('NERO_STEP_DRIVER', 'c')
+    v, f = icosphere(4, 0.5, 0.2)
+    ts = MaterialTrainStep({'shader_cfg': SCFG, 'database_name': 'real/bear'}, (v, np.ascontiguousarray(f[:, ::-1])), points_per_rank=128,
+                           pool_points=512, device='cuda:0')
+    losses = [float(ts.step(5000 + i)['loss']) for i in range(4)]
+    assert all(l == l for l in losses) and ts.drv is not None
