@@ -54,6 +54,13 @@ def _tiles(x):
     return (x + 31) // 32
 
 
+def _rev_k(n_out):
+    """contraction length of a layer's REVERSE GEMM (over its outputs) in the fp16 engines: wide layers are zero-padded to the full
+    256 (the SDF's 217-wide layer 3: 224 -> 256, two all-zero k-steps) so that every reverse GEMM of the chain has 16 k-steps and
+    the walk takes the fully unrolled kernel (bwd_f16_kernel<FIXED>, ~10 % faster)"""
+    return 256 if 128 < n_out <= 256 else _r16(n_out)
+
+
 def row_pad(n):
     return (n + 63) // 64 * 64
 
@@ -117,8 +124,8 @@ class Chain:
                     e['hfm'] = 64 + (_r16(d.k_main) // 16) * nt * 512 if d.k_main else 0
                     e['hfa'] = 64 + (_r16(d.k_aux) // 16) * nt * 512 if d.k_aux else 0
                 if GEMM_MODE['bwd'] in _F16:
-                    e['hbm'] = 64 + (_r16(d.n_out) // 16) * _tiles(d.k_main) * 512 if d.k_main else 0
-                    e['hba'] = 64 + (_r16(d.n_out) // 16) * _tiles(d.k_aux) * 512 if d.k_aux else 0
+                    e['hbm'] = 64 + (_rev_k(d.n_out) // 16) * _tiles(d.k_main) * 512 if d.k_main else 0
+                    e['hba'] = 64 + (_rev_k(d.n_out) // 16) * _tiles(d.k_aux) * 512 if d.k_aux else 0
                 if GEMM_MODE['bwd'] == L.GEMM_BF16X6:
                     e['sbm'] = (_r16(d.n_out) // 16) * _tiles(d.k_main) * 768 if d.k_main else 0
                     e['sba'] = (_r16(d.n_out) // 16) * _tiles(d.k_aux) * 768 if d.k_aux else 0
@@ -177,7 +184,7 @@ class Chain:
                         job(3, W, p[key], d.n_out, W.stride(0), c0, kc, 0, _r16(kc), nt, d.scale)
                 for key, c0, kc in (('hbm', d.main_c0, d.k_main), ('hba', d.aux_c0, d.k_aux)):
                     if kc and key in p:
-                        job(3, W, p[key], d.n_out, W.stride(0), c0, kc, 1, _r16(d.n_out), _tiles(kc), d.scale)
+                        job(3, W, p[key], d.n_out, W.stride(0), c0, kc, 1, _rev_k(d.n_out), _tiles(kc), d.scale)
                 if d.b is not None:
                     b = d.b.detach()
                     job(2, b, p['bias'], 1, d.n_out, 0, d.n_out, 0, 32 * nt, 0)
@@ -298,7 +305,7 @@ class Chain:
             if d is not None and not (skip_last_dense and i == last):
                 bl.w_main_t = L.ptr(p.get(bkeys[0]))
                 bl.w_aux_t = L.ptr(p.get(bkeys[1])) if need_daux else None
-                bl.n_out = rk(d.n_out)
+                bl.n_out = _rev_k(d.n_out) if GEMM_MODE['bwd'] in _F16 else rk(d.n_out)
                 bl.k_main_tiles = _tiles(d.k_main) if d.k_main else 0
                 bl.k_aux_tiles = _tiles(d.k_aux) if d.k_aux else 0
             else:

@@ -18,6 +18,8 @@ inline int r8(int x) { return (x + 7) / 8 * 8; }
 inline int r16(int x) { return (x + 15) / 16 * 16; }
 inline int tiles(int x) { return (x + 31) / 32; }
 inline int rpad(int n) { return NERO_ROW_PAD(n); }
+// contraction length of a layer's reverse GEMM: wide layers are zero-padded to 256 (nero_amd/chain.py::_rev_k)
+inline int rev_k(int n_out) { return (n_out > 128 && n_out <= 256) ? 256 : r16(n_out); }
 inline bool is_f16(int m) { return m == NERO_GEMM_F16X3 || m == NERO_GEMM_F16X3P; }
 
 // ---- workspace arena -------------------------------------------------------------------------------------------------------
@@ -122,8 +124,8 @@ struct Chain {
                 const Dense& d = x.d;
                 const int nt = tiles(d.n_out);
                 t += 32 * nt;
-                if (d.k_main) t += 64 + (size_t)(r16(d.k_main) / 16) * nt * 512 + 64 + (size_t)(r16(d.n_out) / 16) * tiles(d.k_main) * 512;
-                if (d.k_aux) t += 64 + (size_t)(r16(d.k_aux) / 16) * nt * 512 + 64 + (size_t)(r16(d.n_out) / 16) * tiles(d.k_aux) * 512;
+                if (d.k_main) t += 64 + (size_t)(r16(d.k_main) / 16) * nt * 512 + 64 + (size_t)(rev_k(d.n_out) / 16) * tiles(d.k_main) * 512;
+                if (d.k_aux) t += 64 + (size_t)(r16(d.k_aux) / 16) * nt * 512 + 64 + (size_t)(rev_k(d.n_out) / 16) * tiles(d.k_aux) * 512;
             }
             if (x.h.has) t += 4 * NERO_HID + 4;
         }
@@ -145,15 +147,15 @@ struct Chain {
                 x.hfm = x.hfa = x.hbm = x.hba = nullptr;
                 if (d.k_main) {
                     x.hfm = buf; buf += 64 + (size_t)(r16(d.k_main) / 16) * nt * 512;
-                    x.hbm = buf; buf += 64 + (size_t)(r16(d.n_out) / 16) * tiles(d.k_main) * 512;
+                    x.hbm = buf; buf += 64 + (size_t)(rev_k(d.n_out) / 16) * tiles(d.k_main) * 512;
                     job(3, d.W, x.hfm, d.n_out, d.ldw, d.main_c0, d.k_main, 0, r16(d.k_main), nt, d.scale);
-                    job(3, d.W, x.hbm, d.n_out, d.ldw, d.main_c0, d.k_main, 1, r16(d.n_out), tiles(d.k_main), d.scale);
+                    job(3, d.W, x.hbm, d.n_out, d.ldw, d.main_c0, d.k_main, 1, rev_k(d.n_out), tiles(d.k_main), d.scale);
                 }
                 if (d.k_aux) {
                     x.hfa = buf; buf += 64 + (size_t)(r16(d.k_aux) / 16) * nt * 512;
-                    x.hba = buf; buf += 64 + (size_t)(r16(d.n_out) / 16) * tiles(d.k_aux) * 512;
+                    x.hba = buf; buf += 64 + (size_t)(rev_k(d.n_out) / 16) * tiles(d.k_aux) * 512;
                     job(3, d.W, x.hfa, d.n_out, d.ldw, d.aux_c0, d.k_aux, 0, r16(d.k_aux), nt, d.scale);
-                    job(3, d.W, x.hba, d.n_out, d.ldw, d.aux_c0, d.k_aux, 1, r16(d.n_out), tiles(d.k_aux), d.scale);
+                    job(3, d.W, x.hba, d.n_out, d.ldw, d.aux_c0, d.k_aux, 1, rev_k(d.n_out), tiles(d.k_aux), d.scale);
                 }
                 if (d.b) job(2, d.b, x.bias, 1, d.n_out, 0, d.n_out, 0, 32 * nt, 0, 1.f);
             }
@@ -242,7 +244,7 @@ struct Chain {
                 const Dense& d = x.d;
                 bl.w_main_t = x.hbm;
                 bl.w_aux_t = need_daux ? x.hba : nullptr;
-                bl.n_out = r16(d.n_out);
+                bl.n_out = rev_k(d.n_out);
                 bl.k_main_tiles = d.k_main ? tiles(d.k_main) : 0;
                 bl.k_aux_tiles = d.k_aux ? tiles(d.k_aux) : 0;
                 const bool first = j < 0;

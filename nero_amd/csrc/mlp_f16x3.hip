@@ -448,7 +448,13 @@ constexpr int BWD_PA_BYTES = 8 * 8192;
 inline int bwd_lds_bytes() { return 2 * PLANE_A + (64 + 64 + 512) * 4 + BWD_PA_BYTES; }      // 135680
 
 // FIXED: every reverse GEMM of the chain contracts over exactly 256 outputs (16 k-steps) -- the k-loop is then fully unrolled
-// (no ring rotation, clamps or branches: 16 % faster on 256-wide chains); chains with other widths take the generic loop.
+// (no ring rotation, clamps or branches: 16 % faster on 256-wide chains); chains with other widths take the generic loop.  The host
+// pads wide layers to 256 (nero_amd/chain.py::_rev_k: the SDF's 217-wide layer gets two all-zero k-steps), so both SDF reverse passes
+// qualify: 1.47 -> 1.37 ms and 1.84 -> 1.74 ms per step.
+// (Round 3, measured and dropped: requesting the INJECTIONS of the next layer one layer ahead into 32 registers -- they fit, 219 VGPRs,
+// no spill -- instead of reading them in the epilogue: the second-order reverse pass went from 1.74 to 2.69 ms.  vmcnt retires in
+// order, so the weight stream of the next GEMM queued behind eight 1 KB HBM loads per wave, exactly what the LDS-DMA of the saved
+// activations had been introduced to avoid; there is no LDS left for a second DMA target: 135.7 of 160 KB.)
 template <bool FIXED>
 __global__ __launch_bounds__(512, 1) void bwd_f16_kernel(nero_bwd_chain ch, int n_rows) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
