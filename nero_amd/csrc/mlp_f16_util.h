@@ -202,6 +202,26 @@ __device__ __forceinline__ void ops_compute(f32x16 (&aH)[2], f32x16 (&aL)[2], co
     NERO_MFH(aL[0], w.wh, x.xl0); NERO_MFH(aL[1], w.wh, x.xl1);
 }
 #define NERO_FENCE() __builtin_amdgcn_sched_barrier(0)      // (without the fences hipcc sinks the prefetches: the kernels run 40 % slower)
+// One k-step = 2 weight loads (VMEM) + 4 activation-fragment reads (DS) for a LATER step + 6 MFMAs of this step.  Issued as
+// [6 loads][6 MFMAs] the wave spends the load-issue time with an idle matrix pipe and the MFMA time with idle issue slots (an in-order
+// wave: a lone wave reaches 46 % of the pipe rate in the loop, two per SIMD 70 %, profiles/r03_phase_probes.txt).  -DGEMM_SGB interleaves
+// them -- MFMA, DS, MFMA, DS, ..., MFMA, VMEM, MFMA, VMEM (checked in the ISA) -- so that each load would issue in the shadow of the
+// preceding MFMA.  MEASURED SLOWER (round 3, same file): the GEMM phase of a layer-tile goes from 8.6 k to 9.4 k cycles (forward),
+// 4.7 k to 6.0 k (reverse), 17.6 k to 19.4 k (two workgroups per CU) -- a load between two MFMAs costs the pipe more than its issue
+// slot.  Kept as an experiment switch, off.
+#ifdef GEMM_SGB
+#define NERO_KSTEP_SCHED() do { \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); } while (0)
+#define NERO_MID_FENCE()
+#else
+#define NERO_KSTEP_SCHED()
+#define NERO_MID_FENCE() NERO_FENCE()
+#endif
 
 __device__ __forceinline__ void gemm_f16x3_loop(f32x16 (&aH)[2], f32x16 (&aL)[2], const uint4* wp, const char* xp, int half_bytes,
                                            int plane_bytes, int n) {
@@ -216,19 +236,19 @@ __device__ __forceinline__ void gemm_f16x3_loop(f32x16 (&aH)[2], f32x16 (&aL)[2]
     load_x(xa, xp, half_bytes, plane_bytes, 0);
     NERO_FENCE();
     for (int c = 0; c < n; c += 4) {
-        load_w(wd, wp, NERO_CL(c + 3)); load_x(xb, xp, half_bytes, plane_bytes, NERO_CL(c + 1)); NERO_FENCE();
-        ops_compute(aH, aL, wa, xa); NERO_FENCE();
+        load_w(wd, wp, NERO_CL(c + 3)); load_x(xb, xp, half_bytes, plane_bytes, NERO_CL(c + 1)); NERO_MID_FENCE();
+        ops_compute(aH, aL, wa, xa); NERO_KSTEP_SCHED(); NERO_FENCE();
         if (c + 1 < n) {
-            load_w(wa, wp, NERO_CL(c + 4)); load_x(xa, xp, half_bytes, plane_bytes, NERO_CL(c + 2)); NERO_FENCE();
-            ops_compute(aH, aL, wb, xb); NERO_FENCE();
+            load_w(wa, wp, NERO_CL(c + 4)); load_x(xa, xp, half_bytes, plane_bytes, NERO_CL(c + 2)); NERO_MID_FENCE();
+            ops_compute(aH, aL, wb, xb); NERO_KSTEP_SCHED(); NERO_FENCE();
         }
         if (c + 2 < n) {
-            load_w(wb, wp, NERO_CL(c + 5)); load_x(xb, xp, half_bytes, plane_bytes, NERO_CL(c + 3)); NERO_FENCE();
-            ops_compute(aH, aL, wc, xa); NERO_FENCE();
+            load_w(wb, wp, NERO_CL(c + 5)); load_x(xb, xp, half_bytes, plane_bytes, NERO_CL(c + 3)); NERO_MID_FENCE();
+            ops_compute(aH, aL, wc, xa); NERO_KSTEP_SCHED(); NERO_FENCE();
         }
         if (c + 3 < n) {
-            load_w(wc, wp, NERO_CL(c + 6)); load_x(xa, xp, half_bytes, plane_bytes, NERO_CL(c + 4)); NERO_FENCE();
-            ops_compute(aH, aL, wd, xb); NERO_FENCE();
+            load_w(wc, wp, NERO_CL(c + 6)); load_x(xa, xp, half_bytes, plane_bytes, NERO_CL(c + 4)); NERO_MID_FENCE();
+            ops_compute(aH, aL, wd, xb); NERO_KSTEP_SCHED(); NERO_FENCE();
         }
     }
 #undef NERO_CL
@@ -260,8 +280,9 @@ __device__ __forceinline__ void gemm_f16x3_fixed(f32x16 (&aH)[2], f32x16 (&aL)[2
         constexpr int c = cc.value;
         if (c + WD < N) load_w(w[(c + WD) % WN], wp, c + WD);
         if (c + XD < N) load_x(x[(c + XD) % XN], xp, half_bytes, plane_bytes, c + XD);
-        NERO_FENCE();
+        NERO_MID_FENCE();
         ops_compute(aH, aL, w[c % WN], x[c % XN]);
+        if (c + WD < N && c + XD < N) NERO_KSTEP_SCHED();
         NERO_FENCE();
     });
 }

@@ -32,7 +32,10 @@ __device__ __forceinline__ LdsP carve_p(char* smem) {
     l.scr = reinterpret_cast<char*>(l.rmax + 64 * 8);
     return l;
 }
-inline int p_lds_bytes() { return 2 * PLANE_A + (64 + 64 + 512) * 4 + PW * SCRP_BYTES; }      // 79360
+#ifndef P_LDS_EXTRA
+#define P_LDS_EXTRA 0                                   // (timing experiment: > 2560 forces ONE workgroup per CU)
+#endif
+inline int p_lds_bytes() { return 2 * PLANE_A + (64 + 64 + 512) * 4 + PW * SCRP_BYTES + P_LDS_EXTRA; }      // 79360
 
 struct Ctx { LdsP S; int wave, lane, i, h, row0, n_rows; };
 
