@@ -127,6 +127,9 @@ __device__ __forceinline__ void split_shift(int s, int& a, int& b) {
 #ifndef DW_SGB_V
 #define DW_SGB_V 4
 #endif
+// (Round 3, measured and dropped: TWO resident workgroups per CU for the narrow jobs -- 512 slices, __launch_bounds__(512, 4): 128 VGPRs with
+// 12 spilled -- to double the waves pulling the delta stream, which only the four D-staging waves of a workgroup do: every narrow job
+// got slower, 0.109 -> 0.132 ms (27-column job), 0.165 -> 0.226 ms (the SDF's 39-column jobs).)
 template <bool NARROW>
 __global__ __launch_bounds__(512, 1) void dw_f16_kernel(nero_dw_job job, int n_rows, int rows_per_slice, float* __restrict__ partials,
                                                         int n_pad, int k_pad) {
