@@ -267,6 +267,59 @@ def stage2_bench(dev, P_=4096, configs=((128, 128), (512, 256)), warmup=5, steps
     return out
 
 
+def inference_bench(dev, cfg, variance, res_grid=256):
+    """SURVEY.md 8f rows 1-3 (the callers either side of the training path), forward only, on rank 0 at N = 1:
+    mesh extraction (`extract_fields`, network/field.py:1090-1108 via extract_mesh.py:24-27), novel-view / validation rendering
+    (`nvs` / `test_step`, network/renderer.py:189-222,274-317) at the reference's test_ray_num = 1024 and at 8192 rays per chunk,
+    and the Stage-II dataset pre-trace (`_construct_ray_batch`, network/renderer.py:756-802) through the HIP BVH tracer."""
+    import numpy as np
+    from nero_amd.renderer import NeROShapeRenderer, NeROMaterialRenderer
+    from nero_amd.synthetic import look_at_pose, perturb_state
+    out = {}
+    torch.manual_seed(6033)
+    net = NeROShapeRenderer(dict(cfg), training=False)
+    perturb_state(net, variance)
+    net = net.to(dev)
+    net.extract_fields(resolution=64)                                        # warm-up (packing, allocator)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    net.extract_fields(resolution=res_grid)
+    torch.cuda.synchronize()
+    d = time.time() - t0
+    n = res_grid ** 3
+    out['extract_fields'] = {'grid': f'{res_grid}^3', 'sdf_evals_per_s': round(n / d, 1), 'seconds': round(d, 3),
+                             'seconds_at_512^3_extrapolated': round(d * (512 ** 3) / n, 2),
+                             'mlp_tflops': round(n * 2 * C_SDF / d / 1e12, 1), 'includes': 'grid generation, |p| >= 1 mask, D2H copy of the grid'}
+    h = w = 400
+    K = np.array([[500., 0, w / 2], [0, 500., h / 2], [0, 0, 1]], np.float32)
+    pose = look_at_pose(np.array([0.0, -3.0, 0.5], np.float32))
+    for chunk in (1024, 8192):
+        net.render_image(pose, K, 64, 64, chunk=chunk)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        net.render_image(pose, K, h, w, chunk=chunk)
+        torch.cuda.synchronize()
+        d = time.time() - t0
+        out[f'nvs_chunk{chunk}'] = {'image': f'{h}x{w}', 'rays_per_s': round(h * w / d, 1), 'seconds': round(d, 3),
+                                    'seconds_at_800x800_extrapolated': round(d * 4, 2)}
+    del net
+    v, f = _bench_mesh()
+    mat = NeROMaterialRenderer({'database_name': 'synthetic'}, is_train=False, mesh=(v, f)).to(dev)
+    imn, hh, ww = 4, 800, 800
+    Ks = torch.tensor([[1000., 0, ww / 2], [0, 1000., hh / 2], [0, 0, 1]]).repeat(imn, 1, 1)
+    poses = torch.stack([torch.as_tensor(look_at_pose(np.array([3.0 * np.cos(a), 3.0 * np.sin(a), 0.6], np.float32))) for a in np.linspace(0, 5, imn)]).to(dev)
+    mat._trace_views(Ks[:1], poses[:1], 64, 64, dev)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    r = mat._trace_views(Ks, poses, hh, ww, dev)
+    torch.cuda.synchronize()
+    d = time.time() - t0
+    out['stage2_pretrace'] = {'views': f'{imn} x {hh}x{ww}', 'triangles': int(f.shape[0]), 'rays_per_s': round(imn * hh * ww / d, 1), 'seconds': round(d, 3),
+                              'hit_fraction': round(float(r[-1].float().mean()), 3),
+                              'seconds_for_128_views_extrapolated': round(d * 128 / imn, 2), 'includes': 'ray generation + BVH trace in 2^20-ray chunks, all on the device'}
+    return out
+
+
 def dropin_trainer_bench(dev, cfg, rays, variance, step0=25000, warmup=5, steps=20):
     """what INTEGRATION.md option A gives a user of the reference Trainer: NeROShapeRenderer.forward({'step': s}) (pool slicing,
     _process_ray_batch, render, loss_rgb: network/renderer.py:319-330) under a plain torch.optim.Adam loop with the reference's loss
@@ -594,6 +647,7 @@ def main():
             leg('r512', r512)
             leg('dropin_trainer', lambda: {'r4096': dropin_trainer_bench(dev, cfg, args.rays, VARIANCE, args.train_step),
                                            'r512': dropin_trainer_bench(dev, cfg, 512, VARIANCE, args.train_step)})
+            leg('inference', lambda: inference_bench(dev, cfg, VARIANCE))
             leg('stage2', lambda: stage2_bench(dev))
             leg('stage2_bear_2048x512', lambda: stage2_step_bench(dev, 'bear', 2048, 256, 256, _bench_mesh()))
             tg = torch_gpu_baseline(cfg, VARIANCE, args.train_step, args.rays, dev)
