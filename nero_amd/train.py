@@ -200,7 +200,10 @@ class FusedMaterialOptimizer(FusedOptimizer):
 
 class ShapeTrainStep:
     """one process = one GPU.  Every rank holds the same weights and a disjoint slice of each global ray batch
-    (rank-strided); gradients are summed with ONE flat all-reduce per step and divided by world size."""
+    (rank-strided); gradients are summed with ONE flat all-reduce per step and divided by world size.
+    CONSTRUCTION IS COLLECTIVE when world > 1: the priming passes run full forward + backward passes whose loss weights come from an
+    all-reduce of the per-rank sample counts (`global_count_weights`), so every rank must construct its ShapeTrainStep with the same
+    arguments at the same point of the program (what `bench.py` and the 2-rank tests do), exactly like the steps themselves."""
 
     def __init__(self, cfg, rays_per_rank=4096, pool_rays=262144, device='cuda', seed=6033, variance=None, eikonal_weight=0.1,
                  rank=0, world=1, prime_fraction=0.35, fused=None, prime_passes=4):
