@@ -305,7 +305,7 @@ def inference_bench(dev, cfg, variance, res_grid=256):
     del net
     v, f = _bench_mesh()
     mat = NeROMaterialRenderer({'database_name': 'synthetic'}, is_train=False, mesh=(v, f)).to(dev)
-    imn, hh, ww = 4, 800, 800
+    imn, hh, ww = 16, 800, 800
     Ks = torch.tensor([[1000., 0, ww / 2], [0, 1000., hh / 2], [0, 0, 1]]).repeat(imn, 1, 1)
     poses = torch.stack([torch.as_tensor(look_at_pose(np.array([3.0 * np.cos(a), 3.0 * np.sin(a), 0.6], np.float32))) for a in np.linspace(0, 5, imn)]).to(dev)
     mat._trace_views(Ks[:1], poses[:1], 64, 64, dev)

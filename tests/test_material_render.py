@@ -86,12 +86,13 @@ def test_mc_shading_with_hip_tracer_close_to_oracle():
     with torch.no_grad():
         out = net.shade(c('pts'), c('view'), c('normals'), c('human_poses'), True, meta['step'], c('rand_d'), c('rand_s'))
     err = (out['rgb_pr'].cpu() - torch.from_numpy(z['rgb'])).abs().max(-1)[0]
-    # 24 points x 24 directions: the explicit razor-edge accounting is tests/test_parity_at_size.py (P = 512 x 256); here only
-    # the plumbing -- the majority of points must be exact
+    # 24 points x 24 directions: the explicit razor-edge accounting is tests/test_parity_at_size.py (P = 512 x 256).  Measured on
+    # MI355X (profiles/r03_parity_at_size.json, 'mat_bell_24x24_hip_bvh'): all 24 points within 1e-4, worst 1.2e-6 -- no ray of this
+    # fixed case sits on a razor edge.  The bounds leave room for ONE point whose ray is answered differently (1 of 24 directions).
     from tests.helpers import parity_report
     frac, worst = float((err < 1e-4).float().mean()), float(err.max())
     parity_report('mat_bell_24x24_hip_bvh', fraction_points_within_1e4=frac, worst_point=worst)
-    assert frac > 0.7 and worst < 0.1
+    assert frac >= 23 / 24 - 1e-6 and worst < 2e-2
 
 
 def test_material_trainer_entry_point_and_pretrace():
