@@ -332,6 +332,35 @@ int nero_mc_point_setup(const float* pts, const float* view, const float* normal
  * = (n_miss, n_hit) on the device; miss_idx / hit_idx need room for n entries each; tmp: nero_mc_split_tmp_ints(n) int32 of scratch. */
 int nero_mc_split_tmp_ints(int n);
 int nero_mc_split(const float* depth, int n, int* slot, int* miss_idx, int* hit_idx, int* counts, int* tmp, void* stream);
+
+/* ---- Stage-II training glue (nero_amd/csrc/mat_loss.hip): what NeROMaterialRenderer.train_step does between the MLP / shading kernels,
+ * as single launches.
+ * nero_mat_reg_points: out [2P,3] = [pts ; pts + (cos(a) x + sin(a) y) eps], a = 2 pi ang01[p], (x, y) the tangent frame of
+ *   get_orthogonal_directions (network/field.py:756-766, 1066-1076); eps [P] (change_type 'gaussian') or NULL -> eps_const.
+ * nero_mat_head_fwd / _bwd: raw [n,5] -> (metallic, roughness in [0.04^2, 1], albedo[3]) = sigmoid heads of predict_materials
+ *   (network/field.py:915-922) and their backward (d_raw from d_mat; raw is re-read, not the output).
+ * nero_mat_loss_fwd: loss[0] = mean(loss_rgb) + mean(loss_mat_reg) + mean(loss_diffuse_light) (train/trainer.py:134-137 over
+ *   network/renderer.py:837-844); loss[1..3] = the three means; rgb_pr [P,3] = linear_to_srgb(rgb_lin) (may be NULL).
+ *   mat: [2P,5] when has_reg (rows P.. = the materials at the perturbed points), else [P,5]; partials: nero_mat_loss_partials(P) floats.
+ *   hinge_weight: 0 = the reg_min_max hinge is off (step >= 2000), otherwise the weight of the hinge SUM (1 for one process; the
+ *   data-parallel step passes world size).
+ * nero_mat_loss_bwd: gradients of loss[0] * grad_out[0] (grad_out: device scalar, NULL = 1) -> d_mat (same shape as mat), d_rgb_lin, d_dl. */
+typedef struct {
+    int rgb_l1;                 /* 0: Charbonnier sqrt(sum d^2 + 1e-3) (default), 1: L1 */
+    int reg_mat, reg_change;
+    float reg_lambda1;
+    float hinge_weight;
+    int reg_diffuse;
+    float reg_diffuse_lambda;
+} nero_mat_loss_cfg;
+int nero_mat_reg_points(int P, const float* pts, const float* normals, const float* ang01, const float* eps, float eps_const, float* out, void* stream);
+int nero_mat_head_fwd(int n, const float* raw, float* mat, void* stream);
+int nero_mat_head_bwd(int n, const float* raw, const float* d_mat, float* d_raw, void* stream);
+int nero_mat_loss_partials(int P);
+int nero_mat_loss_fwd(const nero_mat_loss_cfg* cfg, int P, int has_reg, const float* mat, const float* rgb_lin, const float* dl, const float* gt,
+                      float* rgb_pr, float* partials, float* loss, void* stream);
+int nero_mat_loss_bwd(const nero_mat_loss_cfg* cfg, int P, int has_reg, const float* mat, const float* rgb_lin, const float* dl, const float* gt,
+                      const float* grad_out, float* d_mat, float* d_rgb_lin, float* d_dl, void* stream);
 int nero_mc_dirs(const float* pt, const float* tab_d, const float* tab_s, int P, int Dd, int Ds, float* dirs, float* origins, void* stream);
 /* sphere != 0 ('sphere_direction'): X [rows,144] = [IDE(w,0) | IDE(unit-sphere exit point,0)], else X [rows,72] */
 int nero_mc_encode_miss(const float* dirs, const int* idx, const float* pt, int D, int sphere, int n, float* X, void* stream);

@@ -97,7 +97,7 @@ class Stage1Driver:
 
     def __del__(self):
         h = getattr(self, 'h', None)
-        if h:
+        if h and _lib is not None:                     # (module globals may already be cleared at interpreter exit)
             _lib.nero_stage1_destroy(h)
             self.h = None
 

@@ -73,7 +73,7 @@ class Stage2Driver:
 
     def __del__(self):
         h = getattr(self, 'h', None)
-        if h:
+        if h and _lib is not None:                     # (module globals may already be cleared at interpreter exit)
             _lib.nero_stage2_destroy(h)
             self.h = None
 
@@ -177,3 +177,86 @@ class MCShadeC(torch.autograd.Function):
                                            _p(d_mat5), L.stream_ptr()))
         ctx.keep = None
         return (None, None, None, None, None, None, None, d_mat5, None, None, None) + tuple(fresh.get(nm) for nm in ctx.names)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the training glue around the two calls above as single launches (nero_amd/csrc/mat_loss.hip)
+# ----------------------------------------------------------------------------------------------------------------------
+class LossCfg(C.Structure):
+    _fields_ = [('rgb_l1', C.c_int), ('reg_mat', C.c_int), ('reg_change', C.c_int), ('reg_lambda1', C.c_float), ('hinge_weight', C.c_float),
+                ('reg_diffuse', C.c_int), ('reg_diffuse_lambda', C.c_float)]
+
+
+_lib.nero_mat_reg_points.argtypes = [C.c_int, _fp, _fp, _fp, _fp, C.c_float, _fp, _fp]
+_lib.nero_mat_head_fwd.argtypes = [C.c_int, _fp, _fp, _fp]
+_lib.nero_mat_head_bwd.argtypes = [C.c_int, _fp, _fp, _fp, _fp]
+_lib.nero_mat_loss_partials.argtypes = [C.c_int]
+_lib.nero_mat_loss_fwd.argtypes = [C.POINTER(LossCfg), C.c_int, C.c_int] + [_fp] * 8
+_lib.nero_mat_loss_bwd.argtypes = [C.POINTER(LossCfg), C.c_int, C.c_int] + [_fp] * 9
+
+
+def loss_cfg(renderer_cfg, shader_cfg, step, world=1):
+    """the switches of NeROMaterialRenderer.train_step's losses (network/renderer.py:837-844, network/field.py:1061-1087) for one step"""
+    if renderer_cfg['rgb_loss'] not in ('charbonier', 'l1'):
+        raise NotImplementedError(renderer_cfg['rgb_loss'])
+    hinge = bool(shader_cfg['reg_min_max']) and step is not None and step < 2000
+    return LossCfg(int(renderer_cfg['rgb_loss'] == 'l1'), int(bool(renderer_cfg['reg_mat'])), int(bool(shader_cfg['reg_change'])),
+                   float(shader_cfg['reg_lambda1']), float(world) if hinge else 0.0, int(bool(renderer_cfg['reg_diffuse_light'])),
+                   float(renderer_cfg['reg_diffuse_light_lambda']))
+
+
+def reg_points(pts, normals, ang01, eps):
+    """[pts ; perturbed pts] as one [2P,3] tensor (regularization_points, network/field.py:1066-1076).  ang01 [P] uniform in [0,1);
+    eps: [P] tensor (change_type 'gaussian') or a float ('constant')"""
+    P = pts.shape[0]
+    pts, normals, ang01 = pts.contiguous().float(), normals.contiguous().float(), ang01.reshape(-1).contiguous().float()
+    out = torch.empty((2 * P, 3), dtype=torch.float32, device=pts.device)
+    e = eps.reshape(-1).contiguous().float() if torch.is_tensor(eps) else None
+    L.check(_lib.nero_mat_reg_points(P, _p(pts), _p(normals), _p(ang01), _p(e), 0.0 if e is not None else float(eps), _p(out), L.stream_ptr()))
+    return out
+
+
+class MaterialHeadC(torch.autograd.Function):
+    """raw [n,5] -> (metallic, roughness in [0.04^2, 1], albedo) (predict_materials, network/field.py:915-922)"""
+
+    @staticmethod
+    def forward(ctx, raw):
+        raw = raw.contiguous()
+        mat = torch.empty_like(raw)
+        L.check(_lib.nero_mat_head_fwd(raw.shape[0], _p(raw), _p(mat), L.stream_ptr()))
+        ctx.raw = raw
+        return mat
+
+    @staticmethod
+    def backward(ctx, d_mat):
+        d_raw = torch.empty_like(ctx.raw)
+        L.check(_lib.nero_mat_head_bwd(ctx.raw.shape[0], _p(ctx.raw), _p(d_mat.contiguous()), _p(d_raw), L.stream_ptr()))
+        return d_raw
+
+
+class MaterialLossC(torch.autograd.Function):
+    """(mat [P or 2P,5], rgb_lin [P,3], diffuse light [P,3], gt [P,3]) -> loss terms [4] = (total, mean loss_rgb, mean loss_mat_reg,
+    mean loss_diffuse_light), rgb_pr [P,3].  Only loss[0] carries a gradient."""
+
+    @staticmethod
+    def forward(ctx, lcfg, P, mat, rgb_lin, dl, gt):
+        mat, rgb_lin, dl, gt = (t.contiguous().float() for t in (mat, rgb_lin, dl, gt))
+        has_reg = int(mat.shape[0] == 2 * P)
+        assert mat.shape[0] in (P, 2 * P) and rgb_lin.shape == (P, 3) and dl.shape == (P, 3) and gt.shape == (P, 3)
+        f32 = dict(dtype=torch.float32, device=mat.device)
+        loss, rgb_pr = torch.empty(4, **f32), torch.empty((P, 3), **f32)
+        part = torch.empty(_lib.nero_mat_loss_partials(P), **f32)
+        L.check(_lib.nero_mat_loss_fwd(C.byref(lcfg), P, has_reg, _p(mat), _p(rgb_lin), _p(dl), _p(gt), _p(rgb_pr), _p(part), _p(loss), L.stream_ptr()))
+        ctx.lcfg, ctx.P, ctx.has_reg, ctx.keep = lcfg, P, has_reg, (mat, rgb_lin, dl, gt)
+        ctx.mark_non_differentiable(rgb_pr)
+        return loss, rgb_pr
+
+    @staticmethod
+    def backward(ctx, d_loss, _d_rgb_pr):
+        mat, rgb_lin, dl, gt = ctx.keep
+        g = d_loss[0:1].contiguous()                        # (the other three entries are reporting only)
+        d_mat, d_rgb, d_dl = torch.empty_like(mat), torch.empty_like(rgb_lin), torch.empty_like(dl)
+        L.check(_lib.nero_mat_loss_bwd(C.byref(ctx.lcfg), ctx.P, ctx.has_reg, _p(mat), _p(rgb_lin), _p(dl), _p(gt), _p(g), _p(d_mat), _p(d_rgb), _p(d_dl),
+                                       L.stream_ptr()))
+        ctx.keep = None
+        return None, None, d_mat, d_rgb, d_dl, None

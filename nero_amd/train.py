@@ -404,7 +404,7 @@ class MaterialTrainStep:
     gradients of all 104 / 112 tensors travel as ONE flat all-reduce (5.6 / 6.3 MB), then the fused weight-norm + Adam kernels."""
 
     def __init__(self, cfg, mesh, points_per_rank=4096, pool_points=None, device='cuda', seed=6033, rank=0, world=1, fused=None,
-                 pool=None):
+                 pool=None, fused_glue=None):
         from .renderer import NeROMaterialRenderer
         self.device, self.rank, self.world, self.P = device, rank, world, points_per_rank
         torch.manual_seed(seed)
@@ -414,6 +414,9 @@ class MaterialTrainStep:
         self.params = [p for p in self.net.parameters()]
         self.fused = (device != 'cpu') if fused is None else fused
         self.drv = None
+        import os
+        # NERO_LOSS_GLUE=torch keeps the tensor-op glue (NeROMaterialRenderer.shade_train) around the C-level calls
+        self.fused_glue = (os.environ.get('NERO_LOSS_GLUE', 'hip') != 'torch') if fused_glue is None else fused_glue
         if self.fused:
             self.fopt = FusedMaterialOptimizer(self.net, device)
             self.bucket = self.fopt.bucket
@@ -448,6 +451,8 @@ class MaterialTrainStep:
         self.bucket.zero()
         b = self._batch()
         hp = self.human_img[b['img_idx']] if net.shader_network.cfg['human_lights'] else None
+        if self.fused and self.fused_glue and self.drv is not None and self.drv.matches_current_modes():
+            return self._forward_backward_fused_glue(b, hp, step, rands or {})
         if self.fused:                                # effective-weight leaves + packed chains of the fused optimiser, and the
             if self.drv is not None and self.drv.matches_current_modes():                        # bucket views the GEMMs write into
                 self.fopt.reparametrise()
@@ -462,6 +467,43 @@ class MaterialTrainStep:
         loss = material_training_loss(net.shader_network.cfg, out, step, self.world)
         loss.backward()
         return {'loss': loss.detach(), 'out': out}
+
+    def _forward_backward_fused_glue(self, b, hp, step, rands):
+        """the same step with the tensor glue between the C-level calls as single launches (nero_amd/csrc/mat_loss.hip): perturbed points,
+        sigmoid heads, the three losses and their gradients -- ~25 launches of glue per step instead of ~240 (the reference's
+        visualisation-only outputs of shade(): specular / diffuse colour, approximate light, are not formed in a training step).
+        Random numbers are drawn in the order the tensor path draws them (reg_ang, reg_eps, rand_d, rand_s)."""
+        from . import stage2 as S2
+        net, drv = self.net, self.drv
+        cfg, scfg = net.cfg, net.shader_network.cfg
+        pts, view, nrm, gt = b['pts'], b['view'], b['normals'], b['rgb']
+        P, dev = pts.shape[0], pts.device
+        self.fopt.reparametrise()
+        drv.pack([t.detach() for t in self.fopt.eff])
+        names, eff, gv = self.fopt.names, self.fopt.eff, self.fopt.grad_views
+        x = pts
+        if cfg['reg_mat'] and scfg['reg_change']:
+            ang = rands['reg_ang'] if rands.get('reg_ang') is not None else torch.rand(P, 1, device=dev)
+            if scfg['change_type'] == 'constant':
+                eps = scfg['change_eps']
+            elif scfg['change_type'] == 'gaussian':
+                eps = rands['reg_eps'] if rands.get('reg_eps') is not None else torch.normal(mean=0.0, std=scfg['change_eps'], size=[P, 1], device=dev)
+            else:
+                raise NotImplementedError(scfg['change_type'])
+            x = S2.reg_points(pts, nrm, ang, eps)
+        raw = S2.PredictMaterialsC.apply(drv, names[:40], gv, P, x, *eff[:40])
+        mat = S2.MaterialHeadC.apply(raw)
+        rand_d = rand_s = None
+        if scfg['random_azimuth']:
+            rand_d = rands['rand_d'] if rands.get('rand_d') is not None else torch.rand(P, 1, 1, device=dev)
+            rand_s = rands['rand_s'] if rands.get('rand_s') is not None else torch.rand(P, 1, 1, device=dev)
+        rgb_lin, dl, _sl, _sp = S2.MCShadeC.apply(drv, net.ray_tracer, names[40:], gv, pts, view, nrm, mat[:P], rand_d, rand_s, hp, *eff[40:])
+        terms, rgb_pr = S2.MaterialLossC.apply(S2.loss_cfg(cfg, scfg, step, self.world), P, mat, rgb_lin, dl, gt)
+        loss = terms[0]
+        loss.backward()
+        m = mat.detach()
+        return {'loss': loss.detach(), 'loss_terms': terms.detach(),
+                'out': {'rgb_pr': rgb_pr, 'rgb_gt': gt, 'metallic': m[:P, 0:1], 'roughness': m[:P, 1:2], 'albedo': m[:P, 2:5]}}
 
     def step(self, step):
         lr = material_lr(step)

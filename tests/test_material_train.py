@@ -65,6 +65,64 @@ def test_fused_material_step_matches_the_torch_path():
     assert n == 96                                                  # every tensor of the bear material model
 
 
+BELL_SCFG = dict(diffuse_sample_num=64, specular_sample_num=32, human_lights=False, outer_light_version='direction', geometry_type='ggx_smith')
+
+
+@pytest.mark.parametrize('step', [5000, 500], ids=['step5000', 'step500_hinge'])
+@pytest.mark.parametrize('kind', ['bear', 'bell_smith', 'bell_l1_constant'])
+def test_hip_loss_glue_matches_the_tensor_glue(kind, step):
+    """nero_amd/csrc/mat_loss.hip (perturbed points, sigmoid heads, loss_rgb + loss_mat_reg + loss_diffuse_light and their gradients as five launches)
+    against the tensor-op glue of NeROMaterialRenderer.shade_train, which the oracle tests pin: same pool, same random draws, same
+    C-level shading calls.  Loss and colours to 1e-6; every gradient tensor to 1e-5 of its own maximum.  The heads must reproduce the
+    tensor ops BIT FOR BIT: one ulp of roughness (a contracted fma in the affine map) moves the specular sample directions and with them
+    the light-MLP gradients by 1e-3 of their maximum -- which is how the first version of the kernel failed this test."""
+    from nero_amd.train import MaterialTrainStep
+    cfg = {'shader_cfg': SCFG if kind == 'bear' else BELL_SCFG, 'database_name': 'real/bear'}
+    if kind == 'bell_l1_constant':
+        cfg = {'shader_cfg': {**BELL_SCFG, 'change_type': 'constant', 'change_eps': 0.03}, 'database_name': 'syn/bell', 'rgb_loss': 'l1'}
+    Pn = 192
+    res = {}
+    for glue in (False, True):
+        ts = MaterialTrainStep(cfg, _mesh(), points_per_rank=Pn, pool_points=4 * Pn, device='cuda:0', fused_glue=glue)
+        assert ts.drv is not None
+        info = ts.forward_backward(step, _rands(Pn, 0, Pn, 'cuda:0'))
+        torch.cuda.synchronize()
+        res[glue] = (float(info['loss']), info['out']['rgb_pr'].detach().clone(), info['out']['roughness'].detach().clone(), ts.bucket.flat.clone(), ts)
+        if glue:
+            terms = info['loss_terms'].cpu()
+            assert abs(float(terms[1] + terms[2] + terms[3]) - float(terms[0])) < 1e-6
+    (lt, rt, qt, ft, ts), (lh, rh, qh, fh, _) = res[False], res[True]
+    assert abs(lt - lh) <= 2e-6 * max(1.0, abs(lt)), (lt, lh)
+    assert float((rt - rh).abs().max()) < 1e-6 and float((qt - qh).abs().max()) < 1e-6
+    off, worst, n = 0, 0.0, 0
+    for p in ts.bucket.params:
+        a, b = fh[off:off + p.numel()], ft[off:off + p.numel()]
+        off += p.numel()
+        scale = float(b.abs().max())
+        if scale < 1e-12:
+            assert float(a.abs().max()) < 1e-12
+            continue
+        worst = max(worst, float((a - b).abs().max()) / scale)
+        n += 1
+    assert n >= 50 and worst < 1e-5, (n, worst)
+
+
+def test_hip_reg_points_match_the_tensor_glue():
+    from nero_amd import stage2 as S2
+    from nero_amd.renderer import NeROMaterialRenderer
+    net = NeROMaterialRenderer({'shader_cfg': BELL_SCFG, 'database_name': 'syn/bell'}, mesh=_mesh()).cuda()
+    g = torch.Generator().manual_seed(3)
+    n = 1000
+    pts = (torch.rand(n, 3, generator=g) - 0.5).cuda()
+    nrm = torch.randn(n, 3, generator=g).cuda()
+    nrm[:3] = torch.tensor([[0.0, 0.0, 1.0], [1.0, 0.0, 0.0], [0.0, -2.0, 0.0]]).cuda()            # axis-aligned normals: both frame branches
+    ang, eps = torch.rand(n, 1, generator=g).cuda(), (torch.randn(n, 1, generator=g) * 0.05).cuda()
+    want = net.regularization_points(pts, nrm, ang, eps)
+    got = S2.reg_points(pts, nrm, ang, eps)
+    assert torch.equal(got[:n], pts)
+    assert float((got[n:] - want).abs().max()) < 2e-7
+
+
 def _rank(rank, world, port, ret, step):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
