@@ -501,9 +501,16 @@ size_t nero_stage1_workspace_bytes(nero_stage1* h, int R) {
     if (!h) return 0;
     const nero_stage1_cfg& c = h->cfg;
     const int T = c.n_samples + c.n_importance + c.n_bg_samples;
-    // worst cases of the data-dependent split: every sample inner (the expensive kind) / every sample outer
-    const size_t a = nero_stage1_workspace_bytes_for(h, R, R * T, 0, 1), b = nero_stage1_workspace_bytes_for(h, R, 0, R * T, 1);
-    return a > b ? a : b;
+    // worst cases of the data-dependent split: every sample inner (the expensive kind) / every sample outer, and one sample short of
+    // either end (both partitions padded to whole 64-row tiles: the carve is linear in the PADDED row counts)
+    const int N = R * T;
+    const int inner[4] = {N, 0, N > 1 ? N - 1 : N, N > 1 ? 1 : 0};
+    size_t worst = 0;
+    for (int k = 0; k < 4; ++k) {
+        const size_t b = nero_stage1_workspace_bytes_for(h, R, inner[k], N - inner[k], 1);
+        worst = b > worst ? b : worst;
+    }
+    return worst + 65536;
 }
 
 int nero_stage1_sample(nero_stage1* h, int R, const float* o, const float* d, const float* near, const float* far, const float* variance,

@@ -274,12 +274,15 @@ int nero_stage2_pack(nero_stage2* h, const nero_stage2_weights* w, void* pack_bu
     return NERO_OK;
 }
 
-// worst case over the hit / miss split of the P * D light rays (all miss / all hit), for n_pred rows through predict_materials
+// worst case over the hit / miss split of the P * D light rays, for n_pred rows through predict_materials.  The carve is linear in the
+// two partitions' row counts AFTER each is padded to whole 64-row tiles, so the maximum sits at an end of the split (all miss / all hit)
+// or one ray short of it (N - 1 / 1: both partitions padded -- what decides for a handful of points; tests/test_edge_cases.py).
 size_t nero_stage2_workspace_bytes(nero_stage2* h, int n_pred, int P) {
     if (!h || n_pred < 0 || P < 0) return 0;
     const int N = P * (h->cfg.diffuse_sample_num + h->cfg.specular_sample_num);
     size_t worst = 0;
-    for (int all_hit = 0; all_hit < 2; ++all_hit) {
+    const int hits[4] = {0, N, N > 1 ? 1 : 0, N > 1 ? N - 1 : N};
+    for (int k = 0; k < 4; ++k) {
         nero_stage2 tmp = *h;
         Arena& A = tmp.A;
         A = Arena();
@@ -291,7 +294,7 @@ size_t nero_stage2_workspace_bytes(nero_stage2* h, int n_pred, int P) {
         tmp.pt = A.f32((size_t)P * 32);
         tmp.slot = A.i32(N); tmp.miss_idx = A.i32(N); tmp.hit_idx = A.i32(N); tmp.counts = A.i32(2);
         (void)A.i32(nero_mc_split_tmp_ints(N));
-        tmp.n_miss = all_hit ? 0 : N; tmp.n_hit = all_hit ? N : 0;
+        tmp.n_hit = hits[k]; tmp.n_miss = N - hits[k];
         (void)do_shade_lights(&tmp, A, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
         const size_t mk = A.mark();
         (void)do_shade_bwd(&tmp, A, nullptr, nullptr, &G, nullptr, nullptr);
@@ -299,7 +302,7 @@ size_t nero_stage2_workspace_bytes(nero_stage2* h, int n_pred, int P) {
         (void)do_predict_bwd(&tmp, A, nullptr, &G, nullptr);
         worst = A.peak > worst ? A.peak : worst;
     }
-    return worst + 4096;
+    return worst + 65536;
 }
 
 int nero_stage2_predict_fwd(nero_stage2* h, const float* x, int n, float* raw5, void* ws, size_t ws_bytes, void* stream) {

@@ -73,15 +73,17 @@ CFG = {'n_samples': 16, 'n_importance': 16, 'n_bg_samples': 8, 'freeze_inv_s_ste
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('kind', ['bell', 'bear'])
-def test_c_driven_step_equals_python_driven_step_bit_for_bit(kind, monkeypatch):
+@pytest.mark.parametrize('kind,rays', [('bell', 256), ('bear', 256), ('bell', 3), ('bell', 65), ('bear', 33)],
+                         ids=['bell', 'bear', 'bell_3_rays', 'bell_65_rays', 'bear_33_rays'])
+def test_c_driven_step_equals_python_driven_step_bit_for_bit(kind, rays, monkeypatch):
+    """(the ragged ray counts: partial ray blocks and tiles, and a workspace query that has to cover BOTH padded partitions)"""
     from nero_amd.train import ShapeTrainStep
     cfg = dict(CFG) if kind == 'bell' else {**CFG, 'shader_config': {'human_light': True}}
     res = {}
     for drv in ('py', 'c'):
         monkeypatch.setenv('NERO_STEP_DRIVER', drv)
         torch.manual_seed(0)
-        ts = ShapeTrainStep(cfg, rays_per_rank=256, pool_rays=1024, device='cuda:0', variance=0.4, prime_fraction=0.0, prime_passes=0)
+        ts = ShapeTrainStep(cfg, rays_per_rank=rays, pool_rays=1024, device='cuda:0', variance=0.4, prime_fraction=0.0, prime_passes=0)
         assert (ts.drv is not None) == (drv == 'c')
         torch.manual_seed(123)                                     # the perturbation draws of the sampler / the occlusion-loss keys
         info = ts.forward_backward(25000)
