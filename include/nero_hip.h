@@ -189,6 +189,12 @@ typedef struct {
 
 int nero_dw_workspace_floats(int n_rows);
 int nero_dw_gemm(const nero_dw_job* job /*host*/, int n_rows, float* partials, void* stream);
+/* The weight gradients of SEVERAL jobs over the same n_rows rows (all layers of one MLP chain).  Same results as n_jobs calls of
+ * nero_dw_gemm up to the order of the row-slice sums: below 131072 rows the fp16 engine runs the jobs as ONE launch per kernel kind
+ * (grid.y = job, ~1024 row slices over all jobs instead of 256 per job) plus one batched reduction -- a chain of the reference's own
+ * train_ray_num = 512 batch, or the 2 P rows of the Stage-II material MLPs, otherwise pays 2 launches and 256 partial matrices per
+ * layer for ~40 k rows.  At or above that row count, and for the other engines, it IS the per-job loop.  partials: as nero_dw_gemm. */
+int nero_dw_gemm_batch(const nero_dw_job* jobs /*host*/, int n_jobs, int n_rows, float* partials, void* stream);
 
 /* Head weight gradient: dWh[j][k] = sum_r dy[r][j] a[r][k] (+ extra[r][k] for j == 0 if extra != NULL), dbh[j] = sum_r dy[r][j]. */
 int nero_head_dw(const float* dy /*[rows,4]*/, const float* a /*[rows,256]*/, const float* extra, int n_head, int n_rows,

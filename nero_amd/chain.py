@@ -354,6 +354,7 @@ class Chain:
         st = L.stream_ptr()
         out = []
         prev = None
+        jobs = []                      # every dense layer's job(s): issued together at the end (nero_dw_gemm_batch)
         for i, (d, h) in enumerate(self.entries):
             g = {}
             if h is not None and i in head_dys:
@@ -392,8 +393,11 @@ class Chain:
                     job.db = db.data_ptr() if pi == 0 else None
                     job.scale, job.accumulate = d.scale, 0
                     job.gemm_mode = GEMM_MODE['dw']
-                    L.check(L.lib.nero_dw_gemm(C.byref(job), n_rows, C.c_void_p(workspace.data_ptr()), st))
+                    jobs.append(job)
                 g['dW'], g['db'] = dW, db
                 prev = i
             out.append(g)
+        if jobs:
+            arr = (L.DwJob * len(jobs))(*jobs)
+            L.check(L.lib.nero_dw_gemm_batch(arr, len(jobs), n_rows, C.c_void_p(workspace.data_ptr()), st))
         return out

@@ -275,6 +275,7 @@ struct Chain {
                      int ld_aux, const float* const* head_dys, const Second* second /*[MAXL] or NULL*/, const float* const* head_extra,
                      float* partials, void* stream) const {
         int prev = -1;
+        std::vector<nero_dw_job> dw_jobs;           // every dense layer's job(s) of this chain: issued together at the end (nero_dw_gemm_batch)
         for (int i = 0; i < n(); ++i) {
             const Entry& x = e[i];
             if (x.h.has && head_dys && head_dys[i] && x.h.dW) {
@@ -312,12 +313,13 @@ struct Chain {
                         job.dW = d.dW; job.ldw = d.ld_dw; job.col0 = parts[pi].c0;
                         job.db = pi == 0 ? d.db : nullptr;
                         job.scale = d.scale; job.accumulate = 0; job.gemm_mode = M.dw;
-                        LAUNCH(nero_dw_gemm(&job, n_rows, partials, stream));
+                        dw_jobs.push_back(job);
                     }
                 }
                 prev = i;
             }
         }
+        if (!dw_jobs.empty()) LAUNCH(nero_dw_gemm_batch(dw_jobs.data(), (int)dw_jobs.size(), n_rows, partials, stream));
         return NERO_OK;
     }
 };

@@ -643,7 +643,7 @@ __global__ __launch_bounds__(512, 2) void dw_gemm_kernel(nero_dw_job job, int n_
 
 // partial reduction: block = 64 outputs x 4 slice groups (fixed order inside a group, groups combined in fixed order ->
 // deterministic), so ~1000 workgroups keep enough loads in flight to run at HBM speed
-__global__ __launch_bounds__(256) void dw_reduce_kernel(nero_dw_job job, const float* __restrict__ partials, int n_slices, int n_pad, int k_pad) {
+__device__ __forceinline__ void dw_reduce_body(const nero_dw_job& job, const float* __restrict__ partials, int n_slices, int n_pad, int k_pad) {
     __shared__ float red[4][64];
     const size_t per = (size_t)n_pad * k_pad + n_pad;
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -679,6 +679,15 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(nero_dw_job job, const f
             job.db[n] = job.accumulate ? job.db[n] + t : t;
         }
     }
+}
+__global__ __launch_bounds__(256) void dw_reduce_kernel(nero_dw_job job, const float* __restrict__ partials, int n_slices, int n_pad, int k_pad) {
+    dw_reduce_body(job, partials, n_slices, n_pad, k_pad);
+}
+// blockIdx.y = job of a batch (nero_dw_gemm_batch); the grid is sized for the largest job, the others' surplus blocks fall through
+__global__ __launch_bounds__(256) void dw_reduce_batch_kernel(nero_dw_batch B, const float* __restrict__ partials, int n_slices) {
+    const int q = blockIdx.y;
+    if ((int)blockIdx.x * 64 >= B.j[q].n_out * B.j[q].k_cols + B.j[q].n_out) return;
+    dw_reduce_body(B.j[q], partials + B.poff[q], n_slices, B.n_pad[q], B.k_pad[q]);
 }
 
 // head weight gradient: dWh[j][k] = sum_r dy[r][j] a[r][k] (+ extra[r][k] for j == 0).  Thread t owns columns 4(t&63)..+3 and the
@@ -770,6 +779,8 @@ __global__ void pack_weight_kernel(const float* __restrict__ W, int nrows, int l
 }
 
 constexpr int DW_MAX_SLICES = 256;          // one row slice per CU
+constexpr int DW_BATCH_SLICES = 1024 + NERO_DW_BATCH_MAX;     // upper bound of slices x jobs of one batched launch (>= DW_MAX_SLICES)
+constexpr int DW_BATCH_ROWS = 131072;                          // batch only below this row count: above it a job alone fills the chip
 
 inline int dw_rows_per_slice(int n_rows) {
     int rps = (n_rows + DW_MAX_SLICES - 1) / DW_MAX_SLICES;
@@ -875,7 +886,8 @@ int nero_dw_workspace_floats(int n_rows) {
     // DW_MAX_SLICES partial matrices for nero_dw_gemm, one 4x256(+4) partial per 128-row block for nero_head_dw.
     const int rows = n_rows < 1 ? 1 : n_rows;
     const int head_blocks = (rows + 127) / 128;
-    const int a = DW_MAX_SLICES * (256 * 256 + 256), b = head_blocks * (4 * NERO_HID + 4);
+    // (DW_BATCH_SLICES: the slices of one batched launch over all its jobs, nero_dw_gemm_batch)
+    const int a = DW_BATCH_SLICES * (256 * 256 + 256), b = head_blocks * (4 * NERO_HID + 4);
     return a > b ? a : b;
 }
 
@@ -902,6 +914,64 @@ int nero_dw_gemm(const nero_dw_job* job, int n_rows, float* partials, void* stre
     const int total = job->n_out * job->k_cols + job->n_out;
     hipLaunchKernelGGL(dw_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, (hipStream_t)stream, *job, partials, slices, n_pad, k_pad);
     return nero_check_launch("nero_dw_gemm");
+}
+
+int nero_dw_gemm_batch(const nero_dw_job* jobs, int n_jobs, int n_rows, float* partials, void* stream) {
+    if (n_jobs < 0 || (n_jobs > 0 && !jobs) || !partials) return nero_fail(NERO_ERR_ARG, "nero_dw_gemm_batch: bad argument");
+    const int rows = n_rows < 1 ? 1 : n_rows;
+    bool f16 = true;
+    for (int i = 0; i < n_jobs; ++i) {
+        const nero_dw_job& J = jobs[i];
+        if (!J.d0 || !J.b0 || !J.dW || J.n_out > 256 || J.k_cols > 256 || J.n_out <= 0 || J.k_cols <= 0)
+            return nero_fail(NERO_ERR_ARG, "nero_dw_gemm_batch: bad job");
+        f16 = f16 && (J.gemm_mode == NERO_GEMM_F16X3 || J.gemm_mode == NERO_GEMM_F16X3P);
+    }
+    if (!f16 || rows >= DW_BATCH_ROWS || n_jobs < 2) {               // the per-job path: one launch (+ reduction) per job
+        for (int i = 0; i < n_jobs; ++i) {
+            const int rc = nero_dw_gemm(jobs + i, n_rows, partials, stream);
+            if (rc != NERO_OK) return rc;
+        }
+        return NERO_OK;
+    }
+    // narrow (k_pad <= 128) and wide jobs are different kernels; inside a kind, groups of NERO_DW_BATCH_MAX in the caller's order.
+    // The partial buffer is reused from group to group (stream order).
+    for (int narrow = 0; narrow < 2; ++narrow) {
+        int idx[256], n = 0;
+        for (int i = 0; i < n_jobs && n < 256; ++i)
+            if ((((jobs[i].k_cols + 31) / 32 * 32) <= 128) == (narrow != 0)) idx[n++] = i;
+        for (int g0 = 0; g0 < n; g0 += NERO_DW_BATCH_MAX) {
+            const int ng = n - g0 < NERO_DW_BATCH_MAX ? n - g0 : NERO_DW_BATCH_MAX;
+            // ~1024 slices over the group's jobs, at least 128 rows (8 chunks) per slice, at most one slice per CU and job
+            int target = 1024 / ng;
+            target = target < 16 ? 16 : (target > DW_MAX_SLICES ? DW_MAX_SLICES : target);
+            int rps = (rows + target - 1) / target;
+            rps = (rps + 15) / 16 * 16;
+            rps = rps < 128 ? 128 : rps;
+            const int slices = (rows + rps - 1) / rps;
+            nero_dw_batch B;
+            memset(&B, 0, sizeof(B));
+            size_t off = 0;
+            double flops = 0.0;
+            int max_total = 0;
+            for (int k = 0; k < ng; ++k) {
+                const nero_dw_job& J = jobs[idx[g0 + k]];
+                B.j[k] = J;
+                B.n_pad[k] = (short)((J.n_out + 31) / 32 * 32);
+                B.k_pad[k] = (short)((J.k_cols + 31) / 32 * 32);
+                B.poff[k] = off;
+                off += (size_t)slices * ((size_t)B.n_pad[k] * B.k_pad[k] + B.n_pad[k]);
+                flops += 2.0 * J.n_out * J.k_cols * (J.d1 ? 2.0 : 1.0) * n_rows;
+                const int total = J.n_out * J.k_cols + J.n_out;
+                max_total = total > max_total ? total : max_total;
+            }
+            if (off > (size_t)DW_BATCH_SLICES * (256 * 256 + 256)) return nero_fail(NERO_ERR_ARG, "nero_dw_gemm_batch: partial buffer too small");
+            nero_prof_begin(NERO_K_DW, flops, (hipStream_t)stream);
+            nero_f16_dw_batch(&B, ng, narrow, n_rows, rps, slices, partials, (hipStream_t)stream);
+            nero_prof_end(NERO_K_DW, (hipStream_t)stream);
+            hipLaunchKernelGGL(dw_reduce_batch_kernel, dim3((max_total + 63) / 64, ng), dim3(256), 0, (hipStream_t)stream, B, partials, slices);
+        }
+    }
+    return nero_check_launch("nero_dw_gemm_batch");
 }
 
 int nero_head_dw(const float* dy, const float* a, const float* extra, int n_head, int n_rows, float* dWh, float* dbh,

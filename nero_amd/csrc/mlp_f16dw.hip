@@ -130,9 +130,10 @@ __device__ __forceinline__ void split_shift(int s, int& a, int& b) {
 // (Round 3, measured and dropped: TWO resident workgroups per CU for the narrow jobs -- 512 slices, __launch_bounds__(512, 4): 128 VGPRs with
 // 12 spilled -- to double the waves pulling the delta stream, which only the four D-staging waves of a workgroup do: every narrow job
 // got slower, 0.109 -> 0.132 ms (27-column job), 0.165 -> 0.226 ms (the SDF's 39-column jobs).)
+// The kernel body; `slice` = the row slice of this workgroup (blockIdx.x of both entry points below).
 template <bool NARROW>
-__global__ __launch_bounds__(512, 1) void dw_f16_kernel(nero_dw_job job, int n_rows, int rows_per_slice, float* __restrict__ partials,
-                                                        int n_pad, int k_pad) {
+__device__ __forceinline__ void dw_f16_body(const nero_dw_job& job, int n_rows, int rows_per_slice, float* __restrict__ partials,
+                                            int n_pad, int k_pad) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* smax = reinterpret_cast<float*>(smem + DWH_SMAX);         // [2 slots][8 waves]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -334,6 +335,20 @@ __global__ __launch_bounds__(512, 1) void dw_f16_kernel(nero_dw_job job, int n_r
     }
 }
 
+template <bool NARROW>
+__global__ __launch_bounds__(512, 1) void dw_f16_kernel(nero_dw_job job, int n_rows, int rows_per_slice, float* __restrict__ partials,
+                                                        int n_pad, int k_pad) {
+    dw_f16_body<NARROW>(job, n_rows, rows_per_slice, partials, n_pad, k_pad);
+}
+// Several jobs over the same rows in ONE launch: blockIdx.y = job.  For the launches of a few ten thousand rows (the reference's own
+// train_ray_num = 512, the 2 P rows of the Stage-II material MLPs) a job alone neither fills the chip nor amortises its 256 partial
+// matrices; batched, the host picks ~1024 slices over ALL jobs of a chain (nero_dw_gemm_batch).
+template <bool NARROW>
+__global__ __launch_bounds__(512, 1) void dw_f16_batch_kernel(nero_dw_batch B, int n_rows, int rows_per_slice, float* __restrict__ partials) {
+    const int q = blockIdx.y;
+    dw_f16_body<NARROW>(B.j[q], n_rows, rows_per_slice, partials + B.poff[q], B.n_pad[q], B.k_pad[q]);
+}
+
 }  // namespace
 
 #ifdef DW_PHASE_TIMING
@@ -351,5 +366,14 @@ int nero_f16_dw(const nero_dw_job* job, int n_rows, int rows_per_slice, int slic
         hipLaunchKernelGGL(dw_f16_kernel<true>, dim3(slices), dim3(512), DWH_LDS, stream, *job, n_rows, rows_per_slice, partials, n_pad, k_pad);
     else
         hipLaunchKernelGGL(dw_f16_kernel<false>, dim3(slices), dim3(512), DWH_LDS, stream, *job, n_rows, rows_per_slice, partials, n_pad, k_pad);
+    return NERO_OK;
+}
+int nero_f16_dw_batch(const nero_dw_batch* B, int n_jobs, int narrow, int n_rows, int rows_per_slice, int slices, float* partials, hipStream_t stream) {
+    NERO_ONCE(hipFuncSetAttribute((const void*)dw_f16_batch_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DWH_LDS));
+    NERO_ONCE(hipFuncSetAttribute((const void*)dw_f16_batch_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DWH_LDS));
+    if (narrow)
+        hipLaunchKernelGGL(dw_f16_batch_kernel<true>, dim3(slices, n_jobs), dim3(512), DWH_LDS, stream, *B, n_rows, rows_per_slice, partials);
+    else
+        hipLaunchKernelGGL(dw_f16_batch_kernel<false>, dim3(slices, n_jobs), dim3(512), DWH_LDS, stream, *B, n_rows, rows_per_slice, partials);
     return NERO_OK;
 }

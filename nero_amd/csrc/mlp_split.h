@@ -19,6 +19,14 @@ int nero_f16_tangent(const nero_tan_chain* ch, int n_rows, hipStream_t stream);
 int nero_f16_backward(const nero_bwd_chain* ch, int n_rows, hipStream_t stream);
 int nero_f16_dw(const nero_dw_job* job, int n_rows, int rows_per_slice, int slices, float* partials, int n_pad, int k_pad,
                 hipStream_t stream);                                                    // mlp_f16dw.hip
+// several weight-gradient jobs over the SAME rows in one launch (grid.y = job): kernel argument of dw_f16_batch_kernel / dw_reduce_batch_kernel
+#define NERO_DW_BATCH_MAX 12
+struct nero_dw_batch {
+    nero_dw_job j[NERO_DW_BATCH_MAX];
+    unsigned long long poff[NERO_DW_BATCH_MAX];      // float offset of the job's partial matrices inside `partials`
+    short n_pad[NERO_DW_BATCH_MAX], k_pad[NERO_DW_BATCH_MAX];
+};
+int nero_f16_dw_batch(const nero_dw_batch* B, int n_jobs, int narrow, int n_rows, int rows_per_slice, int slices, float* partials, hipStream_t stream);
 // fp16 two-plane engine, two workgroups per CU (mlp_f16p.hip)
 int nero_f16p_forward(const nero_fwd_chain* ch, int n_rows, hipStream_t stream);
 int nero_f16p_tangent(const nero_tan_chain* ch, int n_rows, hipStream_t stream);

@@ -122,3 +122,53 @@ def test_fp16_weight_gradient_gemm_ragged_shapes_and_two_pairs(n_out, k):
     dW, db = _dw(L.GEMM_F16X3, D, B, n, D1, B1, n_out=n_out, k=k)
     assert _rel(dW, ref) < 2e-6
     assert _rel(db, D[:, :n_out].double().sum(0)) < 2e-6
+
+
+@pytest.mark.parametrize('n', [1, 700, 33333, 131071, 140000])
+def test_batched_weight_gradient_jobs_vs_fp64(n):
+    """nero_dw_gemm_batch: fourteen jobs over the same rows (wide, narrow, ragged widths, a two-pair job, two column parts of one matrix,
+    one job without a bias) -- one launch per kernel kind below 131072 rows, the per-job loop at and above -- each against fp64"""
+    from nero_amd import _lib as L
+    g = torch.Generator(device='cuda').manual_seed(7)
+    rn = lambda *s: torch.randn(*s, device='cuda', generator=g)
+    D = [rn(n, 256) * torch.exp(rn(n, 1) * 2.0) for _ in range(4)]
+    B = [rn(n, 256) for _ in range(3)] + [torch.relu(rn(n, 256))]
+    shapes = [(256, 256), (256, 256), (217, 256), (256, 39), (3, 256), (256, 96), (256, 48), (256, 256), (256, 128), (64, 64), (256, 256),
+              (256, 200), (1, 1)]
+    ws = torch.empty(L.lib.nero_dw_workspace_floats(n), dtype=torch.float32, device='cuda')
+    jobs, want, outs = [], [], []
+    for i, (n_out, k) in enumerate(shapes):
+        Di, Bi = D[i % 4], B[(i + 1) % 4]
+        dW, db = torch.full((n_out, k), float('nan'), device='cuda'), torch.full((n_out,), float('nan'), device='cuda')
+        job = L.DwJob()
+        job.d0, job.ldd0, job.b0, job.ldb0 = Di.data_ptr(), Di.stride(0), Bi.data_ptr(), Bi.stride(0)
+        ref = Di[:, :n_out].double().t() @ Bi[:, :k].double()
+        if i == 7:                                           # the SDF's double-backward jobs carry a second operand pair
+            job.d1, job.ldd1, job.b1, job.ldb1 = D[3].data_ptr(), D[3].stride(0), B[0].data_ptr(), B[0].stride(0)
+            ref = ref + D[3][:, :n_out].double().t() @ B[0][:, :k].double()
+        job.n_out, job.k_cols, job.dW, job.ldw, job.col0 = n_out, k, dW.data_ptr(), dW.stride(0), 0
+        job.db = db.data_ptr() if i != 5 else None
+        job.scale, job.accumulate, job.gemm_mode = (0.5 if i == 2 else 1.0), 0, L.GEMM_F16X3
+        jobs.append(job)
+        want.append((ref * (0.5 if i == 2 else 1.0), Di[:, :n_out].double().sum(0) if i != 5 else None))
+        outs.append((dW, db))
+    # two column parts of one [256, 295] matrix (a skip layer: main + aux operands)
+    Wsk, bsk = torch.full((256, 295), float('nan'), device='cuda'), torch.full((256,), float('nan'), device='cuda')
+    for c0, k, Bi, has_b in ((0, 256, B[2], True), (256, 39, B[3], False)):
+        job = L.DwJob()
+        job.d0, job.ldd0, job.b0, job.ldb0 = D[1].data_ptr(), D[1].stride(0), Bi.data_ptr(), Bi.stride(0)
+        job.n_out, job.k_cols, job.dW, job.ldw, job.col0 = 256, k, Wsk.data_ptr(), Wsk.stride(0), c0
+        job.db = bsk.data_ptr() if has_b else None
+        job.scale, job.accumulate, job.gemm_mode = 1.0, 0, L.GEMM_F16X3
+        jobs.append(job)
+    arr = (L.DwJob * len(jobs))(*jobs)
+    L.check(L.lib.nero_dw_gemm_batch(arr, len(jobs), n, C.c_void_p(ws.data_ptr()), L.stream_ptr()))
+    torch.cuda.synchronize()
+    for i, ((dW, db), (ref, refb)) in enumerate(zip(outs, want)):
+        assert _rel(dW, ref) < 2e-6, (i, shapes[i], _rel(dW, ref))
+        if refb is not None:
+            assert _rel(db, refb) < 2e-6, (i, shapes[i])
+        else:
+            assert bool(torch.isnan(db).all())                # no bias destination: untouched
+    ref_sk = torch.cat([D[1].double().t() @ B[2].double(), D[1].double().t() @ B[3][:, :39].double()], 1)
+    assert _rel(Wsk, ref_sk) < 2e-6 and _rel(bsk, D[1].double().sum(0)) < 2e-6
