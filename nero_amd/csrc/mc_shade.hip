@@ -12,14 +12,11 @@
 #include <math.h>
 #include "../../include/nero_hip.h"
 #include "common.h"
+#include "ide.h"                                     // IDE_N, the compile-time coefficient table, ide_forward / ide_backward
 
 // IDE helpers live in shade.hip's translation unit; re-declare the small pieces needed here (same formulas, own TU).
 namespace {
 
-constexpr int IDE_N = 36;
-__constant__ float m_ide_mat[17 * IDE_N];
-__constant__ int m_ide_m[IDE_N];
-__constant__ int m_ide_l[IDE_N];
 
 double fact(int n) { double r = 1.0; for (int i = 2; i <= n; ++i) r *= i; return r; }
 double gen_binom(double a, int k) { double p = 1.0; for (int i = 0; i < k; ++i) p *= (a - i); return p / fact(k); }
@@ -31,62 +28,20 @@ int init_tables() {
     static bool done = false;
     if (done) return 0;
     float mat[17 * IDE_N];
-    int ms[IDE_N], ls[IDE_N];
     for (int i = 0; i < 17 * IDE_N; ++i) mat[i] = 0.f;
     int i = 0;
     for (int e = 0; e < 5; ++e) {
         const int l = 1 << e;
         for (int m = 0; m <= l; ++m, ++i) {
-            ms[i] = m; ls[i] = l;
             for (int k = 0; k <= l - m; ++k) mat[k * IDE_N + i] = (float)sph_coeff(l, m, k);
         }
     }
-    if (hipMemcpyToSymbol(HIP_SYMBOL(m_ide_mat), mat, sizeof(mat)) != hipSuccess) return -1;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(m_ide_m), ms, sizeof(ms)) != hipSuccess) return -1;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(m_ide_l), ls, sizeof(ls)) != hipSuccess) return -1;
+    if (!ide_tab_equals(mat)) return -1;               // the compile-time table of ide.h must be this libm one, bit for bit
     done = true;
     return 0;
 }
 
-// IDE with kappa_inv = 0 (no attenuation): out[0..36) Re, [36..72) Im
-__device__ void ide0_forward(float x, float y, float z, float* __restrict__ out) {
-    float zp[17], re[17], im[17];
-    zp[0] = 1.f; re[0] = 1.f; im[0] = 0.f;
-    for (int k = 1; k <= 16; ++k) { zp[k] = zp[k - 1] * z; re[k] = re[k - 1] * x - im[k - 1] * y; im[k] = re[k - 1] * y + im[k - 1] * x; }
-    for (int i = 0; i < IDE_N; ++i) {
-        const int m = m_ide_m[i], l = m_ide_l[i];
-        float poly = 0.f;
-        for (int k = 0; k <= l - m; ++k) poly = fmaf(zp[k], m_ide_mat[k * IDE_N + i], poly);
-        out[i] = re[m] * poly;
-        out[IDE_N + i] = im[m] * poly;
-    }
-}
-__device__ void ide0_backward(float x, float y, float z, const float* __restrict__ g, float& dx, float& dy, float& dz) {
-    float zp[17], re[17], im[17], dre[17], dim_[17];
-    zp[0] = 1.f; re[0] = 1.f; im[0] = 0.f;
-    for (int k = 1; k <= 16; ++k) { zp[k] = zp[k - 1] * z; re[k] = re[k - 1] * x - im[k - 1] * y; im[k] = re[k - 1] * y + im[k - 1] * x; }
-    for (int k = 0; k <= 16; ++k) { dre[k] = 0.f; dim_[k] = 0.f; }
-    float gz = 0.f;
-    for (int i = 0; i < IDE_N; ++i) {
-        const int m = m_ide_m[i], l = m_ide_l[i];
-        float poly = 0.f, dpoly = 0.f;
-        for (int k = 0; k <= l - m; ++k) {
-            const float c = m_ide_mat[k * IDE_N + i];
-            poly = fmaf(zp[k], c, poly);
-            if (k > 0) dpoly = fmaf((float)k * zp[k - 1], c, dpoly);
-        }
-        gz += (g[i] * re[m] + g[IDE_N + i] * im[m]) * dpoly;
-        dre[m] += g[i] * poly;
-        dim_[m] += g[IDE_N + i] * poly;
-    }
-    float gx = 0.f, gy = 0.f;
-    for (int m = 1; m <= 16; ++m) {
-        gx += (float)m * (dre[m] * re[m - 1] + dim_[m] * im[m - 1]);
-        gy += (float)m * (-dre[m] * im[m - 1] + dim_[m] * re[m - 1]);
-    }
-    dx += gx; dy += gy; dz += gz;
-}
-
+// IDE with kappa_inv = 0 (no attenuation): ide_forward<false> / ide_backward<false> of ide.h
 __device__ __forceinline__ float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 __device__ __forceinline__ void norm3(const float* a, float* o) {
     const float n = fmaxf(sqrtf(dot3(a, a)), 1e-12f);
@@ -190,11 +145,11 @@ __global__ void mc_encode_miss_kernel(const float* __restrict__ dirs, const int*
     const int row = idx[k];
     const float* w = dirs + (size_t)row * 3;
     float e[72];
-    ide0_forward(w[0], w[1], w[2], e);
+    ide_forward<false>(w[0], w[1], w[2], 0.f, e);
     for (int c = 0; c < 72; ++c) o[c] = e[c];
     if (sphere) {
         const SphereExit se = sphere_exit(pt + (size_t)(row / D) * 32 + 29, w);
-        ide0_forward(se.sph[0], se.sph[1], se.sph[2], e);
+        ide_forward<false>(se.sph[0], se.sph[1], se.sph[2], 0.f, e);
         for (int c = 0; c < 72; ++c) o[72 + c] = e[c];
     }
 }
@@ -265,7 +220,7 @@ __global__ void mc_encode_hit_kernel(const float* __restrict__ dirs, const float
     }
     float nh[3], vv[3], refl[3], e[72];
     hit_reflection(dirs + (size_t)row * 3, fnrm + (size_t)row * 3, nh, vv, refl);
-    ide0_forward(refl[0], refl[1], refl[2], e);
+    ide_forward<false>(refl[0], refl[1], refl[2], 0.f, e);
     for (int c = 0; c < 72; ++c) o[51 + c] = e[c];
     for (int c = 123; c < 128; ++c) o[c] = 0.f;
 }
@@ -515,17 +470,16 @@ __global__ __launch_bounds__(64) void mc_dir_bwd_kernel(const float* __restrict_
         const float w[3] = {dirs[row * 3], dirs[row * 3 + 1], dirs[row * 3 + 2]};
         float dw[3] = {d_wspec[((size_t)p * Ds + js) * 3], d_wspec[((size_t)p * Ds + js) * 3 + 1], d_wspec[((size_t)p * Ds + js) * 3 + 2]};
         const int s = slot[row];
-        float g[72];
+        float dk_unused = 0.f;
         if (s >= 0) {
             const int ldm = sphere ? 144 : 72;
-            for (int c = 0; c < 72; ++c) g[c] = dX_miss[(size_t)s * ldm + c];
-            ide0_backward(w[0], w[1], w[2], g, dw[0], dw[1], dw[2]);
+            const float* gm = dX_miss + (size_t)s * ldm;
+            ide_backward<false>(w[0], w[1], w[2], 0.f, [&](int c) { return gm[c]; }, dw[0], dw[1], dw[2], dk_unused);
             if (sphere) {
                 // sph = p' + w dist(w), dist = -<p',w> + sqrt(<p',w>^2 - |p'|^2 + 1 + 1e-6)
                 const SphereExit se = sphere_exit(q + 29, w);
-                for (int c = 0; c < 72; ++c) g[c] = dX_miss[(size_t)s * ldm + 72 + c];
                 float ds[3] = {0.f, 0.f, 0.f};
-                ide0_backward(se.sph[0], se.sph[1], se.sph[2], g, ds[0], ds[1], ds[2]);
+                ide_backward<false>(se.sph[0], se.sph[1], se.sph[2], 0.f, [&](int c) { return gm[72 + c]; }, ds[0], ds[1], ds[2], dk_unused);
                 const float dd = dot3(ds, w) * (se.dtx / se.s - 1.f);
                 for (int c = 0; c < 3; ++c) dw[c] += se.dist * ds[c] + dd * se.pp[c];
             }
@@ -552,11 +506,11 @@ __global__ __launch_bounds__(64) void mc_dir_bwd_kernel(const float* __restrict_
             }
         } else {
             const int kk = -s - 1;
-            for (int c = 0; c < 72; ++c) g[c] = dX_hit[(size_t)kk * 128 + 51 + c];
+            const float* gh = dX_hit + (size_t)kk * 128 + 51;
             float nh[3], vv[3], refl[3];
             hit_reflection(w, fnrm + row * 3, nh, vv, refl);
             float drf[3] = {0.f, 0.f, 0.f};
-            ide0_backward(refl[0], refl[1], refl[2], g, drf[0], drf[1], drf[2]);
+            ide_backward<false>(refl[0], refl[1], refl[2], 0.f, [&](int c) { return gh[c]; }, drf[0], drf[1], drf[2], dk_unused);
             // refl = 2 (vv.n) n - vv ; vv = normalize(-w)
             const float dn = dot3(drf, nh);
             float dvv[3];
@@ -647,7 +601,7 @@ __global__ __launch_bounds__(256) void mc_split_scatter_kernel(const float* __re
 }  // namespace
 
 #define GRID1D(n) dim3(((n) + 127) / 128), dim3(128), 0, (hipStream_t)stream
-#define CHECK_T() do { if (init_tables() != 0) return nero_fail(NERO_ERR_LAUNCH, "IDE table upload failed"); } while (0)
+#define CHECK_T() do { if (init_tables() != 0) return nero_fail(NERO_ERR_LAUNCH, "IDE coefficient table of ide.h differs from the libm one"); } while (0)
 
 extern "C" {
 

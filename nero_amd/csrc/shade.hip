@@ -9,16 +9,14 @@
 #include <math.h>
 #include "../../include/nero_hip.h"
 #include "common.h"
+#include "ide.h"                                     // IDE_N, the compile-time coefficient table, ide_forward / ide_backward
 
 namespace {
 
 // ------------------------------------------------------------------------------------------------------------------
-// IDE tables (deg_view = 5): 36 (m,l) pairs, l in {1,2,4,8,16}, polynomial coefficients mat[k][i], k <= 16
+// IDE (deg_view = 5): 36 (m,l) pairs, l in {1,2,4,8,16}, polynomial coefficients mat[k][i], k <= 16.  The kernels use the
+// compile-time table of ide.h; this libm evaluation of utils/ref_utils.py:53-82 stays as its check (once per process).
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int IDE_N = 36;
-__constant__ float c_ide_mat[17 * IDE_N];
-__constant__ int c_ide_m[IDE_N];
-__constant__ int c_ide_l[IDE_N];
 
 double fact(int n) { double r = 1.0; for (int i = 2; i <= n; ++i) r *= i; return r; }
 double gen_binom(double a, int k) { double p = 1.0; for (int i = 0; i < k; ++i) p *= (a - i); return p / fact(k); }
@@ -33,87 +31,30 @@ int init_ide_tables() {
     static bool done = false;
     if (done) return 0;
     float mat[17 * IDE_N];
-    int ms[IDE_N], ls[IDE_N];
     for (int i = 0; i < 17 * IDE_N; ++i) mat[i] = 0.f;
     int i = 0;
     for (int e = 0; e < 5; ++e) {
         const int l = 1 << e;
         for (int m = 0; m <= l; ++m, ++i) {
-            ms[i] = m; ls[i] = l;
             for (int k = 0; k <= l - m; ++k) mat[k * IDE_N + i] = (float)sph_harm_coeff(l, m, k);
         }
     }
-    if (hipMemcpyToSymbol(HIP_SYMBOL(c_ide_mat), mat, sizeof(mat)) != hipSuccess) return -1;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(c_ide_m), ms, sizeof(ms)) != hipSuccess) return -1;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(c_ide_l), ls, sizeof(ls)) != hipSuccess) return -1;
+    if (!ide_tab_equals(mat)) return -1;               // the compile-time table of ide.h must be this libm one, bit for bit
     done = true;
     return 0;
 }
 
-// out[0..36) = Re, out[36..72) = Im of (x+iy)^m * P_i(z) * exp(-l(l+1)/2 * kinv)
-__device__ void ide_forward(float x, float y, float z, float kinv, float* __restrict__ out) {
-    float zp[17], re[17], im[17];
-    zp[0] = 1.f; re[0] = 1.f; im[0] = 0.f;
-    for (int k = 1; k <= 16; ++k) {
-        zp[k] = zp[k - 1] * z;
-        re[k] = re[k - 1] * x - im[k - 1] * y;
-        im[k] = re[k - 1] * y + im[k - 1] * x;
-    }
-    for (int i = 0; i < IDE_N; ++i) {
-        const int m = c_ide_m[i], l = c_ide_l[i];
-        float poly = 0.f;
-        for (int k = 0; k <= l - m; ++k) poly = fmaf(zp[k], c_ide_mat[k * IDE_N + i], poly);
-        const float att = expf(-0.5f * (float)(l * (l + 1)) * kinv);
-        out[i] = re[m] * poly * att;
-        out[IDE_N + i] = im[m] * poly * att;
-    }
-}
-
-// gradient of sum(g * ide(x,y,z,kinv)) w.r.t. (x,y,z,kinv); accumulates into dx,dy,dz,dk
-__device__ void ide_backward(float x, float y, float z, float kinv, const float* __restrict__ g, float& dx, float& dy, float& dz, float& dk) {
-    float zp[17], re[17], im[17], dre[17], dim_[17];
-    zp[0] = 1.f; re[0] = 1.f; im[0] = 0.f;
-    for (int k = 1; k <= 16; ++k) {
-        zp[k] = zp[k - 1] * z;
-        re[k] = re[k - 1] * x - im[k - 1] * y;
-        im[k] = re[k - 1] * y + im[k - 1] * x;
-    }
-    for (int k = 0; k <= 16; ++k) { dre[k] = 0.f; dim_[k] = 0.f; }
-    float gz = 0.f, gk = 0.f;
-    for (int i = 0; i < IDE_N; ++i) {
-        const int m = c_ide_m[i], l = c_ide_l[i];
-        float poly = 0.f, dpoly = 0.f;
-        for (int k = 0; k <= l - m; ++k) {
-            const float c = c_ide_mat[k * IDE_N + i];
-            poly = fmaf(zp[k], c, poly);
-            if (k > 0) dpoly = fmaf((float)k * zp[k - 1], c, dpoly);
-        }
-        const float sig = 0.5f * (float)(l * (l + 1));
-        const float att = expf(-sig * kinv);
-        const float gr = g[i], gi = g[IDE_N + i];
-        const float s = gr * re[m] + gi * im[m];
-        gz += s * att * dpoly;
-        gk += s * poly * (-sig * att);
-        dre[m] += gr * poly * att;
-        dim_[m] += gi * poly * att;
-    }
-    // w^m = re + i im:  d re_m/dx = m re_{m-1}, d im_m/dx = m im_{m-1}, d re_m/dy = -m im_{m-1}, d im_m/dy = m re_{m-1}
-    float gx = 0.f, gy = 0.f;
-    for (int m = 1; m <= 16; ++m) {
-        gx += (float)m * (dre[m] * re[m - 1] + dim_[m] * im[m - 1]);
-        gy += (float)m * (-dre[m] * im[m - 1] + dim_[m] * re[m - 1]);
-    }
-    dx += gx; dy += gy; dz += gz; dk += gk;
-}
-
-__device__ __forceinline__ void pe3(const float* p, int n_freq, float* out) {
+template <int N_FREQ>
+__device__ __forceinline__ void pe3(const float* p, float* out) {      // (unrolled: `out` stays in registers)
+#pragma unroll
     for (int c = 0; c < 3; ++c) out[c] = p[c];
     float f = 1.f;
-    int q = 3;
-    for (int k = 0; k < n_freq; ++k) {
-        for (int c = 0; c < 3; ++c) out[q + c] = sinf(p[c] * f);
-        for (int c = 0; c < 3; ++c) out[q + 3 + c] = cosf(p[c] * f);
-        q += 6;
+#pragma unroll
+    for (int k = 0; k < N_FREQ; ++k) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[3 + 6 * k + c] = sinf(p[c] * f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[3 + 6 * k + 3 + c] = cosf(p[c] * f);
         f *= 2.f;
     }
 }
@@ -296,26 +237,26 @@ __global__ __launch_bounds__(128) void shade_encode_kernel(const float* __restri
     for (int c = 0; c < 3; ++c) mo[2 + c] = sigmoid_f(a_raw[(size_t)k * 4 + c]);
     mo[5] = 0.f; mo[6] = 0.f; mo[7] = 0.f;
     float e[72];
-    ide_forward(q[0], q[1], q[2], 1.0f, e);
+    ide_forward<true>(q[0], q[1], q[2], 1.0f, e);
     for (int c = 0; c < 72; ++c) xd[c] = e[c];
-    ide_forward(q[4], q[5], q[6], r, e);
+    ide_forward<true>(q[4], q[5], q[6], r, e);
     for (int c = 0; c < 72; ++c) { xs[c] = e[c]; xi[51 + c] = e[c]; }
     float pe[51];
     const float p[3] = {x4[(size_t)k * 4], x4[(size_t)k * 4 + 1], x4[(size_t)k * 4 + 2]};
     if (sphere) {
         const float nv[3] = {q[0], q[1], q[2]}, rv[3] = {q[4], q[5], q[6]};
         const SphereDir sn = sphere_dir(p, nv);
-        ide_forward(sn.s[0], sn.s[1], sn.s[2], 1.0f, e);
+        ide_forward<true>(sn.s[0], sn.s[1], sn.s[2], 1.0f, e);
         for (int c = 0; c < 72; ++c) xd[72 + c] = e[c];
         const SphereDir sr = sphere_dir(p, rv);
-        ide_forward(sr.s[0], sr.s[1], sr.s[2], r, e);
+        ide_forward<true>(sr.s[0], sr.s[1], sr.s[2], r, e);
         for (int c = 0; c < 72; ++c) xs[72 + c] = e[c];
     }
-    pe3(p, 8, pe);
+    pe3<8>(p, pe);
     for (int c = 0; c < 51; ++c) { xi[c] = pe[c]; xo[c] = pe[c]; }
     for (int c = 123; c < 128; ++c) xi[c] = 0.f;
     const float rf[3] = {q[4], q[5], q[6]};
-    pe3(rf, 6, pe);
+    pe3<6>(rf, pe);
     for (int c = 0; c < 39; ++c) xo[51 + c] = pe[c];
     for (int c = 90; c < 96; ++c) xo[c] = 0.f;
 }
@@ -593,28 +534,26 @@ __global__ __launch_bounds__(128) void shade_encode_bwd_kernel(const float* __re
     const float* dm = dmat + (size_t)k * 8;
     const float m = mo[0], r = mo[1];
     const int ldd = sphere ? 144 : 72;
-    float g[72];
+    const float* gd = dXd + (size_t)k * ldd;
+    const float* gs_ = dXs + (size_t)k * ldd;
+    const float* gi_ = dXi + (size_t)k * 128 + 51;
     float dnx = 0.f, dny = 0.f, dnz = 0.f, dk1 = 0.f;
-    for (int c = 0; c < 72; ++c) g[c] = dXd[(size_t)k * ldd + c];
-    ide_backward(q[0], q[1], q[2], 1.0f, g, dnx, dny, dnz, dk1);
+    ide_backward<true>(q[0], q[1], q[2], 1.0f, [&](int c) { return gd[c]; }, dnx, dny, dnz, dk1);
     float drx = 0.f, dry = 0.f, drz = 0.f, dkr = 0.f;
-    for (int c = 0; c < 72; ++c) g[c] = dXs[(size_t)k * ldd + c] + dXi[(size_t)k * 128 + 51 + c];
-    ide_backward(q[4], q[5], q[6], r, g, drx, dry, drz, dkr);
+    ide_backward<true>(q[4], q[5], q[6], r, [&](int c) { return gs_[c] + gi_[c]; }, drx, dry, drz, dkr);
     if (sphere) {
         const float p[3] = {x4[(size_t)k * 4], x4[(size_t)k * 4 + 1], x4[(size_t)k * 4 + 2]};
         const float nv[3] = {q[0], q[1], q[2]}, rv[3] = {q[4], q[5], q[6]};
         float gs[3], dv[3], dk = 0.f;
         const SphereDir sn = sphere_dir(p, nv);
-        for (int c = 0; c < 72; ++c) g[c] = dXd[(size_t)k * ldd + 72 + c];
         gs[0] = gs[1] = gs[2] = 0.f;
-        ide_backward(sn.s[0], sn.s[1], sn.s[2], 1.0f, g, gs[0], gs[1], gs[2], dk);
+        ide_backward<true>(sn.s[0], sn.s[1], sn.s[2], 1.0f, [&](int c) { return gd[72 + c]; }, gs[0], gs[1], gs[2], dk);
         dv[0] = dv[1] = dv[2] = 0.f;
         sphere_dir_vjp(sn, nv, gs, dv);
         dnx += dv[0]; dny += dv[1]; dnz += dv[2];
         const SphereDir sr = sphere_dir(p, rv);
-        for (int c = 0; c < 72; ++c) g[c] = dXs[(size_t)k * ldd + 72 + c];
         gs[0] = gs[1] = gs[2] = 0.f;
-        ide_backward(sr.s[0], sr.s[1], sr.s[2], r, g, gs[0], gs[1], gs[2], dkr);
+        ide_backward<true>(sr.s[0], sr.s[1], sr.s[2], r, [&](int c) { return gs_[72 + c]; }, gs[0], gs[1], gs[2], dkr);
         dv[0] = dv[1] = dv[2] = 0.f;
         sphere_dir_vjp(sr, rv, gs, dv);
         drx += dv[0]; dry += dv[1]; drz += dv[2];
@@ -824,7 +763,7 @@ __global__ void gather_sample_grads_kernel(const float* __restrict__ d_alphaRT, 
 }  // namespace
 
 #define GRID1D(n) dim3(((n) + 127) / 128), dim3(128), 0, (hipStream_t)stream
-#define CHECK_IDE() do { if (init_ide_tables() != 0) return nero_fail(NERO_ERR_LAUNCH, "IDE table upload failed"); } while (0)
+#define CHECK_IDE() do { if (init_ide_tables() != 0) return nero_fail(NERO_ERR_LAUNCH, "IDE coefficient table of ide.h differs from the libm one"); } while (0)
 
 extern "C" {
 
