@@ -135,22 +135,25 @@ __device__ __forceinline__ SphereExit sphere_exit(const float* p, const float* w
 }
 
 // miss rows: X[k] = IDE(w, 0) (72) [ | IDE(sphere exit point, 0) (72) when sphere != 0 ]   (predict_outer_lights, field.py:836-854)
-__global__ void mc_encode_miss_kernel(const float* __restrict__ dirs, const int* __restrict__ idx, const float* __restrict__ pt, int D,
+__global__ __launch_bounds__(ROW_BLOCK) void mc_encode_miss_kernel(const float* __restrict__ dirs, const int* __restrict__ idx, const float* __restrict__ pt, int D,
                                       int sphere, int n, int n_pad, float* __restrict__ X) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_pad) return;
+    __shared__ float stage[ROW_BLOCK * 73];               // rows_put / rows_flush (ide.h): the block's rows leave row-major, coalesced
+    const int row0 = blockIdx.x * ROW_BLOCK;
+    const int k = row0 + threadIdx.x;
+    const bool live = k < n;
+    const float z = live ? 1.f : 0.f;                     // rows n .. n_pad-1 are zero rows
     const int ld = sphere ? 144 : 72;
-    float* o = X + (size_t)k * ld;
-    if (k >= n) { for (int c = 0; c < ld; ++c) o[c] = 0.f; return; }
-    const int row = idx[k];
+    const int row = idx[live ? k : 0];
     const float* w = dirs + (size_t)row * 3;
     float e[72];
     ide_forward<false>(w[0], w[1], w[2], 0.f, e);
-    for (int c = 0; c < 72; ++c) o[c] = e[c];
+    rows_put<72, 0, 72>(stage, e, z);
+    rows_flush<72>(stage, X, ld, 0, row0, n_pad);
     if (sphere) {
         const SphereExit se = sphere_exit(pt + (size_t)(row / D) * 32 + 29, w);
         ide_forward<false>(se.sph[0], se.sph[1], se.sph[2], 0.f, e);
-        for (int c = 0; c < 72; ++c) o[72 + c] = e[c];
+        rows_put<72, 0, 72>(stage, e, z);
+        rows_flush<72>(stage, X, ld, 72, row0, n_pad);
     }
 }
 
@@ -202,27 +205,49 @@ __device__ __forceinline__ void hit_reflection(const float* w, const float* fn, 
     const float d = dot3(vv, nh);
     for (int c = 0; c < 3; ++c) refl[c] = d * nh[c] * 2.f - vv[c];
 }
-__global__ void mc_encode_hit_kernel(const float* __restrict__ dirs, const float* __restrict__ pos, const float* __restrict__ fnrm,
+__global__ __launch_bounds__(ROW_BLOCK) void mc_encode_hit_kernel(const float* __restrict__ dirs, const float* __restrict__ pos, const float* __restrict__ fnrm,
                                      const int* __restrict__ idx, int n, int n_pad, float* __restrict__ X) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_pad) return;
-    float* o = X + (size_t)k * 128;
-    if (k >= n) { for (int c = 0; c < 128; ++c) o[c] = 0.f; return; }
-    const int row = idx[k];
+    __shared__ float stage[ROW_BLOCK * 73];
+    const int row0 = blockIdx.x * ROW_BLOCK;
+    const int k = row0 + threadIdx.x;
+    const bool live = k < n;
+    const float z = live ? 1.f : 0.f;
+    const int row = idx[live ? k : 0];
     const float* x = pos + (size_t)row * 3;
-    for (int c = 0; c < 3; ++c) o[c] = x[c];
-    float f = 1.f;
-    int q = 3;
-    for (int i = 0; i < 8; ++i) {
-        for (int c = 0; c < 3; ++c) o[q + c] = sinf(x[c] * f);
-        for (int c = 0; c < 3; ++c) o[q + 3 + c] = cosf(x[c] * f);
-        q += 6; f *= 2.f;
+    // X row = [PE-8(x_hit) 51 | IDE(reflect(-w, n_hit)) 72 | 0 x 5], written as columns 0..63 and 64..127
+    float pe[51];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pe[c] = x[c];
+    {
+        float f = 1.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pe[3 + 6 * i + c] = sinf(x[c] * f);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pe[3 + 6 * i + 3 + c] = cosf(x[c] * f);
+            f *= 2.f;
+        }
     }
     float nh[3], vv[3], refl[3], e[72];
     hit_reflection(dirs + (size_t)row * 3, fnrm + (size_t)row * 3, nh, vv, refl);
     ide_forward<false>(refl[0], refl[1], refl[2], 0.f, e);
-    for (int c = 0; c < 72; ++c) o[51 + c] = e[c];
-    for (int c = 123; c < 128; ++c) o[c] = 0.f;
+    rows_put<64, 0, 51>(stage, pe, z);
+    {
+        float h[13];
+#pragma unroll
+        for (int c = 0; c < 13; ++c) h[c] = e[c];
+        rows_put<64, 51, 13>(stage, h, z);
+    }
+    rows_flush<64>(stage, X, 128, 0, row0, n_pad);
+    {
+        float h[59];
+#pragma unroll
+        for (int c = 0; c < 59; ++c) h[c] = e[13 + c];
+        rows_put<64, 0, 59>(stage, h, z);
+    }
+    rows_zero<64, 59, 5>(stage);
+    rows_flush<64>(stage, X, 128, 64, row0, n_pad);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -622,7 +647,7 @@ int nero_mc_encode_miss(const float* dirs, const int* idx, const float* pt, int 
     CHECK_T();
     const int n_pad = NERO_ROW_PAD(n);
     if (n_pad == 0) return NERO_OK;
-    hipLaunchKernelGGL(mc_encode_miss_kernel, GRID1D(n_pad), dirs, idx, pt, D, sphere, n, n_pad, X);
+    hipLaunchKernelGGL(mc_encode_miss_kernel, dim3((n_pad + ROW_BLOCK - 1) / ROW_BLOCK), dim3(ROW_BLOCK), 0, (hipStream_t)stream, dirs, idx, pt, D, sphere, n, n_pad, X);
     return nero_check_launch("nero_mc_encode_miss");
 }
 
@@ -638,7 +663,7 @@ int nero_mc_encode_hit(const float* dirs, const float* pos, const float* face_no
     CHECK_T();
     const int n_pad = NERO_ROW_PAD(n);
     if (n_pad == 0) return NERO_OK;
-    hipLaunchKernelGGL(mc_encode_hit_kernel, GRID1D(n_pad), dirs, pos, face_normals, idx, n, n_pad, X);
+    hipLaunchKernelGGL(mc_encode_hit_kernel, dim3((n_pad + ROW_BLOCK - 1) / ROW_BLOCK), dim3(ROW_BLOCK), 0, (hipStream_t)stream, dirs, pos, face_normals, idx, n, n_pad, X);
     return nero_check_launch("nero_mc_encode_hit");
 }
 

@@ -216,49 +216,84 @@ __device__ __forceinline__ void sphere_dir_vjp(const SphereDir& e, const float* 
     for (int c = 0; c < 3; ++c) dv[c] += e.t * gu[c] + e.q[c] * k;
 }
 
-__global__ __launch_bounds__(128) void shade_encode_kernel(const float* __restrict__ x4, const float* __restrict__ geo, const float* __restrict__ m_raw,
+__global__ __launch_bounds__(ROW_BLOCK) void shade_encode_kernel(const float* __restrict__ x4, const float* __restrict__ geo, const float* __restrict__ m_raw,
                                     const float* __restrict__ r_raw, const float* __restrict__ a_raw, int n, int n_pad,
                                     float* __restrict__ mat, float* __restrict__ Xd, float* __restrict__ Xs, float* __restrict__ Xi,
                                     float* __restrict__ Xo, int sphere) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_pad) return;
+    __shared__ float stage[ROW_BLOCK * 73];              // <= 72 columns of one output matrix at a time (rows_put / rows_flush, ide.h);
+                                                         // rows k >= n are zero rows.  18.7 KB: 8 blocks per CU
+    const int row0 = blockIdx.x * ROW_BLOCK;
+    const int k = row0 + threadIdx.x;
+    const bool live = k < n;
+    const int kk = live ? k : 0;                          // (dead threads compute on row 0 and store zeros: every thread reaches the barriers)
     const int ldd = sphere ? 144 : 72;
-    float* xd = Xd + (size_t)k * ldd; float* xs = Xs + (size_t)k * ldd; float* xi = Xi + (size_t)k * 128; float* xo = Xo + (size_t)k * 96;
-    if (k >= n) {
-        for (int c = 0; c < ldd; ++c) { xd[c] = 0.f; xs[c] = 0.f; }
-        for (int c = 0; c < 128; ++c) xi[c] = 0.f;
-        for (int c = 0; c < 96; ++c) xo[c] = 0.f;
-        return;
+    const float* q = geo + (size_t)kk * 8;
+    const float m = sigmoid_f(m_raw[(size_t)kk * 4]), r = sigmoid_f(r_raw[(size_t)kk * 4]);
+    if (live) {
+        float* mo = mat + (size_t)k * 8;
+        mo[0] = m; mo[1] = r;
+        for (int c = 0; c < 3; ++c) mo[2 + c] = sigmoid_f(a_raw[(size_t)k * 4 + c]);
+        mo[5] = 0.f; mo[6] = 0.f; mo[7] = 0.f;
     }
-    const float* q = geo + (size_t)k * 8;
-    const float m = sigmoid_f(m_raw[(size_t)k * 4]), r = sigmoid_f(r_raw[(size_t)k * 4]);
-    float* mo = mat + (size_t)k * 8;
-    mo[0] = m; mo[1] = r;
-    for (int c = 0; c < 3; ++c) mo[2 + c] = sigmoid_f(a_raw[(size_t)k * 4 + c]);
-    mo[5] = 0.f; mo[6] = 0.f; mo[7] = 0.f;
+    const float z = live ? 1.f : 0.f;
+    const float p[3] = {x4[(size_t)kk * 4], x4[(size_t)kk * 4 + 1], x4[(size_t)kk * 4 + 2]};
     float e[72];
     ide_forward<true>(q[0], q[1], q[2], 1.0f, e);
-    for (int c = 0; c < 72; ++c) xd[c] = e[c];
+    rows_put<72, 0, 72>(stage, e, z);
+    rows_flush<72>(stage, Xd, ldd, 0, row0, n_pad);
     ide_forward<true>(q[4], q[5], q[6], r, e);
-    for (int c = 0; c < 72; ++c) { xs[c] = e[c]; xi[51 + c] = e[c]; }
+    rows_put<72, 0, 72>(stage, e, z);
+    rows_flush<72>(stage, Xs, ldd, 0, row0, n_pad);
     float pe[51];
-    const float p[3] = {x4[(size_t)k * 4], x4[(size_t)k * 4 + 1], x4[(size_t)k * 4 + 2]};
-    if (sphere) {
+    pe3<8>(p, pe);
+    // Xi = [PE-8(p) 51 | IDE(refl, rough) 72 | 0 x 5] as columns 0..63 and 64..127
+    rows_put<64, 0, 51>(stage, pe, z);
+    {
+        float h[13];
+#pragma unroll
+        for (int c = 0; c < 13; ++c) h[c] = e[c];
+        rows_put<64, 51, 13>(stage, h, z);
+    }
+    rows_flush<64>(stage, Xi, 128, 0, row0, n_pad);
+    {
+        float h[59];
+#pragma unroll
+        for (int c = 0; c < 59; ++c) h[c] = e[13 + c];
+        rows_put<64, 0, 59>(stage, h, z);
+    }
+    rows_zero<64, 59, 5>(stage);
+    rows_flush<64>(stage, Xi, 128, 64, row0, n_pad);
+    // Xo = [PE-8(p) 51 | PE-6(refl) 39 | 0 x 6] as columns 0..47 and 48..95
+    float pr[39];
+    {
+        const float rf[3] = {q[4], q[5], q[6]};
+        pe3<6>(rf, pr);
+    }
+    {
+        float h[48];
+#pragma unroll
+        for (int c = 0; c < 48; ++c) h[c] = pe[c];
+        rows_put<48, 0, 48>(stage, h, z);
+    }
+    rows_flush<48>(stage, Xo, 96, 0, row0, n_pad);
+    {
+        float h[3] = {pe[48], pe[49], pe[50]};
+        rows_put<48, 0, 3>(stage, h, z);
+    }
+    rows_put<48, 3, 39>(stage, pr, z);
+    rows_zero<48, 42, 6>(stage);
+    rows_flush<48>(stage, Xo, 96, 48, row0, n_pad);
+    if (sphere) {                                         // (uniform over the launch)
         const float nv[3] = {q[0], q[1], q[2]}, rv[3] = {q[4], q[5], q[6]};
         const SphereDir sn = sphere_dir(p, nv);
         ide_forward<true>(sn.s[0], sn.s[1], sn.s[2], 1.0f, e);
-        for (int c = 0; c < 72; ++c) xd[72 + c] = e[c];
+        rows_put<72, 0, 72>(stage, e, z);
+        rows_flush<72>(stage, Xd, ldd, 72, row0, n_pad);
         const SphereDir sr = sphere_dir(p, rv);
         ide_forward<true>(sr.s[0], sr.s[1], sr.s[2], r, e);
-        for (int c = 0; c < 72; ++c) xs[72 + c] = e[c];
+        rows_put<72, 0, 72>(stage, e, z);
+        rows_flush<72>(stage, Xs, ldd, 72, row0, n_pad);
     }
-    pe3<8>(p, pe);
-    for (int c = 0; c < 51; ++c) { xi[c] = pe[c]; xo[c] = pe[c]; }
-    for (int c = 123; c < 128; ++c) xi[c] = 0.f;
-    const float rf[3] = {q[4], q[5], q[6]};
-    pe3<6>(rf, pe);
-    for (int c = 0; c < 39; ++c) xo[51 + c] = pe[c];
-    for (int c = 90; c < 96; ++c) xo[c] = 0.f;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -788,7 +823,7 @@ int nero_shade_encode(const float* x4, const float* geo, const float* m_raw, con
     CHECK_IDE();
     const int n_pad = NERO_ROW_PAD(n);
     if (n_pad == 0) return NERO_OK;
-    hipLaunchKernelGGL(shade_encode_kernel, GRID1D(n_pad), x4, geo, m_raw, r_raw, a_raw, n, n_pad, mat, Xd, Xs, Xi, Xo, sphere_direction);
+    hipLaunchKernelGGL(shade_encode_kernel, dim3((n_pad + ROW_BLOCK - 1) / ROW_BLOCK), dim3(ROW_BLOCK), 0, (hipStream_t)stream, x4, geo, m_raw, r_raw, a_raw, n, n_pad, mat, Xd, Xs, Xi, Xo, sphere_direction);
     return nero_check_launch("nero_shade_encode");
 }
 
