@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include "../../include/nero_hip.h"
 #include "common.h"
+#include "rows.h"
 
 namespace {
 
@@ -28,32 +29,20 @@ __global__ void encode_pe_kernel(const float* __restrict__ x, int ldx, int dim, 
 }
 
 // normal = J_e^T (ebar0 + ebar1):  n_c = e_c + sum_k 2^k (cos(2^k x_c) e_sin[k,c] - sin(2^k x_c) e_cos[k,c])
-__global__ void pe_vjp_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ e0, int ld0,
+__global__ __launch_bounds__(ROW_BLOCK) void pe_vjp_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ e0, int ld0,
                               const float* __restrict__ e1, int ld1, int n_freq, int n, float* __restrict__ out, int ldo) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    const float* a = e0 + (size_t)r * ld0;
-    const float* b = e1 ? e1 + (size_t)r * ld1 : nullptr;
-    // the <= 40 values of the row(s) are fetched first, as 16-byte loads where the layout allows: interleaved with the
-    // trigonometric code below, the 4-byte loads of a 160-byte row were spread over so many cycles that every cache line was
-    // re-fetched from HBM ~10 times (rocprofv3 FETCH_SIZE: 959 MB per launch for 96 MB of input)
+    // the <= 40 values of the block's rows (e0 [+ e1]) come in through LDS, consecutive lanes on consecutive floats (rows.h): a thread
+    // fetching its own 160-byte row had every cache line re-fetched from HBM -- 959 MB per launch for 96 MB of input with 4-byte
+    // loads, still 603 MB with 16-byte loads (rocprofv3 FETCH_SIZE)
+    __shared__ float stage[ROW_BLOCK * 41];
+    const int row0 = blockIdx.x * ROW_BLOCK;
+    const int r = row0 + threadIdx.x;
     const int nv = 3 + 6 * n_freq;                     // <= 40 (checked by the host wrapper)
+    rows_load<40>(stage, e0, ld0, 0, e1, ld1, 0, nv, row0, n);
+    if (r >= n) return;
     float e[40];
-    const bool vec = ((ld0 | (e1 ? ld1 : 0)) & 3) == 0 && (((uintptr_t)e0 | (uintptr_t)e1) & 15) == 0;
-    if (vec) {
 #pragma unroll
-        for (int j = 0; j < 10; ++j) {
-            if (4 * j < nv) {
-                float4 va = *reinterpret_cast<const float4*>(a + 4 * j);
-                if (b) { const float4 vb = *reinterpret_cast<const float4*>(b + 4 * j); va.x += vb.x; va.y += vb.y; va.z += vb.z; va.w += vb.w; }
-                e[4 * j] = va.x; e[4 * j + 1] = va.y; e[4 * j + 2] = va.z; e[4 * j + 3] = va.w;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 40; ++j)
-            if (j < nv) e[j] = a[j] + (b ? b[j] : 0.f);
-    }
+    for (int j = 0; j < 40; ++j) e[j] = j < nv ? rows_at<40>(stage, j) : 0.f;
     for (int c = 0; c < 3; ++c) {
         const float xc = x[(size_t)r * ldx + c];
         float acc = e[c];
@@ -71,23 +60,38 @@ __global__ void pe_vjp_kernel(const float* __restrict__ x, int ldx, const float*
 }
 
 // ehat = J_e nbar:  [nbar_c, 2^k cos(2^k x_c) nbar_c, -2^k sin(2^k x_c) nbar_c, ... , 0-pad]; rows >= n are zero
-__global__ void pe_jvp_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ t, int ldt, int n_freq,
+__global__ __launch_bounds__(ROW_BLOCK) void pe_jvp_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ t, int ldt, int n_freq,
                               int n, int n_pad, float* __restrict__ out, int ldo) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_pad) return;
-    float* o = out + (size_t)r * ldo;
-    if (r >= n) { for (int c = 0; c < ldo; ++c) o[c] = 0.f; return; }
-    float xv[3], tv[3];
-    for (int c = 0; c < 3; ++c) { xv[c] = x[(size_t)r * ldx + c]; tv[c] = t[(size_t)r * ldt + c]; o[c] = tv[c]; }
-    int p = 3;
+    __shared__ float stage[ROW_BLOCK * 41];            // rows leave through LDS, row-major (rows.h); ldo <= 40 (host wrapper)
+    const int row0 = blockIdx.x * ROW_BLOCK;
+    const int r = row0 + threadIdx.x;
+    const bool live = r < n;
+    float xv[3] = {0.f, 0.f, 0.f}, tv[3] = {0.f, 0.f, 0.f};
+    if (live)
+        for (int c = 0; c < 3; ++c) { xv[c] = x[(size_t)r * ldx + c]; tv[c] = t[(size_t)r * ldt + c]; }
+    float o[40];
+#pragma unroll
+    for (int c = 0; c < 40; ++c) o[c] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = tv[c];
     float f = 1.f;
-    for (int k = 0; k < n_freq; ++k) {
-        for (int c = 0; c < 3; ++c) o[p + c] = f * cosf(xv[c] * f) * tv[c];
-        for (int c = 0; c < 3; ++c) o[p + 3 + c] = -f * sinf(xv[c] * f) * tv[c];
-        p += 6;
-        f *= 2.f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        if (k < n_freq) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[3 + 6 * k + c] = f * cosf(xv[c] * f) * tv[c];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[3 + 6 * k + 3 + c] = -f * sinf(xv[c] * f) * tv[c];
+            f *= 2.f;
+        }
     }
-    for (; p < ldo; ++p) o[p] = 0.f;
+    rows_put<40, 0, 40>(stage, o, 1.f);                // (rows n .. n_pad-1: tv = 0 -> all-zero rows)
+    __syncthreads();
+    const int rows = n_pad - row0 < ROW_BLOCK ? n_pad - row0 : ROW_BLOCK;
+    for (int idx = threadIdx.x; idx < rows * ldo; idx += ROW_BLOCK) {
+        const int rr = idx / ldo, c = idx - rr * ldo;
+        out[(size_t)(row0 + rr) * ldo + c] = stage[rr * 41 + c];
+    }
 }
 
 }  // namespace
@@ -106,15 +110,16 @@ int nero_pe_vjp(const float* x, int ldx, const float* e0, int ld0, const float* 
                 float* out, int ldo, void* stream) {
     if (!x || !e0 || !out || n_freq < 0 || n_freq > 6) return nero_fail(NERO_ERR_ARG, "nero_pe_vjp: bad argument (n_freq <= 6)");
     if (n == 0) return NERO_OK;
-    hipLaunchKernelGGL(pe_vjp_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, ldx, e0, ld0, e1, ld1, n_freq, n, out, ldo);
+    hipLaunchKernelGGL(pe_vjp_kernel, dim3((n + ROW_BLOCK - 1) / ROW_BLOCK), dim3(ROW_BLOCK), 0, (hipStream_t)stream, x, ldx, e0, ld0, e1, ld1, n_freq, n, out, ldo);
     return nero_check_launch("nero_pe_vjp");
 }
 
 int nero_pe_jvp(const float* x, int ldx, const float* t, int ldt, int n_freq, int n, float* out, int ldo, void* stream) {
-    if (!x || !t || !out || 3 * (1 + 2 * n_freq) > ldo) return nero_fail(NERO_ERR_ARG, "nero_pe_jvp: bad argument");
+    if (!x || !t || !out || n_freq < 0 || n_freq > 6 || 3 * (1 + 2 * n_freq) > ldo || ldo > 40)
+        return nero_fail(NERO_ERR_ARG, "nero_pe_jvp: bad argument (n_freq <= 6, 3 (1 + 2 n_freq) <= ldo <= 40)");
     const int n_pad = NERO_ROW_PAD(n);
     if (n_pad == 0) return NERO_OK;
-    hipLaunchKernelGGL(pe_jvp_kernel, dim3((n_pad + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, ldx, t, ldt, n_freq, n, n_pad, out, ldo);
+    hipLaunchKernelGGL(pe_jvp_kernel, dim3((n_pad + ROW_BLOCK - 1) / ROW_BLOCK), dim3(ROW_BLOCK), 0, (hipStream_t)stream, x, ldx, t, ldt, n_freq, n, n_pad, out, ldo);
     return nero_check_launch("nero_pe_jvp");
 }
 

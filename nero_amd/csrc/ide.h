@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#include "rows.h"                                    // rows_put / rows_flush: the encoders' coalesced row stores
 
 constexpr int IDE_N = 36;
 
@@ -125,32 +126,3 @@ __device__ __forceinline__ void ide_backward(float x, float y, float z, float ki
 }
 
 
-// ---- coalesced row stores for thread-per-row encoders ------------------------------------------------------------------------------
-// A thread that owns a whole row of NC floats and writes it with scalar stores puts 64 lanes on 64 different cache lines per
-// instruction (row pitch 288 ... 512 B); with the unrolled IDE the stores of several output matrices also interleave, and the L2 wrote
-// 923 MB for 650 MB of encodings (WRITE_SIZE, shade_encode_kernel).  Instead the block (ROW_BLOCK threads = rows) parks the rows in
-// LDS at an odd pitch and writes them back row-major: consecutive lanes -> consecutive floats.  All threads of the block must call it.
-constexpr int ROW_BLOCK = 64;
-// rows_put<NC, OFF, N>: this thread's row gets v[0..N) at columns OFF.. of an NC-wide staged matrix (pitch NC + 1); rows_flush<NC>:
-// barrier, cooperative row-major write of the block's rows to g[(row0 + r) * ld + col0 + c], barrier (the buffer is free again).
-template <int NC, int OFF, int N>
-__device__ __forceinline__ void rows_put(float* __restrict__ lds, const float (&v)[N], float scale) {
-    static_assert(OFF + N <= NC, "rows_put: columns out of range");
-#pragma unroll
-    for (int c = 0; c < N; ++c) lds[threadIdx.x * (NC + 1) + OFF + c] = v[c] * scale;
-}
-template <int NC, int OFF, int N>
-__device__ __forceinline__ void rows_zero(float* __restrict__ lds) {
-#pragma unroll
-    for (int c = 0; c < N; ++c) lds[threadIdx.x * (NC + 1) + OFF + c] = 0.f;
-}
-template <int NC>
-__device__ __forceinline__ void rows_flush(const float* __restrict__ lds, float* __restrict__ g, int ld, int col0, int row0, int n_rows_total) {
-    __syncthreads();
-    const int rows = n_rows_total - row0 < ROW_BLOCK ? n_rows_total - row0 : ROW_BLOCK;
-    for (int idx = threadIdx.x; idx < rows * NC; idx += ROW_BLOCK) {
-        const int r = idx / NC, c = idx - r * NC;
-        g[(size_t)(row0 + r) * ld + col0 + c] = lds[r * (NC + 1) + c];
-    }
-    __syncthreads();
-}

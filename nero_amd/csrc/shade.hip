@@ -552,6 +552,8 @@ __global__ void shade_combine_bwd_kernel(const float* __restrict__ geo, const fl
 
 // backward of the encodings: dXd, dXs [rows,72], dXi [rows,128] (cols 51..122 = IDE part) -> d_geo (d_nhat, d_refl; d_NoV
 // already there), total roughness gradient; then the RAW material head gradients dm_raw/dr_raw/da_raw [rows,4]
+// (Measured and dropped: bringing the gradient rows in through LDS like the forward encoders' stores (rows_load, rows.h) -- 95 -> 234 us:
+// four staged loads mean eight barriers, the LDS reads sit inside the unrolled IDE chains, and at 274 VGPRs one wave per SIMD hides none of it.)
 __global__ __launch_bounds__(128) void shade_encode_bwd_kernel(const float* __restrict__ geo, const float* __restrict__ mat, const float* __restrict__ dXd,
                                         const float* __restrict__ dXs, const float* __restrict__ dXi, const float* __restrict__ dmat,
                                         int n, int n_pad, float* __restrict__ d_geo, float* __restrict__ dm_raw,
