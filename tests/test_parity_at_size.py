@@ -172,6 +172,49 @@ def test_c3_bear_1024_rays_per_gpu():
     _run_shape('c3_bear_1024', cfg, 0.5, 1024, 25000, with_f64=True, cpu_floor=True)
 
 
+def test_c2_end_to_end_without_teacher_forcing_statistics():
+    """C2 (4096 rays) with the product's OWN hierarchical sampler -- no oracle z_vals handed over.  The sampler is ill-conditioned end
+    to end (one SDF value within rounding of a section boundary moves a sample into the neighbouring section), so index
+    equality with another fp32 evaluation cannot be demanded; this test MEASURES how far apart two fp32 evaluations land at the
+    benchmarked size, records it, and bounds it: the fraction of z values equal to 1e-5, the fraction of rays with all 128 inner z equal,
+    and the resulting ray colours (median / 99th percentile / worst)."""
+    from nero_amd.synthetic import synthetic_rays
+    R, cfg = 4096, BELL
+    c = {**O.DEFAULT_CFG, **cfg}
+    o, d, poses, gt = synthetic_rays(R, seed=1)
+    g = torch.Generator().manual_seed(3)
+    rand1, rand_bg, keys = torch.rand(R, 1, generator=g), torch.rand(R, c['n_bg_samples'], generator=g), torch.rand(R * 160, generator=g)
+    near, far = O.near_far_from_sphere(o, d)
+    ref = _shape_case(cfg, 0.5, device=ODEV)
+    hp = ref.get_human_coordinate_poses(poses)
+    cu = lambda a: a.to(ODEV)
+    with torch.no_grad(), torch.device(ODEV):
+        sd = {k: v.detach() for k, v in ref.state_dict().items()}
+        P = O.effective_params(sd)
+        zo = O.sample_ray(P, c, cu(o), cu(d), cu(near), cu(far), cu(rand1), cu(rand_bg))
+        rgb_o = O.render_core(P, c, cu(o), cu(d), zo, cu(hp), O.anneal(c, 25000), 25000, keys.to(ODEV))['ray_rgb'].cpu()
+        zo = zo.cpu()
+    del ref, P, sd
+    _free()
+    net = _shape_case(cfg, 0.5, device='cuda')
+    with torch.no_grad():
+        zg = net.sample_ray(o.cuda(), d.cuda(), near.cuda(), far.cuda(), 1.0, rand1.cuda(), rand_bg.cuda())
+        out = net.render(o.cuda(), d.cuda(), near.cuda(), far.cuda(), hp.cuda(), -1, O.anneal(c, 25000), is_train=True, step=25000, z_vals=zg)
+    zg = zg.cpu()
+    nb = c['n_bg_samples']
+    dz = (zg[:, :-nb] - zo[:, :-nb]).abs()
+    e = (out['ray_rgb'].cpu() - rgb_o).abs().max(-1)[0]
+    rec = dict(rays=R, frac_z_equal_1e5=float((dz < 1e-5).float().mean()), frac_rays_all_z_equal_1e5=float((dz.max(-1)[0] < 1e-5).float().mean()),
+               worst_dz=float(dz.max()), bg_z_rel=float((zg[:, -nb:] / zo[:, -nb:] - 1).abs().max()),
+               rgb_abs_err_median=float(e.median()), rgb_abs_err_p99=float(e.kthvalue(int(0.99 * R))[0]), rgb_abs_err_worst=float(e.max()))
+    parity_report('c2_bell_4096_end_to_end_no_teacher_forcing', **rec)
+    assert rec['bg_z_rel'] < 1e-6                                   # the background z do not depend on the SDF: exact arithmetic
+    # measured on MI355X (round 3): 98.86 % of the z equal, 90.0 % of the rays entirely equal (worst dz 3.5e-3: one sample in a neighbouring
+    # section); colours: median 1.2e-7, 99th percentile 4.8e-7, worst ray 1.0e-4 -- the rendering integral barely notices a moved sample
+    assert rec['frac_z_equal_1e5'] > 0.98 and rec['frac_rays_all_z_equal_1e5'] > 0.85, rec
+    assert rec['rgb_abs_err_median'] < 2e-6 and rec['rgb_abs_err_p99'] < 1e-5 and rec['rgb_abs_err_worst'] < 1e-3, rec
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # Stage II at the benchmarked sizes
 # ----------------------------------------------------------------------------------------------------------------------
