@@ -32,6 +32,18 @@ __device__ __forceinline__ void rows_flush(const float* __restrict__ lds, float*
     __syncthreads();
 }
 
+// (the same with fewer columns than the staging pitch holds: nc <= NC)
+template <int NC>
+__device__ __forceinline__ void rows_flush_cols(const float* __restrict__ lds, float* __restrict__ g, int ld, int col0, int nc, int row0, int n_rows_total) {
+    __syncthreads();
+    const int rows = n_rows_total - row0 < ROW_BLOCK ? n_rows_total - row0 : ROW_BLOCK;
+    for (int idx = threadIdx.x; idx < rows * nc; idx += ROW_BLOCK) {
+        const int r = idx / nc, c = idx - r * nc;
+        g[(size_t)(row0 + r) * ld + col0 + c] = lds[r * (NC + 1) + c];
+    }
+    __syncthreads();
+}
+
 // The read side: rows_load<NC> brings columns col0 .. col0+NC-1 of the block's rows into the staging buffer with consecutive lanes on
 // consecutive floats (optionally adding a second matrix of the same shape), barrier; a thread then reads ITS row with rows_at.  A
 // thread reading its own 160 ... 576-byte row with vector loads re-fetched every cache line several times over

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include "../../include/nero_hip.h"
 #include "common.h"
+#include "rows.h"
 
 #pragma clang fp contract(off)      // keep a*b+c un-fused: the oracle's float32 steps are stated without FMA
 
@@ -104,33 +105,65 @@ __global__ void gather_inner_q_kernel(const float* __restrict__ pts4, const int*
     reinterpret_cast<float4*>(pe)[(size_t)k * 10 + q] = v;
 }
 
-// outer rows: units 0..21 = PE-10 of [p/|p|, 1/|p|] (84 + 4 pad), units 22..29 = PE-4 of the view direction (27 + 5 pad); unit 0 also dist
-__global__ void gather_outer_q_kernel(const float* __restrict__ pts4, const float* __restrict__ d, const int* __restrict__ idx, int T,
-                                      int n, int n_pad, float* __restrict__ pe88, float* __restrict__ pev32, float* __restrict__ dist) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_pad * 30) return;
-    const int k = t / 30, q = t - k * 30;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    float dd = 0.f;
-    if (k < n) {
-        const int s = idx[k];
-        const float4 x = reinterpret_cast<const float4*>(pts4)[s];
-        dd = x.w;
-        if (q < 22) {
-            const float nrm = sqrtf(x.x * x.x + x.y * x.y + x.z * x.z);
-            const float p[4] = {x.x / nrm, x.y / nrm, x.z / nrm, 1.0f / nrm};
-            v = pe_quad<4>(p, 10, 4 * q);
-        } else {
-            const int r = s / T;
-            const float dxr = d[r * 3], dyr = d[r * 3 + 1], dzr = d[r * 3 + 2];
-            const float dn = fmaxf(sqrtf(dxr * dxr + dyr * dyr + dzr * dzr), 1e-12f);
-            const float w[3] = {-(dxr / dn), -(dyr / dn), -(dzr / dn)};
-            v = pe_quad<3>(w, 4, 4 * (q - 22));
+// outer rows: PE-10 of [p/|p|, 1/|p|] (84 + 4 pad) -> pe88, PE-4 of the view direction (27 + 5 pad) -> pev32, dist.  One thread per ROW,
+// the rows of a block leave through LDS (rows.h).  The column-quad form of round 3 (a thread per 4 columns) stored coalesced too, but a
+// wave mixed sine and cosine columns -- both branches ran for every lane -- and each of a row's 30 threads renormalised the point:
+// 170 us per step.  Here every lane evaluates the same column at the same time.
+__global__ __launch_bounds__(ROW_BLOCK) void gather_outer_row_kernel(const float* __restrict__ pts4, const float* __restrict__ d, const int* __restrict__ idx,
+                                                                     int T, int n, int n_pad, float* __restrict__ pe88, float* __restrict__ pev32,
+                                                                     float* __restrict__ dist) {
+    __shared__ float stage[ROW_BLOCK * 45];
+    const int row0 = blockIdx.x * ROW_BLOCK;
+    const int k = row0 + threadIdx.x;
+    const bool live = k < n;
+    const float z = live ? 1.f : 0.f;                     // rows n .. n_pad-1 are zero rows
+    const int s = idx[live ? k : 0];
+    const float4 x = reinterpret_cast<const float4*>(pts4)[s];
+    if (k < n_pad) dist[k] = live ? x.w : 0.f;
+    float* mine = stage + threadIdx.x * 45;               // this thread's row of the staged <= 44-column piece (pitch 45)
+    {
+        const float nrm = sqrtf(x.x * x.x + x.y * x.y + x.z * x.z);
+        const float p[4] = {x.x / nrm, x.y / nrm, x.z / nrm, 1.0f / nrm};
+        // columns 0..43: p (4), frequencies 0..4 (sin 4, cos 4 each); columns 44..87: frequencies 5..9, 4 x zero padding
+#pragma unroll
+        for (int c = 0; c < 4; ++c) mine[c] = p[c] * z;
+        float f = 1.f;
+        for (int j = 0; j < 5; ++j, f *= 2.f) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) mine[4 + 8 * j + c] = sinf(p[c] * f) * z;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) mine[8 + 8 * j + c] = cosf(p[c] * f) * z;
         }
+        rows_flush<44>(stage, pe88, 88, 0, row0, n_pad);
+        for (int j = 0; j < 5; ++j, f *= 2.f) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) mine[8 * j + c] = sinf(p[c] * f) * z;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) mine[4 + 8 * j + c] = cosf(p[c] * f) * z;
+        }
+#pragma unroll
+        for (int c = 40; c < 44; ++c) mine[c] = 0.f;
+        rows_flush<44>(stage, pe88, 88, 44, row0, n_pad);
     }
-    if (q < 22) reinterpret_cast<float4*>(pe88)[(size_t)k * 22 + q] = v;
-    else reinterpret_cast<float4*>(pev32)[(size_t)k * 8 + (q - 22)] = v;
-    if (q == 0) dist[k] = dd;
+    {
+        const int r = s / T;
+        const float dxr = d[r * 3], dyr = d[r * 3 + 1], dzr = d[r * 3 + 2];
+        const float dn = fmaxf(sqrtf(dxr * dxr + dyr * dyr + dzr * dzr), 1e-12f);
+        const float w[3] = {-(dxr / dn), -(dyr / dn), -(dzr / dn)};
+        // 27 columns (w, 4 frequencies) + 5 x zero padding, staged at the same pitch
+#pragma unroll
+        for (int c = 0; c < 3; ++c) mine[c] = w[c] * z;
+        float f = 1.f;
+        for (int j = 0; j < 4; ++j, f *= 2.f) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) mine[3 + 6 * j + c] = sinf(w[c] * f) * z;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) mine[6 + 6 * j + c] = cosf(w[c] * f) * z;
+        }
+#pragma unroll
+        for (int c = 27; c < 32; ++c) mine[c] = 0.f;
+        rows_flush_cols<44>(stage, pev32, 32, 0, 32, row0, n_pad);
+    }
 }
 
 // Per-ray working arrays live in LDS as columns of a [index][64 lanes] table (lane-consecutive -> conflict-free): the scans
@@ -667,7 +700,7 @@ int nero_gather_outer(const float* pts4, const float* d, const int* idx, int T, 
     const int n_pad = NERO_ROW_PAD(n);
     if (n_pad == 0) return NERO_OK;
     if (!pts4 || !d || !idx || !pe88 || !pev32 || !dist) return nero_fail(NERO_ERR_ARG, "nero_gather_outer: bad argument");
-    hipLaunchKernelGGL(gather_outer_q_kernel, GRID1D(n_pad * 30), pts4, d, idx, T, n, n_pad, pe88, pev32, dist);
+    hipLaunchKernelGGL(gather_outer_row_kernel, dim3(n_pad / ROW_BLOCK), dim3(ROW_BLOCK), 0, (hipStream_t)stream, pts4, d, idx, T, n, n_pad, pe88, pev32, dist);
     return nero_check_launch("nero_gather_outer");
 }
 
