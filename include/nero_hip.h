@@ -199,6 +199,9 @@ int nero_dw_gemm_batch(const nero_dw_job* jobs /*host*/, int n_jobs, int n_rows,
 /* Head weight gradient: dWh[j][k] = sum_r dy[r][j] a[r][k] (+ extra[r][k] for j == 0 if extra != NULL), dbh[j] = sum_r dy[r][j]. */
 int nero_head_dw(const float* dy /*[rows,4]*/, const float* a /*[rows,256]*/, const float* extra, int n_head, int n_rows,
                  float* dWh /*[n_head,256]*/, float* dbh, float* partials, int accumulate, void* stream);
+/* the same with an explicit destination shape: dWh [n_head rows of k_cols columns, row pitch ld_dwh] (nero_head_dw: 256 / 256) */
+int nero_head_dw_ld(const float* dy, const float* a, const float* extra, int n_head, int n_rows, float* dWh, int ld_dwh, int k_cols, float* dbh,
+                    float* partials, int accumulate, void* stream);
 
 /* ---- trainer-loop fusion (replaces the per-Linear nn.utils.weight_norm reparametrisation, network/field.py:
  *      118-119, 323-331, and torch.optim.Adam over ~125 tensors, train/trainer.py:105-170, ~750 tiny kernels per step) -------------

@@ -279,17 +279,9 @@ struct Chain {
         for (int i = 0; i < n(); ++i) {
             const Entry& x = e[i];
             if (x.h.has && head_dys && head_dys[i] && x.h.dW) {
-                const size_t m = A.mark();
-                float* tW = A.f32(4 * NERO_HID);
-                float* tb = A.f32(4);
-                if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1: workspace too small");
-                LAUNCH(nero_head_dw(head_dys[i], F.saves[prev], head_extra ? head_extra[i] : nullptr, x.h.n_head, n_rows, tW, tb, partials, 0, stream));
-                if (!A.dry) {
-                    const int tot = x.h.n_head * x.h.k;
-                    hipLaunchKernelGGL(copy2d_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, tW, NERO_HID, x.h.dW, x.h.ld_dw, x.h.n_head, x.h.k);
-                    if (x.h.db) hipLaunchKernelGGL(copy2d_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, tb, 4, x.h.db, 4, 1, x.h.n_head);
-                }
-                A.release(m);       // (stream order: the copies above read tW / tb before any later kernel can overwrite them)
+                // (straight into the destination: n_head rows of k columns at pitch ld_dw; db may be NULL)
+                LAUNCH(nero_head_dw_ld(head_dys[i], F.saves[prev], head_extra ? head_extra[i] : nullptr, x.h.n_head, n_rows, x.h.dW, x.h.ld_dw, x.h.k, x.h.db,
+                                       partials, 0, stream));
             }
             if (x.d.has) {
                 const Dense& d = x.d;

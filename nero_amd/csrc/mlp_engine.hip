@@ -732,8 +732,10 @@ __global__ __launch_bounds__(256) void head_dw_kernel(const float* __restrict__ 
     (void)n_head;
 }
 
+// (ld_out / k_cols: dWh is written as n_head rows of k_cols columns with row pitch ld_out -- the chain drivers point it straight at the
+//  destination tensor instead of copying a [4,256] temporary)
 __global__ __launch_bounds__(256) void head_dw_reduce_kernel(const float* __restrict__ partials, int n_slices, int n_head, float* __restrict__ dWh,
-                                                             float* __restrict__ dbh, int accumulate) {
+                                                             float* __restrict__ dbh, int accumulate, int ld_out, int k_cols) {
     __shared__ float red[4][64];
     const size_t per = 4 * NERO_HID + 4;
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -758,8 +760,13 @@ __global__ __launch_bounds__(256) void head_dw_reduce_kernel(const float* __rest
     __syncthreads();
     if (grp == 0 && (is_w || is_b)) {
         const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-        if (is_w) dWh[idx] = accumulate ? dWh[idx] + t : t;
-        else dbh[idx - nw] = accumulate ? dbh[idx - nw] + t : t;
+        if (is_w) {
+            const int j = idx >> 8, k = idx & (NERO_HID - 1);
+            if (k < k_cols) {
+                float* o = dWh + (size_t)j * ld_out + k;
+                *o = accumulate ? *o + t : t;
+            }
+        } else dbh[idx - nw] = accumulate ? dbh[idx - nw] + t : t;
     }
 }
 
@@ -976,7 +983,13 @@ int nero_dw_gemm_batch(const nero_dw_job* jobs, int n_jobs, int n_rows, float* p
 
 int nero_head_dw(const float* dy, const float* a, const float* extra, int n_head, int n_rows, float* dWh, float* dbh,
                  float* partials, int accumulate, void* stream) {
-    if (!dy || !a || !dWh || !partials || n_head < 1 || n_head > 4) return nero_fail(NERO_ERR_ARG, "nero_head_dw: bad argument");
+    return nero_head_dw_ld(dy, a, extra, n_head, n_rows, dWh, NERO_HID, NERO_HID, dbh, partials, accumulate, stream);
+}
+
+int nero_head_dw_ld(const float* dy, const float* a, const float* extra, int n_head, int n_rows, float* dWh, int ld_dwh, int k_cols, float* dbh,
+                    float* partials, int accumulate, void* stream) {
+    if (!dy || !a || !dWh || !partials || n_head < 1 || n_head > 4 || k_cols < 1 || k_cols > NERO_HID || ld_dwh < k_cols)
+        return nero_fail(NERO_ERR_ARG, "nero_head_dw: bad argument");
     const int rows = n_rows < 1 ? 1 : n_rows;
     // rows per block: 512 at the step's 300k-row launches (measured 92 us against 106 at 256, 114 at 768, 141 at 1024), fewer
     // rows for smaller inputs so that ~2 blocks per CU remain
@@ -985,7 +998,8 @@ int nero_head_dw(const float* dy, const float* a, const float* extra, int n_head
     const int slices = (rows + rps - 1) / rps;
     hipLaunchKernelGGL(head_dw_kernel, dim3(slices), dim3(256), 0, (hipStream_t)stream, dy, a, extra, n_head, n_rows, rps, partials);
     const int total = n_head * NERO_HID + n_head;
-    hipLaunchKernelGGL(head_dw_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, (hipStream_t)stream, partials, slices, n_head, dWh, dbh, accumulate);
+    hipLaunchKernelGGL(head_dw_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, (hipStream_t)stream, partials, slices, n_head, dWh, dbh, accumulate,
+                       ld_dwh, k_cols);
     return nero_check_launch("nero_head_dw");
 }
 

@@ -57,52 +57,49 @@ __global__ void background_z_kernel(const float* __restrict__ far, const float* 
 }
 
 
-// column c of a positional-encoding row [x, sin(2^j x), cos(2^j x)]_{j < n_freq} (0 beyond the encoding): the encoders below give one
-// thread FOUR consecutive columns, so that a wave writes 1 KiB of consecutive floats (a thread per ROW wrote 160 / 352-byte records
-// with a 160 / 352-byte lane stride: every store instruction touched 64 cache lines)
-template <int DIM>
-__device__ __forceinline__ float pe_col(const float (&p)[DIM], int n_freq, int c) {
-    if (c < DIM) return p[c];
-    const int q = c - DIM, j = q / (2 * DIM), t = q - j * (2 * DIM);
-    if (j >= n_freq) return 0.f;
-    const float f = (float)(1 << j);
-    return t < DIM ? sinf(p[t] * f) : cosf(p[t - DIM] * f);
-}
-template <int DIM>
-__device__ __forceinline__ float4 pe_quad(const float (&p)[DIM], int n_freq, int c4) {
-    return make_float4(pe_col<DIM>(p, n_freq, c4), pe_col<DIM>(p, n_freq, c4 + 1), pe_col<DIM>(p, n_freq, c4 + 2), pe_col<DIM>(p, n_freq, c4 + 3));
+// this thread's PE-6 row [x(3), sin / cos of 2^j x, j < 6 (36), 0] into its row of a staged 40-column piece (pitch 41); live = 0: a zero row
+__device__ __forceinline__ void pe6_stage_row(float* __restrict__ mine, const float (&p)[3], float z) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) mine[c] = p[c] * z;
+    float f = 1.f;
+    for (int j = 0; j < 6; ++j, f *= 2.f) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) mine[3 + 6 * j + c] = sinf(p[c] * f) * z;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) mine[6 + 6 * j + c] = cosf(p[c] * f) * z;
+    }
+    mine[39] = 0.f;
 }
 
-// PE-6 rows of the points o + d * z[r, col0 + j]: thread <-> (row, column quad), 10 quads per 40-float row
-__global__ void ray_points_pe_q_kernel(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ z, int ldz,
-                                       int col0, int ncols, int R, int n_pad, float* __restrict__ pe) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n_pad * 10) return;
-    const int row = idx / 10, q = idx - row * 10;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < R * ncols) {
-        const int r = row / ncols, j = row - r * ncols;
-        const float t = z[(size_t)r * ldz + col0 + j];
-        const float p[3] = {o[r * 3] + d[r * 3] * t, o[r * 3 + 1] + d[r * 3 + 1] * t, o[r * 3 + 2] + d[r * 3 + 2] * t};
-        v = pe_quad<3>(p, 6, 4 * q);
-    }
-    reinterpret_cast<float4*>(pe)[(size_t)row * 10 + q] = v;
+// PE-6 rows (ld 40) of the points o + d * z[r, col0 + j], row = r * ncols + j: a thread per ROW (every lane on the same column: no
+// sine / cosine divergence), the block's rows leave through LDS (rows.h)
+__global__ __launch_bounds__(ROW_BLOCK) void ray_points_pe_row_kernel(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ z,
+                                                                      int ldz, int col0, int ncols, int R, int n_pad, float* __restrict__ pe) {
+    __shared__ float stage[ROW_BLOCK * 41];
+    const int row0 = blockIdx.x * ROW_BLOCK;
+    const int row = row0 + threadIdx.x;
+    const bool live = row < R * ncols;
+    const int rr = live ? row : 0;
+    const int r = rr / ncols, j = rr - r * ncols;
+    const float t = z[(size_t)r * ldz + col0 + j];
+    const float p[3] = {o[r * 3] + d[r * 3] * t, o[r * 3 + 1] + d[r * 3 + 1] * t, o[r * 3 + 2] + d[r * 3 + 2] * t};
+    pe6_stage_row(stage + threadIdx.x * 41, p, live ? 1.f : 0.f);
+    rows_flush<40>(stage, pe, 40, 0, row0, n_pad);
 }
 
-// inner rows: unit 0 writes x4, units 0..9 the PE-6 quads
-__global__ void gather_inner_q_kernel(const float* __restrict__ pts4, const int* __restrict__ idx, int n, int n_pad,
-                                      float* __restrict__ x4, float* __restrict__ pe) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_pad * 10) return;
-    const int k = t / 10, q = t - k * 10;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f), x = v;
-    if (k < n) {
-        x = reinterpret_cast<const float4*>(pts4)[idx[k]];
-        const float p[3] = {x.x, x.y, x.z};
-        v = pe_quad<3>(p, 6, 4 * q);
-    }
-    if (q == 0) reinterpret_cast<float4*>(x4)[k] = x;
-    reinterpret_cast<float4*>(pe)[(size_t)k * 10 + q] = v;
+// inner rows: x4 = the gathered point, pe = its PE-6 row
+__global__ __launch_bounds__(ROW_BLOCK) void gather_inner_row_kernel(const float* __restrict__ pts4, const int* __restrict__ idx, int n, int n_pad,
+                                                                     float* __restrict__ x4, float* __restrict__ pe) {
+    __shared__ float stage[ROW_BLOCK * 41];
+    const int row0 = blockIdx.x * ROW_BLOCK;
+    const int k = row0 + threadIdx.x;
+    const bool live = k < n;
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) x = reinterpret_cast<const float4*>(pts4)[idx[k]];
+    if (k < n_pad) reinterpret_cast<float4*>(x4)[k] = x;
+    const float p[3] = {x.x, x.y, x.z};
+    pe6_stage_row(stage + threadIdx.x * 41, p, live ? 1.f : 0.f);
+    rows_flush<40>(stage, pe, 40, 0, row0, n_pad);
 }
 
 // outer rows: PE-10 of [p/|p|, 1/|p|] (84 + 4 pad) -> pe88, PE-4 of the view direction (27 + 5 pad) -> pev32, dist.  One thread per ROW,
@@ -622,7 +619,7 @@ int nero_ray_points_pe(const float* o, const float* d, const float* z, int ldz, 
     if (!o || !d || !z || !pe) return nero_fail(NERO_ERR_ARG, "nero_ray_points_pe: bad argument");
     const int n_pad = NERO_ROW_PAD(R * ncols);
     if (n_pad == 0) return NERO_OK;
-    hipLaunchKernelGGL(ray_points_pe_q_kernel, GRID1D(n_pad * 10), o, d, z, ldz, col0, ncols, R, n_pad, pe);
+    hipLaunchKernelGGL(ray_points_pe_row_kernel, dim3(n_pad / ROW_BLOCK), dim3(ROW_BLOCK), 0, (hipStream_t)stream, o, d, z, ldz, col0, ncols, R, n_pad, pe);
     return nero_check_launch("nero_ray_points_pe");
 }
 
@@ -692,7 +689,7 @@ int nero_gather_inner(const float* pts4, const int* idx, int n, float* x4, float
     const int n_pad = NERO_ROW_PAD(n);
     if (n_pad == 0) return NERO_OK;
     if (!pts4 || !idx || !x4 || !pe) return nero_fail(NERO_ERR_ARG, "nero_gather_inner: bad argument");
-    hipLaunchKernelGGL(gather_inner_q_kernel, GRID1D(n_pad * 10), pts4, idx, n, n_pad, x4, pe);
+    hipLaunchKernelGGL(gather_inner_row_kernel, dim3(n_pad / ROW_BLOCK), dim3(ROW_BLOCK), 0, (hipStream_t)stream, pts4, idx, n, n_pad, x4, pe);
     return nero_check_launch("nero_gather_inner");
 }
 
