@@ -74,6 +74,23 @@ def hbm_traffic_per_launch(kernel, prefix='hbm_traffic_per_kernel'):
     return None, None
 
 
+def mfma_busy_of(kernel):
+    """share of all SIMD-cycles of a launch in which the matrix pipe was occupied (profiles/r03_mfma_busy_per_kernel.csv:
+    SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x launch cycles), scripts/prof_mfma_busy.sh), or None"""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_mfma_busy_per_kernel.csv')))
+    if not paths:
+        return None
+    with open(paths[-1]) as f:
+        for line in f:
+            if line.startswith(kernel):
+                try:
+                    return {'frac': float(line.rsplit(',', 1)[1]), 'source': os.path.relpath(paths[-1], ROOT) + ' (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES)'}
+                except ValueError:
+                    return None
+    return None
+
+
 def cpu_baseline(cfg, variance, step, rays=512, budget_s=15.0, max_steps=10):
     """the oracle (a port of the reference's torch path, oracle/nero_oracle.py) timed on this box's host cores on a bounded
     sample of the same workload: `rays` rays x (64+64+32) samples, forward + loss + backward."""
@@ -558,6 +575,7 @@ def main():
         roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
                 'frac': round(ach / peak, 4), 'traffic': traffic, 'kernel': dom[0], 'mfma': MFMA_OF_MODE[dom[5]],
                 'traffic_source': tsrc,
+                'mfma_busy': mfma_busy_of(dom[0]),
                 'avg_launch_ms': round(dom[2] / max(dom[1], 1), 4),
                 'per_kernel': {r[0]: {'launches_per_step': r[1] / 3, 'ms_per_step': round(r[2] / 3, 3),
                                       'tflops': round(r[3] / (r[2] * 1e-3) / 1e12, 2) if r[2] > 0 else 0.0,
