@@ -580,6 +580,19 @@ def main():
                 'per_kernel': {r[0]: {'launches_per_step': r[1] / 3, 'ms_per_step': round(r[2] / 3, 3),
                                       'tflops': round(r[3] / (r[2] * 1e-3) / 1e12, 2) if r[2] > 0 else 0.0,
                                       'peak': round(r[4] / 1e12, 1)} for r in rows}}
+        # HBM side of every class: PMC bytes per launch (committed CSV) / the launch time measured here; the class is labelled by the
+        # ceiling it sits closer to (the weight-gradient GEMM and the tangent chain stream 4-5 TB/s: HBM-shaped, not MFMA-shaped)
+        for r in rows:
+            pk = roof['per_kernel'][r[0]]
+            tb, _ = hbm_traffic_per_launch(r[0])
+            if tb and r[1] > 0 and r[2] > 0:
+                tbs = tb / (r[2] * 1e-3 / r[1]) / 1e12
+                pk['hbm_tb_per_s'] = round(tbs, 2)
+                pk['hbm_frac_of_8tb_s'] = round(tbs / 8.0, 3)
+                pk['bound'] = 'hbm' if tbs / 8.0 > pk['tflops'] / pk['peak'] else 'mfma'
+            mb = mfma_busy_of(r[0])
+            if mb:
+                pk['mfma_busy'] = mb['frac']
     elif world > 1:
         for i in range(3):
             ts.step(args.train_step + 100 + i)
