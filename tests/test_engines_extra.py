@@ -126,7 +126,7 @@ def test_fp16_weight_gradient_gemm_ragged_shapes_and_two_pairs(n_out, k):
 
 @pytest.mark.parametrize('n', [1, 700, 33333, 131071, 140000])
 def test_batched_weight_gradient_jobs_vs_fp64(n):
-    """nero_dw_gemm_batch: fourteen jobs over the same rows (wide, narrow, ragged widths, a two-pair job, two column parts of one matrix,
+    """nero_dw_gemm_batch: twenty-one jobs over the same rows (wide, narrow, ragged widths, a two-pair job, two column parts of one matrix,
     one job without a bias) -- one launch per kernel kind below 131072 rows, the per-job loop at and above -- each against fp64"""
     from nero_amd import _lib as L
     g = torch.Generator(device='cuda').manual_seed(7)
@@ -134,7 +134,7 @@ def test_batched_weight_gradient_jobs_vs_fp64(n):
     D = [rn(n, 256) * torch.exp(rn(n, 1) * 2.0) for _ in range(4)]
     B = [rn(n, 256) for _ in range(3)] + [torch.relu(rn(n, 256))]
     shapes = [(256, 256), (256, 256), (217, 256), (256, 39), (3, 256), (256, 96), (256, 48), (256, 256), (256, 128), (64, 64), (256, 256),
-              (256, 200), (1, 1)]
+              (256, 200), (1, 1), (256, 256), (128, 256), (256, 160), (256, 256), (32, 250), (256, 256)]      # 14 wide jobs: two launch groups of <= 12
     ws = torch.empty(L.lib.nero_dw_workspace_floats(n), dtype=torch.float32, device='cuda')
     jobs, want, outs = [], [], []
     for i, (n_out, k) in enumerate(shapes):
