@@ -18,13 +18,17 @@ from . import _lib as L
 #            (mlp_f16x3.hip), per 16-row chunk with a running accumulator unit in the weight-gradient GEMM (mlp_f16dw.hip)
 #   'bf16x6' three bf16 planes, 6 products (mlp_split.hip)
 #   'f16x3p' the f16x3 arithmetic, operand images and results on 256-thread workgroups, two resident per CU (mlp_f16p.hip):
-#            default for the forward chains (3-9 % faster: one workgroup's input load / epilogue under the other's MFMAs); the
-#            tangent / reverse chains keep the 512-thread kernels (their 2-per-CU versions spill)
+#            3-9 % faster forward chains (one workgroup's input load / epilogue under the other's MFMAs; 0.3 ms of a 32 ms step) and
+#            the default until late round 3 -- NOT any more: with two workgroups co-resident on a CU the forward kernel sporadically
+#            (one launch in three at 390 k rows) returns ONE output column of rows 48-63 of one tile with another k-step's partial
+#            sum (errors of 1e-2 in a saved activation, 1e-5 in a ray colour, 1e-7 in a gradient: below every parity tolerance, found
+#            by scripts/determinism.py).  DESIGN.md section 3i lists what was ruled out; the mechanism is not identified, so the
+#            512-thread kernels, which are bit-reproducible run to run, are the default again.  Opt in with NERO_GEMM_FWD=f16x3p.
 #   'f32'    the f32-input MFMA, an exact fmaf chain
 # NERO_GEMM=<mode> selects all passes, NERO_GEMM_FWD / _TAN / _BWD / _DW one pass.
 _MODE_NAMES = {'f32': L.GEMM_F32, 'bf16x6': L.GEMM_BF16X6, 'f16x3': L.GEMM_F16X3, 'f16x3p': L.GEMM_F16X3P}
 _F16 = (L.GEMM_F16X3, L.GEMM_F16X3P)          # the two engines that share the kind-3 packed images
-_DEFAULT = {'fwd': 'f16x3p', 'tan': 'f16x3', 'bwd': 'f16x3', 'dw': 'f16x3'}
+_DEFAULT = {'fwd': 'f16x3', 'tan': 'f16x3', 'bwd': 'f16x3', 'dw': 'f16x3'}
 
 
 def _resolve(mode, k):

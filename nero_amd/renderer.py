@@ -134,14 +134,42 @@ class NeROShapeRenderer(nn.Module):
         outs = {}
         with torch.no_grad():
             kern = self._kernels()                                # packed ONCE per image (and cached across images), not per chunk
+            drv = None
+            if not extras:
+                # colours only (nvs): the C-level driver issues a chunk's ~200 launches from one call each (a 1024-ray chunk is
+                # launch-bound from Python), and the occlusion-loss march of a training render is left out (a schedule step below
+                # occ_loss_step: nothing else depends on `step` without gradients)
+                drv = self._inference_driver(kern) if chunk <= 4096 else None      # (the driver's workspace is sized for a training step)
+                if self.cfg['apply_occ_loss']:
+                    step = min(step, self.cfg['occ_loss_step'] - 1)
+                step = max(step, 1000)
             for i in range(0, h * w, chunk):
                 batch = {'dirs': dirs[i:i + chunk], 'idxs': torch.zeros(min(chunk, h * w - i), dtype=torch.long, device=dev)}
                 ro, rd, near, far, hp = self._process_ray_batch(batch, pose, hp_img)
-                o = self.render(ro, rd, near, far, hp, 0, 0, is_train=not extras, step=step, _kern=kern)
+                o = self.render(ro, rd, near, far, hp, 0, 0, is_train=not extras, step=step, _kern=kern, _driver=drv)
                 for k, v in o.items():
                     if not k.startswith('_') and torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == ro.shape[0]:
                         outs.setdefault(k, []).append(v)
         return {k: torch.cat(v, 0) for k, v in outs.items()}
+
+    def _inference_driver(self, kern):
+        """a nero_amd.stage1.Stage1Driver packed with the weights of `kern` (= self._kernels() under no_grad), re-packed only when the
+        cached kernels changed; None when the C driver does not cover the selected GEMM engines or the device"""
+        names, eff, _ = kern
+        if eff[0].device.type != 'cuda':
+            return None
+        from . import stage1
+        if not stage1.supported():
+            return None
+        drv = getattr(self, '_infer_drv', None)
+        if drv is None or not drv.matches_current_modes():
+            drv = self._infer_drv = stage1.Stage1Driver(self.cfg, self.color_network.cfg, eff[0].device)
+            self._infer_drv_key = None
+        key = getattr(self, '_kern_cache', (None,))[0]
+        if key is None or self._infer_drv_key != key:
+            drv.pack([t.detach() for t in eff])
+            self._infer_drv_key = key
+        return drv
 
     def extract_fields(self, bound_min=(-1., -1., -1.), bound_max=(1., 1., 1.), resolution=512, chunk=2 ** 21, outside_val=1.0):
         """SDF on a resolution^3 grid for marching cubes (extract_fields, network/field.py:1090-1108; used by extract_mesh.py:24-27):

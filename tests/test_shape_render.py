@@ -215,6 +215,24 @@ def test_nvs_renders_an_image():
     assert img.shape == (24, 24, 3) and np.isfinite(img).all() and img.std() > 1e-3
 
 
+def test_nvs_through_the_c_driver_equals_the_python_sequenced_render(monkeypatch):
+    """render_image(extras=False) issues each chunk through nero_stage1_sample / _render_fwd; same kernels, same order: same bits"""
+    from nero_amd.renderer import NeROShapeRenderer
+    from nero_amd.synthetic import look_at_pose, perturb_state
+    torch.manual_seed(5)
+    net = NeROShapeRenderer({'apply_occ_loss': True, 'occ_loss_step': 20000}, training=False)
+    perturb_state(net, 0.4)
+    net = net.cuda()
+    K = np.array([[90., 0, 32], [0, 90., 32], [0, 0, 1]], np.float32)
+    pose = look_at_pose(np.array([0.5, -2.8, 0.6], np.float32))
+    a = net.render_image(pose, K, 64, 64, chunk=1000)['ray_rgb']
+    assert getattr(net, '_infer_drv', None) is not None
+    monkeypatch.setattr(NeROShapeRenderer, '_inference_driver', lambda self, kern: None)
+    b = net.render_image(pose, K, 64, 64, chunk=1000)['ray_rgb']
+    assert a.shape == (4096, 3) and bool(torch.isfinite(a).all()) and float(a.std()) > 1e-3
+    assert torch.equal(a, b), float((a - b).abs().max())
+
+
 def test_extract_fields_grid():
     """SDF grid for mesh extraction (field.py:1090-1108) vs the oracle's SDF on the same grid points"""
     z, meta = load_golden('bell_s25000')
