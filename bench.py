@@ -75,20 +75,26 @@ def hbm_traffic_per_launch(kernel, prefix='hbm_traffic_per_kernel'):
 
 
 def mfma_busy_of(kernel):
-    """share of all SIMD-cycles of a launch in which the matrix pipe was occupied (profiles/r03_mfma_busy_per_kernel.csv:
-    SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x launch cycles), scripts/prof_mfma_busy.sh), or None"""
+    """share of all SIMD-cycles of the launches of `kernel` (every template instance) in which the matrix pipe was occupied
+    (profiles/r03_mfma_busy_per_kernel.csv: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x launch cycles), scripts/prof_mfma_busy.sh), or None"""
     import glob
     paths = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_mfma_busy_per_kernel.csv')))
     if not paths:
         return None
+    busy = cyc = 0.0
     with open(paths[-1]) as f:
         for line in f:
             if line.startswith(kernel):
+                p = line.rstrip().rsplit(',', 6)
                 try:
-                    return {'frac': float(line.rsplit(',', 1)[1]), 'source': os.path.relpath(paths[-1], ROOT) + ' (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES)'}
-                except ValueError:
-                    return None
-    return None
+                    n, cycles, mb = float(p[1]), float(p[2]), float(p[3])
+                except (ValueError, IndexError):
+                    continue
+                busy += n * mb
+                cyc += n * cycles * 1024.0
+    if cyc <= 0:
+        return None
+    return {'frac': round(busy / cyc, 4), 'source': os.path.relpath(paths[-1], ROOT) + ' (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES)'}
 
 
 def cpu_baseline(cfg, variance, step, rays=512, budget_s=15.0, max_steps=10):
