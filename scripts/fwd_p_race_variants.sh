@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
 cp nero_amd/libnero_hip.so /tmp/lib_orig.so
 OBJS=$(ls build/obj/*.o | grep -v mlp_f16p.o | tr '\n' ' ')
-for V in "" "-DNERO_PLAIN_STORES" "-DP_LDS_EXTRA=2560" "-DP_LDS_EXTRA=4096"; do
+for V in ${VARIANTS:-"" "-DNERO_PLAIN_STORES" "-DP_LDS_EXTRA=2560" "-DP_LDS_EXTRA=4096"}; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $V -c nero_amd/csrc/mlp_f16p.hip -o /tmp/p_var.o 2>/dev/null
   hipcc --offload-arch=gfx950 -shared -fPIC -o nero_amd/libnero_hip.so $OBJS /tmp/p_var.o
   echo "== variant [$V]"
