@@ -265,7 +265,8 @@ def stage2_step_bench(dev, kind, P_, Dd, Ds, mesh, rank=0, world=1, warmup=5, st
         if rows:
             dom = max(rows, key=lambda k: rows[k][1])
             n_l, ms_l, fl = rows[dom]
-            kern = {'fwd': 'fwd_p_kernel', 'bwd': 'bwd_f16_kernel', 'dw': 'dw_f16_kernel', 'tan': 'tan_f16_kernel'}[dom]
+            kern = {'fwd': 'fwd_p_kernel' if CH.GEMM_MODE['fwd'] == L.GEMM_F16X3P else 'fwd_f16_kernel', 'bwd': 'bwd_f16_kernel', 'dw': 'dw_f16_kernel',
+                    'tan': 'tan_f16_kernel'}[dom]
             traffic, tsrc = hbm_traffic_per_launch(kern, 'stage2_hbm_traffic_per_kernel')
             out['roofline'] = {'bound': 'mfma', 'kernel': kern, 'achieved': round(fl / (ms_l * 1e-3) / 1e12, 2), 'peak': round(peak / 1e12, 1),
                                'unit': 'TFLOP/s', 'frac': round(fl / (ms_l * 1e-3) / peak, 4), 'avg_launch_ms': round(ms_l / max(n_l, 1), 4),

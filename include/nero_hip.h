@@ -328,6 +328,10 @@ int nero_bvh_create(const float* verts, int nV, const int* tris, int nT, void** 
 int nero_bvh_trace(void* handle, const float* rays_o, const float* rays_d, int n, float* positions, float* face_normals, float* depth,
                    void* stream);
 int nero_bvh_destroy(void* handle);
+/* which kernel nero_bvh_trace launches: 1 = memory requests of a traversal step overlapped, stack in LDS (default when the tree is no
+ * deeper than the 24-entry LDS stack), 0 = private stack, one request after the other.  Same visit order and arithmetic per ray:
+ * bit-identical outputs. */
+int nero_bvh_set_traversal(void* handle, int mode);
 
 /* ---- Stage-II Monte-Carlo shading glue (MCShadingNetwork.shade_mixed and helpers, network/field.py:756-1012).
  *      Row r = p*D + j, D = Dd + Ds (j < Dd cosine-weighted diffuse samples, then GGX specular samples).

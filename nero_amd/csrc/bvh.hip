@@ -6,9 +6,13 @@
 //
 // Build: host C++, top-down median split on the longest centroid axis (std::nth_element), <= 4 triangles per leaf, nodes in
 // DFS order.  A node is 64 bytes and carries BOTH children's boxes, so one 64-byte fetch decides two subtrees.
-// Traversal: one ray per lane, closest-first descent with a 64-entry private stack; the BVH of a 1 M-triangle mesh is ~50 MB
-// and lives in L2 / Infinity Cache; rays of one launch are spatially coherent by construction (768 directions per surface
-// point), so neighbouring lanes walk the same top levels.
+// Traversal: one ray per lane, closest-first descent; the BVH of a 1 M-triangle mesh is ~50 MB and lives in L2 / Infinity Cache.
+// Two kernels walk the same tree in the same order with the same arithmetic per ray (bit-identical results):
+//   * trace_overlap_kernel (default): a step requests the next node AND all triangles of the leaves it reached before it tests
+//     anything, and keeps the deferred-subtree stack in LDS -- one memory round trip per step instead of up to six (measurements in
+//     the comment above the kernel);
+//   * trace_kernel: private (scratch) stack, one triangle after the other -- for trees deeper than the LDS stack, and the kernel the
+//     default is tested against bit for bit (nero_bvh_set_traversal).
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
@@ -91,24 +95,60 @@ __device__ __forceinline__ bool box_hit(const float* mn, const float* mx, const 
     return t0 <= t1;
 }
 
+// The arithmetic of a ray is the same in every traversal kernel below, operation by operation: contraction is switched off and every
+// fused multiply-add is written out, so that the kernels agree bit for bit whatever hipcc makes of the code around the expressions.
+struct TriQ { float4 a, b, c; };           // the 48 bytes of a Tri: v0 e1 | e1 e2 | e2 pad
+__device__ __forceinline__ float cross_c(float a, float b, float c, float d) {     // a b - c d
+#pragma clang fp contract(off)
+    return fmaf(a, b, -(c * d));
+}
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+#pragma clang fp contract(off)
+    return fmaf(az, bz, fmaf(ay, by, ax * bx));
+}
+__device__ __forceinline__ void tri_test(const TriQ& q, int index, const float* o, const float* d, float& tbest, int& best) {
+#pragma clang fp contract(off)
+    const float v0[3] = {q.a.x, q.a.y, q.a.z}, e1[3] = {q.a.w, q.b.x, q.b.y}, e2[3] = {q.b.z, q.b.w, q.c.x};
+    const float px = cross_c(d[1], e2[2], d[2], e2[1]), py = cross_c(d[2], e2[0], d[0], e2[2]), pz = cross_c(d[0], e2[1], d[1], e2[0]);
+    const float det = dot3(e1[0], e1[1], e1[2], px, py, pz);
+    if (fabsf(det) < 1e-20f) return;
+    const float inv = 1.0f / det;
+    const float tx = o[0] - v0[0], ty = o[1] - v0[1], tz = o[2] - v0[2];
+    const float u = dot3(tx, ty, tz, px, py, pz) * inv;
+    if (u < 0.f || u > 1.f) return;
+    const float qx = cross_c(ty, e1[2], tz, e1[1]), qy = cross_c(tz, e1[0], tx, e1[2]), qz = cross_c(tx, e1[1], ty, e1[0]);
+    const float v = dot3(d[0], d[1], d[2], qx, qy, qz) * inv;
+    if (v < 0.f || u + v > 1.f) return;
+    const float tt = dot3(e2[0], e2[1], e2[2], qx, qy, qz) * inv;
+    if (tt > 0.f && tt < tbest) { tbest = tt; best = index; }
+}
+__device__ __forceinline__ TriQ load_tri(const Tri* __restrict__ tris, int i) {
+    const float4* p = reinterpret_cast<const float4*>(tris + i);
+    TriQ q;
+    q.a = p[0]; q.b = p[1]; q.c = p[2];
+    return q;
+}
+// the triangles of a leaf one after the other (low register use: trace_kernel)
 __device__ __forceinline__ void leaf_test(const Tri* __restrict__ tris, int ref, const float* o, const float* d, float& tbest, int& best) {
     const int code = -ref - 1;
     const int start = code >> 3, count = code & 7;
-    for (int i = 0; i < count; ++i) {
-        const Tri& t = tris[start + i];
-        const float px = d[1] * t.e2[2] - d[2] * t.e2[1], py = d[2] * t.e2[0] - d[0] * t.e2[2], pz = d[0] * t.e2[1] - d[1] * t.e2[0];
-        const float det = t.e1[0] * px + t.e1[1] * py + t.e1[2] * pz;
-        if (fabsf(det) < 1e-20f) continue;
-        const float inv = 1.0f / det;
-        const float tx = o[0] - t.v0[0], ty = o[1] - t.v0[1], tz = o[2] - t.v0[2];
-        const float u = (tx * px + ty * py + tz * pz) * inv;
-        if (u < 0.f || u > 1.f) continue;
-        const float qx = ty * t.e1[2] - tz * t.e1[1], qy = tz * t.e1[0] - tx * t.e1[2], qz = tx * t.e1[1] - ty * t.e1[0];
-        const float v = (d[0] * qx + d[1] * qy + d[2] * qz) * inv;
-        if (v < 0.f || u + v > 1.f) continue;
-        const float tt = (t.e2[0] * qx + t.e2[1] * qy + t.e2[2] * qz) * inv;
-        if (tt > 0.f && tt < tbest) { tbest = tt; best = start + i; }
+    for (int i = 0; i < count; ++i) tri_test(load_tri(tris, start + i), start + i, o, d, tbest, best);
+}
+__device__ __forceinline__ void write_hit(const Tri* __restrict__ tris, int r, const float* o, const float* d, float tbest, int best,
+                                          float* __restrict__ pos, float* __restrict__ nrm, float* __restrict__ depth) {
+#pragma clang fp contract(off)
+    if (best >= 0) {
+        const TriQ q = load_tri(tris, best);
+        const float e1[3] = {q.a.w, q.b.x, q.b.y}, e2[3] = {q.b.z, q.b.w, q.c.x};
+        const float nx = cross_c(e1[1], e2[2], e1[2], e2[1]), ny = cross_c(e1[2], e2[0], e1[0], e2[2]), nz = cross_c(e1[0], e2[1], e1[1], e2[0]);
+        const float nn = fmaxf(sqrtf(dot3(nx, ny, nz, nx, ny, nz)), 1e-30f);
+        nrm[r * 3] = nx / nn; nrm[r * 3 + 1] = ny / nn; nrm[r * 3 + 2] = nz / nn;
+    } else {
+        nrm[r * 3] = 0.f; nrm[r * 3 + 1] = 0.f; nrm[r * 3 + 2] = 0.f;
     }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) pos[r * 3 + a] = fmaf(tbest, d[a], o[a]);
+    depth[r] = tbest;
 }
 
 __global__ __launch_bounds__(256) void trace_kernel(const Node* __restrict__ nodes, const Tri* __restrict__ tris, int root,
@@ -148,19 +188,90 @@ __global__ __launch_bounds__(256) void trace_kernel(const Node* __restrict__ nod
         if (next == NONE && sp > 0) next = stack[--sp];
         cur = next;
     }
-    if (best >= 0) {
-        const Tri& t = tris[best];
-        float nx = t.e1[1] * t.e2[2] - t.e1[2] * t.e2[1], ny = t.e1[2] * t.e2[0] - t.e1[0] * t.e2[2], nz = t.e1[0] * t.e2[1] - t.e1[1] * t.e2[0];
-        const float nn = fmaxf(sqrtf(nx * nx + ny * ny + nz * nz), 1e-30f);
-        nrm[r * 3] = nx / nn; nrm[r * 3 + 1] = ny / nn; nrm[r * 3 + 2] = nz / nn;
-    } else {
-        nrm[r * 3] = 0.f; nrm[r * 3 + 1] = 0.f; nrm[r * 3 + 2] = 0.f;
-    }
-    for (int a = 0; a < 3; ++a) pos[r * 3 + a] = o[a] + tbest * d[a];
-    depth[r] = tbest;
+    write_hit(tris, r, o, d, tbest, best, pos, nrm, depth);
 }
 
-struct Handle { Bvh b; int root; };
+// ---- one ray per thread, memory latencies overlapped --------------------------------------------------------------------------
+// trace_kernel waits for memory several times per step: the node, then the triangles of a leaf ONE AFTER THE OTHER (the loop tests a
+// triangle before it asks for the next), and a pop from the scratch stack before the node it names can be requested.  The counters
+// say that is what the time is (scripts/prof_trace.sh, 1 M secondary rays: 76 % of the wave cycles parked in s_waitcnt, VALU busy
+// 40 %, texture addresser busy 47 %, 3.5 waves per SIMD on average; 4.8 k cycles per step).  Here a step asks for everything at once:
+// the NEXT node (its index is known as soon as the boxes are tested -- the leaf tests only shrink tbest) and all triangles of the
+// leaves, then tests; the stack is in LDS.  Same visit order and the same arithmetic per ray as trace_kernel.
+struct NodeQ { float4 a, b, c, d; };       // the 64 bytes of a Node: lmin lmax | rmin rmax | left right pad pad
+__device__ __forceinline__ NodeQ load_node(const Node* __restrict__ nodes, int i) {
+    const float4* p = reinterpret_cast<const float4*>(nodes + i);
+    NodeQ q;
+    q.a = p[0]; q.b = p[1]; q.c = p[2]; q.d = p[3];
+    return q;
+}
+__device__ __forceinline__ void leaf_test_batched(const Tri* __restrict__ tris, int ref, const float* o, const float* d, float& tbest, int& best) {
+    const int code = -ref - 1;
+    const int start = code >> 3, count = code & 7;            // <= 4 (Builder::build)
+    const float4* p = reinterpret_cast<const float4*>(tris + start);
+    TriQ q[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {          // unconditional (a short leaf re-reads its first triangle): predicated loads come out of hipcc with a
+        const int j = i < count ? i : 0;   // wait inside every predicated block, i.e. one triangle after the other again
+        q[i].a = p[3 * j]; q[i].b = p[3 * j + 1]; q[i].c = p[3 * j + 2];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < count) tri_test(q[i], start + i, o, d, tbest, best);
+}
+
+constexpr int PL_THREADS = 256;
+constexpr int PL_STACK = 24;               // LDS stack entries per ray (24 KB per workgroup); deeper trees take trace_kernel
+
+__global__ __launch_bounds__(PL_THREADS) void trace_overlap_kernel(const Node* __restrict__ nodes, const Tri* __restrict__ tris, int root,
+                                                                   const float* __restrict__ ro, const float* __restrict__ rd, int n,
+                                                                   float* __restrict__ pos, float* __restrict__ nrm, float* __restrict__ depth) {
+    __shared__ int lds_stack[PL_STACK * PL_THREADS];
+    int* const st = lds_stack + threadIdx.x;                                   // entry s of this lane: st[s * PL_THREADS]
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const float o[3] = {ro[r * 3], ro[r * 3 + 1], ro[r * 3 + 2]};
+    const float d[3] = {rd[r * 3], rd[r * 3 + 1], rd[r * 3 + 2]};
+    float inv[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) inv[a] = 1.0f / (fabsf(d[a]) > 1e-20f ? d[a] : (d[a] < 0.f ? -1e-20f : 1e-20f));
+    float tbest = MISS_DEPTH;
+    int best = -1, sp = 0, cur = root;
+    NodeQ nd;
+    if (cur < 0) { leaf_test(tris, cur, o, d, tbest, best); cur = NONE; }
+    else nd = load_node(nodes, cur);
+    while (cur != NONE) {
+        const float lmin[3] = {nd.a.x, nd.a.y, nd.a.z}, lmax[3] = {nd.a.w, nd.b.x, nd.b.y};
+        const float rmin[3] = {nd.b.z, nd.b.w, nd.c.x}, rmax[3] = {nd.c.y, nd.c.z, nd.c.w};
+        const int left = __float_as_int(nd.d.x), right = __float_as_int(nd.d.y);
+        float tl, tr;
+        const bool hl = box_hit(lmin, lmax, o, inv, tbest, tl);
+        const bool hr = box_hit(rmin, rmax, o, inv, tbest, tr);
+        int next = NONE, leaf_a = NONE, leaf_b = NONE;
+        int first = left, second = right;
+        bool hf = hl, hs = hr;
+        if (hl && hr && tr < tl) { first = right; second = left; }
+        if (!hl) { first = right; hf = hr; hs = false; }
+        if (hf) {
+            if (first < 0) leaf_a = first; else next = first;
+        }
+        if (hs) {
+            if (second < 0) leaf_b = second;
+            else if (next == NONE) next = second;
+            else if (sp < PL_STACK) st[(sp++) * PL_THREADS] = second;
+        }
+        if (next == NONE && sp > 0) next = st[(--sp) * PL_THREADS];
+        NodeQ nn = nd;
+        if (next != NONE) nn = load_node(nodes, next);                         // in flight while the triangles are fetched and tested
+        if (leaf_a != NONE) leaf_test_batched(tris, leaf_a, o, d, tbest, best);
+        if (leaf_b != NONE) leaf_test_batched(tris, leaf_b, o, d, tbest, best);
+        nd = nn;
+        cur = next;
+    }
+    write_hit(tris, r, o, d, tbest, best, pos, nrm, depth);
+}
+
+struct Handle { Bvh b; int root; int max_depth; int mode; };
 
 }  // namespace
 
@@ -200,10 +311,14 @@ int nero_bvh_create(const float* verts, int nV, const int* tris, int nT, void** 
     }
     Handle* h = new Handle();
     h->root = root;
+    h->max_depth = B.max_depth;
+    h->mode = B.max_depth <= PL_STACK ? 1 : 0;             // a deferred sibling per level: deeper trees take the private-stack kernel
     h->b.n_nodes = (int)B.nodes.size();
     h->b.n_tris = nT;
     const size_t nb = std::max<size_t>(1, B.nodes.size()) * sizeof(Node);
     if (hipMalloc(&h->b.d_nodes, nb) != hipSuccess || hipMalloc(&h->b.d_tris, (size_t)nT * sizeof(Tri)) != hipSuccess) {
+        (void)hipFree(h->b.d_nodes);
+        (void)hipFree(h->b.d_tris);
         delete h;
         return nero_fail(NERO_ERR_LAUNCH, "nero_bvh_create: hipMalloc failed");
     }
@@ -225,9 +340,22 @@ int nero_bvh_trace(void* handle, const float* rays_o, const float* rays_d, int n
     if (!handle || !rays_o || !rays_d || !positions || !face_normals || !depth) return nero_fail(NERO_ERR_ARG, "nero_bvh_trace: bad argument");
     if (n == 0) return NERO_OK;
     Handle* h = (Handle*)handle;
-    hipLaunchKernelGGL(trace_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->b.d_nodes, h->b.d_tris, h->root,
-                       rays_o, rays_d, n, positions, face_normals, depth);
+    if (h->mode == 0) {
+        hipLaunchKernelGGL(trace_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->b.d_nodes, h->b.d_tris, h->root,
+                           rays_o, rays_d, n, positions, face_normals, depth);
+        return nero_check_launch("nero_bvh_trace");
+    }
+    hipLaunchKernelGGL(trace_overlap_kernel, dim3((n + PL_THREADS - 1) / PL_THREADS), dim3(PL_THREADS), 0, (hipStream_t)stream, h->b.d_nodes, h->b.d_tris,
+                       h->root, rays_o, rays_d, n, positions, face_normals, depth);
     return nero_check_launch("nero_bvh_trace");
+}
+
+int nero_bvh_set_traversal(void* handle, int mode) {
+    if (!handle || mode < 0 || mode > 1) return nero_fail(NERO_ERR_ARG, "nero_bvh_set_traversal: bad argument");
+    Handle* h = (Handle*)handle;
+    if (mode == 1 && h->max_depth > PL_STACK) return nero_fail(NERO_ERR_UNSUPPORTED, "nero_bvh_set_traversal: tree deeper than the LDS traversal stack");
+    h->mode = mode;
+    return NERO_OK;
 }
 
 int nero_bvh_destroy(void* handle) {

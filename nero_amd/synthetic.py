@@ -98,3 +98,44 @@ def icosphere(subdiv=3, radius=0.5, bumps=0.0, seed=0):
             k = rg.normal(size=3) * 3.0
             r = r + bumps * radius * np.sin(v @ k + rg.uniform(0, 6.28))
     return (v * r[:, None]).astype(np.float32), f.astype(np.int32)
+
+
+def secondary_rays(v, f, P, D, seed=0, device='cuda'):
+    """Stage-II shaped secondary rays for tracer tests and scripts/trace_bench.py: P points on the mesh (lifted 1e-3 along the outward
+    normal), D directions each -- half cosine-distributed over the hemisphere, half in a lobe around a mirror direction --> (o, d) [P*D,3]"""
+    g = torch.Generator().manual_seed(seed)
+    v, f = torch.from_numpy(v).double(), torch.from_numpy(f.astype(np.int64))
+    ti = torch.randint(0, f.shape[0], (P,), generator=g)
+    tri = v[f[ti]]
+    c = tri.mean(1)
+    n = torch.linalg.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    n = n / n.norm(dim=1, keepdim=True)
+    n = torch.where((n * c).sum(1, keepdim=True) < 0, -n, n)                     # outward
+    a = torch.where(n[:, :1].abs() < 0.9, torch.tensor([[1.0, 0, 0]], dtype=torch.float64), torch.tensor([[0, 1.0, 0]], dtype=torch.float64))
+    t = torch.linalg.cross(n, a)
+    t = t / t.norm(dim=1, keepdim=True)
+    b = torch.linalg.cross(n, t)
+    h = D // 2
+    u1, u2 = torch.rand(P, h, generator=g, dtype=torch.float64), torch.rand(P, h, generator=g, dtype=torch.float64)
+    r, ph = u1.sqrt(), 2 * np.pi * u2
+    dd = (r * ph.cos())[..., None] * t[:, None] + (r * ph.sin())[..., None] * b[:, None] + (1 - u1).sqrt()[..., None] * n[:, None]
+    view = torch.randn(P, 3, generator=g, dtype=torch.float64)
+    view = view / view.norm(dim=1, keepdim=True)
+    view = torch.where((view * n).sum(1, keepdim=True) < 0, -view, view)
+    refl = 2 * (view * n).sum(1, keepdim=True) * n - view
+    ds = refl[:, None] + 0.3 * torch.randn(P, D - h, 3, generator=g, dtype=torch.float64)
+    ds = ds / ds.norm(dim=-1, keepdim=True)
+    dn = (ds * n[:, None]).sum(-1, keepdim=True)
+    ds = torch.where(dn < 0, ds - 2 * dn * n[:, None], ds)
+    d = torch.cat([dd, ds], 1).reshape(-1, 3).float()
+    o = (c + 1e-3 * n).float().repeat_interleave(D, 0)
+    return o.contiguous().to(device), d.contiguous().to(device)
+
+
+def camera_rays(n_side, device='cuda'):
+    """coherent primary rays: a pinhole camera at distance 2 looking at the origin (the dataset pre-trace of renderer.py:756-802)"""
+    ys, xs = torch.meshgrid(torch.linspace(-0.4, 0.4, n_side), torch.linspace(-0.4, 0.4, n_side), indexing='ij')
+    d = torch.stack([xs, ys, -torch.ones_like(xs)], -1).reshape(-1, 3)
+    d = d / d.norm(dim=-1, keepdim=True)
+    o = torch.tensor([[0.0, 0.0, 2.0]]).expand_as(d)
+    return o.contiguous().to(device), d.contiguous().to(device)

@@ -54,3 +54,32 @@ def test_reference_wrapper_contract():
     assert (nrm[..., 2] > 0.9).all()                   # outward winding -> +z at the north pole
     with pytest.raises(AssertionError):
         RayTracer(v, f[:4])
+
+
+@pytest.mark.parametrize('subdiv,n_pts,n_dir', [(2, 37, 33), (5, 300, 64), (7, 1024, 128)])
+def test_both_traversal_kernels_agree_bit_for_bit(subdiv, n_pts, n_dir):
+    """nero_bvh_set_traversal: the default kernel (memory requests of a step overlapped, LDS stack) visits the tree in the same order
+    with the same arithmetic as the one-request-after-the-other kernel -- positions, normals and depths identical, on secondary rays
+    leaving the surface (incoherent) and on camera rays; ray counts that are not a multiple of the workgroup size"""
+    import ctypes as C
+    from nero_amd import _lib as L
+    from nero_amd.raytracing import RayTracer
+    from nero_amd.synthetic import camera_rays, icosphere, secondary_rays
+    v, f = icosphere(subdiv, 0.5, 0.2)
+    f = np.ascontiguousarray(f[:, ::-1])
+    rt = RayTracer(v, f)
+    h = rt._handle()
+    o1, d1 = secondary_rays(v, f, n_pts, n_dir, seed=subdiv)
+    o2, d2 = camera_rays(61)
+    o, d = torch.cat([o1, o2]), torch.cat([d1, d2])
+    res = []
+    for mode in (0, 1):
+        L.check(L.lib.nero_bvh_set_traversal(h, mode))
+        res.append([x.clone() for x in rt.trace(o, d)])
+    L.check(L.lib.nero_bvh_set_traversal(h, 1))
+    hit = res[0][2] < 10
+    assert 0.05 < float(hit.float().mean()) < 0.95
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b), int((a != b).sum())
+    with pytest.raises(RuntimeError):
+        L.check(L.lib.nero_bvh_set_traversal(h, 2))
