@@ -220,8 +220,13 @@ __device__ __forceinline__ void leaf_test_batched(const Tri* __restrict__ tris, 
         if (i < count) tri_test(q[i], start + i, o, d, tbest, best);
 }
 
-constexpr int PL_THREADS = 256;
-constexpr int PL_STACK = 24;               // LDS stack entries per ray (24 KB per workgroup); deeper trees take trace_kernel
+// one wavefront per workgroup: the workgroups of a launch retire at very different times (secondary rays), and small ones refill the
+// CUs sooner (3.1 M rays: 1.39 ms with 256 threads, 1.30 with 128, 1.28 with 64; 1 M rays: 0.57 either way).  Measured and dropped:
+// both leaves of a step requested together (116 VGPRs: 0.65 ms per 1 M rays instead of 0.57); persistent wavefronts that refill idle
+// lanes from a ray counter (42 % of the lanes are busy in a step of this kernel, scripts/probe/trace_stats.cpp -- but the refilled
+// wavefronts execute as many instructions, every step then has some lane in a leaf: 0.92 ms).
+constexpr int PL_THREADS = 64;
+constexpr int PL_STACK = 24;               // LDS stack entries per ray (6 KB per workgroup); deeper trees take trace_kernel
 
 __global__ __launch_bounds__(PL_THREADS) void trace_overlap_kernel(const Node* __restrict__ nodes, const Tri* __restrict__ tris, int root,
                                                                    const float* __restrict__ ro, const float* __restrict__ rd, int n,
