@@ -22,7 +22,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = colle
 for r in csv.DictReader(open(fs[0])):
     k = r['Kernel_Name']
     if 'trace_' not in k: continue
-    k = 'trace_refill_kernel' if 'refill' in k else 'trace_kernel'
+    k = 'trace_overlap_kernel' if 'overlap' in k else 'trace_kernel'
     acc[k][r['Counter_Name']] += float(r['Counter_Value'])
     n[(k, r['Counter_Name'])] += 1
 for k in acc:
