@@ -221,10 +221,11 @@ __device__ __forceinline__ void leaf_test_batched(const Tri* __restrict__ tris, 
 }
 
 // one wavefront per workgroup: the workgroups of a launch retire at very different times (secondary rays), and small ones refill the
-// CUs sooner (3.1 M rays: 1.39 ms with 256 threads, 1.30 with 128, 1.28 with 64; 1 M rays: 0.57 either way).  Measured and dropped:
-// both leaves of a step requested together (116 VGPRs: 0.65 ms per 1 M rays instead of 0.57); persistent wavefronts that refill idle
-// lanes from a ray counter (42 % of the lanes are busy in a step of this kernel, scripts/probe/trace_stats.cpp -- but the refilled
-// wavefronts execute as many instructions, every step then has some lane in a leaf: 0.92 ms).
+// CUs sooner (1 M / 3.1 M secondary rays: 0.52 / 1.22 ms with 64 threads, 0.53 / 1.26 with 128, 0.56 / 1.38 with 256; coherent camera
+// rays prefer 128: 0.30 against 0.34 ms per 1 M -- the training step's rays decide).  Measured and dropped: both leaves of a step
+// requested together (116 VGPRs: +0.08 ms per 1 M rays); persistent wavefronts that refill idle lanes from a ray counter (42 % of the
+// lanes are busy in a step, scripts/probe/trace_stats.cpp -- but the refilled wavefronts execute as many instructions, every step then
+// has some lane in a leaf, on fewer resident waves: 0.92 ms).
 constexpr int PL_THREADS = 64;
 constexpr int PL_STACK = 24;               // LDS stack entries per ray (6 KB per workgroup); deeper trees take trace_kernel
 
@@ -245,33 +246,38 @@ __global__ __launch_bounds__(PL_THREADS) void trace_overlap_kernel(const Node* _
     NodeQ nd;
     if (cur < 0) { leaf_test(tris, cur, o, d, tbest, best); cur = NONE; }
     else nd = load_node(nodes, cur);
-    while (cur != NONE) {
-        const float lmin[3] = {nd.a.x, nd.a.y, nd.a.z}, lmax[3] = {nd.a.w, nd.b.x, nd.b.y};
-        const float rmin[3] = {nd.b.z, nd.b.w, nd.c.x}, rmax[3] = {nd.c.y, nd.c.z, nd.c.w};
-        const int left = __float_as_int(nd.d.x), right = __float_as_int(nd.d.y);
-        float tl, tr;
-        const bool hl = box_hit(lmin, lmax, o, inv, tbest, tl);
-        const bool hr = box_hit(rmin, rmax, o, inv, tbest, tr);
-        int next = NONE, leaf_a = NONE, leaf_b = NONE;
-        int first = left, second = right;
-        bool hf = hl, hs = hr;
-        if (hl && hr && tr < tl) { first = right; second = left; }
-        if (!hl) { first = right; hf = hr; hs = false; }
-        if (hf) {
-            if (first < 0) leaf_a = first; else next = first;
+    // ONE leaf section per step: the second leaf of a node is tested at the start of the lane's next step, before its next node -- the
+    // same order of visits, but a wavefront executes the triangle code once per step instead of twice (0.57 -> 0.52 ms per 1 M rays)
+    int pend = NONE;
+    while (cur != NONE || pend != NONE) {
+        int leaf = pend;
+        pend = NONE;
+        if (leaf == NONE) {
+            const float lmin[3] = {nd.a.x, nd.a.y, nd.a.z}, lmax[3] = {nd.a.w, nd.b.x, nd.b.y};
+            const float rmin[3] = {nd.b.z, nd.b.w, nd.c.x}, rmax[3] = {nd.c.y, nd.c.z, nd.c.w};
+            const int left = __float_as_int(nd.d.x), right = __float_as_int(nd.d.y);
+            float tl, tr;
+            const bool hl = box_hit(lmin, lmax, o, inv, tbest, tl);
+            const bool hr = box_hit(rmin, rmax, o, inv, tbest, tr);
+            int next = NONE, leaf_a = NONE, leaf_b = NONE;
+            int first = left, second = right;
+            bool hf = hl, hs = hr;
+            if (hl && hr && tr < tl) { first = right; second = left; }
+            if (!hl) { first = right; hf = hr; hs = false; }
+            if (hf) {
+                if (first < 0) leaf_a = first; else next = first;
+            }
+            if (hs) {
+                if (second < 0) leaf_b = second;
+                else if (next == NONE) next = second;
+                else if (sp < PL_STACK) st[(sp++) * PL_THREADS] = second;
+            }
+            if (next == NONE && sp > 0) next = st[(--sp) * PL_THREADS];
+            if (next != NONE) nd = load_node(nodes, next);                     // in flight while the triangles are fetched and tested
+            cur = next;
+            if (leaf_a != NONE) { leaf = leaf_a; pend = leaf_b; } else leaf = leaf_b;
         }
-        if (hs) {
-            if (second < 0) leaf_b = second;
-            else if (next == NONE) next = second;
-            else if (sp < PL_STACK) st[(sp++) * PL_THREADS] = second;
-        }
-        if (next == NONE && sp > 0) next = st[(--sp) * PL_THREADS];
-        NodeQ nn = nd;
-        if (next != NONE) nn = load_node(nodes, next);                         // in flight while the triangles are fetched and tested
-        if (leaf_a != NONE) leaf_test_batched(tris, leaf_a, o, d, tbest, best);
-        if (leaf_b != NONE) leaf_test_batched(tris, leaf_b, o, d, tbest, best);
-        nd = nn;
-        cur = next;
+        if (leaf != NONE) leaf_test_batched(tris, leaf, o, d, tbest, best);
     }
     write_hit(tris, r, o, d, tbest, best, pos, nrm, depth);
 }
