@@ -78,14 +78,18 @@ __device__ __forceinline__ void eval_head_f16(const char* planes, const float* r
                                               float* __restrict__ out, int n_head, int hk, int row0, int tid) {
     const int r = tid >> 3, q = tid & 7;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
+    float bj[4] = {0.f, 0.f, 0.f, 0.f};                    // (the four biases together, ahead of the sums: they were four serial loads at the end)
+    if (b) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bj[j] = b[j < n_head ? j : 0];
+    }
     for (int c4 = 4 * q; c4 < hk; c4 += 32) {
         const float4 x = load_planes4h(planes + r * SA + c4 * 2, PLANE_A);
+        float4 ww[4];                                      // all four rows requested together (a missing head re-reads row 0): with the
+#pragma unroll                                             // load inside `if (j < n_head)` every row was waited for separately
+        for (int j = 0; j < 4; ++j) ww[j] = *reinterpret_cast<const float4*>(w + (j < n_head ? j : 0) * NERO_HID + c4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (j < n_head) {
-                const float4 ww = *reinterpret_cast<const float4*>(w + j * NERO_HID + c4);
-                s[j] = fmaf(x.x, ww.x, fmaf(x.y, ww.y, fmaf(x.z, ww.z, fmaf(x.w, ww.w, s[j]))));
-            }
+        for (int j = 0; j < 4; ++j) s[j] = fmaf(x.x, ww[j].x, fmaf(x.y, ww[j].y, fmaf(x.z, ww[j].z, fmaf(x.w, ww[j].w, s[j]))));
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -97,7 +101,7 @@ __device__ __forceinline__ void eval_head_f16(const char* planes, const float* r
         const float sc = rs[r];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (j < n_head) out[(size_t)(row0 + r) * 4 + j] = s[j] * sc + (b ? b[j] : 0.f);
+            if (j < n_head) out[(size_t)(row0 + r) * 4 + j] = s[j] * sc + bj[j];
     }
 }
 
@@ -393,42 +397,61 @@ template <int ACT, bool HEAD>
 __device__ __forceinline__ void bwd_values(const float4 (&gq)[2][4], const float4 (&pa)[2][4], size_t goff, bool has_inj,
                                            const nero_bwd_layer& L, int row0, int i, int fbase, int n_rows, float4 (&val)[2][4],
                                            float (&m)[2]) {
+    // the global operands of the epilogue are requested in branch-free batches ahead of their use: with the loads inside
+    // `if (has_inj)` / `if (j < nh)` hipcc waited for each of them separately (147 of the reverse kernel's 240 loads were followed by
+    // s_waitcnt vmcnt(0)) -- eight serial HBM round trips per layer-tile for the injections of the second-order pass, up to 32 serial
+    // L2 round trips for the head weights of a chain's first step.  Now: four head-weight rows per request group, and the four
+    // injection vectors of a row half together (both halves at once costs 32 more registers: 255 + spills).
     const int nh = L.n_head;
+    float4 gs[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gs[r][g] = gq[r][g];
+    if (HEAD) {
+        float dj[2][4];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const float4 dyh = *reinterpret_cast<const float4*>(L.head_dy + (size_t)(row0 + 32 * r + i) * 4);
+            dj[r][0] = dyh.x; dj[r][1] = dyh.y; dj[r][2] = dyh.z; dj[r][3] = dyh.w;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 hw[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hw[j] = *reinterpret_cast<const float4*>(L.head_w + (j < nh ? j : 0) * NERO_HID + fbase + 8 * g);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < nh) {
+                        gs[r][g].x = fmaf(dj[r][j], hw[j].x, gs[r][g].x); gs[r][g].y = fmaf(dj[r][j], hw[j].y, gs[r][g].y);
+                        gs[r][g].z = fmaf(dj[r][j], hw[j].z, gs[r][g].z); gs[r][g].w = fmaf(dj[r][j], hw[j].w, gs[r][g].w);
+                    }
+            __builtin_amdgcn_sched_barrier(0);         // (one request group at a time: all sixteen hoisted cost 40 registers and spills)
+        }
+    }
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        const int grow = row0 + 32 * r + i;
-        const bool live = grow < n_rows;
-        float dj[4] = {0.f, 0.f, 0.f, 0.f};
-        if (HEAD) {
-            const float4 dyh = *reinterpret_cast<const float4*>(L.head_dy + (size_t)grow * 4);
-            dj[0] = dyh.x; dj[1] = dyh.y; dj[2] = dyh.z; dj[3] = dyh.w;
+        const bool live = (row0 + 32 * r + i) < n_rows;
+        float4 ij[4];
+        if (has_inj) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ij[g] = *reinterpret_cast<const float4*>(L.inj + goff + (size_t)r * 32 * NERO_HID + 8 * g);
         }
         m[r] = 0.f;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            float4 gs = gq[r][g];
-            if (HEAD) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (j < nh) {
-                        const float4 hw = *reinterpret_cast<const float4*>(L.head_w + j * NERO_HID + fbase + 8 * g);
-                        gs.x = fmaf(dj[j], hw.x, gs.x); gs.y = fmaf(dj[j], hw.y, gs.y);
-                        gs.z = fmaf(dj[j], hw.z, gs.z); gs.w = fmaf(dj[j], hw.w, gs.w);
-                    }
-                }
-            }
             const float4 a = pa[r][g];
             float4 d;
-            d.x = act_grad<ACT>(a.x, gs.x); d.y = act_grad<ACT>(a.y, gs.y);
-            d.z = act_grad<ACT>(a.z, gs.z); d.w = act_grad<ACT>(a.w, gs.w);
-            if (has_inj) {
-                const float4 ij = *reinterpret_cast<const float4*>(L.inj + goff + (size_t)r * 32 * NERO_HID + 8 * g);
-                d.x += ij.x; d.y += ij.y; d.z += ij.z; d.w += ij.w;
-            }
+            d.x = act_grad<ACT>(a.x, gs[r][g].x); d.y = act_grad<ACT>(a.y, gs[r][g].y);
+            d.z = act_grad<ACT>(a.z, gs[r][g].z); d.w = act_grad<ACT>(a.w, gs[r][g].w);
+            if (has_inj) { d.x += ij[g].x; d.y += ij[g].y; d.z += ij[g].z; d.w += ij[g].w; }
             if (!live) d = make_float4(0.f, 0.f, 0.f, 0.f);
             val[r][g] = d;
             m[r] = fmaxf(m[r], amax4(d));
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 template <int ACT>
