@@ -12,7 +12,7 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_
            "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" \
            "TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum TCP_TA_TCP_STATE_READ_sum"; do
     i=$((i+1)); O=gpurun_out/prof/tr$i; rm -rf $O; mkdir -p $O
-    timeout 200 rocprofv3 --pmc $grp --kernel-trace -d $O -o p --output-format csv -- python scripts/trace_bench.py > $O.log 2>&1
+    timeout 200 rocprofv3 --pmc $grp --kernel-trace -d $O -o p --output-format csv -- python ${TRACE_SCRIPT:-scripts/trace_bench.py} > $O.log 2>&1
     python - "$O" "$grp" >> gpurun_out/trace_pmc.txt <<'P'
 import collections, csv, glob, sys
 fs = glob.glob(sys.argv[1] + '/**/*counter_collection.csv', recursive=True)
