@@ -45,7 +45,7 @@ def main():
                 'step origins, synthetic directions': (o, sd), 'synthetic origins, step directions': (so, d),
                 'step rays, inward directions mirrored outward': (o, torch.where(up < 0, d - 2 * up * rad, d).contiguous()), 'synthetic rays': (so, sd)}
     if os.environ.get('STEP_RAYS_ONLY'):
-        variants = {k: variants[k] for k in ('step rays', 'synthetic rays')}
+        variants = {k: variants[k] for k in os.environ['STEP_RAYS_ONLY'].split('|')}
     for name, (oo, dd) in variants.items():
         for mode in (0, 1):
             L.check(L.lib.nero_bvh_set_traversal(h, mode))
