@@ -149,6 +149,38 @@ def test_tracer_oracle_c_restatement_equals_numpy_oracle():
     assert 0.3 < (b[3] >= 0).mean() < 1.0 and b[4].mean() < 0.01
 
 
+def test_secondary_ray_generator_for_the_tracer_tests():
+    """nero_amd.synthetic.secondary_rays / camera_rays (inputs of tests/test_tracer.py and scripts/trace_bench.py): unit directions, point-major
+    layout, origins 1e-3 off the surface on the outside, every direction in the outer half space of its triangle; against the brute-force
+    oracle: a bumpy mesh is hit by some of them and a camera ray through the centre hits the front of the mesh"""
+    from nero_amd.synthetic import camera_rays, icosphere, secondary_rays
+    from oracle.tracer_oracle import trace_bruteforce
+    v, f = icosphere(3, 0.5, 0.2)
+    f = np.ascontiguousarray(f[:, ::-1])
+    P, D = 40, 16
+    o, d = secondary_rays(v, f, P, D, seed=3, device='cpu')
+    assert o.shape == (P * D, 3) and d.shape == (P * D, 3) and o.dtype == torch.float32
+    assert float((d.norm(dim=-1) - 1).abs().max()) < 1e-5
+    ob = o.reshape(P, D, 3)
+    assert float((ob - ob[:, :1]).abs().max()) == 0.0                         # the D rays of a point share its origin
+    on, dn = o.numpy().astype(np.float64), d.numpy().astype(np.float64)
+    # the origin is 1e-3 from the nearest triangle plane on its outer side: a ray straight back down hits at t = 1e-3
+    tri = v[f].astype(np.float64)
+    c = tri.mean(1)
+    k = np.argmin(np.linalg.norm(c[None] - on[::D, None], axis=-1), axis=1)
+    n = np.cross(tri[k, 1] - tri[k, 0], tri[k, 2] - tri[k, 0])
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    n = np.where((n * c[k]).sum(1, keepdims=True) < 0, -n, n)
+    assert np.abs(((on[::D] - c[k]) * n).sum(1) - 1e-3).max() < 1e-6
+    assert ((dn.reshape(P, D, 3) * n[:, None]).sum(-1) > -1e-6).all()
+    hit = trace_bruteforce(v, f, on, dn)[3] >= 0
+    assert 0.02 < hit.mean() < 0.9
+    co, cd = camera_rays(9, device='cpu')
+    assert co.shape == (81, 3) and float((cd.norm(dim=-1) - 1).abs().max()) < 1e-6
+    pos, nrm, depth, idx = trace_bruteforce(v, f, co.numpy().astype(np.float64), cd.numpy().astype(np.float64))
+    assert idx[40] >= 0 and 1.0 < depth[40] < 2.0 and pos[40, 2] > 0               # the central ray: camera at z = 2, front of the mesh
+
+
 def test_bench_gpus_flag_spawns_one_rank_per_gpu(monkeypatch):
     """`python bench.py --gpus N` without a torch.distributed environment re-launches itself under torch.distributed.run with
     N ranks on 127.0.0.1 (the flag used to be parsed and ignored)"""
