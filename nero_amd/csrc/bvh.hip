@@ -225,7 +225,10 @@ __device__ __forceinline__ void leaf_test_batched(const Tri* __restrict__ tris, 
 // rays prefer 128: 0.30 against 0.34 ms per 1 M -- the training step's rays decide).  Measured and dropped: both leaves of a step
 // requested together (116 VGPRs: +0.08 ms per 1 M rays); persistent wavefronts that refill idle lanes from a ray counter (42 % of the
 // lanes are busy in a step, scripts/probe/trace_stats.cpp -- but the refilled wavefronts execute as many instructions, every step then
-// has some lane in a leaf, on fewer resident waves: 0.92 ms).
+// has some lane in a leaf, on fewer resident waves: 0.92 ms); a 4-WIDE TREE (128-byte nodes collapsed from the binary tree, the four
+// boxes of a node tested and sorted per step, hit leaves queued one per step; its visit logic checked on the CPU against this kernel's:
+// same closest triangle on every ray) -- half the dependent steps per ray (36 -> 20), but 101 VGPRs and twice the box work per step:
+// 0.57 ms per 1 M synthetic rays against 0.51, 0.83 against 0.73 on the rays of a training step.
 constexpr int PL_THREADS = 64;
 constexpr int PL_STACK = 24;               // LDS stack entries per ray (6 KB per workgroup); deeper trees take trace_kernel
 
@@ -273,7 +276,10 @@ __global__ __launch_bounds__(PL_THREADS) void trace_overlap_kernel(const Node* _
                 else if (sp < PL_STACK) st[(sp++) * PL_THREADS] = second;
             }
             if (next == NONE && sp > 0) next = st[(--sp) * PL_THREADS];
-            if (next != NONE) nd = load_node(nodes, next);                     // in flight while the triangles are fetched and tested
+            nd = load_node(nodes, next != NONE ? next : 0);                    // in flight while the triangles are fetched and tested.  Unconditional (a
+                                                                               // finished lane re-reads node 0): behind `if (next != NONE)` hipcc reused a padding register of
+                                                                               // the load as scratch and waited for the node before it requested the triangles (0.77 -> 0.73 ms
+                                                                               // on the rays of a training step)
             cur = next;
             if (leaf_a != NONE) { leaf = leaf_a; pend = leaf_b; } else leaf = leaf_b;
         }
