@@ -265,7 +265,7 @@ def stage2_step_bench(dev, kind, P_, Dd, Ds, mesh, rank=0, world=1, warmup=5, st
         if rows:
             dom = max(rows, key=lambda k: rows[k][1])
             n_l, ms_l, fl = rows[dom]
-            kern = {'fwd': 'fwd_p_kernel' if CH.GEMM_MODE['fwd'] == L.GEMM_F16X3P else 'fwd_f16_kernel', 'bwd': 'bwd_f16_kernel', 'dw': 'dw_f16_kernel',
+            kern = {'fwd': 'fwd_f16_kernel', 'bwd': 'bwd_f16_kernel', 'dw': 'dw_f16_kernel',
                     'tan': 'tan_f16_kernel'}[dom]
             traffic, tsrc = hbm_traffic_per_launch(kern, 'stage2_hbm_traffic_per_kernel')
             out['roofline'] = {'bound': 'mfma', 'kernel': kern, 'achieved': round(fl / (ms_l * 1e-3) / 1e12, 2), 'peak': round(peak / 1e12, 1),
@@ -567,10 +567,10 @@ def main():
         L.lib.nero_prof_enable(0)
         rep = (C.c_double * 12)()
         L.lib.nero_prof_report(rep)
-        kname = {'fwd': ('mlp_fwd_kernel', 'fwd_split_kernel', 'fwd_f16_kernel', 'fwd_p_kernel'),
-                 'tan': ('mlp_tan_kernel', 'tan_split_kernel', 'tan_f16_kernel', 'tan_p_kernel'),
-                 'bwd': ('mlp_bwd_kernel', 'bwd_split_kernel', 'bwd_f16_kernel', 'bwd_p_kernel'),
-                 'dw': ('dw_gemm_kernel', 'dw_split_kernel', 'dw_f16_kernel', 'dw_f16_kernel')}
+        kname = {'fwd': ('mlp_fwd_kernel', 'fwd_split_kernel', 'fwd_f16_kernel'),
+                 'tan': ('mlp_tan_kernel', 'tan_split_kernel', 'tan_f16_kernel'),
+                 'bwd': ('mlp_bwd_kernel', 'bwd_split_kernel', 'bwd_f16_kernel'),
+                 'dw': ('dw_gemm_kernel', 'dw_split_kernel', 'dw_f16_kernel')}
         passes = ('fwd', 'tan', 'bwd', 'dw')
         kinds = [kname[m][CH.GEMM_MODE[m]] for m in passes]
         peaks = [PEAK_OF_MODE[CH.GEMM_MODE[m]] for m in passes]
@@ -607,7 +607,7 @@ def main():
     res = None
     if rank == 0:
         split = CH.GEMM_MODE['fwd'] != L.GEMM_F32
-        modes = {k: {0: 'f32', 1: 'bf16x6', 2: 'f16x3', 3: 'f16x3p'}[v] for k, v in CH.GEMM_MODE.items()}
+        modes = {k: {0: 'f32', 1: 'bf16x6', 2: 'f16x3'}[v] for k, v in CH.GEMM_MODE.items()}
         # whole-step algorithmic FLOPs with the measured inner/outer split of this rank
         sampler_evals = args.rays * (64 + 3 * 16)
         flop_step = (n_in / args.steps) * 2 * (6 * C_SDF + 3 * c_app) + (n_out / args.steps) * 2 * 3 * C_NERF + sampler_evals * 2 * C_SDF

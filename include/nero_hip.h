@@ -34,10 +34,10 @@ enum { NERO_ACT_NONE = 0, NERO_ACT_RELU = 1, NERO_ACT_SOFTPLUS100 = 2 };
 /* F16X3: operands as two fp16 planes (h, l*2^11) of their block-scaled value (per activation row / per weight matrix, exact
  * powers of two), three plane products in two accumulator sets -- half the MFMA count of BF16X6 at the same error class
  * (representation error <= 2^-24 of the block maximum, dropped term <= 2^-24 of the product). */
-/* F16X3P: the F16X3 arithmetic, packed images and results (bit for bit) on 256-thread workgroups, two resident per CU
- * (mlp_f16p.hip): a wave computes two feature tiles one after the other, the aux operand is converted from global memory, so that
- * one workgroup's epilogue / barriers / HBM waits are covered by the other's MFMAs. */
-enum { NERO_GEMM_F32 = 0, NERO_GEMM_BF16X6 = 1, NERO_GEMM_F16X3 = 2, NERO_GEMM_F16X3P = 3 };
+/* (value 3 was NERO_GEMM_F16X3P, the two-workgroups-per-CU forward engine of rounds 2-3: removed in round 4 -- it returned a wrong
+ * partial sum in one launch of three at size and the mechanism was never identified; every entry point now answers
+ * NERO_ERR_UNSUPPORTED / NERO_ERR_ARG to it.) */
+enum { NERO_GEMM_F32 = 0, NERO_GEMM_BF16X6 = 1, NERO_GEMM_F16X3 = 2 };
 enum { NERO_OK = 0, NERO_ERR_ARG = -1, NERO_ERR_LAUNCH = -2, NERO_ERR_UNSUPPORTED = -3 };
 
 const char* nero_last_error(void);
@@ -182,7 +182,7 @@ typedef struct {
     float* db;                          /* [n_out] or NULL                    */
     float scale;
     int accumulate;                     /* 0: overwrite, 1: add into dW/db    */
-    int gemm_mode, pad_;                /* NERO_GEMM_* (operands are plain fp32 matrices in every mode).  F16X3 / F16X3P: three fp16
+    int gemm_mode, pad_;                /* NERO_GEMM_* (operands are plain fp32 matrices in every mode).  F16X3: three fp16
                                            plane products, each 16-row chunk block-scaled to the top of fp16's range, one fp32
                                            accumulator with a running unit (mlp_f16dw.hip); BF16X6: six bf16 products */
 } nero_dw_job;
@@ -403,7 +403,7 @@ int nero_mc_dir_bwd(const float* pt, const float* dirs, const float* face_normal
  * any language runs the step without Python.  ALL memory is the caller's: one workspace (nero_stage1_workspace_bytes) from which every
  * intermediate is carved, one buffer for the packed operand images (nero_stage1_pack_bytes).  The only host synchronisation is the
  * read-back of the inner / outer sample counts inside nero_stage1_render_fwd (they size every later launch).
- * The fp16 two-plane engines only (gemm_* in {NERO_GEMM_F16X3, NERO_GEMM_F16X3P}); NERO_ERR_UNSUPPORTED otherwise. */
+ * The fp16 two-plane engines only (gemm_* = NERO_GEMM_F16X3); NERO_ERR_UNSUPPORTED otherwise. */
 #define NERO_S1_LINEARS 49
 /* index of a Linear in nero_stage1_weights / _grads: sdf_network.lin0..8 = 0..8, outer_nerf.pts_linears.0..7 = 9..16, views_linears.0 = 17,
  * feature_linear = 18, alpha_linear = 19, rgb_linear = 20, then the predictors' four Linears each: metallic 21.., roughness 25.., albedo

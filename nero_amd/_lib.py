@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get('NERO_HIP_LIB') or os.path.join(_HERE, 'libnero_hip.so
 MAX_LAYERS = 10
 HID = 256
 ACT_NONE, ACT_RELU, ACT_SOFTPLUS100 = 0, 1, 2
-GEMM_F32, GEMM_BF16X6, GEMM_F16X3, GEMM_F16X3P = 0, 1, 2, 3
+GEMM_F32, GEMM_BF16X6, GEMM_F16X3 = 0, 1, 2
 
 _fp = C.c_void_p   # device pointers travel as integers
 

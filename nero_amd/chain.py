@@ -17,22 +17,20 @@ from . import _lib as L
 #   'f16x3'  (default) two block-scaled fp16 planes, 3 MFMA products: per activation row / weight matrix in the chain kernels
 #            (mlp_f16x3.hip), per 16-row chunk with a running accumulator unit in the weight-gradient GEMM (mlp_f16dw.hip)
 #   'bf16x6' three bf16 planes, 6 products (mlp_split.hip)
-#   'f16x3p' the f16x3 arithmetic, operand images and results on 256-thread workgroups, two resident per CU (mlp_f16p.hip):
-#            3-9 % faster forward chains (one workgroup's input load / epilogue under the other's MFMAs; 0.3 ms of a 32 ms step) and
-#            the default until late round 3 -- NOT any more: with two workgroups co-resident on a CU the forward kernel sporadically
-#            (one launch in three at 390 k rows) returns ONE output column of rows 48-63 of one tile with another k-step's partial
-#            sum (errors of 1e-2 in a saved activation, 1e-5 in a ray colour, 1e-7 in a gradient: below every parity tolerance, found
-#            by scripts/determinism.py).  DESIGN.md section 3i lists what was ruled out; the mechanism is not identified, so the
-#            512-thread kernels, which are bit-reproducible run to run, are the default again.  Opt in with NERO_GEMM_FWD=f16x3p.
+#   ('f16x3p', the two-workgroups-per-CU forward engine of rounds 2-3, is gone: it sporadically returned a wrong partial sum at size
+#            and the mechanism was never identified; asking for it raises)
 #   'f32'    the f32-input MFMA, an exact fmaf chain
 # NERO_GEMM=<mode> selects all passes, NERO_GEMM_FWD / _TAN / _BWD / _DW one pass.
-_MODE_NAMES = {'f32': L.GEMM_F32, 'bf16x6': L.GEMM_BF16X6, 'f16x3': L.GEMM_F16X3, 'f16x3p': L.GEMM_F16X3P}
-_F16 = (L.GEMM_F16X3, L.GEMM_F16X3P)          # the two engines that share the kind-3 packed images
+_MODE_NAMES = {'f32': L.GEMM_F32, 'bf16x6': L.GEMM_BF16X6, 'f16x3': L.GEMM_F16X3}
+_F16 = (L.GEMM_F16X3,)                        # the engine of the kind-3 packed images
 _DEFAULT = {'fwd': 'f16x3', 'tan': 'f16x3', 'bwd': 'f16x3', 'dw': 'f16x3'}
 
 
 def _resolve(mode, k):
-    return _MODE_NAMES['f16x3' if (mode == 'f16x3p' and k == 'dw') else mode]      # (one fp16 weight-gradient kernel)
+    if mode not in _MODE_NAMES:
+        raise ValueError(f"NERO_GEMM{'_' + k.upper()}: unknown arithmetic {mode!r} (one of {sorted(_MODE_NAMES)}; 'f16x3p' was removed in "
+                         "round 4, DESIGN.md 3i)")
+    return _MODE_NAMES[mode]
 
 
 GEMM_MODE = {k: _resolve(os.environ.get('NERO_GEMM_' + k.upper(), os.environ.get('NERO_GEMM', _DEFAULT[k])), k)
@@ -215,13 +213,8 @@ class Chain:
         ch.aux, ch.ld_aux, ch.k_aux = L.ptr(aux), (aux.stride(0) if aux is not None else 0), self.k_aux
         ch.n_layers, ch.aux_wide = len(self.entries), int(self.aux_wide)
         split = GEMM_MODE['fwd'] != L.GEMM_F32
-        fkeys = {L.GEMM_F32: ('fm', 'fa'), L.GEMM_BF16X6: ('sfm', 'sfa'), L.GEMM_F16X3: ('hfm', 'hfa'), L.GEMM_F16X3P: ('hfm', 'hfa')}[GEMM_MODE['fwd']]
+        fkeys = {L.GEMM_F32: ('fm', 'fa'), L.GEMM_BF16X6: ('sfm', 'sfa'), L.GEMM_F16X3: ('hfm', 'hfa')}[GEMM_MODE['fwd']]
         ch.gemm_mode = GEMM_MODE['fwd']
-        if ch.gemm_mode == L.GEMM_F16X3P and self.aux_wide:
-            # same images, same results: the engine is picked per launch.  The paired kernels convert the aux operand from global
-            # memory in every wave; with an 88-column aux input (the NeRF++ trunk) the 512-thread kernel, whose aux tile lives in
-            # LDS, is faster (-0.3 ms per training step)
-            ch.gemm_mode = L.GEMM_F16X3
         ch.macs_per_row = float(sum(d.n_out * (d.k_main + d.k_aux) for d, _ in self.entries if d is not None))
         if init is not None:
             assert init.shape[0] >= rp and init.shape[1] >= self.k_init
@@ -276,7 +269,7 @@ class Chain:
         ch = L.BwdChain()
         ch.n_layers, ch.aux_wide = len(self.entries), 0
         split = GEMM_MODE['bwd'] != L.GEMM_F32
-        bkeys = {L.GEMM_F32: ('bm', 'ba'), L.GEMM_BF16X6: ('sbm', 'sba'), L.GEMM_F16X3: ('hbm', 'hba'), L.GEMM_F16X3P: ('hbm', 'hba')}[GEMM_MODE['bwd']]
+        bkeys = {L.GEMM_F32: ('bm', 'ba'), L.GEMM_BF16X6: ('sbm', 'sba'), L.GEMM_F16X3: ('hbm', 'hba')}[GEMM_MODE['bwd']]
         ch.gemm_mode = GEMM_MODE['bwd']
         rk = _r16 if split else _r8
         last = len(self.entries) - 1

@@ -20,7 +20,7 @@ inline int tiles(int x) { return (x + 31) / 32; }
 inline int rpad(int n) { return NERO_ROW_PAD(n); }
 // contraction length of a layer's reverse GEMM: wide layers are zero-padded to 256 (nero_amd/chain.py::_rev_k)
 inline int rev_k(int n_out) { return (n_out > 128 && n_out <= 256) ? 256 : r16(n_out); }
-inline bool is_f16(int m) { return m == NERO_GEMM_F16X3 || m == NERO_GEMM_F16X3P; }
+inline bool is_f16(int m) { return m == NERO_GEMM_F16X3; }
 
 // ---- workspace arena -------------------------------------------------------------------------------------------------------
 struct Arena {
@@ -178,7 +178,6 @@ struct Chain {
         ch.aux = aux; ch.ld_aux = aux ? ld_aux : 0; ch.k_aux = k_aux;
         ch.n_layers = n(); ch.aux_wide = aux_wide;
         ch.gemm_mode = M.fwd;
-        if (ch.gemm_mode == NERO_GEMM_F16X3P && aux_wide) ch.gemm_mode = NERO_GEMM_F16X3;     // (chain.py: the wide-aux trunk stays on the 512-thread kernel)
         double macs = 0.0;
         for (const Entry& x : e) if (x.d.has) macs += (double)x.d.n_out * (x.d.k_main + x.d.k_aux);
         ch.macs_per_row = macs;

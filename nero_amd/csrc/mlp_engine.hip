@@ -851,9 +851,8 @@ int nero_mlp_forward(const nero_fwd_chain* ch, int n_rows, void* stream) {
         return nero_fail(NERO_ERR_ARG, "nero_mlp_forward: init/aux width out of range");
     const dim3 grid((n_rows + 63) / 64), block(256);
     nero_prof_begin(NERO_K_FWD, 2.0 * ch->macs_per_row * n_rows, (hipStream_t)stream);
-    if (ch->gemm_mode == NERO_GEMM_BF16X6 || ch->gemm_mode == NERO_GEMM_F16X3 || ch->gemm_mode == NERO_GEMM_F16X3P) {
-        const int rc = ch->gemm_mode == NERO_GEMM_F16X3P ? nero_f16p_forward(ch, n_rows, (hipStream_t)stream)
-                     : ch->gemm_mode == NERO_GEMM_F16X3 ? nero_f16_forward(ch, n_rows, (hipStream_t)stream)
+    if (ch->gemm_mode == NERO_GEMM_BF16X6 || ch->gemm_mode == NERO_GEMM_F16X3) {
+        const int rc = ch->gemm_mode == NERO_GEMM_F16X3 ? nero_f16_forward(ch, n_rows, (hipStream_t)stream)
                                                         : nero_split_forward(ch, n_rows, (hipStream_t)stream);
         nero_prof_end(NERO_K_FWD, (hipStream_t)stream);
         return rc != NERO_OK ? rc : nero_check_launch("nero_mlp_forward(split)");
@@ -874,9 +873,8 @@ int nero_mlp_tangent(const nero_tan_chain* ch, int n_rows, void* stream) {
     if (n_rows == 0) return NERO_OK;
     const dim3 grid((n_rows + 63) / 64), block(256);
     nero_prof_begin(NERO_K_TAN, 2.0 * ch->macs_per_row * n_rows, (hipStream_t)stream);
-    if (ch->gemm_mode == NERO_GEMM_BF16X6 || ch->gemm_mode == NERO_GEMM_F16X3 || ch->gemm_mode == NERO_GEMM_F16X3P) {
-        const int rc = ch->gemm_mode == NERO_GEMM_F16X3P ? nero_f16p_tangent(ch, n_rows, (hipStream_t)stream)
-                     : ch->gemm_mode == NERO_GEMM_F16X3 ? nero_f16_tangent(ch, n_rows, (hipStream_t)stream)
+    if (ch->gemm_mode == NERO_GEMM_BF16X6 || ch->gemm_mode == NERO_GEMM_F16X3) {
+        const int rc = ch->gemm_mode == NERO_GEMM_F16X3 ? nero_f16_tangent(ch, n_rows, (hipStream_t)stream)
                                                         : nero_split_tangent(ch, n_rows, (hipStream_t)stream);
         nero_prof_end(NERO_K_TAN, (hipStream_t)stream);
         return rc != NERO_OK ? rc : nero_check_launch("nero_mlp_tangent(bf16x6)");
@@ -898,9 +896,8 @@ int nero_mlp_backward(const nero_bwd_chain* ch, int n_rows, void* stream) {
     const dim3 grid((n_rows + 63) / 64), block(256);
     NERO_ONCE(hipFuncSetAttribute((const void*)mlp_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(0)));
     nero_prof_begin(NERO_K_BWD, 2.0 * ch->macs_per_row * n_rows, (hipStream_t)stream);
-    if (ch->gemm_mode == NERO_GEMM_BF16X6 || ch->gemm_mode == NERO_GEMM_F16X3 || ch->gemm_mode == NERO_GEMM_F16X3P) {
-        const int rc = ch->gemm_mode == NERO_GEMM_F16X3P ? nero_f16p_backward(ch, n_rows, (hipStream_t)stream)
-                     : ch->gemm_mode == NERO_GEMM_F16X3 ? nero_f16_backward(ch, n_rows, (hipStream_t)stream)
+    if (ch->gemm_mode == NERO_GEMM_BF16X6 || ch->gemm_mode == NERO_GEMM_F16X3) {
+        const int rc = ch->gemm_mode == NERO_GEMM_F16X3 ? nero_f16_backward(ch, n_rows, (hipStream_t)stream)
                                                         : nero_split_backward(ch, n_rows, (hipStream_t)stream);
         nero_prof_end(NERO_K_BWD, (hipStream_t)stream);
         return rc != NERO_OK ? rc : nero_check_launch("nero_mlp_backward(bf16x6)");
@@ -934,7 +931,7 @@ int nero_dw_gemm(const nero_dw_job* job, int n_rows, float* partials, void* stre
     nero_prof_begin(NERO_K_DW, 2.0 * job->n_out * job->k_cols * (job->d1 ? 2.0 : 1.0) * n_rows, (hipStream_t)stream);
     if (job->gemm_mode == NERO_GEMM_BF16X6)
         nero_split_dw(job, n_rows, rps, slices, partials, n_pad, k_pad, (hipStream_t)stream);
-    else if (job->gemm_mode == NERO_GEMM_F16X3 || job->gemm_mode == NERO_GEMM_F16X3P)
+    else if (job->gemm_mode == NERO_GEMM_F16X3)
         nero_f16_dw(job, n_rows, rps, slices, partials, n_pad, k_pad, (hipStream_t)stream);
     else if (k_pad <= 128)
         hipLaunchKernelGGL(dw_gemm_kernel<true>, dim3(slices), dim3(512), lds, (hipStream_t)stream, *job, n_rows, rps, partials, n_pad, k_pad);
@@ -954,7 +951,7 @@ int nero_dw_gemm_batch(const nero_dw_job* jobs, int n_jobs, int n_rows, float* p
         const nero_dw_job& J = jobs[i];
         if (!J.d0 || !J.b0 || !J.dW || J.n_out > 256 || J.k_cols > 256 || J.n_out <= 0 || J.k_cols <= 0)
             return nero_fail(NERO_ERR_ARG, "nero_dw_gemm_batch: bad job");
-        f16 = f16 && (J.gemm_mode == NERO_GEMM_F16X3 || J.gemm_mode == NERO_GEMM_F16X3P);
+        f16 = f16 && J.gemm_mode == NERO_GEMM_F16X3;
     }
     if (!f16 || rows >= DW_BATCH_ROWS || n_jobs < 2) {               // the per-job path: one launch (+ reduction) per job
         for (int i = 0; i < n_jobs; ++i) {

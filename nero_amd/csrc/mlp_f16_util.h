@@ -1,5 +1,4 @@
-// mlp_f16_util.h -- device helpers shared by the fp16 two-plane chain kernels (mlp_f16x3.hip: one 512-thread workgroup per CU;
-// mlp_f16p.hip: two 256-thread workgroups per CU): block scaling, fp32 <-> fp16 plane pairs, the softplus (beta = 100) family,
+// mlp_f16_util.h -- device helpers of the fp16 two-plane chain kernels (mlp_f16x3.hip: one 512-thread workgroup per CU): block scaling, fp32 <-> fp16 plane pairs, the softplus (beta = 100) family,
 // the three-product GEMM core.  Include inside an anonymous namespace.
 #pragma once
 

@@ -27,7 +27,3 @@ struct nero_dw_batch {
     short n_pad[NERO_DW_BATCH_MAX], k_pad[NERO_DW_BATCH_MAX];
 };
 int nero_f16_dw_batch(const nero_dw_batch* B, int n_jobs, int narrow, int n_rows, int rows_per_slice, int slices, float* partials, hipStream_t stream);
-// fp16 two-plane engine, two workgroups per CU (mlp_f16p.hip)
-int nero_f16p_forward(const nero_fwd_chain* ch, int n_rows, hipStream_t stream);
-int nero_f16p_tangent(const nero_tan_chain* ch, int n_rows, hipStream_t stream);
-int nero_f16p_backward(const nero_bwd_chain* ch, int n_rows, hipStream_t stream);

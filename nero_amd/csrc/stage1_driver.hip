@@ -431,7 +431,7 @@ int nero_stage1_create(const nero_stage1_cfg* cfg, nero_stage1** out) {
     if (cfg->n_importance % (cfg->up_sample_steps > 0 ? cfg->up_sample_steps : 1) || cfg->up_sample_steps < 1 || cfg->n_samples < 2)
         return nero_fail(NERO_ERR_ARG, "nero_stage1_create: n_importance must be a multiple of up_sample_steps");
     if (!is_f16(cfg->gemm_fwd) || cfg->gemm_tan != NERO_GEMM_F16X3 || cfg->gemm_bwd != NERO_GEMM_F16X3 || !is_f16(cfg->gemm_dw))
-        return nero_fail(NERO_ERR_UNSUPPORTED, "nero_stage1_create: the C-level driver packs fp16 two-plane operands only (F16X3 / F16X3P)");
+        return nero_fail(NERO_ERR_UNSUPPORTED, "nero_stage1_create: the C-level driver packs fp16 two-plane operands only (F16X3)");
     nero_stage1* h = new (std::nothrow) nero_stage1();
     if (!h) return nero_fail(NERO_ERR_ARG, "nero_stage1_create: out of host memory");
     h->cfg = *cfg;

@@ -239,7 +239,7 @@ int nero_stage2_create(const nero_stage2_cfg* cfg, nero_stage2** out) {
     if (!cfg || !out || cfg->diffuse_sample_num < 1 || cfg->specular_sample_num < 1) return nero_fail(NERO_ERR_ARG, "nero_stage2_create: bad argument");
     if (cfg->geometry_type != 0 && cfg->geometry_type != 1) return nero_fail(NERO_ERR_UNSUPPORTED, "nero_stage2_create: geometry_type must be 0 (schlick) or 1 (ggx_smith)");
     if (!is_f16(cfg->gemm_fwd) || cfg->gemm_bwd != NERO_GEMM_F16X3 || !is_f16(cfg->gemm_dw))
-        return nero_fail(NERO_ERR_UNSUPPORTED, "nero_stage2_create: the C-level driver packs fp16 two-plane operands only (F16X3 / F16X3P)");
+        return nero_fail(NERO_ERR_UNSUPPORTED, "nero_stage2_create: the C-level driver packs fp16 two-plane operands only (F16X3)");
     nero_stage2* h = new (std::nothrow) nero_stage2();
     if (!h) return nero_fail(NERO_ERR_ARG, "nero_stage2_create: out of host memory");
     h->cfg = *cfg;

@@ -102,7 +102,7 @@ class SDFField:
             tc.aux, tc.ld_aux, tc.k_aux = ehat.data_ptr(), LD_PE, LD_PE
             tc.n_layers, tc.aux_wide = 8, 0
             tsplit = GEMM_MODE['tan'] != L.GEMM_F32
-            tkeys = {L.GEMM_F32: ('fm', 'fa'), L.GEMM_BF16X6: ('sfm', 'sfa'), L.GEMM_F16X3: ('hfm', 'hfa'), L.GEMM_F16X3P: ('hfm', 'hfa')}[GEMM_MODE['tan']]
+            tkeys = {L.GEMM_F32: ('fm', 'fa'), L.GEMM_BF16X6: ('sfm', 'sfa'), L.GEMM_F16X3: ('hfm', 'hfa')}[GEMM_MODE['tan']]
             tc.gemm_mode = GEMM_MODE['tan']
             rk = _r16 if tsplit else _r8
             tc.macs_per_row = float(sum(ch.entries[l][0].n_out * (ch.entries[l][0].k_main + ch.entries[l][0].k_aux) for l in range(8)))

@@ -58,8 +58,7 @@ _lib.nero_stage1_destroy.argtypes = [_fp]
 
 def supported():
     """the C driver packs fp16 two-plane operands only (the default engines)"""
-    return (GEMM_MODE['fwd'] in (L.GEMM_F16X3, L.GEMM_F16X3P) and GEMM_MODE['tan'] == L.GEMM_F16X3 and GEMM_MODE['bwd'] == L.GEMM_F16X3
-            and GEMM_MODE['dw'] in (L.GEMM_F16X3, L.GEMM_F16X3P))
+    return all(GEMM_MODE[k] == L.GEMM_F16X3 for k in ('fwd', 'tan', 'bwd', 'dw'))
 
 
 def current_modes():

@@ -44,7 +44,7 @@ GEOMETRY_TYPES = {'schlick': 0, 'ggx_smith': 1}
 
 
 def supported():
-    return GEMM_MODE['fwd'] in (L.GEMM_F16X3, L.GEMM_F16X3P) and GEMM_MODE['bwd'] == L.GEMM_F16X3 and GEMM_MODE['dw'] in (L.GEMM_F16X3, L.GEMM_F16X3P)
+    return all(GEMM_MODE[k] == L.GEMM_F16X3 for k in ('fwd', 'bwd', 'dw'))
 
 
 class Stage2Driver:

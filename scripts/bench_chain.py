@@ -11,7 +11,7 @@ from nero_amd.sdf import SDFField, encode_pe
 
 g = torch.Generator().manual_seed(0)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 524288
-modes = sys.argv[2].split(',') if len(sys.argv) > 2 else ['f32', 'f16x3', 'f16x3p']
+modes = sys.argv[2].split(',') if len(sys.argv) > 2 else ['f32', 'bf16x6', 'f16x3']
 rp = row_pad(N)
 x = torch.randn(rp, 256, device='cuda') * 0.1
 def mk(n_out, n_in, s=1.0): return ((torch.randn(n_out, n_in, generator=g) * s / math.sqrt(n_in)).cuda(), (torch.randn(n_out, generator=g) * 0.01).cuda())

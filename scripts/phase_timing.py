@@ -17,7 +17,7 @@ def mk(n_out, n_in, s=1.0): return ((torch.randn(n_out, n_in, generator=g) * s /
 Ws = [mk(256, 256, 1.4) for _ in range(8)]
 MODE = sys.argv[2] if len(sys.argv) > 2 else 'f16x3'
 CH.set_gemm_mode(MODE)
-fn = 'nero_debug_phases_p' if MODE == 'f16x3p' else 'nero_debug_phases'
+fn = 'nero_debug_phases'
 has_ph = hasattr(L.lib, fn)
 buf = (C.c_ulonglong * 16)()
 def phases(reset=True):
@@ -33,8 +33,6 @@ def timeit(f, n=5):
     return dt, phases()
 tiles = rp // 64
 FW = ('init', 'pre-gemm', 'gemm', 'act', 'save+mask', 'rowmax+bar1', 'planes', 'bar2')
-if MODE == 'f16x3p':          # two tiles per wave; slot 7 = workgroup residence time
-    FW = ('init', 'pre-gemm', 'gemm', 'act', 'save+mask+pub', 'commit', '-', 'WG-residence')
 BW = ('-', 'pre-gemm', 'gemm', 'gq', 'values', 'delta st', 'commit', '-')
 QUICK = len(sys.argv) > 3 and sys.argv[3] == 'quick'
 for name, act in ((('relu', L.ACT_RELU),) if QUICK else (('relu', L.ACT_RELU), ('softplus', L.ACT_SOFTPLUS100))):
@@ -44,11 +42,8 @@ for name, act in ((('relu', L.ACT_RELU),) if QUICK else (('relu', L.ACT_RELU), (
         fl = 2 * 8 * 65536 * N
         print(f'fwd {name:8s} save={int(save)}: {t*1e3:7.3f} ms {fl/t/1e12:6.1f} TF  ({t*1e6/ (tiles/256*8):.2f} us per layer-tile per CU)')
         if ph:
-            tot = sum(ph[:7]) if MODE == 'f16x3p' else sum(ph)
+            tot = sum(ph)
             print('      ' + '  '.join(f'{n}={p/(5*tiles*8):.0f}' for n, p in zip(FW, ph)) + f'   total={tot/(5*tiles*8):.0f} cycles/layer-tile')
-            if MODE == 'f16x3p':   # sum of residence (cycles) / (256 CUs x kernel time) = f_clk x average resident workgroups per CU
-                print(f'      sum(residence)/256/time = {ph[7]/5/256/t/1e9:.2f} GHz x workgroups-in-flight per CU')
-    if MODE == 'f16x3p': continue
     fwd = ch.forward(x, None, N, save=True)
     t, ph = timeit(lambda: ch.backward(fwd, N, dy=dy, need_dinit=True))
     print(f'bwd {name:8s}       : {t*1e3:7.3f} ms {fl/t/1e12:6.1f} TF')

@@ -8,7 +8,7 @@ N = 524288
 g = torch.Generator().manual_seed(0)
 x = torch.randn(row_pad(N), 256, device='cuda') * 0.1
 Ws = [((torch.randn(256, 256, generator=g) * 1.4 / 16).cuda(), (torch.randn(256, generator=g) * 0.01).cuda()) for _ in range(8)]
-for mode in (sys.argv[1].split(',') if len(sys.argv) > 1 else ['f16x3', 'f16x3p']):
+for mode in (sys.argv[1].split(',') if len(sys.argv) > 1 else ['f16x3']):
     CH.set_gemm_mode(mode)
     ch = Chain([(Dense(W, b, L.ACT_RELU, 256), None) for W, b in Ws[:7]] + [(Dense(Ws[7][0], Ws[7][1], L.ACT_NONE, 256), None)], k_init=256).pack()
     for _ in range(3):

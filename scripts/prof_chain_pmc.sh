@@ -23,7 +23,7 @@ for f in glob.glob(out + '/pass*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
         if 'fwd' not in k: continue
-        name = 'fwd_p' if 'fwd_p' in k else 'fwd_f16'
+        name = 'fwd_f16'
         rows[name][r['Counter_Name']].append(float(r['Counter_Value']))
 with open(out + '/summary.txt', 'w') as fo:
     for name, d in rows.items():

@@ -1,7 +1,7 @@
 """Bit-reproducibility of ONE forward chain launch: records the NeRF++ head chain (256 -> 256 -> 128 (+27 aux) -> 3, ~390 k rows) of a
 4096-ray render, takes the 512-thread engine's result as the reference and replays the chain 60 times on the engine named in
-NERO_REPLAY_ENGINE (default f16x3p, the two-workgroups-per-CU kernel), counting the launches whose first saved activation differs.
-This is the reproducer of the fwd_p_kernel fault described in DESIGN.md section 3i.  usage: python scripts/replay_fwd_chain.py"""
+the forward engine, counting the launches whose first saved activation differs.
+It was the reproducer of the fault of the removed two-workgroups-per-CU kernel and stays as a determinism probe.  usage: python scripts/replay_fwd_chain.py"""
 import sys
 sys.path.insert(0, '.')
 import numpy as np, torch
@@ -33,8 +33,8 @@ with torch.no_grad():
     o_ = orig(c, init, aux, n, save)
     good = o_['saves'][0][:n].clone()
     import os
-    eng = os.environ.get('NERO_REPLAY_ENGINE', 'f16x3p')
-    CH.GEMM_MODE['fwd'] = {'f16x3p': L.GEMM_F16X3P, 'f16x3': L.GEMM_F16X3}[eng]
+    eng = 'f16x3'
+    CH.GEMM_MODE['fwd'] = L.GEMM_F16X3
     nbad, total_bad_elems, col_hist, row_hist = 0, 0, {}, {}
     N = 60
     for k in range(N):

@@ -6,5 +6,3 @@ if [ -z "$SKIP_BASE" ]; then
 run "all f16x3, dW bf16x6" "NERO_GEMM_DW=bf16x6"
 run "dW f16x3" "NERO_GEMM_DW=f16x3"
 fi
-run "fwd f16x3p + dW f16x3" "NERO_GEMM_FWD=f16x3p"
-run "fwd/tan/bwd f16x3p + dW f16x3" "NERO_GEMM=f16x3p"

@@ -1,6 +1,6 @@
 """GPU tier: run-to-run bit reproducibility.  No kernel of the path uses floating-point atomics and every reduction has a fixed order,
 so the same batch with the same random draws must give the same loss and the same gradients BIT FOR BIT, however the workgroups are
-scheduled.  This is the test that found the fault of the two-workgroups-per-CU forward kernel (`NERO_GEMM_FWD=f16x3p`):
+scheduled.  This is the test that found the fault of the two-workgroups-per-CU forward kernel (`f16x3p`, removed in round 4: DESIGN.md 3i):
 one launch in three returned one column of 16 rows with another partial sum -- 1e-7 of a gradient, below every parity tolerance, and
 invisible to a comparison of single runs."""
 import numpy as np
@@ -57,7 +57,7 @@ def test_stage2_training_step_is_bit_reproducible():
 
 def test_forward_chain_launches_are_bit_reproducible():
     """a NeRF++-head shaped chain (256 -> 256 -> 128 with a 27-column aux operand -> 3) over 300 k rows, forty launches on the default
-    forward engine: every saved activation and the head identical to the first launch (the shape and size at which the f16x3p kernel
+    forward engine: every saved activation and the head identical to the first launch (the shape and size at which the removed f16x3p kernel
     failed in a third of its launches)"""
     from nero_amd import _lib as L
     from nero_amd import chain as CH

@@ -1,6 +1,6 @@
 """GPU tier: properties of the round-2 kernels that the per-mode engine tests do not state on their own.
-* the paired-workgroup forward engine (NERO_GEMM_F16X3P, mlp_f16p.hip) reproduces the 512-thread fp16 engine BIT FOR BIT
-  (same packed images, same per-row scales, same MFMA order): chains with a skip / aux input, heads, saves and ReLU masks;
+* the persistent forward kernel (several 64-row tiles per workgroup, operands of the next tile / layer requested ahead) gives every
+  tile the result it has in a launch of its own: chains with a skip / aux input, heads, saves and ReLU masks, bit for bit;
 * the fp16 three-product weight-gradient GEMM (mlp_f16dw.hip) against an fp64 matmul on operands built to stress its block
   scaling: row magnitudes spread over 2^40, an outlier block at the start (the running accumulator unit is set high first),
   ReLU-sparse operands, two operand pairs, ragged shapes."""
@@ -17,10 +17,12 @@ def _mk(n_out, n_in, g, s=1.4):
     return (torch.randn(n_out, n_in, generator=g) * s / math.sqrt(n_in)).cuda(), (torch.randn(n_out, generator=g) * 0.05).cuda()
 
 
-@pytest.mark.parametrize('n_rows', [777, 20000])
-def test_paired_forward_engine_is_bit_identical_to_the_512_thread_engine(n_rows):
+@pytest.mark.parametrize('n_rows', [777, 20000, 70001])
+def test_forward_chain_is_independent_of_the_launch_tiling(n_rows):
+    """the persistent forward kernel walks several 64-row tiles per workgroup (next tile's input and next layer's first weight fragments
+    requested ahead): every saved activation, head and ReLU mask of a launch over n rows must equal, BIT FOR BIT, what two launches over the
+    two halves of the same rows produce (a tile's result may not depend on which workgroup reached it, or after which other tile)."""
     from nero_amd import _lib as L
-    from nero_amd import chain as CH
     from nero_amd.chain import Chain, Dense, Head, row_pad
     g = torch.Generator().manual_seed(1)
     rp = row_pad(n_rows)
@@ -32,33 +34,33 @@ def test_paired_forward_engine_is_bit_identical_to_the_512_thread_engine(n_rows)
     x8[:n_rows, :3] = torch.randn(n_rows, 3, generator=g).cuda()
     feat = torch.randn(rp, 256, generator=g).cuda() * 0.3
     pw = [_mk(256, 259, g), _mk(256, 256, g), _mk(3, 256, g)]
-    old = dict(CH.GEMM_MODE)
-    outs = {}
-    try:
-        for mode in ('f16x3', 'f16x3p'):
-            CH.set_gemm_mode(mode)
-            sdf = Chain([(Dense(*ws[0], L.ACT_SOFTPLUS100, 39), None), (Dense(*ws[1], L.ACT_SOFTPLUS100, 256), None),
-                         (Dense(*ws[2], L.ACT_SOFTPLUS100, 256), None),
-                         (Dense(*ws[3], L.ACT_SOFTPLUS100, 217, 0, 39, 217, 1.0 / math.sqrt(2)), None),
-                         (Dense(ws[4][0][1:], ws[4][1][1:], L.ACT_NONE, 256), Head(ws[4][0][0:1], ws[4][1][0:1]))],
-                        k_init=40, k_aux=40).pack()
-            f = sdf.forward(pe, pe, n_rows, save=True)
-            pred = Chain([(Dense(*pw[0], L.ACT_RELU, 256, 0, 3, 256), None), (Dense(*pw[1], L.ACT_RELU, 256), None),
-                          (None, Head(*pw[2]))], k_init=256, k_aux=8).pack()
-            p = pred.forward(feat, x8, n_rows, save=True)
-            # (a save holds whole 32-column tiles of the layer's output; the columns of tiles the layer does not have are not written)
-            wid = lambda ch_, i: 32 * ((ch_.entries[i][0].n_out + 31) // 32)
-            outs[mode] = [s[:n_rows, :wid(sdf, i)].clone() for i, s in enumerate(f['saves']) if s is not None] + \
-                         [f['heads'][4][:n_rows, :1].clone()] + \
-                         [s[:n_rows, :wid(pred, i)].clone() for i, s in enumerate(p['saves']) if s is not None] + \
-                         [p['heads'][2][:n_rows, :3].clone()] + [m[:n_rows].clone() for m in p['masks'] if m is not None]
-    finally:
-        CH.GEMM_MODE.update(old)
-    assert len(outs['f16x3']) == len(outs['f16x3p']) >= 9
-    for k, (a, b) in enumerate(zip(outs['f16x3'], outs['f16x3p'])):
-        if not torch.equal(a, b):
-            bad = (a != b).nonzero()
-            raise AssertionError((k, tuple(a.shape), int(bad.shape[0]), bad[:4].tolist(), a[tuple(bad[0])].item(), b[tuple(bad[0])].item()))
+    sdf = Chain([(Dense(*ws[0], L.ACT_SOFTPLUS100, 39), None), (Dense(*ws[1], L.ACT_SOFTPLUS100, 256), None),
+                 (Dense(*ws[2], L.ACT_SOFTPLUS100, 256), None),
+                 (Dense(*ws[3], L.ACT_SOFTPLUS100, 217, 0, 39, 217, 1.0 / math.sqrt(2)), None),
+                 (Dense(ws[4][0][1:], ws[4][1][1:], L.ACT_NONE, 256), Head(ws[4][0][0:1], ws[4][1][0:1]))],
+                k_init=40, k_aux=40).pack()
+    pred = Chain([(Dense(*pw[0], L.ACT_RELU, 256, 0, 3, 256), None), (Dense(*pw[1], L.ACT_RELU, 256), None),
+                  (None, Head(*pw[2]))], k_init=256, k_aux=8).pack()
+    # (a save holds whole 32-column tiles of the layer's output; the columns of tiles the layer does not have are not written)
+    wid = lambda ch_, i: 32 * ((ch_.entries[i][0].n_out + 31) // 32)
+
+    def run(pe_, feat_, x8_, n):
+        f = sdf.forward(pe_, pe_, n, save=True)
+        p = pred.forward(feat_, x8_, n, save=True)
+        return [s[:n, :wid(sdf, i)].clone() for i, s in enumerate(f['saves']) if s is not None] + [f['heads'][4][:n, :1].clone()] + \
+               [s[:n, :wid(pred, i)].clone() for i, s in enumerate(p['saves']) if s is not None] + [p['heads'][2][:n, :3].clone()] + \
+               [m[:n].clone() for m in p['masks'] if m is not None]
+    whole = run(pe, feat, x8, n_rows)
+    h = (n_rows // 2 + 63) // 64 * 64           # the halves start on tile boundaries, so the tiles are the same rows
+    pad = lambda t, r0, r1: torch.cat([t[r0:r1], torch.zeros(row_pad(r1 - r0) - (r1 - r0), t.shape[1], device='cuda')]).contiguous()
+    lo = run(pad(pe, 0, h), pad(feat, 0, h), pad(x8, 0, h), h)
+    hi = run(pad(pe, h, n_rows), pad(feat, h, n_rows), pad(x8, h, n_rows), n_rows - h)
+    assert len(whole) == len(lo) == len(hi) >= 9
+    for k, (a, b, c) in enumerate(zip(whole, lo, hi)):
+        both = torch.cat([b, c])
+        if not torch.equal(a, both):
+            bad = (a != both).nonzero()
+            raise AssertionError((k, tuple(a.shape), int(bad.shape[0]), bad[:4].tolist(), a[tuple(bad[0])].item(), both[tuple(bad[0])].item()))
 
 
 def _dw(mode, D, B, n, D1=None, B1=None, n_out=256, k=256):

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 
 
-@pytest.fixture(params=['f32', 'bf16x6', 'f16x3', 'f16x3p'], autouse=True)
+@pytest.fixture(params=['f32', 'bf16x6', 'f16x3'], autouse=True)
 def gemm_mode(request):
     """every engine test runs on all dense-layer arithmetics (include/nero_hip.h NERO_GEMM_*): the exact fp32 MFMA, the
     3-plane bf16 split and the 2-plane block-scaled fp16 split, against the same fp64 reference and the same tolerance."""
