@@ -29,7 +29,7 @@ def test_driver_struct_layouts_match_header():
     assert sizes == mine, (sizes, mine)
 
 
-def _handle(human=0, fwd=3):
+def _handle(human=0, fwd=2):
     from nero_amd import _lib as L
     from nero_amd import stage1 as S1
     c = S1.Cfg(64, 64, 32, 4, 1, human, 0, 0.0, fwd, 2, 2, 2)
