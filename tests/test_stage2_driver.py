@@ -33,7 +33,7 @@ def test_stage2_workspace_query_without_a_gpu():
     lib = S2._lib
     hs = []
     for human in (0, 1):
-        c = S2.Cfg(128, 128, human, human, 0, 5.0, 5.0, 3, 2, 2)
+        c = S2.Cfg(128, 128, human, human, 0, 5.0, 5.0, 2, 2, 2)
         h = C.c_void_p()
         L.check(lib.nero_stage2_create(C.byref(c), C.byref(h)))
         hs.append(h)
@@ -42,7 +42,7 @@ def test_stage2_workspace_query_without_a_gpu():
     assert 4e9 < w_bell < 30e9 and w_bear > w_bell, (w_bell, w_bear)
     assert lib.nero_stage2_workspace_bytes(hs[0], 1024, 512) < w_bell / 6
     assert lib.nero_stage2_pack_bytes(hs[1]) > lib.nero_stage2_pack_bytes(hs[0]) > 8e6
-    bad = S2.Cfg(128, 128, 0, 0, 7, 5.0, 5.0, 3, 2, 2)
+    bad = S2.Cfg(128, 128, 0, 0, 7, 5.0, 5.0, 2, 2, 2)
     h = C.c_void_p()
     assert lib.nero_stage2_create(C.byref(bad), C.byref(h)) == -3
     for h in hs:
