@@ -11,6 +11,7 @@
 // k-ordering inside a chunk of 8: MFMA t (t=0..3) consumes k = 8c + 4h + t from lane half h, which makes the A fragment
 // 4 contiguous floats per lane (one ds_read_b128) and the packed B image a plain float4 per lane.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -953,7 +954,17 @@ int nero_dw_gemm_batch(const nero_dw_job* jobs, int n_jobs, int n_rows, float* p
             return nero_fail(NERO_ERR_ARG, "nero_dw_gemm_batch: bad job");
         f16 = f16 && J.gemm_mode == NERO_GEMM_F16X3;
     }
-    if (!f16 || rows >= DW_BATCH_ROWS || n_jobs < 2) {               // the per-job path: one launch (+ reduction) per job
+    // experiment switches: NERO_DW_BATCH_ROWS (batch below this row count; default 131072), NERO_DW_BATCH_TOTAL (slices over a group's
+    // jobs; default 1024), NERO_DW_BATCH_GROUP (jobs per launch; default / maximum NERO_DW_BATCH_MAX)
+    static int batch_rows = -1, batch_total = 1024, batch_group = NERO_DW_BATCH_MAX;
+    if (batch_rows < 0) {
+        const char* e = getenv("NERO_DW_BATCH_ROWS"); batch_rows = e ? atoi(e) : DW_BATCH_ROWS;
+        e = getenv("NERO_DW_BATCH_TOTAL"); if (e) batch_total = atoi(e);
+        e = getenv("NERO_DW_BATCH_GROUP"); if (e) batch_group = atoi(e);
+        batch_group = batch_group < 1 ? 1 : (batch_group > NERO_DW_BATCH_MAX ? NERO_DW_BATCH_MAX : batch_group);
+        batch_total = batch_total < 16 ? 16 : (batch_total > 1024 ? 1024 : batch_total);
+    }
+    if (!f16 || rows >= batch_rows || n_jobs < 2) {               // the per-job path: one launch (+ reduction) per job
         for (int i = 0; i < n_jobs; ++i) {
             const int rc = nero_dw_gemm(jobs + i, n_rows, partials, stream);
             if (rc != NERO_OK) return rc;
@@ -966,10 +977,10 @@ int nero_dw_gemm_batch(const nero_dw_job* jobs, int n_jobs, int n_rows, float* p
         int idx[256], n = 0;
         for (int i = 0; i < n_jobs && n < 256; ++i)
             if ((((jobs[i].k_cols + 31) / 32 * 32) <= 128) == (narrow != 0)) idx[n++] = i;
-        for (int g0 = 0; g0 < n; g0 += NERO_DW_BATCH_MAX) {
-            const int ng = n - g0 < NERO_DW_BATCH_MAX ? n - g0 : NERO_DW_BATCH_MAX;
+        for (int g0 = 0; g0 < n; g0 += batch_group) {
+            const int ng = n - g0 < batch_group ? n - g0 : batch_group;
             // ~1024 slices over the group's jobs, at least 128 rows (8 chunks) per slice, at most one slice per CU and job
-            int target = 1024 / ng;
+            int target = batch_total / ng;
             target = target < 16 ? 16 : (target > DW_MAX_SLICES ? DW_MAX_SLICES : target);
             int rps = (rows + target - 1) / target;
             rps = (rps + 15) / 16 * 16;

@@ -222,16 +222,26 @@ __device__ __forceinline__ void ops_compute(f32x16 (&aH)[2], f32x16 (&aL)[2], co
 #define NERO_MID_FENCE() NERO_FENCE()
 #endif
 
+// The first three weight fragments of a GEMM can be requested by the CALLER ahead of time (`pre`: wa, wb, wc already hold -- or are about
+// to receive -- steps 0, 1, 2; see prefetch_w): a layer's first MFMA then waits for an LDS read instead of an L2 round trip behind
+// the barrier that ends the previous layer (~900 cycles per layer-tile).
+#ifndef F16_PW_N
+#define F16_PW_N 3                                   // fragments requested ahead by the caller (the rest at the start of the GEMM)
+#endif
+__device__ __forceinline__ void prefetch_w(WF& wa, WF& wb, WF& wc, const uint4* wp, int n, int from = 0) {
+    const int last = n - 1;
+    if (from <= 0) load_w(wa, wp, 0);
+    if (from <= 1) load_w(wb, wp, 1 < last ? 1 : last);
+    if (from <= 2) load_w(wc, wp, 2 < last ? 2 : last);
+}
 __device__ __forceinline__ void gemm_f16x3_loop(f32x16 (&aH)[2], f32x16 (&aL)[2], const uint4* wp, const char* xp, int half_bytes,
-                                           int plane_bytes, int n) {
+                                           int plane_bytes, int n, bool pre, WF& wa, WF& wb, WF& wc) {
     if (n <= 0) return;
-    WF wa, wb, wc, wd;
+    WF wd;
     XF xa, xb;
     const int last = n - 1;
 #define NERO_CL(c) ((c) < last ? (c) : last)
-    load_w(wa, wp, 0);
-    load_w(wb, wp, NERO_CL(1));
-    load_w(wc, wp, NERO_CL(2));
+    prefetch_w(wa, wb, wc, wp, n, pre ? F16_PW_N : 0);
     load_x(xa, xp, half_bytes, plane_bytes, 0);
     NERO_FENCE();
     for (int c = 0; c < n; c += 4) {
@@ -251,6 +261,11 @@ __device__ __forceinline__ void gemm_f16x3_loop(f32x16 (&aH)[2], f32x16 (&aL)[2]
         }
     }
 #undef NERO_CL
+}
+__device__ __forceinline__ void gemm_f16x3_loop(f32x16 (&aH)[2], f32x16 (&aL)[2], const uint4* wp, const char* xp, int half_bytes,
+                                           int plane_bytes, int n) {
+    WF wa, wb, wc;
+    gemm_f16x3_loop(aH, aL, wp, xp, half_bytes, plane_bytes, n, false, wa, wb, wc);
 }
 
 

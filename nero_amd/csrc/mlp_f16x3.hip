@@ -17,6 +17,7 @@
 // of 12, and one more barrier per layer for the row-maximum exchange between the 8 waves.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/nero_hip.h"
 #include "common.h"
 #include "mlp_split.h"
@@ -40,30 +41,36 @@ __device__ __forceinline__ void acc_to_global(float* scr, const float4 (&q)[4], 
 }
 
 // rows [row0, row0+64) x first k columns (k multiple of 4, <= 256) of a row-major fp32 matrix -> scaled plane pairs + the per-row
-// scale rs[row] = 2^e.  8 threads per row: each keeps its float4s in registers, the row maximum is a 3-step shuffle.
-__device__ __forceinline__ void load_planes_scaled(char* planes, int stride, int plane_bytes, float* rs, const float* __restrict__ src,
-                                                   int ld, int k, int row0, int n_rows, int tid) {
+// scale rs[row] = 2^e.  8 threads per row: each keeps its float4s in registers, the row maximum is a 3-step shuffle.  In two halves, so
+// that a persistent workgroup can REQUEST the next tile while the current one still computes and convert it when it is done:
+// tile_request (global loads into NV float4 registers per thread: NV = 8 covers 256 columns) and tile_commit (maximum, scale, planes).
+template <int NV>
+__device__ __forceinline__ void tile_request(float4 (&v)[NV], const float* __restrict__ src, int ld, int k, int row0, int n_rows, int tid) {
     const int r = tid >> 3, q = tid & 7;
-    const int k16 = (k + 15) & ~15, q4 = k16 >> 2;
     int gr = row0 + r;
     gr = gr < n_rows ? gr : n_rows - 1;
     const float* rowp = src + (size_t)gr * ld;
-    float4 v[8];
-    float m = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < NV; ++j) {
         const int c4 = 4 * (q + 8 * j);
         v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c4 < k) v[j] = *reinterpret_cast<const float4*>(rowp + c4);
-        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[j].x), fabsf(v[j].y)), fmaxf(fabsf(v[j].z), fabsf(v[j].w))));
     }
+}
+template <int NV>
+__device__ __forceinline__ void tile_commit(char* planes, int stride, int plane_bytes, float* rs, const float4 (&v)[NV], int k, int tid) {
+    const int r = tid >> 3, q = tid & 7;
+    const int k16 = (k + 15) & ~15, q4 = k16 >> 2;
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) m = fmaxf(m, fmaxf(fmaxf(fabsf(v[j].x), fabsf(v[j].y)), fmaxf(fabsf(v[j].z), fabsf(v[j].w))));
     m = fmaxf(m, __shfl_xor(m, 1));
     m = fmaxf(m, __shfl_xor(m, 2));
     m = fmaxf(m, __shfl_xor(m, 4));
     const int e = scale_exp(m);
     const float inv = pow2i(-e);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < NV; ++j) {
         const int c4 = 4 * (q + 8 * j);
         if (q + 8 * j < q4) {
             const float4 s = make_float4(v[j].x * inv, v[j].y * inv, v[j].z * inv, v[j].w * inv);
@@ -71,6 +78,12 @@ __device__ __forceinline__ void load_planes_scaled(char* planes, int stride, int
         }
     }
     if (q == 0) rs[r] = pow2i(e);
+}
+__device__ __forceinline__ void load_planes_scaled(char* planes, int stride, int plane_bytes, float* rs, const float* __restrict__ src,
+                                                   int ld, int k, int row0, int n_rows, int tid) {
+    float4 v[8];
+    tile_request<8>(v, src, ld, k, row0, n_rows, tid);
+    tile_commit<8>(planes, stride, plane_bytes, rs, v, k, tid);
 }
 
 // VALU head on the current activation planes: out[r][j] = b[j] + sum_k x[r][k] W[j][k], k < hk (8 threads per row)
@@ -146,19 +159,71 @@ __device__ __forceinline__ void fwd_values(const f32x16 (&aH)[2], const f32x16 (
     }
 }
 
-template <bool WIDE>
-__global__ __launch_bounds__(512, 1) void fwd_f16_kernel(nero_fwd_chain ch, int n_rows) {
+// PERSISTENT (round 4): a workgroup walks the tiles blockIdx.x, blockIdx.x + gridDim.x, ... (one workgroup per CU).  While the
+// last GEMM of a tile runs its epilogue, the NEXT tile's input rows are already on their way from HBM into registers (tile_request;
+// converted into planes when the tile is done), and after every GEMM the first three weight fragments of the next layer's first GEMM
+// are requested (prefetch_w), so that neither the workgroup dispatch + a cold 64 KB HBM read per tile (~7 k cycles) nor an L2 round trip
+// behind every layer's closing barrier (~900 cycles) sits in front of an idle matrix pipe.  Both requests are issued AFTER the last
+// weight load of the running GEMM: vmcnt retires in order, anything issued earlier would hold the weight stream back.
+#ifdef F16_NO_W_PRE
+#define F16_W_PRE false
+#else
+#define F16_W_PRE true
+#endif
+// NVI = float4 registers per thread that hold the NEXT tile's input rows while the current tile finishes (tile_request): 4 covers
+// k_init <= 128 (the SDF, NeRF++ trunk and light chains), 0 = the input is read at the top of the tile (256-wide inputs: eight more
+// float4 registers on top of the weight fragments do not fit without spilling).
+template <bool WIDE, int NVI>
+__global__ __launch_bounds__(512, 1) void fwd_f16_kernel(nero_fwd_chain ch, int n_rows, int n_tiles_total) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SX = WIDE ? SX_W : SX_N;
     constexpr int PLANE_X = 64 * SX;
+    constexpr int NVX = WIDE ? 3 : 2;                    // float4s per thread of an aux tile (<= 96 / 48 columns)
+    constexpr int NVR = NVI > 0 ? NVI : 1, NXR = NVI > 0 ? NVX : 1;
     const Lds S = carve<SX>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
-    const int row0 = blockIdx.x * 64;
+    // the layers that have a GEMM (bit l), the first and the last of them
+    unsigned gmask = 0u;
+    for (int l = 0; l < ch.n_layers; ++l) gmask |= (ch.layer[l].n_tiles > 0 ? 1u : 0u) << l;
+    const int first_gemm = gmask ? __builtin_ctz(gmask) : 0, last_gemm = gmask ? 31 - __builtin_clz(gmask) : -1;
+    // first weight fragments of layer `Ln`'s first GEMM (the aux part when it has one) -> pw
+    WF pw0, pw1, pw2;
+    auto prefetch_layer = [&](const nero_fwd_layer& Ln) {
+#ifdef F16_NO_W_PRE
+        return;
+#endif
+        if (wave >= Ln.n_tiles) return;
+        const int sx = Ln.k_aux >> 4, sm = Ln.k_main >> 4;
+        const int n = sx > 0 ? sx : sm;
+        if (n <= 0) return;
+        const float* img = sx > 0 ? Ln.w_aux : Ln.w_main;
+        const uint4* wp = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(img) + HDR_BYTES) + (size_t)wave * n * 128 + lane;
+        const int last = n - 1;
+        load_w(pw0, wp, 0);
+        if (F16_PW_N > 1) load_w(pw1, wp, 1 < last ? 1 : last);
+        if (F16_PW_N > 2) load_w(pw2, wp, 2 < last ? 2 : last);
+    };
+    float4 tin[NVR], tax[NXR];
+    auto request_tile = [&](int t) {
+        if (ch.init) tile_request<NVR>(tin, ch.init, ch.ld_init, ch.k_init, t * 64, n_rows, tid);
+        if (ch.aux) tile_request<NXR>(tax, ch.aux, ch.ld_aux, ch.k_aux, t * 64, n_rows, tid);
+    };
+    int tile = blockIdx.x;
+    if (tile >= n_tiles_total) return;
+    if (NVI > 0) request_tile(tile);
+    if (last_gemm >= 0) prefetch_layer(ch.layer[first_gemm]);
+    for (; tile < n_tiles_total; tile += gridDim.x) {
+    const int row0 = tile * 64;
     PH_DECL;
-    if (ch.init) load_planes_scaled(S.actp, SA, PLANE_A, S.rs_main, ch.init, ch.ld_init, ch.k_init, row0, n_rows, tid);
-    if (ch.aux) load_planes_scaled(S.auxp, SX, PLANE_X, S.rs_aux, ch.aux, ch.ld_aux, ch.k_aux, row0, n_rows, tid);
+    if (NVI > 0) {
+        if (ch.init) tile_commit<NVR>(S.actp, SA, PLANE_A, S.rs_main, tin, ch.k_init, tid);
+        if (ch.aux) tile_commit<NXR>(S.auxp, SX, PLANE_X, S.rs_aux, tax, ch.k_aux, tid);
+    } else {
+        if (ch.init) load_planes_scaled(S.actp, SA, PLANE_A, S.rs_main, ch.init, ch.ld_init, ch.k_init, row0, n_rows, tid);
+        if (ch.aux) load_planes_scaled(S.auxp, SX, PLANE_X, S.rs_aux, ch.aux, ch.ld_aux, ch.k_aux, row0, n_rows, tid);
+    }
     __syncthreads();
     PH(0);
     for (int l = 0; l < ch.n_layers; ++l) {
@@ -179,8 +244,8 @@ __global__ __launch_bounds__(512, 1) void fwd_f16_kernel(nero_fwd_chain ch, int 
             const int sm = L.k_main >> 4, sx = L.k_aux >> 4;
             if (sx > 0) {
                 const float wsc = *reinterpret_cast<const float*>(L.w_aux);
-                gemm_f16x3(aH, aL, reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(L.w_aux) + HDR_BYTES) + (size_t)wave * sx * 128 + lane,
-                           S.auxp + i * SX + 16 * h, 32 * SX, PLANE_X, sx);
+                gemm_f16x3_loop(aH, aL, reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(L.w_aux) + HDR_BYTES) + (size_t)wave * sx * 128 + lane,
+                                S.auxp + i * SX + 16 * h, 32 * SX, PLANE_X, sx, F16_W_PRE, pw0, pw1, pw2);
                 U[0] = wsc * S.rs_aux[i];
                 U[1] = wsc * S.rs_aux[32 + i];
             }
@@ -195,10 +260,20 @@ __global__ __launch_bounds__(512, 1) void fwd_f16_kernel(nero_fwd_chain ch, int 
                 }
                 U[0] = u0;
                 U[1] = u1;
-                gemm_f16x3(aH, aL, reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(L.w_main) + HDR_BYTES) + (size_t)wave * sm * 128 + lane,
-                           S.actp + i * SA + 16 * h, 32 * SA, PLANE_A, sm);
+                gemm_f16x3_loop(aH, aL, reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(L.w_main) + HDR_BYTES) + (size_t)wave * sm * 128 + lane,
+                                S.actp + i * SA + 16 * h, 32 * SA, PLANE_A, sm, F16_W_PRE && sx == 0, pw0, pw1, pw2);
             }
         }
+        // requests for what comes next, behind this layer's last weight load (vmcnt retires in order): the next layer's first weight
+        // fragments, or -- after the tile's last GEMM -- the next tile's input rows and the first layer's fragments again.  The
+        // epilogue, two barriers and the plane conversion that follow (~6 k cycles) cover the L2 / HBM latency.
+        NERO_FENCE();
+        if (l != last_gemm) prefetch_layer(ch.layer[l + 1 + __builtin_ctz(gmask >> (l + 1))]);
+        else {
+            if (NVI > 0 && tile + (int)gridDim.x < n_tiles_total) request_tile(tile + gridDim.x);
+            prefetch_layer(ch.layer[first_gemm]);
+        }
+        NERO_FENCE();
         // values, optional saves, row maxima
         float4 val[2][4];
         float m[2] = {0.f, 0.f};
@@ -259,6 +334,8 @@ __global__ __launch_bounds__(512, 1) void fwd_f16_kernel(nero_fwd_chain ch, int 
         PH(7);
     }
     PH_END;
+    __syncthreads();                                       // (a trailing head-only layer still reads the planes the next tile overwrites)
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -284,13 +361,15 @@ __device__ __forceinline__ void commit_planes(const Lds& S, const float4 (&val)[
     __syncthreads();
 }
 
-// aux part first (its own unit), converted into the main part's unit, then the main part: returns the unit of the result
+// aux part first (its own unit), converted into the main part's unit, then the main part: returns the unit of the result.  The first
+// GEMM (the aux part when there is one) starts on the fragments the caller requested ahead (pw0..2, `pre`).
 __device__ __forceinline__ void gemm_two_sources(f32x16 (&aH)[2], f32x16 (&aL)[2], float (&U)[2], const Lds& S, const float* w_main,
-                                                 const float* w_aux, int sm, int sx, int SXb, int PLANE_Xb, int wave, int lane, int i, int h) {
+                                                 const float* w_aux, int sm, int sx, int SXb, int PLANE_Xb, int wave, int lane, int i, int h,
+                                                 bool pre, WF& pw0, WF& pw1, WF& pw2) {
     if (sx > 0) {
         const float wsc = *w_aux;
-        gemm_f16x3(aH, aL, reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w_aux) + HDR_BYTES) + (size_t)wave * sx * 128 + lane,
-                   S.auxp + i * SXb + 16 * h, 32 * SXb, PLANE_Xb, sx);
+        gemm_f16x3_loop(aH, aL, reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w_aux) + HDR_BYTES) + (size_t)wave * sx * 128 + lane,
+                        S.auxp + i * SXb + 16 * h, 32 * SXb, PLANE_Xb, sx, pre, pw0, pw1, pw2);
         U[0] = wsc * S.rs_aux[i];
         U[1] = wsc * S.rs_aux[32 + i];
     }
@@ -304,35 +383,64 @@ __device__ __forceinline__ void gemm_two_sources(f32x16 (&aH)[2], f32x16 (&aL)[2
         }
         U[0] = u0;
         U[1] = u1;
-        gemm_f16x3(aH, aL, reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w_main) + HDR_BYTES) + (size_t)wave * sm * 128 + lane,
-                   S.actp + i * SA + 16 * h, 32 * SA, PLANE_A, sm);
+        gemm_f16x3_loop(aH, aL, reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w_main) + HDR_BYTES) + (size_t)wave * sm * 128 + lane,
+                        S.actp + i * SA + 16 * h, 32 * SA, PLANE_A, sm, pre && sx == 0, pw0, pw1, pw2);
     }
 }
 
-__global__ __launch_bounds__(512, 1) void tan_f16_kernel(nero_tan_chain ch, int n_rows) {
+// PERSISTENT (round 4, as the forward kernel): tiles blockIdx.x, + gridDim.x, ...; the next layer's first weight fragments and the
+// next tile's input rows (k_init = 40: two float4 per thread and source) are requested ahead.
+__global__ __launch_bounds__(512, 1) void tan_f16_kernel(nero_tan_chain ch, int n_rows, int n_tiles_total) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SX = SX_N;
     constexpr int PLANE_X = 64 * SX;
+    constexpr int NV = 2;                              // float4s per thread of an input tile: k_init, k_aux <= 48 (host-checked)
     const Lds S = carve<SX>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
-    const int row0 = blockIdx.x * 64;
     // the saved activations of the NEXT layer arrive by LDS-DMA in this lane's fragment order (as in the reverse kernel: 8 KB per
     // wave in place of the store scratch, which they double as once read out); the first-order signal gbar stays a register load
     char* pa_lds = S.scr + wave * 8192;
     const unsigned pa_addr = __builtin_amdgcn_readfirstlane(lds_offset_of(pa_lds));
-    const size_t goff = (size_t)(row0 + i) * NERO_HID + 32 * wave + 4 * h;     // + r*32*HID + 8g
-    auto prefetch_act = [&](const nero_tan_layer& Ln) {
+    auto prefetch_act = [&](const nero_tan_layer& Ln, int r0) {
         if (wave >= Ln.n_tiles) return;
+        const size_t go = (size_t)(r0 + i) * NERO_HID + 32 * wave + 4 * h;
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) lds_dma16(Ln.a_saved + goff + (size_t)r * 32 * NERO_HID + 8 * g, pa_addr + (r * 4 + g) * 1024);
+            for (int g = 0; g < 4; ++g) lds_dma16(Ln.a_saved + go + (size_t)r * 32 * NERO_HID + 8 * g, pa_addr + (r * 4 + g) * 1024);
     };
-    prefetch_act(ch.layer[0]);
-    if (ch.init) load_planes_scaled(S.actp, SA, PLANE_A, S.rs_main, ch.init, ch.ld_init, ch.k_init, row0, n_rows, tid);
-    if (ch.aux) load_planes_scaled(S.auxp, SX, PLANE_X, S.rs_aux, ch.aux, ch.ld_aux, ch.k_aux, row0, n_rows, tid);
+    WF pw0, pw1, pw2;
+    // (UNCONDITIONAL on purpose -- a wave without a tile in that layer reads tile 0's fragments and never uses them: a conditional
+    //  request would keep the stale fragments of the finished GEMM alive through the epilogue, 24 registers)
+    auto prefetch_layer = [&](const nero_tan_layer& Ln) {
+        const int sx = Ln.k_aux >> 4, sm = Ln.k_main >> 4;
+        const int n = sx > 0 ? sx : sm;
+        const float* img = sx > 0 ? Ln.w_aux : Ln.w_main;
+        const int wt = wave < Ln.n_tiles ? wave : 0;
+        prefetch_w(pw0, pw1, pw2, reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(img) + HDR_BYTES) + (size_t)wt * n * 128 + lane, n);
+    };
+    float4 tin[NV], tax[NV];
+    auto request_tile = [&](int t) {
+        if (ch.init) tile_request<NV>(tin, ch.init, ch.ld_init, ch.k_init, t * 64, n_rows, tid);
+        if (ch.aux) tile_request<NV>(tax, ch.aux, ch.ld_aux, ch.k_aux, t * 64, n_rows, tid);
+    };
+    int tile = blockIdx.x;
+    if (tile >= n_tiles_total) return;
+    prefetch_act(ch.layer[0], tile * 64);
+#ifdef TAN_TILE_AHEAD
+    request_tile(tile);
+#endif
+    prefetch_layer(ch.layer[0]);
+    for (; tile < n_tiles_total; tile += gridDim.x) {
+    const int row0 = tile * 64;
+    const size_t goff = (size_t)(row0 + i) * NERO_HID + 32 * wave + 4 * h;     // + r*32*HID + 8g
+#ifndef TAN_TILE_AHEAD
+    request_tile(tile);                                // (the 40-column input tile is read here: holding it across the last layer spills)
+#endif
+    if (ch.init) tile_commit<NV>(S.actp, SA, PLANE_A, S.rs_main, tin, ch.k_init, tid);
+    if (ch.aux) tile_commit<NV>(S.auxp, SX, PLANE_X, S.rs_aux, tax, ch.k_aux, tid);
     __syncthreads();
     for (int l = 0; l < ch.n_layers; ++l) {
         const nero_tan_layer& L = ch.layer[l];
@@ -349,7 +457,9 @@ __global__ __launch_bounds__(512, 1) void tan_f16_kernel(nero_tan_chain ch, int 
         zero2(aH);
         zero2(aL);
         float U[2] = {1.f, 1.f};
-        if (live_wave) gemm_two_sources(aH, aL, U, S, L.w_main, L.w_aux, L.k_main >> 4, L.k_aux >> 4, SX, PLANE_X, wave, lane, i, h);
+        if (live_wave) gemm_two_sources(aH, aL, U, S, L.w_main, L.w_aux, L.k_main >> 4, L.k_aux >> 4, SX, PLANE_X, wave, lane, i, h, true, pw0, pw1, pw2);
+        const bool last_layer = l + 1 == ch.n_layers;
+        const bool more = tile + (int)gridDim.x < n_tiles_total;
         float4 val[2][4];
         float m[2] = {0.f, 0.f};
         if (live_wave) {
@@ -382,11 +492,21 @@ __global__ __launch_bounds__(512, 1) void tan_f16_kernel(nero_tan_chain ch, int 
                 acc_to_global(scr, ijq, L.inj + boff + (size_t)r * 32 * NERO_HID, lane);
             }
         }
-        if (l + 1 < ch.n_layers) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the scratch reads are done before the DMA may land
-            prefetch_act(ch.layer[l + 1]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the scratch reads are done before the DMA may land
+        // requests for the next layer (or the next tile's first): saved activations by LDS-DMA, the first weight fragments into
+        // registers (here, not behind the GEMM: the epilogue above is this kernel's register peak); commit_planes' two barriers cover them
+        NERO_FENCE();
+        if (!last_layer) { prefetch_act(ch.layer[l + 1], row0); prefetch_layer(ch.layer[l + 1]); }
+        else {
+            if (more) prefetch_act(ch.layer[0], (tile + gridDim.x) * 64);
+#ifdef TAN_TILE_AHEAD
+            if (more) request_tile(tile + gridDim.x);
+#endif
+            prefetch_layer(ch.layer[0]);
         }
+        NERO_FENCE();
         commit_planes(S, val, m[0], m[1], live_wave, wave, i, h);
+    }
     }
 }
 
@@ -478,8 +598,10 @@ inline int bwd_lds_bytes() { return 2 * PLANE_A + (64 + 64 + 512) * 4 + BWD_PA_B
 // no spill -- instead of reading them in the epilogue: the second-order reverse pass went from 1.74 to 2.69 ms.  vmcnt retires in
 // order, so the weight stream of the next GEMM queued behind eight 1 KB HBM loads per wave, exactly what the LDS-DMA of the saved
 // activations had been introduced to avoid; there is no LDS left for a second DMA target: 135.7 of 160 KB.)
+// PERSISTENT (round 4, as the forward kernel): a workgroup walks the tiles blockIdx.x, blockIdx.x + gridDim.x, ...; the saved
+// activations / sign words the FIRST step of the next tile needs are requested as soon as this tile has read out its last ones.
 template <bool FIXED>
-__global__ __launch_bounds__(512, 1) void bwd_f16_kernel(nero_bwd_chain ch, int n_rows) {
+__global__ __launch_bounds__(512, 1) void bwd_f16_kernel(nero_bwd_chain ch, int n_rows, int n_tiles_total) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Lds S;
     S.actp = smem;
@@ -491,26 +613,31 @@ __global__ __launch_bounds__(512, 1) void bwd_f16_kernel(nero_bwd_chain ch, int 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
-    const int row0 = blockIdx.x * 64;
     char* pa_lds = reinterpret_cast<char*>(S.rmax + 64 * 8) + wave * 8192;
     const unsigned pa_addr = __builtin_amdgcn_readfirstlane(lds_offset_of(pa_lds));
-    const size_t goff = (size_t)(row0 + i) * NERO_HID + 32 * wave + 4 * h;
     unsigned mbits[2] = {0u, 0u};                      // ReLU sign masks of the layer being processed
-    // request what the epilogue of layer `Ln` needs of its input activation: the sign words (registers) or the fp32 tile (LDS-DMA)
-    auto prefetch_act = [&](const nero_bwd_layer& Ln) {
+    // request what the epilogue of layer `Ln` needs of its input activation (rows of the tile at `r0`): the sign words (registers) or
+    // the fp32 tile (LDS-DMA)
+    auto prefetch_act = [&](const nero_bwd_layer& Ln, int r0) {
         if (Ln.a_prev == nullptr || wave >= Ln.k_main_tiles) return;
         if (Ln.mask_prev && Ln.act_prev == NERO_ACT_RELU) {
 #pragma unroll
-            for (int r = 0; r < 2; ++r) mbits[r] = Ln.mask_prev[(size_t)(row0 + 32 * r + i) * 8 + wave];
+            for (int r = 0; r < 2; ++r) mbits[r] = Ln.mask_prev[(size_t)(r0 + 32 * r + i) * 8 + wave];
         } else {
+            const size_t go = (size_t)(r0 + i) * NERO_HID + 32 * wave + 4 * h;
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    lds_dma16(Ln.a_prev + goff + (size_t)r * 32 * NERO_HID + 8 * g, pa_addr + (r * 4 + g) * 1024);
+                    lds_dma16(Ln.a_prev + go + (size_t)r * 32 * NERO_HID + 8 * g, pa_addr + (r * 4 + g) * 1024);
         }
     };
-    prefetch_act(ch.layer[ch.n_layers - 1]);
+    int tile = blockIdx.x;
+    if (tile >= n_tiles_total) return;
+    prefetch_act(ch.layer[ch.n_layers - 1], tile * 64);
+    for (; tile < n_tiles_total; tile += gridDim.x) {
+    const int row0 = tile * 64;
+    const size_t goff = (size_t)(row0 + i) * NERO_HID + 32 * wave + 4 * h;
     if (ch.dy) load_planes_scaled(S.actp, SA, PLANE_A, S.rs_main, ch.dy, ch.ld_dy, ch.k_dy, row0, n_rows, tid);
     else {
         for (int idx = tid; idx < 2 * PLANE_A / 16; idx += 512) reinterpret_cast<uint4*>(S.actp)[idx] = make_uint4(0u, 0u, 0u, 0u);
@@ -634,13 +761,21 @@ __global__ __launch_bounds__(512, 1) void bwd_f16_kernel(nero_bwd_chain ch, int 
         }
         if (l > 0) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the scratch reads are done before the DMA may land
-            prefetch_act(ch.layer[l - 1]);
+            prefetch_act(ch.layer[l - 1], row0);
         }
         PH(5);
         commit_planes(S, val, m[0], m[1], live_wave, wave, i, h);
         PH(6);
     }
     PH_END;
+    // the next tile: its first step's saved activations / sign words go out now (this wave's PA buffer has been read out and, as the
+    // store scratch, been drained: lgkmcnt(0)); the barrier keeps a fast wave from overwriting planes a slow one still multiplies
+    if (tile + (int)gridDim.x < n_tiles_total) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        prefetch_act(ch.layer[ch.n_layers - 1], (tile + gridDim.x) * 64);
+    }
+    __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -725,34 +860,65 @@ int nero_f16_pack_batch(const nero_pack_job* jobs, int n_jobs, hipStream_t strea
     return nero_check_launch("nero_pack_batch(f16x3)");
 }
 
+#ifndef F16_TILE_AHEAD
+#define F16_TILE_AHEAD 1
+#endif
+// persistent chain kernels: one workgroup per CU, each walks its share of the 64-row tiles
+static int nero_cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n = v;
+    }
+    return n;
+}
+// workgroups of a chain launch over n_tiles tiles.  NERO_F16_PERSIST (bit 0 forward, 1 reverse, 2 tangent; default 7) is an experiment
+// switch: a cleared bit launches one workgroup per tile, i.e. the same kernel without the persistent walk.
+static int nero_chain_grid(int n_tiles, int kind_bit) {
+    static int mask = -1;
+    if (mask < 0) { const char* e = getenv("NERO_F16_PERSIST"); mask = e ? atoi(e) : 7; }
+    const int cus = nero_cu_count();
+    return ((mask >> kind_bit) & 1) && n_tiles > cus ? cus : n_tiles;
+}
+
+template <bool WIDE, int NVI>
+static void launch_fwd(const nero_fwd_chain* ch, int n_rows, int n_tiles, dim3 grid, hipStream_t stream) {
+    NERO_ONCE(hipFuncSetAttribute((const void*)fwd_f16_kernel<WIDE, NVI>, hipFuncAttributeMaxDynamicSharedMemorySize, f16_lds_bytes(WIDE ? 1 : 0)));
+    hipLaunchKernelGGL((fwd_f16_kernel<WIDE, NVI>), grid, dim3(512), f16_lds_bytes(WIDE ? 1 : 0), stream, *ch, n_rows, n_tiles);
+}
+
 int nero_f16_forward(const nero_fwd_chain* ch, int n_rows, hipStream_t stream) {
-    const dim3 grid((n_rows + 63) / 64), block(512);
+    const int n_tiles = (n_rows + 63) / 64, cus = nero_cu_count();
+    const dim3 grid(nero_chain_grid(n_tiles, 0));
     for (int l = 0; l < ch->n_layers; ++l)
         if ((ch->layer[l].k_main | ch->layer[l].k_aux) & 15)
             return nero_fail(NERO_ERR_ARG, "nero_mlp_forward(f16x3): k_main / k_aux must be multiples of 16");
-    if (ch->aux_wide) {
-        NERO_ONCE(hipFuncSetAttribute((const void*)fwd_f16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, f16_lds_bytes(1)));
-        hipLaunchKernelGGL(fwd_f16_kernel<true>, grid, block, f16_lds_bytes(1), stream, *ch, n_rows);
-    } else {
-        NERO_ONCE(hipFuncSetAttribute((const void*)fwd_f16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, f16_lds_bytes(0)));
-        hipLaunchKernelGGL(fwd_f16_kernel<false>, grid, block, f16_lds_bytes(0), stream, *ch, n_rows);
-    }
+    // the next tile's input travels in registers while the current tile finishes when it is narrow enough (k_init <= 128) and the
+    // launch has more tiles than workgroups
+    const bool ahead = F16_TILE_AHEAD && (!ch->init || ch->k_init <= 128) && (int)grid.x < n_tiles;
+    (void)cus;
+    if (ch->aux_wide) { if (ahead) launch_fwd<true, 4>(ch, n_rows, n_tiles, grid, stream); else launch_fwd<true, 0>(ch, n_rows, n_tiles, grid, stream); }
+    else              { if (ahead) launch_fwd<false, 4>(ch, n_rows, n_tiles, grid, stream); else launch_fwd<false, 0>(ch, n_rows, n_tiles, grid, stream); }
     return NERO_OK;
 }
 
 int nero_f16_tangent(const nero_tan_chain* ch, int n_rows, hipStream_t stream) {
-    const dim3 grid((n_rows + 63) / 64), block(512);
+    const int n_tiles = (n_rows + 63) / 64;
+    const dim3 grid(nero_chain_grid(n_tiles, 2)), block(512);
+    if (ch->k_init > 48 || ch->k_aux > 48) return nero_fail(NERO_ERR_UNSUPPORTED, "nero_mlp_tangent(f16x3): k_init / k_aux up to 48 columns");
     for (int l = 0; l < ch->n_layers; ++l)
         if ((ch->layer[l].k_main | ch->layer[l].k_aux) & 15)
             return nero_fail(NERO_ERR_ARG, "nero_mlp_tangent(f16x3): k_main / k_aux must be multiples of 16");
     if (ch->aux_wide) return nero_fail(NERO_ERR_UNSUPPORTED, "nero_mlp_tangent(f16x3): aux_wide chains are not supported");
     NERO_ONCE(hipFuncSetAttribute((const void*)tan_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tan_lds_bytes()));
-    hipLaunchKernelGGL(tan_f16_kernel, grid, block, tan_lds_bytes(), stream, *ch, n_rows);
+    hipLaunchKernelGGL(tan_f16_kernel, grid, block, tan_lds_bytes(), stream, *ch, n_rows, n_tiles);
     return NERO_OK;
 }
 
 int nero_f16_backward(const nero_bwd_chain* ch, int n_rows, hipStream_t stream) {
-    const dim3 grid((n_rows + 63) / 64), block(512);
+    const int n_tiles = (n_rows + 63) / 64;
+    const dim3 grid(nero_chain_grid(n_tiles, 1)), block(512);
     for (int l = 0; l < ch->n_layers; ++l)
         if (ch->layer[l].n_out & 15) return nero_fail(NERO_ERR_ARG, "nero_mlp_backward(f16x3): n_out must be a multiple of 16");
     if (ch->d_aux && (ch->ld_daux & 3)) return nero_fail(NERO_ERR_ARG, "nero_mlp_backward(f16x3): ld_daux must be a multiple of 4");
@@ -761,7 +927,7 @@ int nero_f16_backward(const nero_bwd_chain* ch, int n_rows, hipStream_t stream) 
     for (int l = 0; l < ch->n_layers; ++l) fixed = fixed && (ch->layer[l].n_out == 0 || ch->layer[l].n_out == 256);
     NERO_ONCE(hipFuncSetAttribute((const void*)bwd_f16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bwd_lds_bytes()));
     NERO_ONCE(hipFuncSetAttribute((const void*)bwd_f16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bwd_lds_bytes()));
-    if (fixed) hipLaunchKernelGGL(bwd_f16_kernel<true>, grid, block, bwd_lds_bytes(), stream, *ch, n_rows);
-    else hipLaunchKernelGGL(bwd_f16_kernel<false>, grid, block, bwd_lds_bytes(), stream, *ch, n_rows);
+    if (fixed) hipLaunchKernelGGL(bwd_f16_kernel<true>, grid, block, bwd_lds_bytes(), stream, *ch, n_rows, n_tiles);
+    else hipLaunchKernelGGL(bwd_f16_kernel<false>, grid, block, bwd_lds_bytes(), stream, *ch, n_rows, n_tiles);
     return NERO_OK;
 }
