@@ -17,6 +17,7 @@ the same MI355X: the ">= 10x reference single-GPU PyTorch" yard-stick of north_s
 box) and `cpu_baseline` (the oracle on the host cores).  The two baselines are the only places that touch oracle/.
 """
 import argparse
+import glob
 import json
 import os
 import socket
@@ -129,6 +130,23 @@ def cpu_baseline(cfg, variance, step, rays=512, budget_s=15.0, max_steps=10):
     return {'value': rays * n / dt, 'unit': 'rays/s', 'cores': cores, 'kind': 'port',
             'sample': f'{rays} rays x (64+64+32) samples, oracle (torch-CPU port of the reference path) forward+loss+backward, '
                       f'{n} step(s), {dt:.1f} s'}
+
+
+def reference_cpu_record():
+    """the newest committed profiles/rNN_ref_vs_port_cpu.json: the UNMODIFIED reference (shimmed, network/renderer.py:608-627) and the
+    oracle port timed on the same host cores in the build container by oracle/ref_vs_port_cpu.py (BASELINE.md section 3's C1 protocol).
+    Read-only bookkeeping: nothing under oracle/ or /root/reference is touched here."""
+    paths = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_ref_vs_port_cpu.json')))
+    if not paths:
+        return None
+    try:
+        with open(paths[-1]) as f:
+            r = json.load(f)
+    except (OSError, ValueError):
+        return None
+    return {'value': r['reference']['rays_per_s'], 'unit': 'rays/s', 'cores': r['cores'], 'kind': 'reference', 'where': r['where'],
+            'workload': r['workload'], 'protocol': r['protocol'], 'port_on_the_same_cores': r['port']['rays_per_s'],
+            'port_over_reference': r['port_over_reference'], 'source': os.path.relpath(paths[-1], ROOT)}
 
 
 def torch_gpu_baseline(cfg, variance, step, rays, dev, warmup=10, steps=50):
@@ -690,9 +708,18 @@ def main():
             leg('stage2_bear_2048x512', lambda: stage2_step_bench(dev, 'bear', 2048, 256, 256, _bench_mesh()))
             tg = torch_gpu_baseline(cfg, VARIANCE, args.train_step, args.rays, dev)
             res['torch_gpu_baseline'] = tg
+            # both baselines time the PORT (oracle/nero_oracle.py): the unmodified reference cannot travel to the GPU box.  The ratio below is
+            # therefore "vs port"; the port / reference rate measured on the build container's host cores travels as a committed record
+            # (profiles/rNN_ref_vs_port_cpu.json, oracle/ref_vs_port_cpu.py) and is reported BESIDE the ratio, never multiplied in.
             res['x_torch_gpu_baseline'] = round(res['protocol_8d']['rays_per_s_at_median'] / tg['value'], 2)
+            res['x_torch_gpu_baseline_is'] = 'vs port (same algorithm as plain PyTorch ops on this GPU); see cpu_baseline.reference for port / reference'
+            refrec = reference_cpu_record()
             if not args.no_cpu_baseline:
                 res['cpu_baseline'] = cpu_baseline(cfg, VARIANCE, args.train_step)
+                if refrec:
+                    res['cpu_baseline']['reference'] = refrec
+            elif refrec:
+                res['cpu_baseline_reference'] = refrec
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

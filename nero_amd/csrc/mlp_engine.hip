@@ -954,28 +954,37 @@ int nero_dw_gemm_batch(const nero_dw_job* jobs, int n_jobs, int n_rows, float* p
             return nero_fail(NERO_ERR_ARG, "nero_dw_gemm_batch: bad job");
         f16 = f16 && J.gemm_mode == NERO_GEMM_F16X3;
     }
-    // experiment switches: NERO_DW_BATCH_ROWS (batch below this row count; default 131072), NERO_DW_BATCH_TOTAL (slices over a group's
-    // jobs; default 1024), NERO_DW_BATCH_GROUP (jobs per launch; default / maximum NERO_DW_BATCH_MAX)
-    static int batch_rows = -1, batch_total = 1024, batch_group = NERO_DW_BATCH_MAX;
+    // Two batching regimes (both: blockIdx.y = job, one reduction launch per group).  Below DW_BATCH_ROWS rows a job alone neither fills
+    // the chip nor amortises its partial matrices: ~1024 slices over groups of up to NERO_DW_BATCH_MAX jobs.  At or above it (round 4) the
+    // jobs of a chain still run in groups, of 8, with ONE slice per CU over the whole group (256 slices in all, 32 per job): every
+    // workgroup streams ~9 k rows of one job, and the group writes 8 x 32 partial matrices instead of 8 x 256 -- a job alone spent a
+    // fifth of its HBM traffic (67 MB written + read back for 610 MB of operands) and ~11 us of dirty-line write-back at the kernel
+    // boundary on them: 31.28 -> 30.75 ms per step at 4096 rays (same box, profiles/r04_dw_batch_sweep.txt).
+    // Experiment switches: NERO_DW_BATCH_ROWS (the regime boundary), NERO_DW_BATCH_TOTAL / NERO_DW_BATCH_GROUP (slices per group / jobs
+    // per group of the large-row regime; 0 rows = the old per-job launches).
+    static int batch_rows = -1, big_total = 256, big_group = 8;
     if (batch_rows < 0) {
         const char* e = getenv("NERO_DW_BATCH_ROWS"); batch_rows = e ? atoi(e) : DW_BATCH_ROWS;
-        e = getenv("NERO_DW_BATCH_TOTAL"); if (e) batch_total = atoi(e);
-        e = getenv("NERO_DW_BATCH_GROUP"); if (e) batch_group = atoi(e);
-        batch_group = batch_group < 1 ? 1 : (batch_group > NERO_DW_BATCH_MAX ? NERO_DW_BATCH_MAX : batch_group);
-        batch_total = batch_total < 16 ? 16 : (batch_total > 1024 ? 1024 : batch_total);
+        e = getenv("NERO_DW_BATCH_TOTAL"); if (e) big_total = atoi(e);
+        e = getenv("NERO_DW_BATCH_GROUP"); if (e) big_group = atoi(e);
+        big_group = big_group < 0 ? 0 : (big_group > NERO_DW_BATCH_MAX ? NERO_DW_BATCH_MAX : big_group);
+        big_total = big_total < 16 ? 16 : (big_total > 1024 ? 1024 : big_total);
     }
-    if (!f16 || rows >= batch_rows || n_jobs < 2) {               // the per-job path: one launch (+ reduction) per job
+    const bool big = rows >= batch_rows;
+    const int batch_total = big ? big_total : 1024, batch_group = big ? big_group : NERO_DW_BATCH_MAX;
+    if (!f16 || n_jobs < 2 || batch_group < 1) {                 // the per-job path: one launch (+ reduction) per job
         for (int i = 0; i < n_jobs; ++i) {
             const int rc = nero_dw_gemm(jobs + i, n_rows, partials, stream);
             if (rc != NERO_OK) return rc;
         }
         return NERO_OK;
     }
+    if (n_jobs > 256) return nero_fail(NERO_ERR_ARG, "nero_dw_gemm_batch: at most 256 jobs per call");
     // narrow (k_pad <= 128) and wide jobs are different kernels; inside a kind, groups of NERO_DW_BATCH_MAX in the caller's order.
     // The partial buffer is reused from group to group (stream order).
     for (int narrow = 0; narrow < 2; ++narrow) {
         int idx[256], n = 0;
-        for (int i = 0; i < n_jobs && n < 256; ++i)
+        for (int i = 0; i < n_jobs; ++i)
             if ((((jobs[i].k_cols + 31) / 32 * 32) <= 128) == (narrow != 0)) idx[n++] = i;
         for (int g0 = 0; g0 < n; g0 += batch_group) {
             const int ng = n - g0 < batch_group ? n - g0 : batch_group;

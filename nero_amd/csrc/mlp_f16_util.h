@@ -281,9 +281,12 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& 
 #ifndef GEMM_WD
 #define GEMM_WD 3
 #endif
-template <int N>
-__device__ __forceinline__ void gemm_f16x3_fixed(f32x16 (&aH)[2], f32x16 (&aL)[2], const uint4* wp, const char* xp, int half_bytes,
-                                                 int plane_bytes) {
+// `hook(IC<c>)` runs in every step behind that step's operand requests: the caller issues its own global loads at the step after
+// which the GEMM requests no more weights (c = N - WD: vmcnt retires in order, a load issued earlier would hold the weight stream back,
+// one issued later has less of the GEMM left to hide behind).
+template <int N, class F>
+__device__ __forceinline__ void gemm_f16x3_fixed_hook(f32x16 (&aH)[2], f32x16 (&aL)[2], const uint4* wp, const char* xp, int half_bytes,
+                                                      int plane_bytes, F&& hook) {
     constexpr int XD = GEMM_XD, XN = XD + 1, WD = GEMM_WD, WN = WD + 1;
     WF w[WN];
     XF x[XN];
@@ -294,11 +297,17 @@ __device__ __forceinline__ void gemm_f16x3_fixed(f32x16 (&aH)[2], f32x16 (&aL)[2
         constexpr int c = cc.value;
         if (c + WD < N) load_w(w[(c + WD) % WN], wp, c + WD);
         if (c + XD < N) load_x(x[(c + XD) % XN], xp, half_bytes, plane_bytes, c + XD);
+        hook(cc);
         NERO_MID_FENCE();
         ops_compute(aH, aL, w[c % WN], x[c % XN]);
         if (c + WD < N && c + XD < N) NERO_KSTEP_SCHED();
         NERO_FENCE();
     });
+}
+template <int N>
+__device__ __forceinline__ void gemm_f16x3_fixed(f32x16 (&aH)[2], f32x16 (&aL)[2], const uint4* wp, const char* xp, int half_bytes,
+                                                 int plane_bytes) {
+    gemm_f16x3_fixed_hook<N>(aH, aL, wp, xp, half_bytes, plane_bytes, [](auto) {});
 }
 
 __device__ __forceinline__ void gemm_f16x3(f32x16 (&aH)[2], f32x16 (&aL)[2], const uint4* wp, const char* xp, int half_bytes,

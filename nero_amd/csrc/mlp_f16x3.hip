@@ -361,15 +361,13 @@ __device__ __forceinline__ void commit_planes(const Lds& S, const float4 (&val)[
     __syncthreads();
 }
 
-// aux part first (its own unit), converted into the main part's unit, then the main part: returns the unit of the result.  The first
-// GEMM (the aux part when there is one) starts on the fragments the caller requested ahead (pw0..2, `pre`).
+// aux part first (its own unit), converted into the main part's unit, then the main part: returns the unit of the result
 __device__ __forceinline__ void gemm_two_sources(f32x16 (&aH)[2], f32x16 (&aL)[2], float (&U)[2], const Lds& S, const float* w_main,
-                                                 const float* w_aux, int sm, int sx, int SXb, int PLANE_Xb, int wave, int lane, int i, int h,
-                                                 bool pre, WF& pw0, WF& pw1, WF& pw2) {
+                                                 const float* w_aux, int sm, int sx, int SXb, int PLANE_Xb, int wave, int lane, int i, int h) {
     if (sx > 0) {
         const float wsc = *w_aux;
-        gemm_f16x3_loop(aH, aL, reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w_aux) + HDR_BYTES) + (size_t)wave * sx * 128 + lane,
-                        S.auxp + i * SXb + 16 * h, 32 * SXb, PLANE_Xb, sx, pre, pw0, pw1, pw2);
+        gemm_f16x3(aH, aL, reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w_aux) + HDR_BYTES) + (size_t)wave * sx * 128 + lane,
+                   S.auxp + i * SXb + 16 * h, 32 * SXb, PLANE_Xb, sx);
         U[0] = wsc * S.rs_aux[i];
         U[1] = wsc * S.rs_aux[32 + i];
     }
@@ -383,64 +381,35 @@ __device__ __forceinline__ void gemm_two_sources(f32x16 (&aH)[2], f32x16 (&aL)[2
         }
         U[0] = u0;
         U[1] = u1;
-        gemm_f16x3_loop(aH, aL, reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w_main) + HDR_BYTES) + (size_t)wave * sm * 128 + lane,
-                        S.actp + i * SA + 16 * h, 32 * SA, PLANE_A, sm, pre && sx == 0, pw0, pw1, pw2);
+        gemm_f16x3(aH, aL, reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w_main) + HDR_BYTES) + (size_t)wave * sm * 128 + lane,
+                   S.actp + i * SA + 16 * h, 32 * SA, PLANE_A, sm);
     }
 }
 
-// PERSISTENT (round 4, as the forward kernel): tiles blockIdx.x, + gridDim.x, ...; the next layer's first weight fragments and the
-// next tile's input rows (k_init = 40: two float4 per thread and source) are requested ahead.
-__global__ __launch_bounds__(512, 1) void tan_f16_kernel(nero_tan_chain ch, int n_rows, int n_tiles_total) {
+__global__ __launch_bounds__(512, 1) void tan_f16_kernel(nero_tan_chain ch, int n_rows) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SX = SX_N;
     constexpr int PLANE_X = 64 * SX;
-    constexpr int NV = 2;                              // float4s per thread of an input tile: k_init, k_aux <= 48 (host-checked)
     const Lds S = carve<SX>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
+    const int row0 = blockIdx.x * 64;
     // the saved activations of the NEXT layer arrive by LDS-DMA in this lane's fragment order (as in the reverse kernel: 8 KB per
     // wave in place of the store scratch, which they double as once read out); the first-order signal gbar stays a register load
     char* pa_lds = S.scr + wave * 8192;
     const unsigned pa_addr = __builtin_amdgcn_readfirstlane(lds_offset_of(pa_lds));
-    auto prefetch_act = [&](const nero_tan_layer& Ln, int r0) {
+    const size_t goff = (size_t)(row0 + i) * NERO_HID + 32 * wave + 4 * h;     // + r*32*HID + 8g
+    auto prefetch_act = [&](const nero_tan_layer& Ln) {
         if (wave >= Ln.n_tiles) return;
-        const size_t go = (size_t)(r0 + i) * NERO_HID + 32 * wave + 4 * h;
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) lds_dma16(Ln.a_saved + go + (size_t)r * 32 * NERO_HID + 8 * g, pa_addr + (r * 4 + g) * 1024);
+            for (int g = 0; g < 4; ++g) lds_dma16(Ln.a_saved + goff + (size_t)r * 32 * NERO_HID + 8 * g, pa_addr + (r * 4 + g) * 1024);
     };
-    WF pw0, pw1, pw2;
-    // (UNCONDITIONAL on purpose -- a wave without a tile in that layer reads tile 0's fragments and never uses them: a conditional
-    //  request would keep the stale fragments of the finished GEMM alive through the epilogue, 24 registers)
-    auto prefetch_layer = [&](const nero_tan_layer& Ln) {
-        const int sx = Ln.k_aux >> 4, sm = Ln.k_main >> 4;
-        const int n = sx > 0 ? sx : sm;
-        const float* img = sx > 0 ? Ln.w_aux : Ln.w_main;
-        const int wt = wave < Ln.n_tiles ? wave : 0;
-        prefetch_w(pw0, pw1, pw2, reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(img) + HDR_BYTES) + (size_t)wt * n * 128 + lane, n);
-    };
-    float4 tin[NV], tax[NV];
-    auto request_tile = [&](int t) {
-        if (ch.init) tile_request<NV>(tin, ch.init, ch.ld_init, ch.k_init, t * 64, n_rows, tid);
-        if (ch.aux) tile_request<NV>(tax, ch.aux, ch.ld_aux, ch.k_aux, t * 64, n_rows, tid);
-    };
-    int tile = blockIdx.x;
-    if (tile >= n_tiles_total) return;
-    prefetch_act(ch.layer[0], tile * 64);
-#ifdef TAN_TILE_AHEAD
-    request_tile(tile);
-#endif
-    prefetch_layer(ch.layer[0]);
-    for (; tile < n_tiles_total; tile += gridDim.x) {
-    const int row0 = tile * 64;
-    const size_t goff = (size_t)(row0 + i) * NERO_HID + 32 * wave + 4 * h;     // + r*32*HID + 8g
-#ifndef TAN_TILE_AHEAD
-    request_tile(tile);                                // (the 40-column input tile is read here: holding it across the last layer spills)
-#endif
-    if (ch.init) tile_commit<NV>(S.actp, SA, PLANE_A, S.rs_main, tin, ch.k_init, tid);
-    if (ch.aux) tile_commit<NV>(S.auxp, SX, PLANE_X, S.rs_aux, tax, ch.k_aux, tid);
+    prefetch_act(ch.layer[0]);
+    if (ch.init) load_planes_scaled(S.actp, SA, PLANE_A, S.rs_main, ch.init, ch.ld_init, ch.k_init, row0, n_rows, tid);
+    if (ch.aux) load_planes_scaled(S.auxp, SX, PLANE_X, S.rs_aux, ch.aux, ch.ld_aux, ch.k_aux, row0, n_rows, tid);
     __syncthreads();
     for (int l = 0; l < ch.n_layers; ++l) {
         const nero_tan_layer& L = ch.layer[l];
@@ -457,9 +426,7 @@ __global__ __launch_bounds__(512, 1) void tan_f16_kernel(nero_tan_chain ch, int 
         zero2(aH);
         zero2(aL);
         float U[2] = {1.f, 1.f};
-        if (live_wave) gemm_two_sources(aH, aL, U, S, L.w_main, L.w_aux, L.k_main >> 4, L.k_aux >> 4, SX, PLANE_X, wave, lane, i, h, true, pw0, pw1, pw2);
-        const bool last_layer = l + 1 == ch.n_layers;
-        const bool more = tile + (int)gridDim.x < n_tiles_total;
+        if (live_wave) gemm_two_sources(aH, aL, U, S, L.w_main, L.w_aux, L.k_main >> 4, L.k_aux >> 4, SX, PLANE_X, wave, lane, i, h);
         float4 val[2][4];
         float m[2] = {0.f, 0.f};
         if (live_wave) {
@@ -492,31 +459,22 @@ __global__ __launch_bounds__(512, 1) void tan_f16_kernel(nero_tan_chain ch, int 
                 acc_to_global(scr, ijq, L.inj + boff + (size_t)r * 32 * NERO_HID, lane);
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the scratch reads are done before the DMA may land
-        // requests for the next layer (or the next tile's first): saved activations by LDS-DMA, the first weight fragments into
-        // registers (here, not behind the GEMM: the epilogue above is this kernel's register peak); commit_planes' two barriers cover them
-        NERO_FENCE();
-        if (!last_layer) { prefetch_act(ch.layer[l + 1], row0); prefetch_layer(ch.layer[l + 1]); }
-        else {
-            if (more) prefetch_act(ch.layer[0], (tile + gridDim.x) * 64);
-#ifdef TAN_TILE_AHEAD
-            if (more) request_tile(tile + gridDim.x);
-#endif
-            prefetch_layer(ch.layer[0]);
+        if (l + 1 < ch.n_layers) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the scratch reads are done before the DMA may land
+            prefetch_act(ch.layer[l + 1]);
         }
-        NERO_FENCE();
         commit_planes(S, val, m[0], m[1], live_wave, wave, i, h);
-    }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // reverse chain:  delta_{l-1} = (delta_l W_l [+ dy_head W_head]) * act'(a_{l-1}) [+ inj_{l-1}]
 // ---------------------------------------------------------------------------------------------------------------------
-template <int ACT, bool HEAD>
+// PRE: the injections were requested inside the GEMM (ijp, bwd_f16_kernel<true>); otherwise they are read here
+template <int ACT, bool HEAD, bool PRE>
 __device__ __forceinline__ void bwd_values(const float4 (&gq)[2][4], const float4 (&pa)[2][4], size_t goff, bool has_inj,
                                            const nero_bwd_layer& L, int row0, int i, int fbase, int n_rows, float4 (&val)[2][4],
-                                           float (&m)[2]) {
+                                           float (&m)[2], const float4 (&ijp)[2][4]) {
     // the global operands of the epilogue are requested in branch-free batches ahead of their use: with the loads inside
     // `if (has_inj)` / `if (j < nh)` hipcc waited for each of them separately (147 of the reverse kernel's 240 loads were followed by
     // s_waitcnt vmcnt(0)) -- eight serial HBM round trips per layer-tile for the injections of the second-order pass, up to 32 serial
@@ -555,7 +513,10 @@ __device__ __forceinline__ void bwd_values(const float4 (&gq)[2][4], const float
     for (int r = 0; r < 2; ++r) {
         const bool live = (row0 + 32 * r + i) < n_rows;
         float4 ij[4];
-        if (has_inj) {
+        if (PRE) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ij[g] = ijp[r][g];
+        } else if (has_inj) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) ij[g] = *reinterpret_cast<const float4*>(L.inj + goff + (size_t)r * 32 * NERO_HID + 8 * g);
         }
@@ -574,12 +535,12 @@ __device__ __forceinline__ void bwd_values(const float4 (&gq)[2][4], const float
         __builtin_amdgcn_sched_barrier(0);
     }
 }
-template <int ACT>
+template <int ACT, bool PRE>
 __device__ __forceinline__ void bwd_values_h(const float4 (&gq)[2][4], const float4 (&pa)[2][4], size_t goff, bool has_inj,
                                              const nero_bwd_layer& L, int row0, int i, int fbase, int n_rows, float4 (&val)[2][4],
-                                             float (&m)[2]) {
-    if (L.n_head > 0) bwd_values<ACT, true>(gq, pa, goff, has_inj, L, row0, i, fbase, n_rows, val, m);
-    else bwd_values<ACT, false>(gq, pa, goff, has_inj, L, row0, i, fbase, n_rows, val, m);
+                                             float (&m)[2], const float4 (&ijp)[2][4]) {
+    if (L.n_head > 0) bwd_values<ACT, true, PRE>(gq, pa, goff, has_inj, L, row0, i, fbase, n_rows, val, m, ijp);
+    else bwd_values<ACT, false, PRE>(gq, pa, goff, has_inj, L, row0, i, fbase, n_rows, val, m, ijp);
 }
 
 // LDS of the reverse kernel: planes | row scales, row maxima | PA: the saved activations of the layer the walk reaches NEXT,
@@ -598,10 +559,8 @@ inline int bwd_lds_bytes() { return 2 * PLANE_A + (64 + 64 + 512) * 4 + BWD_PA_B
 // no spill -- instead of reading them in the epilogue: the second-order reverse pass went from 1.74 to 2.69 ms.  vmcnt retires in
 // order, so the weight stream of the next GEMM queued behind eight 1 KB HBM loads per wave, exactly what the LDS-DMA of the saved
 // activations had been introduced to avoid; there is no LDS left for a second DMA target: 135.7 of 160 KB.)
-// PERSISTENT (round 4, as the forward kernel): a workgroup walks the tiles blockIdx.x, blockIdx.x + gridDim.x, ...; the saved
-// activations / sign words the FIRST step of the next tile needs are requested as soon as this tile has read out its last ones.
 template <bool FIXED>
-__global__ __launch_bounds__(512, 1) void bwd_f16_kernel(nero_bwd_chain ch, int n_rows, int n_tiles_total) {
+__global__ __launch_bounds__(512, 1) void bwd_f16_kernel(nero_bwd_chain ch, int n_rows) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Lds S;
     S.actp = smem;
@@ -613,31 +572,26 @@ __global__ __launch_bounds__(512, 1) void bwd_f16_kernel(nero_bwd_chain ch, int 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
+    const int row0 = blockIdx.x * 64;
     char* pa_lds = reinterpret_cast<char*>(S.rmax + 64 * 8) + wave * 8192;
     const unsigned pa_addr = __builtin_amdgcn_readfirstlane(lds_offset_of(pa_lds));
+    const size_t goff = (size_t)(row0 + i) * NERO_HID + 32 * wave + 4 * h;
     unsigned mbits[2] = {0u, 0u};                      // ReLU sign masks of the layer being processed
-    // request what the epilogue of layer `Ln` needs of its input activation (rows of the tile at `r0`): the sign words (registers) or
-    // the fp32 tile (LDS-DMA)
-    auto prefetch_act = [&](const nero_bwd_layer& Ln, int r0) {
+    // request what the epilogue of layer `Ln` needs of its input activation: the sign words (registers) or the fp32 tile (LDS-DMA)
+    auto prefetch_act = [&](const nero_bwd_layer& Ln) {
         if (Ln.a_prev == nullptr || wave >= Ln.k_main_tiles) return;
         if (Ln.mask_prev && Ln.act_prev == NERO_ACT_RELU) {
 #pragma unroll
-            for (int r = 0; r < 2; ++r) mbits[r] = Ln.mask_prev[(size_t)(r0 + 32 * r + i) * 8 + wave];
+            for (int r = 0; r < 2; ++r) mbits[r] = Ln.mask_prev[(size_t)(row0 + 32 * r + i) * 8 + wave];
         } else {
-            const size_t go = (size_t)(r0 + i) * NERO_HID + 32 * wave + 4 * h;
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    lds_dma16(Ln.a_prev + go + (size_t)r * 32 * NERO_HID + 8 * g, pa_addr + (r * 4 + g) * 1024);
+                    lds_dma16(Ln.a_prev + goff + (size_t)r * 32 * NERO_HID + 8 * g, pa_addr + (r * 4 + g) * 1024);
         }
     };
-    int tile = blockIdx.x;
-    if (tile >= n_tiles_total) return;
-    prefetch_act(ch.layer[ch.n_layers - 1], tile * 64);
-    for (; tile < n_tiles_total; tile += gridDim.x) {
-    const int row0 = tile * 64;
-    const size_t goff = (size_t)(row0 + i) * NERO_HID + 32 * wave + 4 * h;
+    prefetch_act(ch.layer[ch.n_layers - 1]);
     if (ch.dy) load_planes_scaled(S.actp, SA, PLANE_A, S.rs_main, ch.dy, ch.ld_dy, ch.k_dy, row0, n_rows, tid);
     else {
         for (int idx = tid; idx < 2 * PLANE_A / 16; idx += 512) reinterpret_cast<uint4*>(S.actp)[idx] = make_uint4(0u, 0u, 0u, 0u);
@@ -656,6 +610,11 @@ __global__ __launch_bounds__(512, 1) void bwd_f16_kernel(nero_bwd_chain ch, int 
         const int steps = L.n_out >> 4;
         const bool has_inj = !first && L.inj != nullptr;
         float4 gq[2][4];                                   // incoming gradient of this lane's outputs, true units
+        float4 ijp[2][4];                                  // injections of this lane's outputs, requested inside the GEMM (FIXED)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ijp[r][g] = make_float4(0.f, 0.f, 0.f, 0.f);
         const float rs0 = S.rs_main[i], rs1 = S.rs_main[32 + i];
         PH(1);
         if (L.n_out > 0) {
@@ -687,8 +646,25 @@ __global__ __launch_bounds__(512, 1) void bwd_f16_kernel(nero_bwd_chain ch, int 
             if (live_wave) {
                 const float wsc = *L.w_main_t;
                 const uint4* wpm = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(L.w_main_t) + HDR_BYTES) + (size_t)wave * steps * 128 + lane;
-                if constexpr (FIXED) gemm_f16x3_fixed<16>(aH, aL, wpm, S.actp + i * SA + 16 * h, 32 * SA, PLANE_A);
-                else gemm_f16x3(aH, aL, wpm, S.actp + i * SA + 16 * h, 32 * SA, PLANE_A, steps);
+                if constexpr (FIXED) {
+#ifdef BWD_INJ_IN_GEMM
+                    // the second-order pass: the injections of this tile (8 KB per wave from HBM) are requested behind the GEMM's last
+                    // weight request (step 16 - GEMM_WD) -- read in the epilogue they were an exposed round trip per layer
+                    // (values = 9.2 k cycles against 1.9 k without them, profiles/r02_phase_timing.txt)
+                    gemm_f16x3_fixed_hook<16>(aH, aL, wpm, S.actp + i * SA + 16 * h, 32 * SA, PLANE_A, [&](auto cc) {
+                        if constexpr (decltype(cc)::value == 16 - GEMM_WD) {
+                            if (has_inj) {
+#pragma unroll
+                                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                                    for (int g = 0; g < 4; ++g) ijp[r][g] = *reinterpret_cast<const float4*>(L.inj + goff + (size_t)r * 32 * NERO_HID + 8 * g);
+                            }
+                        }
+                    });
+#else
+                    gemm_f16x3_fixed<16>(aH, aL, wpm, S.actp + i * SA + 16 * h, 32 * SA, PLANE_A);
+#endif
+                } else gemm_f16x3(aH, aL, wpm, S.actp + i * SA + 16 * h, 32 * SA, PLANE_A, steps);
                 u[0] = wsc * rs0;
                 u[1] = wsc * rs1;
             }
@@ -749,9 +725,14 @@ __global__ __launch_bounds__(512, 1) void bwd_f16_kernel(nero_bwd_chain ch, int 
 #pragma unroll
                     for (int g = 0; g < 4; ++g) pa[r][g] = *reinterpret_cast<const float4*>(pa_lds + (r * 4 + g) * 1024 + lane * 16);
             }
-            if (L.act_prev == NERO_ACT_RELU) bwd_values_h<NERO_ACT_RELU>(gq, pa, goff, has_inj, L, row0, i, fbase, n_rows, val, m);
-            else if (L.act_prev == NERO_ACT_SOFTPLUS100) bwd_values_h<NERO_ACT_SOFTPLUS100>(gq, pa, goff, has_inj, L, row0, i, fbase, n_rows, val, m);
-            else bwd_values_h<NERO_ACT_NONE>(gq, pa, goff, has_inj, L, row0, i, fbase, n_rows, val, m);
+#ifdef BWD_INJ_IN_GEMM
+            constexpr bool PRE = FIXED;
+#else
+            constexpr bool PRE = false;
+#endif
+            if (L.act_prev == NERO_ACT_RELU) bwd_values_h<NERO_ACT_RELU, PRE>(gq, pa, goff, has_inj, L, row0, i, fbase, n_rows, val, m, ijp);
+            else if (L.act_prev == NERO_ACT_SOFTPLUS100) bwd_values_h<NERO_ACT_SOFTPLUS100, PRE>(gq, pa, goff, has_inj, L, row0, i, fbase, n_rows, val, m, ijp);
+            else bwd_values_h<NERO_ACT_NONE, PRE>(gq, pa, goff, has_inj, L, row0, i, fbase, n_rows, val, m, ijp);
             PH(4);
         }
         if (live_wave && L.delta_prev) {                   // (the PA buffer has been read out: it is the transposition scratch now)
@@ -761,21 +742,13 @@ __global__ __launch_bounds__(512, 1) void bwd_f16_kernel(nero_bwd_chain ch, int 
         }
         if (l > 0) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the scratch reads are done before the DMA may land
-            prefetch_act(ch.layer[l - 1], row0);
+            prefetch_act(ch.layer[l - 1]);
         }
         PH(5);
         commit_planes(S, val, m[0], m[1], live_wave, wave, i, h);
         PH(6);
     }
     PH_END;
-    // the next tile: its first step's saved activations / sign words go out now (this wave's PA buffer has been read out and, as the
-    // store scratch, been drained: lgkmcnt(0)); the barrier keeps a fast wave from overwriting planes a slow one still multiplies
-    if (tile + (int)gridDim.x < n_tiles_total) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        prefetch_act(ch.layer[ch.n_layers - 1], (tile + gridDim.x) * 64);
-    }
-    __syncthreads();
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -873,11 +846,12 @@ static int nero_cu_count() {
     }
     return n;
 }
-// workgroups of a chain launch over n_tiles tiles.  NERO_F16_PERSIST (bit 0 forward, 1 reverse, 2 tangent; default 7) is an experiment
+// workgroups of a chain launch over n_tiles tiles.  NERO_F16_PERSIST (bit 0 = the forward kernel, default 1; the reverse and tangent kernels measured 2-5 % SLOWER as persistent walks
+// -- their register budget has no room for the loop state: 12-20 spilled VGPRs, 40-50 spilled SGPRs -- and stayed as they were) is an experiment
 // switch: a cleared bit launches one workgroup per tile, i.e. the same kernel without the persistent walk.
 static int nero_chain_grid(int n_tiles, int kind_bit) {
     static int mask = -1;
-    if (mask < 0) { const char* e = getenv("NERO_F16_PERSIST"); mask = e ? atoi(e) : 7; }
+    if (mask < 0) { const char* e = getenv("NERO_F16_PERSIST"); mask = e ? atoi(e) : 1; }
     const int cus = nero_cu_count();
     return ((mask >> kind_bit) & 1) && n_tiles > cus ? cus : n_tiles;
 }
@@ -904,21 +878,18 @@ int nero_f16_forward(const nero_fwd_chain* ch, int n_rows, hipStream_t stream) {
 }
 
 int nero_f16_tangent(const nero_tan_chain* ch, int n_rows, hipStream_t stream) {
-    const int n_tiles = (n_rows + 63) / 64;
-    const dim3 grid(nero_chain_grid(n_tiles, 2)), block(512);
-    if (ch->k_init > 48 || ch->k_aux > 48) return nero_fail(NERO_ERR_UNSUPPORTED, "nero_mlp_tangent(f16x3): k_init / k_aux up to 48 columns");
+    const dim3 grid((n_rows + 63) / 64), block(512);
     for (int l = 0; l < ch->n_layers; ++l)
         if ((ch->layer[l].k_main | ch->layer[l].k_aux) & 15)
             return nero_fail(NERO_ERR_ARG, "nero_mlp_tangent(f16x3): k_main / k_aux must be multiples of 16");
     if (ch->aux_wide) return nero_fail(NERO_ERR_UNSUPPORTED, "nero_mlp_tangent(f16x3): aux_wide chains are not supported");
     NERO_ONCE(hipFuncSetAttribute((const void*)tan_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tan_lds_bytes()));
-    hipLaunchKernelGGL(tan_f16_kernel, grid, block, tan_lds_bytes(), stream, *ch, n_rows, n_tiles);
+    hipLaunchKernelGGL(tan_f16_kernel, grid, block, tan_lds_bytes(), stream, *ch, n_rows);
     return NERO_OK;
 }
 
 int nero_f16_backward(const nero_bwd_chain* ch, int n_rows, hipStream_t stream) {
-    const int n_tiles = (n_rows + 63) / 64;
-    const dim3 grid(nero_chain_grid(n_tiles, 1)), block(512);
+    const dim3 grid((n_rows + 63) / 64), block(512);
     for (int l = 0; l < ch->n_layers; ++l)
         if (ch->layer[l].n_out & 15) return nero_fail(NERO_ERR_ARG, "nero_mlp_backward(f16x3): n_out must be a multiple of 16");
     if (ch->d_aux && (ch->ld_daux & 3)) return nero_fail(NERO_ERR_ARG, "nero_mlp_backward(f16x3): ld_daux must be a multiple of 4");
@@ -927,7 +898,7 @@ int nero_f16_backward(const nero_bwd_chain* ch, int n_rows, hipStream_t stream) 
     for (int l = 0; l < ch->n_layers; ++l) fixed = fixed && (ch->layer[l].n_out == 0 || ch->layer[l].n_out == 256);
     NERO_ONCE(hipFuncSetAttribute((const void*)bwd_f16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bwd_lds_bytes()));
     NERO_ONCE(hipFuncSetAttribute((const void*)bwd_f16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bwd_lds_bytes()));
-    if (fixed) hipLaunchKernelGGL(bwd_f16_kernel<true>, grid, block, bwd_lds_bytes(), stream, *ch, n_rows, n_tiles);
-    else hipLaunchKernelGGL(bwd_f16_kernel<false>, grid, block, bwd_lds_bytes(), stream, *ch, n_rows, n_tiles);
+    if (fixed) hipLaunchKernelGGL(bwd_f16_kernel<true>, grid, block, bwd_lds_bytes(), stream, *ch, n_rows);
+    else hipLaunchKernelGGL(bwd_f16_kernel<false>, grid, block, bwd_lds_bytes(), stream, *ch, n_rows);
     return NERO_OK;
 }
