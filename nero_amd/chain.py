@@ -44,6 +44,24 @@ def set_gemm_mode(mode, passes=('fwd', 'tan', 'bwd', 'dw')):
         GEMM_MODE[k] = _resolve(_DEFAULT[k] if mode == 'default' else mode, k)
 
 
+# test hook (tests/test_parity_at_size.py, gate-teacher-forced gradient parity): when a list, every saving forward launch appends the
+# ReLU sign masks its kernel wrote (nero_fwd_layer.relu_mask: one word per (row, 32-column tile)) with the chain's signature
+MASK_CAPTURE = None
+
+
+def decode_relu_masks(words, n_rows, n_out):
+    """[rows_pad, 8] int32 sign words of one layer -> bool [n_rows, n_out]: gate[r, f] = (the layer's output f of row r is > 0).
+    Bit 16 h + 4 g + j of word (r, t) is output 32 t + 8 g + 4 h + j (the accumulator layout of the chain kernels, mlp_f16x3.hip)."""
+    import torch
+    b = torch.arange(32, device=words.device)
+    h, g, j = b >> 4, (b >> 2) & 3, b & 3
+    perm = 8 * g + 4 * h + j                                        # bit -> output inside the tile
+    bits = ((words[:n_rows].unsqueeze(-1) >> b) & 1).bool()        # [n, 8, 32] in bit order
+    gate = torch.empty_like(bits)
+    gate[:, :, perm] = bits
+    return gate.reshape(n_rows, 256)[:, :n_out]
+
+
 def _r8(x):
     return (x + 7) // 8 * 8
 
@@ -254,6 +272,9 @@ class Chain:
                 if masks[i] is not None:
                     fl.relu_mask = masks[i].data_ptr()
         L.check(L.lib.nero_mlp_forward(C.byref(ch), n_rows, L.stream_ptr()))
+        if MASK_CAPTURE is not None and relu_idx:
+            MASK_CAPTURE.append({'k_init': self.k_init, 'k_aux': self.k_aux, 'aux_wide': bool(self.aux_wide), 'n_rows': n_rows,
+                                 'n_out': [d.n_out if d is not None else 0 for d, _ in self.entries], 'masks': masks})
         return {'saves': saves, 'heads': heads, 'masks': masks, '_keep': (init, aux)}
 
     # ------------------------------------------------------------------------------------------------------------

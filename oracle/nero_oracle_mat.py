@@ -15,6 +15,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from . import nero_oracle as _O
 from .nero_oracle import (camera_plane_intersection, ide, ipe, linear_to_srgb, pos_enc, predictor, sphere_exit_dist,
                           _exp_act)
 
@@ -103,15 +104,16 @@ def geometry_ggx_smith_correlated(nov, nol, a):
 
 def feats_network(P, x, prefix='shader_network.feats_network'):
     """MaterialFeatsNetwork (network/field.py:660-689)"""
+    call = _O.next_call(prefix)                      # (forced ReLU gates, a test hook: nero_oracle.forced_relu_gates)
     e = pos_enc(x, 8)
     h = e
-    for l in (0, 2, 4, 6):
-        h = F.relu(F.linear(h, P[f'{prefix}.module0.{l}.weight'], P[f'{prefix}.module0.{l}.bias']))
+    for i, l in enumerate((0, 2, 4, 6)):
+        h = _O._relu(F.linear(h, P[f'{prefix}.module0.{l}.weight'], P[f'{prefix}.module0.{l}.bias']), f'{prefix}@{call}/m0_{i}')
     h = torch.cat([h, e], -1)
     for i, l in enumerate((0, 2, 4, 6)):
         h = F.linear(h, P[f'{prefix}.module1.{l}.weight'], P[f'{prefix}.module1.{l}.bias'])
         if i < 3:
-            h = F.relu(h)
+            h = _O._relu(h, f'{prefix}@{call}/m1_{i}')
     return h
 
 
@@ -247,7 +249,8 @@ def material_regularization(P, cfg, pts, normals, metallic, rough, albedo, step,
         else:
             raise NotImplementedError
         m0, r0, a0 = predict_materials(P, pts + change)
-        reg = reg + torch.mean((torch.abs(m0 - metallic) + torch.abs(r0 - rough) + torch.abs(a0 - albedo)) * cfg['reg_lambda1'], dim=1)
+        reg = reg + torch.mean((_O._abs(m0 - metallic, 'abs/reg_metallic') + _O._abs(r0 - rough, 'abs/reg_roughness')
+                                + _O._abs(a0 - albedo, 'abs/reg_albedo')) * cfg['reg_lambda1'], dim=1)
     if cfg['reg_min_max'] and step is not None and step < 2000:
         reg = reg + torch.sum(torch.clamp(rough - 0.98 ** 2, min=0))
         reg = reg + torch.sum(torch.clamp(0.02 ** 2 - rough, min=0))
@@ -267,7 +270,7 @@ def material_train_outputs(P, rcfg, trace_fn, pts, view_dirs, normals, poses, rg
                                                       reg_ang, reg_eps)
     if rcfg.get('reg_diffuse_light', True):
         dl = out['diffuse_light']
-        out['loss_diffuse_light'] = torch.sum(torch.abs(dl - torch.mean(dl, dim=-1, keepdim=True)), dim=-1) * rcfg.get('reg_diffuse_light_lambda', 0.1)
+        out['loss_diffuse_light'] = torch.sum(_O._abs(dl - torch.mean(dl, dim=-1, keepdim=True), 'abs/diffuse_light'), dim=-1) * rcfg.get('reg_diffuse_light_lambda', 0.1)
     return out
 
 

@@ -270,3 +270,56 @@ def tracer_contract(tr):
         depth = depth.reshape(-1, 1)
         return pos, torch.nn.functional.normalize(-nrm, dim=-1), depth, (depth < 10)[:, 0]
     return fn
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# gate-teacher-forced gradient parity: the ReLU decisions of the HIP forward, as keys of oracle.nero_oracle.forced_relu_gates
+# ----------------------------------------------------------------------------------------------------------------------
+def forced_gates_from_capture(capture, stage, n_primary, human=False):
+    """capture: nero_amd.chain.MASK_CAPTURE after ONE forward of the Python-sequenced HIP step (records in launch order).
+    stage 1: n_primary = n_in (inner rows); stage 2: n_primary = P (surface points; predict_materials may run on [pts; reg_pts]).
+    -> {oracle gate key: bool [rows, n_out]} (on the device of the masks)."""
+    from nero_amd.chain import decode_relu_masks, row_pad
+    gates = {}
+    mats = ['metallic_predictor', 'roughness_predictor', 'albedo_predictor']
+    pre = 'color_network' if stage == 1 else 'shader_network'
+
+    def put(key, words, r0, n, n_out):
+        gates[key] = decode_relu_masks(words[r0:], n, n_out)
+
+    def put_pred(prefix, rec, splits):
+        for call, (r0, n) in enumerate(splits):
+            for i in range(3):
+                put(f'{prefix}@{call}/{i}', rec['masks'][i], r0, n, rec['n_out'][i])
+    for rec in capture:
+        k, ka, n = rec['k_init'], rec['k_aux'], rec['n_rows']
+        if stage == 1 and rec['aux_wide'] and k == 88:                       # NeRF++ trunk
+            for i in range(8):
+                put(f'outer_nerf/pts{i}', rec['masks'][i], 0, n, 256)
+        elif stage == 1 and k == 256 and ka == 32:                           # NeRF++ head chain: entry 1 = views_linears.0
+            put('outer_nerf/views', rec['masks'][1], 0, n, 128)
+        elif stage == 2 and rec['aux_wide'] and k == 56:                     # MaterialFeatsNetwork on [pts; reg_pts]
+            splits = [(0, n_primary)] + ([(n_primary, n - n_primary)] if n > n_primary else [])
+            for call, (r0, m) in enumerate(splits):
+                for i in range(4):
+                    put(f'{pre}.feats_network@{call}/m0_{i}', rec['masks'][i], r0, m, 256)
+                for i in range(3):
+                    put(f'{pre}.feats_network@{call}/m1_{i}', rec['masks'][4 + i], r0, m, 256)
+        elif k == 256 and ka == 8:                                           # metallic / roughness / albedo, in this order
+            name = mats.pop(0)
+            splits = [(0, n_primary)] + ([(n_primary, n - n_primary)] if n > n_primary else [])
+            put_pred(f'{pre}.{name}', rec, splits)
+        elif k in (72, 144) and ka == 0:
+            if stage == 1:                                                   # rows [0, rpi): IDE(n, 1) diffuse; [rpi, rpi + n_in): IDE(refl, rough)
+                put_pred(f'{pre}.outer_light', rec, [(0, n_primary), (row_pad(n_primary), n_primary)])
+            else:
+                put_pred(f'{pre}.outer_light', rec, [(0, n)])
+        elif k == 128:
+            put_pred(f'{pre}.inner_light', rec, [(0, n)])
+        elif k == 96 and stage == 1:
+            put_pred(f'{pre}.inner_weight', rec, [(0, n)])
+        elif k == 24:
+            put_pred(f'{pre}.human_light_predictor' if stage == 1 else f'{pre}.human_light', rec, [(0, n)])
+        else:
+            raise AssertionError(('unrecognised chain in the mask capture', k, ka, rec['aux_wide'], n))
+    return gates
