@@ -252,7 +252,8 @@ def stage2_step_bench(dev, kind, P_, Dd, Ds, mesh, rank=0, world=1, warmup=5, st
         ts.step(5000 + warmup + i)
         ev[i + 1].record()
     sync()
-    wall = mx(time.time() - t0) / steps
+    wall_local = (time.time() - t0) / steps
+    wall = mx(wall_local * steps) / steps
     ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
     rec['on'] = True
     ts.step(6000)
@@ -264,7 +265,7 @@ def stage2_step_bench(dev, kind, P_, Dd, Ds, mesh, rank=0, world=1, warmup=5, st
     flop_pt = 2 * 3 * (2 * C_MAT + D * ((1 - h) * c_miss + h * C_INNER))
     peak = PEAK_OF_MODE[CH.GEMM_MODE['fwd']]
     out = {'model': kind, 'points_per_gpu': P_, 'directions': f'{Dd}+{Ds}', 'n_gpus': world, 'trainer': 'fused (nero_wn_forward_batch / nero_wn_adam_batch)',
-           'ms_per_step': round(wall * 1e3, 3), 'ms_per_step_median': round(ms[len(ms) // 2], 3),
+           'ms_per_step': round(wall * 1e3, 3), 'ms_per_step_this_rank': round(wall_local * 1e3, 3), 'ms_per_step_median': round(ms[len(ms) // 2], 3),
            'points_per_s': round(P_ * world / wall, 1), 'light_rays_per_s': round(P_ * world * D / wall, 1),
            'tracer_rays_per_s': round(rec['n'] / (rec['ms'] * 1e-3), 1) if rec['ms'] > 0 else None, 'tracer_ms': round(rec['ms'], 3),
            'hit_fraction': round(h, 4), 'mlp_mflop_per_point': round(flop_pt / 1e6, 1),
@@ -425,13 +426,14 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
-def run_stage2(args, dev, rank, world, sync, max_over_ranks):
+def run_stage2(args, dev, rank, world, sync, max_over_ranks, rank_table=None):
     """`--stage 2`: the Stage-II material step as the headline (BASELINE configs[3] at N = 1; configs[4] = `--config bear --points 2048
     --dirs 256+256` at N = 8).  Same contract: W untimed steps, K timed between barrier + synchronize, max over ranks."""
     Dd, Ds = (int(x) for x in args.dirs.split('+'))
     P_ = args.points or (2048 if args.config == 'bear' else 4096)
     mesh = _bench_mesh()
     r = stage2_step_bench(dev, args.config, P_, Dd, Ds, mesh, rank, world, args.warmup, args.steps, sync, max_over_ranks)
+    ranks = rank_table(r['ms_per_step_this_rank']) if rank_table else {}
     if rank != 0:
         return
     res = {'metric': 'Stage-II material training surface points/sec', 'value': r['points_per_s'], 'unit': 'points/s', 'n_gpus': world,
@@ -441,7 +443,7 @@ def run_stage2(args, dev, rank, world, sync, max_over_ranks):
            'config': {'workload': f"Glossy{'Real' if args.config == 'bear' else 'Synthetic'} '{args.config}' Stage-II material, {P_} surface points x "
                                   f'({Dd}+{Ds}) MC light directions per GPU, {int(mesh[1].shape[0])}-triangle mesh, step 5000',
                       'points_per_gpu': P_, 'parallelism': f'dp{world}', 'optimizer': 'adam(fused)'},
-           'stage2': r}
+           'stage2': r, **ranks}
     if 'roofline' in r:
         res['roofline'] = r['roofline']
     print(json.dumps(res), flush=True)
@@ -471,9 +473,13 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     import torch.distributed as dist
-    if world > 1:
+    under_launcher = 'WORLD_SIZE' in os.environ          # torch.distributed.run set the rendezvous: RCCL is initialised even for ONE rank,
+    if under_launcher:                                   # so that the N = 1 point of a scaling run goes through the same collectives
         torch.cuda.set_device(local)
         dist.init_process_group('nccl')
+        if world == 1:
+            from nero_amd import parallel
+            parallel.FORCE_COLLECTIVES = True
     dev = f'cuda:{local}'
     torch.cuda.set_device(dev)
 
@@ -497,8 +503,19 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t)
 
+    def rank_table(ms_local):
+        """one record per rank (device name / UUID / its own ms per step): the line then shows WHICH devices ran and how evenly"""
+        pr = torch.cuda.get_device_properties(dev)
+        me = {'rank': rank, 'local_rank': local, 'device': pr.name, 'uuid': str(getattr(pr, 'uuid', 'unknown')), 'host': socket.gethostname(),
+              'ms_per_step': round(ms_local, 3)}
+        if not (dist.is_available() and dist.is_initialized()):
+            return {'rccl_ranks': 0, 'backend': None, 'ranks': [me]}
+        table = [None] * world
+        dist.all_gather_object(table, me)
+        return {'rccl_ranks': world, 'backend': dist.get_backend(), 'ranks': table}
+
     if args.stage == 2:
-        run_stage2(args, dev, rank, world, sync, max_over_ranks)
+        run_stage2(args, dev, rank, world, sync, max_over_ranks, rank_table)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -519,8 +536,10 @@ def main():
         n_in += info['n_in']
         n_out += info['n_out']
     sync()
-    dt = max_over_ranks(time.time() - t0)
+    dt_local = time.time() - t0
+    dt = max_over_ranks(dt_local)
     value = args.rays * world * args.steps / dt
+    ranks = rank_table(dt_local / args.steps * 1e3)
 
     # ---- SURVEY.md 8d protocol: median of >= 50 steps (HIP events at the step boundaries) after >= 10 warm-up steps ------------
     proto = None
@@ -642,7 +661,7 @@ def main():
             'step_mlp_flop_frac': round(flop_step / (dt / args.steps) / PEAK_OF_MODE[CH.GEMM_MODE['fwd']], 4),
             'step_mlp_flop_frac_of_f32_mfma_peak': round(flop_step / (dt / args.steps) / PEAK_F32_MFMA, 4),
             'inner_samples_per_ray': round(n_in / args.steps / args.rays, 2),
-            'protocol_8d': proto, 'forward_only': fwd_only, 'roofline': roof,
+            'protocol_8d': proto, 'forward_only': fwd_only, 'roofline': roof, **ranks,
         }
         if alt is not None:
             res['f32_mfma_engine'] = alt

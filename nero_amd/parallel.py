@@ -61,7 +61,7 @@ class GradBucket:
 
     def all_reduce_mean(self, world, group=None):
         self.reattach()
-        if world <= 1:
+        if world <= 1 and not (FORCE_COLLECTIVES and dist.is_available() and dist.is_initialized()):
             return
         _all_reduce_sum(self.flat, group)
         self.flat.mul_(1.0 / world)
@@ -100,6 +100,24 @@ def global_count_weights(local_counts, world, device, group=None):
     _all_reduce_sum(t, group)
     tot = t.tolist()
     return [float(c) * world / g if g > 0 else 1.0 for c, g in zip(local_counts, tot)]
+
+
+def device_count_weights(local_counts, world, device, group=None):
+    """global_count_weights WITHOUT the host stall: the weights stay on the device (a float32 tensor, one element per term) and
+    multiply the loss terms there -- the all-reduce is enqueued on the stream like every other launch of the step and nothing waits
+    for it on the host (the blocking .tolist() cost one host round trip per step and rank on the DP path)."""
+    if world <= 1 and not (group is None and FORCE_COLLECTIVES and dist.is_available() and dist.is_initialized()):
+        return torch.ones(len(local_counts), dtype=torch.float32, device=device)
+    loc = torch.tensor([float(c) for c in local_counts], dtype=torch.float64, device=device)
+    tot = loc.clone()
+    _all_reduce_sum(tot, group)
+    w = torch.where(tot > 0, loc * float(world) / tot.clamp(min=1.0), torch.ones_like(loc))
+    return w.to(torch.float32)
+
+
+# set by bench.py when it runs as ONE rank under torch.distributed.run: the collectives of the data-parallel path (count weights, the
+# flat gradient all-reduce) are then issued although world == 1, so that the N = 1 point of a scaling run exercises the RCCL code path
+FORCE_COLLECTIVES = False
 
 
 def per_rank_occ_cap(max_pn, world):

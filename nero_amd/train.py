@@ -10,7 +10,7 @@ import gc
 import torch
 import torch.distributed as dist  # noqa: F401
 
-from .parallel import GradBucket, global_count_weights, per_rank_occ_cap, rank_slice
+from .parallel import GradBucket, device_count_weights, per_rank_occ_cap, rank_slice
 
 from .renderer import NeROShapeRenderer
 from .synthetic import perturb_state, synthetic_rays
@@ -202,7 +202,7 @@ class ShapeTrainStep:
     """one process = one GPU.  Every rank holds the same weights and a disjoint slice of each global ray batch
     (rank-strided); gradients are summed with ONE flat all-reduce per step and divided by world size.
     CONSTRUCTION IS COLLECTIVE when world > 1: the priming passes run full forward + backward passes whose loss weights come from an
-    all-reduce of the per-rank sample counts (`global_count_weights`), so every rank must construct its ShapeTrainStep with the same
+    all-reduce of the per-rank sample counts (`device_count_weights`), so every rank must construct its ShapeTrainStep with the same
     arguments at the same point of the program (what `bench.py` and the 2-rank tests do), exactly like the steps themselves."""
 
     def __init__(self, cfg, rays_per_rank=4096, pool_rays=262144, device='cuda', seed=6033, variance=None, eikonal_weight=0.1,
@@ -321,7 +321,7 @@ class ShapeTrainStep:
         out = net.render(o, d, near, far, self._hp, -1, net.get_anneal_val(step), is_train=True, step=step, **self._render_args(step))
         # data parallel: the eikonal mean runs over each rank's own inner samples and the occlusion loss over its own candidate
         # set -> weight both by their global counts so that N ranks reproduce the single-process means
-        w_eik, w_occ = global_count_weights([out['_state']['n_in'], out.get('_occ_count', 0)], self.world, self.device)
+        w_eik, w_occ = device_count_weights([out['_state']['n_in'], out.get('_occ_count', 0)], self.world, self.device)
         loss = shape_training_loss(net, out, gt, step, self.eik_w, w_eik, w_occ)
         loss.backward()
         st = out['_state']

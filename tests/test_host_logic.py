@@ -198,3 +198,33 @@ def test_bench_gpus_flag_spawns_one_rank_per_gpu(monkeypatch):
     assert calls['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
     monkeypatch.setattr(bench.torch.cuda, 'device_count', lambda: 1)
     assert bench.spawn_ranks(2) == 2                                   # refuses to fake ranks it has no GPU for
+    # the result line of a distributed run carries one record per rank (device, UUID, its own ms per step) and the backend that ran
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    for field in ("'rccl_ranks'", "'backend'", "'ranks'", "'uuid'", "'ms_per_step'", 'all_gather_object', "init_process_group('nccl')",
+                  'FORCE_COLLECTIVES = True'):
+        assert field in src, field
+
+
+def test_forced_collectives_run_at_world_one_and_device_count_weights_match_the_host_version():
+    """bench.py under torch.distributed.run with ONE rank sets parallel.FORCE_COLLECTIVES: the flat all-reduce and the count weights
+    are then issued (gloo here) although world == 1 and must be the identity; device_count_weights equals global_count_weights"""
+    import torch.distributed as dist
+    from nero_amd import parallel
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', str(29650 + os.getpid() % 300))
+    dist.init_process_group('gloo', rank=0, world_size=1)
+    try:
+        p = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7))]
+        b = parallel.GradBucket(p)
+        b.flat.copy_(torch.arange(b.flat.numel(), dtype=torch.float32))
+        want = b.flat.clone()
+        parallel.FORCE_COLLECTIVES = True
+        b.all_reduce_mean(1)
+        assert torch.equal(b.flat, want)
+        w = parallel.device_count_weights([1234, 0], 1, 'cpu')
+        assert w.dtype == torch.float32 and w.tolist() == [1.0, 1.0]
+        parallel.FORCE_COLLECTIVES = False
+        assert parallel.device_count_weights([10, 3], 1, 'cpu').tolist() == parallel.global_count_weights([10, 3], 1, 'cpu')
+    finally:
+        parallel.FORCE_COLLECTIVES = False
+        dist.destroy_process_group()

@@ -123,16 +123,18 @@ def test_hip_reg_points_match_the_tensor_glue():
     assert float((got[n:] - want).abs().max()) < 2e-7
 
 
-def _rank(rank, world, port, ret, step):
+def _rank(rank, world, port, ret, step, backend='gloo', one_device=True):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dev = 'cuda:0' if one_device else f'cuda:{rank}'
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     from nero_amd.train import MaterialTrainStep
-    ts = MaterialTrainStep({'shader_cfg': SCFG, 'database_name': 'real/bear'}, _mesh(), points_per_rank=P, pool_points=4 * P, device='cuda:0',
+    ts = MaterialTrainStep({'shader_cfg': SCFG, 'database_name': 'real/bear'}, _mesh(), points_per_rank=P, pool_points=4 * P, device=dev,
                            rank=rank, world=world)
-    info = ts.forward_backward(step, _rands(world * P, rank * P, (rank + 1) * P, 'cuda:0'))
+    info = ts.forward_backward(step, _rands(world * P, rank * P, (rank + 1) * P, dev))
     ts.bucket.all_reduce_mean(world)
     torch.cuda.synchronize()
     if rank == 0:
@@ -147,11 +149,21 @@ def test_two_ranks_reproduce_the_big_batch_gradient(step):
     """Both processes share the test box's one device (RCCL refuses duplicate GPUs: gloo with nero_amd.parallel's host hop);
     rank-strided point shards, replicated BVH, ONE flat all-reduce.  step 500: the reg_min_max hinge is a SUM over the batch
     (network/field.py:1079-1084) and needs its `world` weight."""
+    _two_rank_material(step, 'gloo', True)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='RCCL needs one device per rank: a box with >= 2 GPUs')
+def test_rccl_one_rank_per_device_material_step_reproduces_the_big_batch_gradient():
+    """Stage II over backend `nccl` (= RCCL), rank r on cuda:r (bench.py --stage 2 --gpus N): skipped on the one-GPU test box"""
+    _two_rank_material(5000, 'nccl', False)
+
+
+def _two_rank_material(step, backend, one_device):
     from nero_amd.train import MaterialTrainStep
     mgr = mp.Manager()
     ret = mgr.dict()
-    port = 35500 + os.getpid() % 2000
-    mp.spawn(_rank, args=(2, port, ret, step), nprocs=2, join=True)
+    port = 35500 + os.getpid() % 2000 + (11 if backend == 'nccl' else 0)
+    mp.spawn(_rank, args=(2, port, ret, step, backend, one_device), nprocs=2, join=True)
     ts = MaterialTrainStep({'shader_cfg': SCFG, 'database_name': 'real/bear'}, _mesh(), points_per_rank=2 * P, pool_points=4 * P, device='cuda:0')
     info = ts.forward_backward(step, _rands(2 * P, 0, 2 * P, 'cuda:0'))
     torch.cuda.synchronize()

@@ -16,14 +16,16 @@ CFG = {'n_samples': 16, 'n_importance': 16, 'n_bg_samples': 8, 'freeze_inv_s_ste
 R, STEP = 96, 25000
 
 
-def _rank(rank, world, port, ret):
+def _rank(rank, world, port, ret, backend='gloo', one_device=True):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dev = 'cuda:0' if one_device else f'cuda:{rank}'
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     from nero_amd.train import ShapeTrainStep
-    ts = ShapeTrainStep(CFG, rays_per_rank=R, pool_rays=4 * R, device='cuda:0', variance=0.4, rank=rank, world=world, prime_fraction=0.0)
+    ts = ShapeTrainStep(CFG, rays_per_rank=R, pool_rays=4 * R, device=dev, variance=0.4, rank=rank, world=world, prime_fraction=0.0)
     assert ts.net.cfg['occ_loss_max_pn'] == 2048 // world
     info = ts.forward_backward(STEP)
     ts.bucket.all_reduce_mean(world)
@@ -37,11 +39,22 @@ def _rank(rank, world, port, ret):
 
 
 def test_two_ranks_on_one_device_reproduce_the_big_batch_gradient():
+    _two_ranks_vs_big_batch('gloo', True)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='RCCL needs one device per rank: a box with >= 2 GPUs')
+def test_rccl_one_rank_per_device_reproduces_the_big_batch_gradient():
+    """the same comparison over backend `nccl` (= RCCL) with rank r on cuda:r -- the configuration bench.py --gpus N runs.  Skipped on
+    the one-GPU test box; it is here so that the first multi-GPU box executes the RCCL branch under a test, not under the bench."""
+    _two_ranks_vs_big_batch('nccl', False)
+
+
+def _two_ranks_vs_big_batch(backend, one_device):
     from nero_amd.train import ShapeTrainStep
     mgr = mp.Manager()
     ret = mgr.dict()
-    port = 33500 + os.getpid() % 2000
-    mp.spawn(_rank, args=(2, port, ret), nprocs=2, join=True)
+    port = 33500 + os.getpid() % 2000 + (7 if backend == 'nccl' else 0)
+    mp.spawn(_rank, args=(2, port, ret, backend, one_device), nprocs=2, join=True)
     ts = ShapeTrainStep(CFG, rays_per_rank=2 * R, pool_rays=4 * R, device='cuda:0', variance=0.4, rank=0, world=1, prime_fraction=0.0)
     info = ts.forward_backward(STEP)
     torch.cuda.synchronize()
