@@ -516,7 +516,7 @@ def main():
 
     if args.stage == 2:
         run_stage2(args, dev, rank, world, sync, max_over_ranks, rank_table)
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -740,7 +740,7 @@ def main():
             elif refrec:
                 res['cpu_baseline_reference'] = refrec
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -442,6 +442,8 @@ int nero_stage1_pack(nero_stage1* h, const nero_stage1_weights* w, void* pack_bu
 /* worst case over the data-dependent inner / outer split for R rays (sampler + forward + backward) */
 size_t nero_stage1_workspace_bytes(nero_stage1* h, int R);
 size_t nero_stage1_workspace_bytes_for(nero_stage1* h, int R, int n_in, int n_out, int with_sampler);
+/* sampler + render forward only (inference chunks: no nero_stage1_render_bwd on this workspace), worst case over the split */
+size_t nero_stage1_workspace_bytes_fwd(nero_stage1* h, int R);
 /* z_vals [R, n_samples + n_importance + n_bg_samples]; rand1 [R] / rand_bg [R, n_bg] uniform draws or NULL (no perturbation) */
 int nero_stage1_sample(nero_stage1* h, int R, const float* o, const float* d, const float* near, const float* far, const float* variance,
                        const float* rand1, const float* rand_bg, float* z_vals, void* ws, size_t ws_bytes, void* stream);

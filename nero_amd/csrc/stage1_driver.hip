@@ -435,7 +435,7 @@ int nero_stage1_create(const nero_stage1_cfg* cfg, nero_stage1** out) {
     nero_stage1* h = new (std::nothrow) nero_stage1();
     if (!h) return nero_fail(NERO_ERR_ARG, "nero_stage1_create: out of host memory");
     h->cfg = *cfg;
-    h->M = {cfg->gemm_fwd, cfg->gemm_tan, cfg->gemm_bwd, NERO_GEMM_F16X3};
+    h->M = {cfg->gemm_fwd, cfg->gemm_tan, cfg->gemm_bwd, cfg->gemm_dw};      // (validated above: all four are NERO_GEMM_F16X3)
     memset(&h->st, 0, sizeof(h->st));
     nero_stage1_weights zero;
     memset(&zero, 0, sizeof(zero));
@@ -470,7 +470,13 @@ int nero_stage1_pack(nero_stage1* h, const nero_stage1_weights* w, void* pack_bu
     return NERO_OK;
 }
 
+static size_t workspace_bytes_impl(nero_stage1* h, int R, int n_in, int n_out, int with_sampler, bool with_backward);
+
 size_t nero_stage1_workspace_bytes_for(nero_stage1* h, int R, int n_in, int n_out, int with_sampler) {
+    return workspace_bytes_impl(h, R, n_in, n_out, with_sampler, true);
+}
+
+static size_t workspace_bytes_impl(nero_stage1* h, int R, int n_in, int n_out, int with_sampler, bool with_backward) {
     if (!h || R < 0) return 0;
     const nero_stage1_cfg& c = h->cfg;
     const int T = c.n_samples + c.n_importance + c.n_bg_samples;
@@ -492,12 +498,12 @@ size_t nero_stage1_workspace_bytes_for(nero_stage1* h, int R, int n_in, int n_ou
     nero_stage1_grads G;
     memset(&G, 0, sizeof(G));
     for (int i = 0; i < NERO_S1_LINEARS; ++i) { G.lin[i].dW = reinterpret_cast<float*>(0x1000); G.lin[i].db = reinterpret_cast<float*>(0x1000); }
-    (void)do_backward(&tmp, A, nullptr, nullptr, nullptr, &G, nullptr, nullptr);
+    if (with_backward) (void)do_backward(&tmp, A, nullptr, nullptr, nullptr, &G, nullptr, nullptr);
     peak = A.peak > peak ? A.peak : peak;
     return peak + 4096;
 }
 
-size_t nero_stage1_workspace_bytes(nero_stage1* h, int R) {
+static size_t workspace_worst(nero_stage1* h, int R, bool with_backward) {
     if (!h) return 0;
     const nero_stage1_cfg& c = h->cfg;
     const int T = c.n_samples + c.n_importance + c.n_bg_samples;
@@ -507,11 +513,16 @@ size_t nero_stage1_workspace_bytes(nero_stage1* h, int R) {
     const int inner[4] = {N, 0, N > 1 ? N - 1 : N, N > 1 ? 1 : 0};
     size_t worst = 0;
     for (int k = 0; k < 4; ++k) {
-        const size_t b = nero_stage1_workspace_bytes_for(h, R, inner[k], N - inner[k], 1);
+        const size_t b = workspace_bytes_impl(h, R, inner[k], N - inner[k], 1, with_backward);
         worst = b > worst ? b : worst;
     }
     return worst + 65536;
 }
+
+size_t nero_stage1_workspace_bytes(nero_stage1* h, int R) { return workspace_worst(h, R, true); }
+
+// sampler + render forward only (inference: nvs / test_step never call nero_stage1_render_bwd on this workspace)
+size_t nero_stage1_workspace_bytes_fwd(nero_stage1* h, int R) { return workspace_worst(h, R, false); }
 
 int nero_stage1_sample(nero_stage1* h, int R, const float* o, const float* d, const float* near, const float* far, const float* variance,
                        const float* rand1, const float* rand_bg, float* z_vals, void* ws, size_t ws_bytes, void* stream) {

@@ -243,7 +243,7 @@ int nero_stage2_create(const nero_stage2_cfg* cfg, nero_stage2** out) {
     nero_stage2* h = new (std::nothrow) nero_stage2();
     if (!h) return nero_fail(NERO_ERR_ARG, "nero_stage2_create: out of host memory");
     h->cfg = *cfg;
-    h->M = {cfg->gemm_fwd, NERO_GEMM_F16X3, cfg->gemm_bwd, NERO_GEMM_F16X3};
+    h->M = {cfg->gemm_fwd, NERO_GEMM_F16X3, cfg->gemm_bwd, cfg->gemm_dw};     // (validated above: NERO_GEMM_F16X3; the tangent slot is unused in Stage II)
     nero_stage2_weights zero;
     memset(&zero, 0, sizeof(zero));
     build_chains(h, &zero);

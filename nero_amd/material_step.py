@@ -232,11 +232,12 @@ class MCShade(torch.autograd.Function):
         d_ir = torch.zeros((max(row_pad(n_hit), 64), 4), **f32)
         d_mat5 = torch.empty((Pn, 5), **f32)
         d_w = torch.zeros((Pn * Ds, 3), **f32)
+        d_rgb_c, d_dl_c = d_rgb.contiguous(), (d_dl.contiguous() if d_dl is not None else None)     # locals: both live across the C call
         L.check(lib.nero_mc_combine_bwd(_p(S['pt']), _p(S['dirs']), _p(S['depth']), _p(S['slot']),
                                         _p(fo['heads'][3] if fo else None), _p(fi['heads'][3] if fi else None),
                                         _p(fh['heads'][3] if fh else None), _p(S['hmask']),
                                         C.c_float(cfg['light_exp_max']), C.c_float(cfg['inner_light_exp_max']), Pn, Dd, Ds,
-                                        GEOMETRY_TYPES[cfg['geometry_type']], _p(d_rgb.contiguous()), _p(d_dl.contiguous() if d_dl is not None else None),
+                                        GEOMETRY_TYPES[cfg['geometry_type']], _p(d_rgb_c), _p(d_dl_c),
                                         _p(d_or), _p(d_ir), _p(d_hr), _p(d_mat5), _p(d_w), st))
         ws = torch.empty(L.lib.nero_dw_workspace_floats(max(n_miss, n_hit, 1)), **f32)
         G = {}

@@ -139,10 +139,14 @@ class NeROShapeRenderer(nn.Module):
                 # colours only (nvs): the C-level driver issues a chunk's ~200 launches from one call each (a 1024-ray chunk is
                 # launch-bound from Python), and the occlusion-loss march of a training render is left out (a schedule step below
                 # occ_loss_step: nothing else depends on `step` without gradients)
-                drv = self._inference_driver(kern) if chunk <= 4096 else None      # (the driver's workspace is sized for a training step)
-                if self.cfg['apply_occ_loss']:
-                    step = min(step, self.cfg['occ_loss_step'] - 1)
-                step = max(step, 1000)
+                drv = self._inference_driver(kern)                    # (any chunk size: its workspace is sized for sampler + forward only)
+                # a schedule step in [1000, occ_loss_step): no sdf_pts extras below, no occlusion-loss march above.  A configuration whose
+                # occ_loss_step <= 1000 has no such step: it keeps the caller's step and the Python-sequenced path
+                hi = self.cfg['occ_loss_step'] - 1 if self.cfg['apply_occ_loss'] else max(step, 1000)
+                if hi >= 1000:
+                    step = min(max(step, 1000), hi)
+                else:
+                    drv = None
             for i in range(0, h * w, chunk):
                 batch = {'dirs': dirs[i:i + chunk], 'idxs': torch.zeros(min(chunk, h * w - i), dtype=torch.long, device=dev)}
                 ro, rd, near, far, hp = self._process_ray_batch(batch, pose, hp_img)
@@ -164,6 +168,7 @@ class NeROShapeRenderer(nn.Module):
         drv = getattr(self, '_infer_drv', None)
         if drv is None or not drv.matches_current_modes():
             drv = self._infer_drv = stage1.Stage1Driver(self.cfg, self.color_network.cfg, eff[0].device)
+            drv.forward_only = True
             self._infer_drv_key = None
         key = getattr(self, '_kern_cache', (None,))[0]
         if key is None or self._infer_drv_key != key:
@@ -461,9 +466,22 @@ class NeROMaterialRenderer(nn.Module):
         return inters, normals, depth, ~(depth >= 10)[..., 0]
 
     def _kernels(self):
+        """effective weights + packed HIP chains of the shader network.  Under no_grad (test_step / predict_materials_of_vertices: one
+        shade() per 1024-ray chunk) the packed operand images are cached until a parameter changes, exactly like
+        NeROShapeRenderer._kernels -- an 800 x 800 view used to re-flatten and re-pack all networks 625 times."""
         from .material_step import MaterialKernels, flatten_material_effective, unflatten_material_effective
+        from .chain import GEMM_MODE
+        key = None
+        if not torch.is_grad_enabled():
+            key = (tuple((p.data_ptr(), p._version) for p in self.shader_network.parameters()), tuple(sorted(GEMM_MODE.items())),
+                   getattr(self, '_param_epoch', 0))
+            cached = getattr(self, '_kern_cache', None)
+            if cached is not None and cached[0] == key:
+                return cached[1]
         names, eff = flatten_material_effective(self.shader_network)
         K = MaterialKernels(unflatten_material_effective(names, [t.detach() for t in eff]), self.shader_network.cfg, eff[0].device).pack()
+        if key is not None:
+            self._kern_cache = (key, (names, eff, K))
         return names, eff, K
 
     def predict_materials(self, pts, _kern=None):

@@ -43,6 +43,7 @@ _lib = L.lib
 _lib.nero_stage1_pack_bytes.restype = C.c_size_t
 _lib.nero_stage1_workspace_bytes.restype = C.c_size_t
 _lib.nero_stage1_workspace_bytes_for.restype = C.c_size_t
+_lib.nero_stage1_workspace_bytes_fwd.restype = C.c_size_t
 _lib.nero_stage1_destroy.restype = None
 _lib.nero_stage1_sample.argtypes = [_fp, C.c_int] + [_fp] * 8 + [_fp, C.c_size_t, _fp]
 _lib.nero_stage1_render_fwd.argtypes = [_fp, C.c_int] + [_fp] * 6 + [C.c_float] + [_fp] * 3 + [C.POINTER(C.c_int), C.POINTER(C.c_int), _fp, C.c_size_t, _fp]
@@ -50,6 +51,7 @@ _lib.nero_stage1_render_bwd.argtypes = [_fp, _fp, _fp, _fp, C.POINTER(Grads), _f
 _lib.nero_stage1_sdf_from_pe.argtypes = [_fp, _fp, C.c_int, _fp, _fp, C.c_size_t, _fp]
 _lib.nero_stage1_pack.argtypes = [_fp, C.POINTER(Weights), _fp, _fp]
 _lib.nero_stage1_workspace_bytes.argtypes = [_fp, C.c_int]
+_lib.nero_stage1_workspace_bytes_fwd.argtypes = [_fp, C.c_int]
 _lib.nero_stage1_workspace_bytes_for.argtypes = [_fp, C.c_int, C.c_int, C.c_int, C.c_int]
 _lib.nero_stage1_pack_bytes.argtypes = [_fp]
 _lib.nero_stage1_get_state.argtypes = [_fp, C.POINTER(State)]
@@ -86,6 +88,8 @@ class Stage1Driver:
         self.n_lin = 49 if c.human_light else 45
         self._pack_buf = torch.empty(_lib.nero_stage1_pack_bytes(h), dtype=torch.uint8, device=device)
         self._ws = None
+        self._ws_need = {}
+        self.forward_only = False              # True (inference driver): the workspace is sized for sampler + forward only
         self._scratch = None
         self._w = Weights()
         self._keep = None
@@ -102,8 +106,13 @@ class Stage1Driver:
 
     # ---- memory ---------------------------------------------------------------------------------------------------------------
     def workspace_bytes(self, R, n_in=None, n_out=None):
+        """(cached per R: the query is four dry runs of sampler + forward + backward on a copy of the handle, and it used to be repeated
+        on every sample() and every render forward)"""
         if n_in is None:
-            return _lib.nero_stage1_workspace_bytes(self.h, R)
+            if R not in self._ws_need:
+                q = _lib.nero_stage1_workspace_bytes_fwd if self.forward_only else _lib.nero_stage1_workspace_bytes
+                self._ws_need[R] = q(self.h, R)
+            return self._ws_need[R]
         return _lib.nero_stage1_workspace_bytes_for(self.h, R, n_in, n_out, 1)
 
     def workspace(self, R):
@@ -225,7 +234,8 @@ class RenderCoreC(torch.autograd.Function):
         dsum = torch.zeros(1, **f32)
         d_gerr_c = d_gerr.contiguous() if (d_gerr is not None and n_in > 0) else None
         d_occ_c = d_occ.contiguous() if (d_occ is not None and n_in > 0) else None
-        L.check(_lib.nero_stage1_render_bwd(drv.h, _p(d_rgb.contiguous()), _p(d_gerr_c), _p(d_occ_c), C.byref(G), _p(dsum), L.stream_ptr()))
+        d_rgb_c = d_rgb.contiguous()          # (bound to a local: a temporary's block could be re-used by the next .contiguous() while the C call still reads it)
+        L.check(_lib.nero_stage1_render_bwd(drv.h, _p(d_rgb_c), _p(d_gerr_c), _p(d_occ_c), C.byref(G), _p(dsum), L.stream_ptr()))
         d_var = None
         if n_in > 0 and not meta['freeze_inv_s']:
             v = ctx.variance.detach()

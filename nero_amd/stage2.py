@@ -65,6 +65,7 @@ class Stage2Driver:
         self.n_lin = 32 if c.human_lights else 28
         self._pack_buf = torch.empty(_lib.nero_stage2_pack_bytes(h), dtype=torch.uint8, device=device)
         self._ws, self._w, self._keep = None, Weights(), None
+        self._ws_need = {}
 
         def table(n):                                  # the fixed Fibonacci (azimuth, elevation) tables, network/field.py:741-749
             az, el = fibonacci_az_el(n)
@@ -81,7 +82,9 @@ class Stage2Driver:
         return self.modes == (GEMM_MODE['fwd'], GEMM_MODE['bwd'], GEMM_MODE['dw'])
 
     def workspace(self, n_pred, P):
-        need = _lib.nero_stage2_workspace_bytes(self.h, n_pred, P)
+        if (n_pred, P) not in self._ws_need:          # (cached: the query is a dry run of the whole step on a copy of the handle)
+            self._ws_need[(n_pred, P)] = _lib.nero_stage2_workspace_bytes(self.h, n_pred, P)
+        need = self._ws_need[(n_pred, P)]
         if self._ws is None or self._ws.numel() < need:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
@@ -133,7 +136,8 @@ class PredictMaterialsC(torch.autograd.Function):
     def backward(ctx, d_raw):
         drv = ctx.drv
         G, fresh = _grad_table(ctx.names, ctx.shapes, ctx.gv, 0, len(ctx.names) // 2, d_raw.device)
-        L.check(_lib.nero_stage2_predict_bwd(drv.h, _p(d_raw.contiguous()), C.byref(G), L.stream_ptr()))
+        d_raw_c = d_raw.contiguous()
+        L.check(_lib.nero_stage2_predict_bwd(drv.h, _p(d_raw_c), C.byref(G), L.stream_ptr()))
         return (None, None, None, None, None) + tuple(fresh.get(nm) for nm in ctx.names)
 
 
@@ -173,7 +177,8 @@ class MCShadeC(torch.autograd.Function):
         dev = d_rgb.device
         G, fresh = _grad_table(ctx.names, ctx.shapes, ctx.gv, 20, 20 + len(ctx.names) // 2, dev)
         d_mat5 = torch.empty((ctx.P, 5), dtype=torch.float32, device=dev)
-        L.check(_lib.nero_stage2_shade_bwd(drv.h, _p(d_rgb.contiguous()), _p(d_dl.contiguous() if d_dl is not None else None), C.byref(G),
+        d_rgb_c, d_dl_c = d_rgb.contiguous(), (d_dl.contiguous() if d_dl is not None else None)     # locals: both live across the C call
+        L.check(_lib.nero_stage2_shade_bwd(drv.h, _p(d_rgb_c), _p(d_dl_c), C.byref(G),
                                            _p(d_mat5), L.stream_ptr()))
         ctx.keep = None
         return (None, None, None, None, None, None, None, d_mat5, None, None, None) + tuple(fresh.get(nm) for nm in ctx.names)
@@ -230,7 +235,8 @@ class MaterialHeadC(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_mat):
         d_raw = torch.empty_like(ctx.raw)
-        L.check(_lib.nero_mat_head_bwd(ctx.raw.shape[0], _p(ctx.raw), _p(d_mat.contiguous()), _p(d_raw), L.stream_ptr()))
+        d_mat_c = d_mat.contiguous()
+        L.check(_lib.nero_mat_head_bwd(ctx.raw.shape[0], _p(ctx.raw), _p(d_mat_c), _p(d_raw), L.stream_ptr()))
         return d_raw
 
 

@@ -95,6 +95,33 @@ def test_mc_shading_with_hip_tracer_close_to_oracle():
     assert frac >= 23 / 24 - 1e-6 and worst < 2e-2
 
 
+def test_inference_packs_the_shader_network_once_until_a_parameter_changes():
+    """NeROMaterialRenderer._kernels under no_grad: one packing for all chunks of a test_step (it re-packed per 1024-ray
+    chunk); an in-place parameter update invalidates the cache and the outputs follow the new weights"""
+    from nero_amd.renderer import NeROMaterialRenderer
+    z, meta = load_golden('mat_bell')
+    ref = build_material_case(meta)
+    net = NeROMaterialRenderer({'shader_cfg': meta['shader_cfg'], 'database_name': 'syn/bell'}, mesh=golden_mesh())
+    net.load_state_dict(ref.state_dict())
+    net = net.cuda()
+    c = lambda k: T(z, k, 'cuda')
+    with torch.no_grad():
+        k1 = net._kernels()
+        out1 = net.shade(c('pts'), c('view'), c('normals'), c('human_poses'), True, meta['step'], c('rand_d'), c('rand_s'))
+        k2 = net._kernels()
+        assert k2[2] is k1[2]                                          # the same packed chains served both calls
+        out2 = net.shade(c('pts'), c('view'), c('normals'), c('human_poses'), True, meta['step'], c('rand_d'), c('rand_s'))
+        assert torch.equal(out1['rgb_pr'], out2['rgb_pr'])
+        p = next(q for n, q in net.shader_network.named_parameters() if 'albedo' in n and n.endswith('bias'))
+        p.add_(0.25)                                                   # in place: torch's version counter moves
+        k3 = net._kernels()
+        assert k3[2] is not k1[2]
+        out3 = net.shade(c('pts'), c('view'), c('normals'), c('human_poses'), True, meta['step'], c('rand_d'), c('rand_s'))
+        assert float((out3['albedo'] - out1['albedo']).abs().max()) > 1e-3
+    k4 = net._kernels()                                                # with autograd on nothing is cached: fresh effective-weight leaves
+    assert k4[2] is not k3[2]
+
+
 def test_material_trainer_entry_point_and_pretrace():
     """forward({'step':...}) over the device-side pre-traced pixel pool (camera rays through the HIP BVH) + per-vertex materials"""
     from nero_amd.renderer import NeROMaterialRenderer
