@@ -64,12 +64,28 @@ class SDFNetwork(nn.Module):
 
 
 class SingleVarianceNetwork(nn.Module):
-    def __init__(self, init_val):
+    """network/field.py:184-198.  activation: 'exp' (every shipped YAML) | 'linear' | 'square'."""
+
+    def __init__(self, init_val, activation='exp'):
         super().__init__()
+        if activation not in ('exp', 'linear', 'square'):
+            raise NotImplementedError(activation)                # (the reference raises NotImplementedError in forward, field.py:197)
+        self.act = activation
         self.register_parameter('variance', nn.Parameter(torch.tensor(init_val)))
 
     def inv_s(self):
-        return torch.exp(self.variance * 10.0)
+        v10 = self.variance * 10.0
+        return torch.exp(v10) if self.act == 'exp' else (v10 if self.act == 'linear' else v10 ** 2)
+
+    def kernel_variance(self):
+        """the scalar the HIP kernels are handed as `variance`: they all form inv_s = exp(10 * variance) (sampler.hip, shade.hip), so
+        for 'linear' / 'square' they get v' = log(inv_s) / 10 -- a differentiable torch expression of the parameter, through which
+        autograd chains d inv_s / d variance (10, resp. 200 v) onto the kernels' d inv_s.  inv_s <= 1e-6 (a non-positive 'linear'
+        variance; the reference then divides by a non-positive inv_s) is clamped to 1e-6, the lower clip of render_core
+        (network/renderer.py:493)."""
+        if self.act == 'exp':
+            return self.variance
+        return torch.log(self.inv_s().clamp(min=1e-6)) / 10.0
 
 
 class NeRFNetwork(nn.Module):
@@ -138,7 +154,7 @@ def build_shape_fields(cfg):
     (network/renderer.py:117-130)."""
     sdf = SDFNetwork(d_out=cfg['sdf_d_out'], n_layers=cfg['sdf_n_layers'], bias=cfg['sdf_bias'],
                      geometric_init=cfg['geometry_init'])
-    dev = SingleVarianceNetwork(cfg['inv_s_init'])
+    dev = SingleVarianceNetwork(cfg['inv_s_init'], cfg['std_act'])
     nerf = NeRFNetwork()
     nn.init.constant_(nerf.rgb_linear.bias, math.log(0.5))
     color = AppShadingNetwork(cfg['shader_config'])

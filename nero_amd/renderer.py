@@ -28,9 +28,12 @@ class NeROShapeRenderer(nn.Module):
         super().__init__()
         self.cfg = {**self.default_cfg, **cfg}
         c = self.cfg
-        if c['std_act'] != 'exp' or c['sdf_activation'] != 'none' or c['sdf_freq'] != 6 or c['sdf_n_layers'] != 8 \
-                or c['sdf_d_out'] != 257:
-            raise NotImplementedError('only the configuration family used by the shipped YAMLs is implemented in HIP')
+        if c['std_act'] not in ('exp', 'linear', 'square'):
+            raise NotImplementedError(f"std_act {c['std_act']!r}")      # (as the reference: network/field.py:197)
+        if c['sdf_activation'] != 'none' or c['sdf_freq'] != 6 or c['sdf_n_layers'] != 8 or c['sdf_d_out'] != 257:
+            # the SDF chain kernels, their packed operand images and the second-order backward are laid out for the 8 x 256 network with a
+            # PE-6 input and 257 outputs that every shipped YAML uses (INTEGRATION.md lists the keys that raise)
+            raise NotImplementedError('sdf_activation / sdf_freq / sdf_n_layers / sdf_d_out other than none / 6 / 8 / 257 are not implemented in HIP')
         sc = c['shader_config']
         if sc.get('light_pos_freq', 8) != 8:
             # the HIP encoders (shade_encode / mc_encode_hit) hard-wire PE-8 for the light-MLP position input
@@ -325,7 +328,7 @@ class NeROShapeRenderer(nn.Module):
             rand1 = rand_bg = None
         with torch.no_grad():
             return sample_ray(K, self.cfg, rays_o.contiguous(), rays_d.contiguous(), near.contiguous(), far.contiguous(),
-                              self.deviation_network.variance.detach(), rand1, rand_bg, trace)
+                              self.deviation_network.kernel_variance().detach().contiguous(), rand1, rand_bg, trace)
 
     def render(self, rays_o, rays_d, near, far, human_poses, perturb_overwrite=-1, cos_anneal_ratio=0.0, is_train=True,
                step=None, rand1=None, rand_bg=None, z_vals=None, occ_keys=None, _kern=None, _grad_views=None, _driver=None):
@@ -346,7 +349,7 @@ class NeROShapeRenderer(nn.Module):
                     rand1 = rand_bg = None
                 with torch.no_grad():
                     z_vals = _driver.sample(rays_o.contiguous(), rays_d.contiguous(), near.contiguous(), far.contiguous(),
-                                            self.deviation_network.variance.detach(),
+                                            self.deviation_network.kernel_variance().detach().contiguous(),
                                             rand1.contiguous() if rand1 is not None else None, rand_bg.contiguous() if rand_bg is not None else None)
             else:
                 z_vals = self.sample_ray(rays_o, rays_d, near, far, perturb, rand1, rand_bg, K)
@@ -367,7 +370,7 @@ class NeROShapeRenderer(nn.Module):
         meta = {'names': names, 'shapes': [tuple(t.shape) for t in eff], 'shader_cfg': self.color_network.cfg, 'K': Kpre,
                 'anneal': float(cos_anneal_ratio), 'exp_max': float(self.color_network.cfg['light_exp_max']),
                 'freeze_inv_s': c['freeze_inv_s_step'] is not None and step < c['freeze_inv_s_step'], 'grad_views': _grad_views}
-        var = self.deviation_network.variance
+        var = self.deviation_network.kernel_variance()          # (std_act 'exp': the parameter itself)
         poses = None
         if self.color_network.cfg['human_light']:
             if human_poses is None:
@@ -383,7 +386,7 @@ class NeROShapeRenderer(nn.Module):
                                                    self.color_network.FG_LUT, poses, *eff)
         n_in = gerr.shape[0]
         outputs = {'ray_rgb': rgb, 'gradient_error': gerr if n_in > 0 else torch.zeros(1, device=rgb.device)}
-        inv_s = torch.exp(var * 10.0).clip(1e-6, 1e6)
+        inv_s = self.deviation_network.inv_s().clip(1e-6, 1e6)
         if meta['freeze_inv_s']:
             inv_s = inv_s.detach()
         outputs['std'] = torch.mean(1.0 / inv_s) if n_in > 0 else torch.zeros(1, device=rgb.device)

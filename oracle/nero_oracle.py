@@ -149,6 +149,18 @@ def fg_lut_fetch(lut, u, v):
 # networks
 # ----------------------------------------------------------------------------------------------------------------------
 
+def deviation_inv_s(P, act='exp'):
+    """SingleVarianceNetwork.forward (network/field.py:190-198): exp(10 v) | 10 v | (10 v)^2"""
+    v10 = P['deviation_network.variance'] * 10.0
+    if act == 'exp':
+        return torch.exp(v10)
+    if act == 'linear':
+        return v10
+    if act == 'square':
+        return v10 ** 2
+    raise NotImplementedError(act)
+
+
 def softplus100(x):
     return F.softplus(x, beta=100)          # threshold 20 (network/field.py:124)
 
@@ -363,7 +375,7 @@ def sample_ray(P, cfg, o, d, near, far, rand1=None, rand_bg=None, trace=None):
         R = z.shape[0]
         pts = o[:, None, :] + d[:, None, :] * z[..., None]
         sdf = sdf_network(P, pts.reshape(-1, 3))[:, 0].reshape(R, -1)
-        inv_s_net = float(torch.exp(P['deviation_network.variance'] * 10.0))
+        inv_s_net = float(deviation_inv_s(P, cfg.get('std_act', 'exp')))
         for i in range(up):
             inv_s = min(inv_s_net, 64.0 * 2 ** i) if cfg['clip_sample_variance'] else 64.0 * 2 ** i
             w = upsample_weights(o, d, z, sdf, inv_s)
@@ -514,7 +526,7 @@ def section_weights(P, z, origins, dirs, inv_s):
     return transmittance_weights(alpha), torch.where(surf, mid, -torch.ones_like(mid))
 
 
-def secondary_ray_occlusion(P, pts, dirs, sn0, sn1):
+def secondary_ray_occlusion(P, pts, dirs, sn0, sn1, std_act='exp'):
     """get_intersection (network/field.py:454-484), returns sum of the sn1-1 section weights = occ probability.
     Points with |p| >= 0.999 get 0."""
     inside = torch.norm(pts, dim=-1) < 0.999
@@ -523,7 +535,7 @@ def secondary_ray_occlusion(P, pts, dirs, sn0, sn1):
         return out
     p, dd = pts[inside], dirs[inside]
     with torch.no_grad():
-        inv_s = float(torch.exp(P['deviation_network.variance'] * 10.0))
+        inv_s = float(deviation_inv_s(P, std_act))
         maxd = sphere_exit_dist(p, dd)
         z = maxd * torch.linspace(0, 1, sn0, dtype=p.dtype, device=p.device).unsqueeze(0)
         w, _ = section_weights(P, z, p, dd, inv_s)
@@ -540,7 +552,7 @@ def secondary_ray_occlusion(P, pts, dirs, sn0, sn1):
 DEFAULT_CFG = {
     'n_samples': 64, 'n_bg_samples': 32, 'n_importance': 64, 'up_sample_steps': 4, 'perturb': 1.0,
     'anneal_end': 50000, 'clip_sample_variance': True, 'freeze_inv_s_step': None, 'apply_occ_loss': True,
-    'occ_loss_step': 20000, 'occ_loss_max_pn': 2048, 'occ_sdf_thresh': 0.01, 'rgb_loss': 'charbonier',
+    'occ_loss_step': 20000, 'occ_loss_max_pn': 2048, 'occ_sdf_thresh': 0.01, 'rgb_loss': 'charbonier', 'std_act': 'exp',
     'shader_config': {},
 }
 
@@ -578,7 +590,7 @@ def render_core(P, cfg, o, d, z_vals, poses, cos_anneal, step, occ_keys=None):
         pi = pts[ii]
         y, grad = sdf_value_and_normal(P, pi)
         sdf, feat = y[:, 0], y[:, 1:]
-        inv_s = torch.exp(P['deviation_network.variance'] * 10.0).clamp(1e-6, 1e6)
+        inv_s = deviation_inv_s(P, cfg.get('std_act', 'exp')).clamp(1e-6, 1e6)
         if cfg['freeze_inv_s_step'] is not None and step < cfg['freeze_inv_s_step']:
             inv_s = inv_s.detach()
         di = dirs[ii]
@@ -619,7 +631,7 @@ def render_core(P, cfg, o, d, z_vals, poses, cos_anneal, step, occ_keys=None):
                 keep = torch.sort(torch.argsort(keys, stable=True)[:cfg['occ_loss_max_pn']])[0]
                 cand = cand[keep]
             if cand.numel() > 0:
-                gt = secondary_ray_occlusion(P, pi[cand].detach(), occ_info['reflective'][cand].detach(), 64, 16)
+                gt = secondary_ray_occlusion(P, pi[cand].detach(), occ_info['reflective'][cand].detach(), 64, 16, cfg.get('std_act', 'exp'))
                 out['loss_occ'] = F.l1_loss(occ_info['occ_prob'][cand], gt)
             out['occ_count'] = cand.numel()
     out['n_inner'] = ii.numel()
@@ -636,7 +648,7 @@ def validation_info(P, cfg, o, d, z_vals, weights, poses):
     inner = (torch.norm(pts, dim=-1, keepdim=True) <= 1.0).float()
     out = {'depth': depth, 'normal': ((F.normalize(grad, dim=-1) + 1.0) * 0.5) * inner}
     _, occ_info, inter = app_shading(P, cfg['shader_config'], pts, grad, -F.normalize(d, dim=-1), y[:, 1:], poses, want_inter=True)
-    out['occ_prob_gt'] = secondary_ray_occlusion(P, pts.detach(), occ_info['reflective'].detach(), 128, 9)
+    out['occ_prob_gt'] = secondary_ray_occlusion(P, pts.detach(), occ_info['reflective'].detach(), 128, 9, cfg.get('std_act', 'exp'))
     for k, v in inter.items():
         out[k] = v * inner
     return {k: v.detach() for k, v in out.items()}

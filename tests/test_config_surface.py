@@ -40,3 +40,26 @@ def test_material_yaml_constructs(path):
     assert ('shader_network.human_light.0.weight_g' in keys) == bool(human)
     n_params = sum(p.numel() for p in net.parameters())
     assert n_params == (1561886 if (human and cfg['shader_cfg']['outer_light_version'] == 'sphere_direction') else 1403670), n_params
+
+
+@pytest.mark.parametrize('act', ['exp', 'linear', 'square'])
+def test_std_act_matches_the_reference_variance_network(act):
+    """std_act (network/field.py:184-198) -- the reference class under the import shim against the drop-in module, the oracle's
+    restatement, and the log-domain scalar the HIP kernels are handed (they form exp(10 v'))"""
+    from oracle import ref_shim
+    from oracle import nero_oracle as O
+    from nero_amd.fields import SingleVarianceNetwork
+    _, field = ref_shim.load_reference()
+    for v in (0.3, 0.07, 2.0):
+        ref = field.SingleVarianceNetwork(v, act)
+        want = float(ref(torch.zeros(1, 3))[0, 0])
+        mine = SingleVarianceNetwork(v, act)
+        assert abs(float(mine.inv_s()) - want) <= 1e-6 * abs(want)
+        assert abs(float(O.deviation_inv_s({'deviation_network.variance': torch.tensor(v)}, act)) - want) <= 1e-6 * abs(want)
+        kv = mine.kernel_variance()
+        assert abs(float(torch.exp(kv * 10.0)) - want) <= 3e-6 * abs(want)
+        kv.backward()                                              # d v' / d variance chains the activation's slope onto the kernels' d inv_s
+        slope = {'exp': 10.0 * want, 'linear': 10.0, 'square': 200.0 * v}[act]
+        assert abs(float(mine.variance.grad) * 10.0 * want - slope) <= 1e-4 * slope
+    with pytest.raises(NotImplementedError):
+        SingleVarianceNetwork(0.3, 'tanh')

@@ -121,6 +121,42 @@ def test_render_core_outputs_and_grads(name):
     assert_grads_fp32_grade(named_grads(net), named_grads(ref), g64, where=name)
 
 
+@pytest.mark.parametrize('act,variance', [('linear', 2.0), ('square', 0.45)])
+def test_std_act_linear_and_square_render_and_variance_gradient(act, variance):
+    """std_act != 'exp' (network/field.py:193-196; no shipped YAML uses it): sampler, render_core, occlusion-loss march and the gradient
+    of the variance parameter against the oracle (the kernels are handed v' = log(inv_s) / 10, nero_amd.fields.SingleVarianceNetwork)"""
+    z, meta = load_golden('bell_s25000')
+    meta = {**meta, 'cfg': {**meta['cfg'], 'std_act': act}, 'variance': variance}
+    net = build_case_model(meta).cuda()
+    ref = build_case_model(meta)
+    assert abs(float(net.deviation_network.inv_s()) - 20.0) < 0.5
+    sd = {k: v for k, v in ref.named_parameters()}
+    sd.update({k: v for k, v in ref.named_buffers()})
+    P = O.effective_params(sd)
+    cfg = {**O.DEFAULT_CFG, **meta['cfg']}
+    with torch.no_grad():
+        zo = O.sample_ray(P, cfg, T(z, 'o'), T(z, 'd'), T(z, 'near'), T(z, 'far'), T(z, 'rand1'), T(z, 'rand_bg'))
+        zg = net.sample_ray(T(z, 'o', 'cuda'), T(z, 'd', 'cuda'), T(z, 'near', 'cuda'), T(z, 'far', 'cuda'), 1.0, T(z, 'rand1', 'cuda'),
+                            T(z, 'rand_bg', 'cuda')).cpu()
+    assert float(((zg - zo).abs() < 1e-5).float().mean()) > 0.97          # (the sampler is ill-conditioned end to end: a statistic)
+    g = torch.Generator().manual_seed(3)
+    keys = torch.rand(zo.numel(), generator=g)
+    oo = O.render_core(P, cfg, T(z, 'o'), T(z, 'd'), zo, T(z, 'human_poses'), meta['anneal'], meta['step'], keys)
+    loss_o = O.training_loss(cfg, oo, T(z, 'gt'), meta['step'])
+    loss_o.backward()
+    out = net.render(T(z, 'o', 'cuda'), T(z, 'd', 'cuda'), T(z, 'near', 'cuda'), T(z, 'far', 'cuda'), T(z, 'human_poses', 'cuda'),
+                     -1, meta['anneal'], is_train=True, step=meta['step'], z_vals=zo.cuda(), occ_keys=keys)
+    assert rel(out['ray_rgb'], oo['ray_rgb']) < 1e-4 and rel(out['gradient_error'], oo['gradient_error']) < 1e-4
+    assert abs(float(out['std']) - float(oo['std'])) < 1e-6 * max(1.0, float(oo['std']))
+    assert abs(float(out['loss_occ']) - float(oo['loss_occ'])) < 1e-5
+    from nero_amd.train import shape_training_loss
+    loss = shape_training_loss(net, out, T(z, 'gt', 'cuda'), meta['step'])
+    assert abs(float(loss) - float(loss_o)) < 2e-5
+    loss.backward()
+    gv, gvo = float(net.deviation_network.variance.grad), float(ref.deviation_network.variance.grad)
+    assert abs(gvo) > 1e-9 and abs(gv - gvo) < 2e-4 * abs(gvo), (gv, gvo)
+
+
 @pytest.mark.parametrize('name', ['bell_s25000', 'bell_occcap', 'bell_s500', 'bear_s25000', 'bell_sphdir', 'bell_noclip_l1', 'bell_l2', 'bell_smoothl1'])
 def test_full_training_loss_with_occ_and_init_reg(name):
     """trainer loss incl. the occlusion loss (step >= 20000, with and without the random cap) and the InitSDFRegLoss inputs
