@@ -119,9 +119,11 @@ int nero_mlp_forward(const nero_fwd_chain* chain /*host*/, int n_rows, void* str
 typedef struct {
     const float* w_main; const float* w_aux;
     const float* a_saved;  /* [rows_pad,256] activations saved by the forward pass (for sigma')                       */
-    const float* gbar;     /* [rows_pad,256] first-order backward signal saved by the normal pass                     */
+    const float* gbar;     /* [rows_pad,256] first-order backward signal saved by the normal pass; may be NULL when   */
+                           /* inj is NULL (round 4: the F16X3 reverse kernel forms the injection itself, see          */
+                           /* nero_bwd_layer.inj_adot)                                                                 */
     float* adot;           /* out [rows_pad,256]                                                                      */
-    float* inj;            /* out [rows_pad,256]                                                                      */
+    float* inj;            /* out [rows_pad,256], or NULL = not written (saves 1 KB read + 1 KB written per row and layer) */
     int k_main, k_aux, n_tiles, pad_;
 } nero_tan_layer;
 
@@ -152,6 +154,10 @@ typedef struct {
     int act_prev;          /* activation that produced a_prev                                                         */
     int pad_;
     const uint32_t* mask_prev; /* optional relu_mask of the layer that produced a_prev (F16X3 engine): replaces reading a_prev */
+    const float* inj_adot; /* F16X3 engine, softplus a_prev only.  When set, `inj` holds the first-order signal gbar_{l-1} and this the
+                              tangent adot_{l-1} (both [rows_pad,256]) and the kernel forms the injection itself,
+                              gbar * beta (1 - s) * adot / s  with s = sigma'(a_prev) -- the tangent pass then neither reads gbar
+                              nor writes inj.  NULL = `inj` is the finished additive term (every engine).                    */
 } nero_bwd_layer;
 
 typedef struct {

@@ -42,7 +42,7 @@ class TanChain(C.Structure):
 class BwdLayer(C.Structure):
     _fields_ = [('w_main_t', _fp), ('w_aux_t', _fp), ('a_prev', _fp), ('inj', _fp), ('delta_prev', _fp),
                 ('head_w', _fp), ('head_dy', _fp), ('n_out', C.c_int), ('k_main_tiles', C.c_int),
-                ('k_aux_tiles', C.c_int), ('n_head', C.c_int), ('act_prev', C.c_int), ('pad_', C.c_int), ('mask_prev', _fp)]
+                ('k_aux_tiles', C.c_int), ('n_head', C.c_int), ('act_prev', C.c_int), ('pad_', C.c_int), ('mask_prev', _fp), ('inj_adot', _fp)]
 
 
 class BwdChain(C.Structure):

@@ -282,7 +282,8 @@ class Chain:
                  dinit_out=None, accumulate_dinit=False, skip_last_dense=False):
         """reverse pass.  dy: [rows_pad, >=n_out_last] gradient w.r.t. the last dense output (or w.r.t. the last
         pseudo-entry's input tile).  head_dys: {entry: [rows_pad,4]}.  injs: {dense entry: [rows_pad,256]} added to the
-        delta of that entry's OUTPUT.  -> dict(deltas={entry: [rows_pad,256]}, d_init, d_aux)"""
+        delta of that entry's OUTPUT -- or {dense entry: (gbar, adot)}: the fp16 engine then forms the sigma'' injection of a
+        softplus entry itself (nero_bwd_layer.inj_adot).  -> dict(deltas={entry: [rows_pad,256]}, d_init, d_aux)"""
         head_dys = head_dys or {}
         injs = injs or {}
         rp = row_pad(n_rows)
@@ -339,7 +340,11 @@ class Chain:
                     bl.mask_prev = mk[j].data_ptr()
                 bl.delta_prev = deltas[j].data_ptr()
                 if j in injs:
-                    bl.inj = injs[j].data_ptr()
+                    if isinstance(injs[j], tuple):
+                        assert GEMM_MODE['bwd'] in _F16 and self.entries[j][0].act == L.ACT_SOFTPLUS100
+                        bl.inj, bl.inj_adot = injs[j][0].data_ptr(), injs[j][1].data_ptr()
+                    else:
+                        bl.inj = injs[j].data_ptr()
         # the delta of the last dense entry is dy itself when that entry is the chain's last entry
         if self.entries[last][0] is not None and not skip_last_dense:
             assert dy is not None and self.entries[last][0].act == L.ACT_NONE

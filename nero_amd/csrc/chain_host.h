@@ -207,7 +207,8 @@ struct Chain {
     // nero_amd/chain.py::Chain.backward
     int backward(Arena& A, const Modes& M, const Fwd& F, int n_rows, const float* dy, int ld_dy, const float* const* head_dys /*[MAXL] or NULL*/,
                  bool need_dinit, bool need_daux, const float* const* injs /*[MAXL] or NULL*/, float* dinit_out, int ld_dinit_out,
-                 bool accumulate_dinit, bool skip_last_dense, Bwd& B, void* stream) const {
+                 bool accumulate_dinit, bool skip_last_dense, Bwd& B, void* stream,
+                 const float* const* inj_adots = nullptr /*[MAXL]: injs then holds gbar, nero_bwd_layer.inj_adot*/) const {
         const int rp = rpad(n_rows), last = n() - 1;
         nero_bwd_chain ch;
         memset(&ch, 0, sizeof(ch));
@@ -259,7 +260,7 @@ struct Chain {
                 bl.act_prev = e[j].d.act;
                 if (F.masks[j]) bl.mask_prev = F.masks[j];
                 bl.delta_prev = dw[j];
-                if (injs && injs[j]) bl.inj = injs[j];
+                if (injs && injs[j]) { bl.inj = injs[j]; if (inj_adots && inj_adots[j]) bl.inj_adot = inj_adots[j]; }
             }
         }
         if (e[last].d.has && !skip_last_dense) { B.deltas[last] = dy; B.ld_delta[last] = ld_dy; }   // (the delta of the last dense entry is dy itself)

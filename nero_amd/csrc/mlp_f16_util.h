@@ -162,6 +162,13 @@ __device__ __forceinline__ void tan_elem(float a, float zd, float gb, bool live,
     const float r2 = (BETA * a > 20.f) ? 0.f : BETA * (1.f - s);
     ij = live ? gb * r2 * zd : 0.f;
 }
+// the same injection from the tangent's OUTPUT: adot = s zdot  =>  inj = gbar * beta (1 - s) * adot / s   (s == 0: a == 0 exactly, then
+// gbar = upstream * s is 0 too and the term vanishes; beyond torch's threshold sigma'' is 0)
+__device__ __forceinline__ float inj_elem(float a, float gb, float ad) {
+    const float s = softplus100_grad_from_out(a);
+    const float r2 = (BETA * a > 20.f) ? 0.f : BETA * (1.f - s);
+    return s > 0.f ? gb * r2 * (ad / s) : 0.f;
+}
 __device__ __forceinline__ float amax4(float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
 __device__ __forceinline__ float4 scale4(float4 v, float s) { return make_float4(v.x * s, v.y * s, v.z * s, v.w * s); }
 

@@ -416,7 +416,12 @@ __global__ __launch_bounds__(512, 1) void tan_f16_kernel(nero_tan_chain ch, int 
         const bool live_wave = wave < L.n_tiles;
         const size_t boff = (size_t)row0 * NERO_HID + 32 * wave;
         float4 pg[2][4];
-        if (live_wave) {
+        const bool want_inj = L.inj != nullptr;            // (round 4 default: NULL -- the reverse kernel forms the injection, nero_bwd_layer.inj_adot)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pg[r][g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live_wave && want_inj) {
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -456,7 +461,7 @@ __global__ __launch_bounds__(512, 1) void tan_f16_kernel(nero_tan_chain ch, int 
                     ijq[g] = ij;
                 }
                 acc_to_global(scr, adq, L.adot + boff + (size_t)r * 32 * NERO_HID, lane);
-                acc_to_global(scr, ijq, L.inj + boff + (size_t)r * 32 * NERO_HID, lane);
+                if (want_inj) acc_to_global(scr, ijq, L.inj + boff + (size_t)r * 32 * NERO_HID, lane);
             }
         }
         if (l + 1 < ch.n_layers) {
@@ -519,6 +524,19 @@ __device__ __forceinline__ void bwd_values(const float4 (&gq)[2][4], const float
         } else if (has_inj) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) ij[g] = *reinterpret_cast<const float4*>(L.inj + goff + (size_t)r * 32 * NERO_HID + 8 * g);
+            if (ACT == NERO_ACT_SOFTPLUS100 && L.inj_adot) {
+                // `inj` is gbar and inj_adot the tangent: the sigma'' injection gbar beta (1 - s) zdot with zdot = adot / s is formed here
+                // (s = sigma'(a_prev) is in hand anyway), so the tangent pass neither reads gbar nor writes a finished term
+                float4 ad[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) ad[g] = *reinterpret_cast<const float4*>(L.inj_adot + goff + (size_t)r * 32 * NERO_HID + 8 * g);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 a = pa[r][g];
+                    ij[g].x = inj_elem(a.x, ij[g].x, ad[g].x); ij[g].y = inj_elem(a.y, ij[g].y, ad[g].y);
+                    ij[g].z = inj_elem(a.z, ij[g].z, ad[g].z); ij[g].w = inj_elem(a.w, ij[g].w, ad[g].w);
+                }
+            }
         }
         m[r] = 0.f;
 #pragma unroll
@@ -646,25 +664,11 @@ __global__ __launch_bounds__(512, 1) void bwd_f16_kernel(nero_bwd_chain ch, int 
             if (live_wave) {
                 const float wsc = *L.w_main_t;
                 const uint4* wpm = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(L.w_main_t) + HDR_BYTES) + (size_t)wave * steps * 128 + lane;
-                if constexpr (FIXED) {
-#ifdef BWD_INJ_IN_GEMM
-                    // the second-order pass: the injections of this tile (8 KB per wave from HBM) are requested behind the GEMM's last
-                    // weight request (step 16 - GEMM_WD) -- read in the epilogue they were an exposed round trip per layer
-                    // (values = 9.2 k cycles against 1.9 k without them, profiles/r02_phase_timing.txt)
-                    gemm_f16x3_fixed_hook<16>(aH, aL, wpm, S.actp + i * SA + 16 * h, 32 * SA, PLANE_A, [&](auto cc) {
-                        if constexpr (decltype(cc)::value == 16 - GEMM_WD) {
-                            if (has_inj) {
-#pragma unroll
-                                for (int r = 0; r < 2; ++r)
-#pragma unroll
-                                    for (int g = 0; g < 4; ++g) ijp[r][g] = *reinterpret_cast<const float4*>(L.inj + goff + (size_t)r * 32 * NERO_HID + 8 * g);
-                            }
-                        }
-                    });
-#else
-                    gemm_f16x3_fixed<16>(aH, aL, wpm, S.actp + i * SA + 16 * h, 32 * SA, PLANE_A);
-#endif
-                } else gemm_f16x3(aH, aL, wpm, S.actp + i * SA + 16 * h, 32 * SA, PLANE_A, steps);
+                // (Round 4, measured and dropped: the injections requested INSIDE the GEMM, behind its last weight request, so that the
+                //  epilogue does not wait for them -- the second-order pass stayed at 1.55 ms: it is bound by its HBM traffic, 3 KB per row
+                //  and layer at 4.6 TB/s, not by that round trip.)
+                if constexpr (FIXED) gemm_f16x3_fixed<16>(aH, aL, wpm, S.actp + i * SA + 16 * h, 32 * SA, PLANE_A);
+                else gemm_f16x3(aH, aL, wpm, S.actp + i * SA + 16 * h, 32 * SA, PLANE_A, steps);
                 u[0] = wsc * rs0;
                 u[1] = wsc * rs1;
             }
@@ -725,11 +729,7 @@ __global__ __launch_bounds__(512, 1) void bwd_f16_kernel(nero_bwd_chain ch, int 
 #pragma unroll
                     for (int g = 0; g < 4; ++g) pa[r][g] = *reinterpret_cast<const float4*>(pa_lds + (r * 4 + g) * 1024 + lane * 16);
             }
-#ifdef BWD_INJ_IN_GEMM
-            constexpr bool PRE = FIXED;
-#else
             constexpr bool PRE = false;
-#endif
             if (L.act_prev == NERO_ACT_RELU) bwd_values_h<NERO_ACT_RELU, PRE>(gq, pa, goff, has_inj, L, row0, i, fbase, n_rows, val, m, ijp);
             else if (L.act_prev == NERO_ACT_SOFTPLUS100) bwd_values_h<NERO_ACT_SOFTPLUS100, PRE>(gq, pa, goff, has_inj, L, row0, i, fbase, n_rows, val, m, ijp);
             else bwd_values_h<NERO_ACT_NONE, PRE>(gq, pa, goff, has_inj, L, row0, i, fbase, n_rows, val, m, ijp);

@@ -377,7 +377,7 @@ int do_backward(nero_stage1* h, Arena& A, const float* d_rgb, const float* d_ger
             set_head_grad(sc.e[8], g[L_SDF + 8], 256);
         }
         float* ehat = A.f32((size_t)rpi * LD_PE);
-        float* tbuf = A.f32((size_t)2 * 8 * rpi * NERO_HID);
+        float* tbuf = A.f32((size_t)8 * rpi * NERO_HID);               // adot_0..7 (the injections are formed inside the reverse kernel)
         if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_bwd: workspace too small");
         LAUNCH(nero_pe_jvp(S.x4, 4, d_grad, 3, N_FREQ, n_in, ehat, LD_PE, stream));
         nero_tan_chain tc;
@@ -385,6 +385,7 @@ int do_backward(nero_stage1* h, Arena& A, const float* d_rgb, const float* d_ger
         tc.init = ehat; tc.ld_init = LD_PE; tc.k_init = LD_PE; tc.aux = ehat; tc.ld_aux = LD_PE; tc.k_aux = LD_PE;
         tc.n_layers = 8; tc.aux_wide = 0; tc.gemm_mode = M.tan;
         const float* injs[MAXL] = {};
+        const float* adots[MAXL] = {};
         Second second[MAXL];
         const float* head_extra[MAXL] = {};
         double macs = 0.0;
@@ -393,11 +394,12 @@ int do_backward(nero_stage1* h, Arena& A, const float* d_rgb, const float* d_ger
             macs += (double)dd.n_out * (dd.k_main + dd.k_aux);
             nero_tan_layer& tl = tc.layer[l];
             tl.w_main = sc.e[l].hfm; tl.w_aux = sc.e[l].hfa;
-            tl.a_saved = h->f_sdf.saves[l]; tl.gbar = h->b_normal.deltas[l];
+            tl.a_saved = h->f_sdf.saves[l]; tl.gbar = nullptr;
             tl.adot = tbuf + (size_t)l * rpi * NERO_HID;
-            tl.inj = tbuf + (size_t)(8 + l) * rpi * NERO_HID;
+            tl.inj = nullptr;
             tl.k_main = r16(dd.k_main); tl.k_aux = dd.k_aux ? r16(dd.k_aux) : 0; tl.n_tiles = tiles(dd.n_out);
-            injs[l] = tl.inj;
+            injs[l] = h->b_normal.deltas[l];                   // (gbar_l: the reverse kernel forms gbar beta (1 - s) adot / s itself)
+            adots[l] = tl.adot;
             second[l].D1 = h->b_normal.deltas[l]; second[l].ldd1 = NERO_HID;
             second[l].B1m = l == 0 ? ehat : tbuf + (size_t)(l - 1) * rpi * NERO_HID; second[l].ldb1m = l == 0 ? LD_PE : NERO_HID;
             second[l].B1a = ehat; second[l].ldb1a = LD_PE;
@@ -408,7 +410,7 @@ int do_backward(nero_stage1* h, Arena& A, const float* d_rgb, const float* d_ger
         const float* sd[MAXL] = {};
         sd[8] = d_sdf4;
         Bwd sb;
-        RC(sc.backward(A, M, h->f_sdf, n_in, d_feat, NERO_HID, sd, false, false, injs, nullptr, 0, false, false, sb, stream));
+        RC(sc.backward(A, M, h->f_sdf, n_in, d_feat, NERO_HID, sd, false, false, injs, nullptr, 0, false, false, sb, stream, adots));
         RC(sc.weight_grads(A, M, h->f_sdf, sb, n_in, h->pe40, LD_PE, h->pe40, LD_PE, sd, second, head_extra, partials, stream));
         float* part = A.f32(128);
         if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_bwd: workspace too small");

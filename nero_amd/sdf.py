@@ -106,15 +106,18 @@ class SDFField:
             tc.gemm_mode = GEMM_MODE['tan']
             rk = _r16 if tsplit else _r8
             tc.macs_per_row = float(sum(ch.entries[l][0].n_out * (ch.entries[l][0].k_main + ch.entries[l][0].k_aux) for l in range(8)))
-            tbuf = torch.empty((2, 8, rp, L.HID), dtype=torch.float32, device=self.device)
+            # fp16 engines: the reverse kernel forms the injections from (gbar, adot) itself -- the tangent pass then reads no gbar and
+            # writes no inj (4 -> 2 KB per row and layer; the reverse pass reads 1 KB more)
+            fused_inj = GEMM_MODE['tan'] == L.GEMM_F16X3 and GEMM_MODE['bwd'] == L.GEMM_F16X3
+            tbuf = torch.empty((1 if fused_inj else 2, 8, rp, L.HID), dtype=torch.float32, device=self.device)
             for l in range(8):
                 d, p = ch.entries[l][0], ch._packed[l]
                 tl = tc.layer[l]
                 tl.w_main, tl.w_aux = L.ptr(p.get(tkeys[0])), L.ptr(p.get(tkeys[1]))
-                tl.a_saved, tl.gbar = fwd['saves'][l].data_ptr(), gbar[l].data_ptr()
-                tl.adot, tl.inj = tbuf[0, l].data_ptr(), tbuf[1, l].data_ptr()
+                tl.a_saved, tl.gbar = fwd['saves'][l].data_ptr(), (None if fused_inj else gbar[l].data_ptr())
+                tl.adot, tl.inj = tbuf[0, l].data_ptr(), (None if fused_inj else tbuf[1, l].data_ptr())
                 tl.k_main, tl.k_aux, tl.n_tiles = rk(d.k_main), (rk(d.k_aux) if d.k_aux else 0), _tiles(d.n_out)
-                injs[l] = tbuf[1, l]
+                injs[l] = (gbar[l], tbuf[0, l]) if fused_inj else tbuf[1, l]
             L.check(L.lib.nero_mlp_tangent(C.byref(tc), n, L.stream_ptr()))
             for l in range(8):
                 second[l] = (gbar[l], ehat if l == 0 else tbuf[0, l - 1], ehat)
