@@ -15,3 +15,4 @@ int nero_check_launch(const char* what);           // hipGetLastError() -> NERO_
 enum { NERO_K_FWD = 0, NERO_K_TAN = 1, NERO_K_BWD = 2, NERO_K_DW = 3, NERO_K_COUNT = 4 };
 void nero_prof_begin(int kind, double flops, hipStream_t s);
 void nero_prof_end(int kind, hipStream_t s);
+bool nero_prof_is_on();                            // (the step drivers keep ONE stream while launches are being timed)

@@ -43,6 +43,7 @@ void nero_prof_end(int kind, hipStream_t s) {
     (void)kind;
     (void)hipEventRecord(g_recs.back().b, s);
 }
+bool nero_prof_is_on() { return g_prof_on; }
 extern "C" int nero_prof_enable(int on) {
     g_prof_on = on != 0;
     return 0;

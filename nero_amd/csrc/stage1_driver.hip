@@ -10,6 +10,10 @@
 // validation extras).  The only host synchronisation is the read-back of the inner / outer sample counts after render_prep
 // (they size every later launch), as in the Python driver.
 #include "chain_host.h"
+#include <stdlib.h>
+#ifndef NERO_STREAMS_DEFAULT
+#define NERO_STREAMS_DEFAULT 2
+#endif
 
 
 // ---- the handle -----------------------------------------------------------------------------------------------------------------
@@ -34,9 +38,29 @@ struct nero_stage1 {
           *Xo = nullptr, *Xh = nullptr, *hmask = nullptr, *alphaRT = nullptr, *colorRT = nullptr;
     const float *o = nullptr, *d = nullptr, *variance = nullptr, *lut = nullptr, *poses = nullptr;
     float anneal = 0.f;
+    // ---- a second stream for the NeRF++ (outer-sample) branch (round 4): it shares no intermediate with the SDF / shading branch between
+    // the compaction and the compositing (forward), resp. between the compositing backward and the end of the step (backward), so the
+    // two run concurrently: one branch's partial last rounds of workgroups and its ~300 kernel boundaries are filled by the other's
+    // work.  NERO_STREAMS=1 restores the single-stream order (also used while launches are timed: nero_prof_enable).
+    int n_streams = 1;
+    hipStream_t s2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 namespace {
+
+// the stream of the side branch: s2 behind everything `main` holds so far -- or `main` itself (dry runs, one-stream mode, timed launches)
+hipStream_t fork_side(nero_stage1* h, const Arena& A, hipStream_t main) {
+    if (A.dry || h->n_streams < 2 || !h->s2 || nero_prof_is_on()) return main;
+    (void)hipEventRecord(h->ev_fork, main);
+    (void)hipStreamWaitEvent(h->s2, h->ev_fork, 0);
+    return h->s2;
+}
+void join_side(nero_stage1* h, hipStream_t side, hipStream_t main) {
+    if (side == main) return;
+    (void)hipEventRecord(h->ev_join, side);
+    (void)hipStreamWaitEvent(main, h->ev_join, 0);
+}
 
 void build_chains(nero_stage1* h, const nero_stage1_weights* w) {
     const nero_linear* L = w->lin;
@@ -167,20 +191,24 @@ int do_forward(nero_stage1* h, Arena& A, int R, int T, int n_in, int n_out, cons
         (void)hipMemsetAsync(h->alphaRT, 0, (size_t)R * T * 4, hs);
         (void)hipMemsetAsync(h->colorRT, 0, (size_t)R * T * 12, hs);
     }
+    const bool two = h->n_streams >= 2;                // (memory decisions follow the handle, not the moment: the size query is a dry run)
+    hipStream_t so_ = hs;
     if (n_out > 0) {
+        so_ = fork_side(h, A, hs);                     // the NeRF++ branch: behind the compaction and the two memsets
+        void* so = (void*)so_;
         h->pe88 = A.f32((size_t)rpo * 88); h->pev32 = A.f32((size_t)rpo * 32); h->dist_o = A.f32(rpo);
         if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_fwd: workspace too small");
-        LAUNCH(nero_gather_outer(S.pts4, d, S.outer_idx, T, n_out, h->pe88, h->pev32, h->dist_o, stream));
+        LAUNCH(nero_gather_outer(S.pts4, d, S.outer_idx, T, n_out, h->pe88, h->pev32, h->dist_o, so));
         h->f_trunk = Fwd(); h->f_head = Fwd();
-        RC(h->nerf_trunk.forward(A, M, h->pe88, 88, h->pe88, 88, n_out, true, h->f_trunk, stream));
-        RC(h->nerf_head.forward(A, M, h->f_trunk.saves[7], NERO_HID, h->pev32, 32, n_out, true, h->f_head, stream));
+        RC(h->nerf_trunk.forward(A, M, h->pe88, 88, h->pe88, 88, n_out, true, h->f_trunk, so));
+        RC(h->nerf_head.forward(A, M, h->f_trunk.saves[7], NERO_HID, h->pev32, 32, n_out, true, h->f_head, so));
         const size_t mk = A.mark();
         float* alpha_o = A.f32(rpo);
         float* color_o = A.f32((size_t)rpo * 3);
         if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_fwd: workspace too small");
-        LAUNCH(nero_nerf_head_fwd(h->f_trunk.heads[8], h->f_head.heads[2], h->dist_o, n_out, alpha_o, color_o, stream));
-        LAUNCH(nero_scatter_samples(alpha_o, color_o, S.outer_idx, n_out, h->alphaRT, h->colorRT, stream));
-        A.release(mk);
+        LAUNCH(nero_nerf_head_fwd(h->f_trunk.heads[8], h->f_head.heads[2], h->dist_o, n_out, alpha_o, color_o, so));
+        LAUNCH(nero_scatter_samples(alpha_o, color_o, S.outer_idx, n_out, h->alphaRT, h->colorRT, so));
+        if (!two) A.release(mk);                       // (concurrent branches: the other one carves on while these are still read)
     }
     if (n_in > 0) {
         S.x4 = A.f32((size_t)rpi * 4);
@@ -241,6 +269,7 @@ int do_forward(nero_stage1* h, Arena& A, int R, int T, int n_in, int n_out, cons
     }
     S.weights = A.f32((size_t)R * T);
     if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_fwd: workspace too small");
+    if (!A.dry) join_side(h, so_, hs);                 // both branches have scattered their alpha / colour
     LAUNCH(nero_composite_fwd(h->alphaRT, h->colorRT, R, T, S.weights, rgb, stream));
     return NERO_OK;
 }
@@ -258,9 +287,17 @@ int do_backward(nero_stage1* h, Arena& A, const float* d_rgb, const float* d_ger
     float* d_cRT = A.f32((size_t)R * T * 3);
     const int ws_rows = (n_in + rpi) > n_out ? (n_in + rpi) : n_out;
     float* partials = A.f32((size_t)nero_dw_workspace_floats(ws_rows > 1 ? ws_rows : 1));
+    const bool two = h->n_streams >= 2;
+    float* partials_o = two ? A.f32((size_t)nero_dw_workspace_floats(n_out > 1 ? n_out : 1)) : partials;      // (the side branch's own partial sums)
     if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_bwd: workspace too small");
     LAUNCH(nero_composite_bwd(h->alphaRT, h->colorRT, S.weights, d_rgb, R, T, d_aRT, d_cRT, stream));
+    hipStream_t so_ = hs;
     if (n_out > 0) {
+        so_ = fork_side(h, A, hs);                     // the NeRF++ branch of the backward: behind the compositing backward
+        void* const main_stream = stream;
+        stream = (void*)so_;                           // (the block below issues everything on `stream`)
+        float* const main_partials = partials;
+        partials = partials_o;
         const size_t mk = A.mark();
         float* d_ao = A.f32(rpo);
         float* d_co = A.f32((size_t)rpo * 3);
@@ -286,7 +323,9 @@ int do_backward(nero_stage1* h, Arena& A, const float* d_rgb, const float* d_ger
         Bwd tb;
         RC(tc.backward(A, M, h->f_trunk, n_out, hb.d_init, hb.ld_dinit, td, false, false, nullptr, nullptr, 0, false, false, tb, stream));
         RC(tc.weight_grads(A, M, h->f_trunk, tb, n_out, h->pe88, 88, h->pe88, 88, td, nullptr, nullptr, partials, stream));
-        A.release(mk);
+        if (!two) A.release(mk);
+        stream = main_stream;
+        partials = main_partials;
     }
     if (n_in > 0) {
         float* d_ai = A.f32(rpi);
@@ -421,6 +460,7 @@ int do_backward(nero_stage1* h, Arena& A, const float* d_rgb, const float* d_ger
     } else if (d_inv_s_sum && !A.dry) {
         (void)hipMemsetAsync(d_inv_s_sum, 0, 4, hs);
     }
+    if (!A.dry) join_side(h, so_, hs);                 // the caller's stream continues behind BOTH branches
     return nero_check_launch("nero_stage1_render_bwd");
 }
 
@@ -443,11 +483,26 @@ int nero_stage1_create(const nero_stage1_cfg* cfg, nero_stage1** out) {
     memset(&zero, 0, sizeof(zero));
     build_chains(h, &zero);                      // shapes only: the size queries work before the first pack
     make_value_chain(h);
+    const char* e = getenv("NERO_STREAMS");
+    h->n_streams = e ? atoi(e) : NERO_STREAMS_DEFAULT;
+    if (h->n_streams >= 2) {
+        if (hipStreamCreateWithFlags(&h->s2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();             // (no device in reach -- the CPU-side size queries still work -- or out of handles: one stream)
+            h->s2 = nullptr;
+        }
+    }
     *out = h;
     return NERO_OK;
 }
 
-void nero_stage1_destroy(nero_stage1* h) { delete h; }
+void nero_stage1_destroy(nero_stage1* h) {
+    if (!h) return;
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->s2) (void)hipStreamDestroy(h->s2);
+    delete h;
+}
 
 size_t nero_stage1_pack_bytes(nero_stage1* h) { return h ? pack_floats_total(h) * 4 : 0; }
 
