@@ -127,6 +127,14 @@ __device__ __forceinline__ void split_shift(int s, int& a, int& b) {
 #ifndef DW_SGB_V
 #define DW_SGB_V 4
 #endif
+// (Round 4, measured and dropped: staging through LDS-DMA.  global_load_lds_dwordx4 into a raw fp32 stage of 2 x 32 KB beside the planes, a
+// chunk requested TWO iterations before its maxima are taken -- no registers while in flight, 233 instead of 248 VGPRs -- on the theory that
+// the loop waits for loads it requested only one iteration earlier.  It does not: bit-identical results, 0.177 -> 0.194 ms per 298 k-row
+// job, 7.0 -> 7.7 ms of weight gradients per step.  Phase clocks of wave 0 per chunk (scripts/bench_dw.py on -DDW_PHASE_TIMING builds):
+// buffer loads  fetch 367, fragments 156, convert 797, MFMA 744, wait + publish 1033, barrier 911 = 4.0 k cycles;  LDS-DMA  248 / 180 /
+// 808 / 744 / 1549 / 831 = 4.4 k -- the read-out of the raw stage and four DMA requests with their 64-bit addresses cost more issue
+// slots than the wait they remove.  What the loop pays is ISSUE: ~200 VALU instructions per wave and chunk (800 cycles) beside 768 cycles
+// of its own MFMAs, two waves per SIMD, and the two do not co-issue while both waves run the same phase between two barriers.)
 // (Round 3, measured and dropped: TWO resident workgroups per CU for the narrow jobs -- 512 slices, __launch_bounds__(512, 4): 128 VGPRs with
 // 12 spilled -- to double the waves pulling the delta stream, which only the four D-staging waves of a workgroup do: every narrow job
 // got slower, 0.109 -> 0.132 ms (27-column job), 0.165 -> 0.226 ms (the SDF's 39-column jobs).)
