@@ -134,7 +134,10 @@ __device__ __forceinline__ void split_shift(int s, int& a, int& b) {
 // buffer loads  fetch 367, fragments 156, convert 797, MFMA 744, wait + publish 1033, barrier 911 = 4.0 k cycles;  LDS-DMA  248 / 180 /
 // 808 / 744 / 1549 / 831 = 4.4 k -- the read-out of the raw stage and four DMA requests with their 64-bit addresses cost more issue
 // slots than the wait they remove.  What the loop pays is ISSUE: ~200 VALU instructions per wave and chunk (800 cycles) beside 768 cycles
-// of its own MFMAs, two waves per SIMD, and the two do not co-issue while both waves run the same phase between two barriers.)
+// of its own MFMAs, two waves per SIMD, and the two do not co-issue while both waves run the same phase between two barriers.
+// Also tried: PHASE-SHIFTING the two waves of a SIMD (the D-stagers multiply chunk q while the B-stagers convert chunk q + 1, a barrier,
+// roles swapped) so that one feeds the matrix pipe while the other feeds the VALU.  Not measurable: with the product block behind a
+// wave-uniform branch hipcc spills the accumulators (158 VGPRs with two copies of the block, 286 with one copy in a half-step loop).)
 // (Round 3, measured and dropped: TWO resident workgroups per CU for the narrow jobs -- 512 slices, __launch_bounds__(512, 4): 128 VGPRs with
 // 12 spilled -- to double the waves pulling the delta stream, which only the four D-staging waves of a workgroup do: every narrow job
 // got slower, 0.109 -> 0.132 ms (27-column job), 0.165 -> 0.226 ms (the SDF's 39-column jobs).)
