@@ -908,15 +908,33 @@ int nero_mlp_backward(const nero_bwd_chain* ch, int n_rows, void* stream) {
     return nero_check_launch("nero_mlp_backward");
 }
 
+// the batching policy of nero_dw_gemm_batch (shared with the workspace query below)
+struct DwBatchPolicy { int rows, big_total, big_group; };
+static const DwBatchPolicy& dw_batch_policy() {
+    static DwBatchPolicy P = {-1, 256, 8};
+    if (P.rows < 0) {
+        const char* e = getenv("NERO_DW_BATCH_ROWS"); P.rows = e ? atoi(e) : DW_BATCH_ROWS;
+        e = getenv("NERO_DW_BATCH_TOTAL"); if (e) P.big_total = atoi(e);
+        e = getenv("NERO_DW_BATCH_GROUP"); if (e) P.big_group = atoi(e);
+        P.big_group = P.big_group < 0 ? 0 : (P.big_group > NERO_DW_BATCH_MAX ? NERO_DW_BATCH_MAX : P.big_group);
+        P.big_total = P.big_total < 16 ? 16 : (P.big_total > 1024 ? 1024 : P.big_total);
+    }
+    return P;
+}
+
 int nero_dw_workspace_floats(int n_rows) {
-    // The slice count ceil(n / rows_per_slice(n)) is NOT monotonic in n (rows_per_slice rounds up to a multiple of 32), so a
-    // buffer sized for the largest job of a step could be too small for a smaller one.  Always size for the worst case:
-    // DW_MAX_SLICES partial matrices for nero_dw_gemm, one 4x256(+4) partial per 128-row block for nero_head_dw.
+    // Partial matrices ([n_pad][k_pad] + n_pad floats, at most 256 x 256 + 256) of one launch: per-job launches write 256, small-row batches
+    // up to 1024 + 12, large-row batches `big_total` + a few.  The bound must be MONOTONIC in n_rows -- callers size one buffer for the
+    // largest row count of a step and hand it to launches over fewer rows, which may sit in the small-row regime -- so it is the
+    // maximum over the regimes whatever n_rows is (a round-4 attempt to size it by regime let a 100 k-row launch overrun a buffer sized
+    // for 300 k rows: found by tests/test_determinism.py).  One 4 x 256 (+4) partial per 128-row block for nero_head_dw.
     const int rows = n_rows < 1 ? 1 : n_rows;
-    const int head_blocks = (rows + 127) / 128;
-    // (DW_BATCH_SLICES: the slices of one batched launch over all its jobs, nero_dw_gemm_batch)
-    const int a = DW_BATCH_SLICES * (256 * 256 + 256), b = head_blocks * (4 * NERO_HID + 4);
-    return a > b ? a : b;
+    const DwBatchPolicy& P = dw_batch_policy();
+    long mats = DW_BATCH_SLICES;
+    if (P.big_total + NERO_DW_BATCH_MAX + 8 > mats) mats = P.big_total + NERO_DW_BATCH_MAX + 8;
+    const long head_blocks = (rows + 127) / 128;
+    const long a = mats * (256 * 256 + 256), b = head_blocks * (4 * NERO_HID + 4);
+    return (int)(a > b ? a : b);
 }
 
 int nero_dw_gemm(const nero_dw_job* job, int n_rows, float* partials, void* stream) {
@@ -962,14 +980,8 @@ int nero_dw_gemm_batch(const nero_dw_job* jobs, int n_jobs, int n_rows, float* p
     // boundary on them: 31.28 -> 30.75 ms per step at 4096 rays (same box, profiles/r04_dw_batch_sweep.txt).
     // Experiment switches: NERO_DW_BATCH_ROWS (the regime boundary), NERO_DW_BATCH_TOTAL / NERO_DW_BATCH_GROUP (slices per group / jobs
     // per group of the large-row regime; 0 rows = the old per-job launches).
-    static int batch_rows = -1, big_total = 256, big_group = 8;
-    if (batch_rows < 0) {
-        const char* e = getenv("NERO_DW_BATCH_ROWS"); batch_rows = e ? atoi(e) : DW_BATCH_ROWS;
-        e = getenv("NERO_DW_BATCH_TOTAL"); if (e) big_total = atoi(e);
-        e = getenv("NERO_DW_BATCH_GROUP"); if (e) big_group = atoi(e);
-        big_group = big_group < 0 ? 0 : (big_group > NERO_DW_BATCH_MAX ? NERO_DW_BATCH_MAX : big_group);
-        big_total = big_total < 16 ? 16 : (big_total > 1024 ? 1024 : big_total);
-    }
+    const DwBatchPolicy& POL = dw_batch_policy();
+    const int batch_rows = POL.rows, big_total = POL.big_total, big_group = POL.big_group;
     const bool big = rows >= batch_rows;
     const int batch_total = big ? big_total : 1024, batch_group = big ? big_group : NERO_DW_BATCH_MAX;
     if (!f16 || n_jobs < 2 || batch_group < 1) {                 // the per-job path: one launch (+ reduction) per job
@@ -1011,7 +1023,7 @@ int nero_dw_gemm_batch(const nero_dw_job* jobs, int n_jobs, int n_rows, float* p
                 const int total = J.n_out * J.k_cols + J.n_out;
                 max_total = total > max_total ? total : max_total;
             }
-            if (off > (size_t)DW_BATCH_SLICES * (256 * 256 + 256)) return nero_fail(NERO_ERR_ARG, "nero_dw_gemm_batch: partial buffer too small");
+            if (off > (size_t)nero_dw_workspace_floats(n_rows)) return nero_fail(NERO_ERR_ARG, "nero_dw_gemm_batch: partial buffer too small");
             nero_prof_begin(NERO_K_DW, flops, (hipStream_t)stream);
             nero_f16_dw_batch(&B, ng, narrow, n_rows, rps, slices, partials, (hipStream_t)stream);
             nero_prof_end(NERO_K_DW, (hipStream_t)stream);

@@ -7,6 +7,10 @@
 // Memory: one caller-owned workspace, carved by the same arena as the Stage-I driver; host synchronisation: one read-back of the
 // (miss, hit) ray counts, which size the light-MLP launches.
 #include "chain_host.h"
+#include <stdlib.h>
+#ifndef NERO_STREAMS_DEFAULT
+#define NERO_STREAMS_DEFAULT 2
+#endif
 
 enum { M_FEATS = 0, M_METALLIC = 8, M_ROUGHNESS = 12, M_ALBEDO = 16, M_OUTER = 20, M_INNER = 24, M_HUMAN = 28 };
 
@@ -60,9 +64,26 @@ struct nero_stage2 {
     int *slot = nullptr, *miss_idx = nullptr, *hit_idx = nullptr, *counts = nullptr;
     Fwd f_out, f_in, f_hum;
     const float *dirs = nullptr, *depth = nullptr, *fnrm = nullptr, *poses = nullptr, *tab_s = nullptr;
+    // a second stream for the HIT rows (inner-light MLP) beside the MISS rows (outer / human light): the two row sets share nothing
+    // between the compaction and the estimator (forward), resp. between its backward and the direction backward (as stage1_driver.hip)
+    int n_streams = 1;
+    hipStream_t s2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 namespace {
+
+hipStream_t fork_side(nero_stage2* h, const Arena& A, hipStream_t main) {
+    if (A.dry || h->n_streams < 2 || !h->s2 || nero_prof_is_on()) return main;
+    (void)hipEventRecord(h->ev_fork, main);
+    (void)hipStreamWaitEvent(h->s2, h->ev_fork, 0);
+    return h->s2;
+}
+void join_side(nero_stage2* h, hipStream_t side, hipStream_t main) {
+    if (side == main) return;
+    (void)hipEventRecord(h->ev_join, side);
+    (void)hipStreamWaitEvent(main, h->ev_join, 0);
+}
 
 void build_chains(nero_stage2* h, const nero_stage2_weights* w) {
     const nero_linear* L = w->lin;
@@ -154,6 +175,8 @@ int do_shade_lights(nero_stage2* h, Arena& A, const float* pos, float* rgb, floa
     h->Xhum = h->hmask = nullptr;
     h->f_out = Fwd(); h->f_in = Fwd(); h->f_hum = Fwd();
     if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage2_shade_fwd: workspace too small");
+    // the hit branch starts behind everything the caller's stream holds NOW (before the miss branch is issued on it)
+    const hipStream_t fork_side_early = (n_miss > 0 && n_hit > 0) ? fork_side(h, A, (hipStream_t)stream) : (hipStream_t)stream;
     if (n_miss > 0) {
         LAUNCH(nero_mc_encode_miss(h->dirs, h->miss_idx, h->pt, D, c.sphere_direction, n_miss, h->Xm, stream));
         RC(h->outer_light.forward(A, h->M, h->Xm, h->kout, nullptr, 0, n_miss, true, h->f_out, stream));
@@ -164,10 +187,13 @@ int do_shade_lights(nero_stage2* h, Arena& A, const float* pos, float* rgb, floa
             RC(h->human_light.forward(A, h->M, h->Xhum, 24, nullptr, 0, n_miss, true, h->f_hum, stream));
         }
     }
+    hipStream_t side = (hipStream_t)stream;
     if (n_hit > 0) {
-        LAUNCH(nero_mc_encode_hit(h->dirs, pos, h->fnrm, h->hit_idx, n_hit, h->Xh, stream));
-        RC(h->inner_light.forward(A, h->M, h->Xh, 128, nullptr, 0, n_hit, true, h->f_in, stream));
+        if (n_miss > 0) side = fork_side_early;            // (forked before the miss branch was issued, see above)
+        LAUNCH(nero_mc_encode_hit(h->dirs, pos, h->fnrm, h->hit_idx, n_hit, h->Xh, (void*)side));
+        RC(h->inner_light.forward(A, h->M, h->Xh, 128, nullptr, 0, n_hit, true, h->f_in, (void*)side));
     }
+    if (!A.dry) join_side(h, side, (hipStream_t)stream);
     LAUNCH(nero_mc_combine_fwd(h->pt, h->dirs, h->depth, h->slot, n_miss > 0 ? h->f_out.heads[3] : nullptr, n_hit > 0 ? h->f_in.heads[3] : nullptr,
                                (n_miss > 0 && c.human_lights) ? h->f_hum.heads[3] : nullptr, h->hmask, c.light_exp_max, c.inner_light_exp_max,
                                h->P, c.diffuse_sample_num, c.specular_sample_num, c.geometry_type, rgb, dl, sl, sp, stream));
@@ -187,6 +213,8 @@ int do_shade_bwd(nero_stage2* h, Arena& A, const float* d_rgb, const float* d_dl
     float* d_w = A.f32((size_t)P * Ds * 3);
     const int mx = n_miss > n_hit ? n_miss : n_hit;
     float* partials = A.f32((size_t)nero_dw_workspace_floats(mx > 1 ? mx : 1));
+    const bool two = h->n_streams >= 2;
+    float* partials_h = two ? A.f32((size_t)nero_dw_workspace_floats(n_hit > 1 ? n_hit : 1)) : partials;     // (the hit branch's own partial sums)
     float* dXm = n_miss > 0 ? A.f32((size_t)rpad(n_miss) * h->kout) : nullptr;
     float* dXh = n_hit > 0 ? A.f32((size_t)rpad(n_hit) * 128) : nullptr;
     float* dXhum = hum ? A.f32((size_t)rpad(n_miss) * 24) : nullptr;
@@ -201,6 +229,8 @@ int do_shade_bwd(nero_stage2* h, Arena& A, const float* d_rgb, const float* d_dl
                                hum ? h->f_hum.heads[3] : nullptr, h->hmask, c.light_exp_max, c.inner_light_exp_max, P, Dd, Ds, c.geometry_type,
                                d_rgb, d_dl, d_or, d_ir, d_hr, d_mat5, d_w, stream));
     const float* hd[MAXL] = {};
+    // the hit branch (inner light) starts behind the estimator's backward, beside the miss branch
+    const hipStream_t side = (n_miss > 0 && n_hit > 0) ? fork_side(h, A, hs) : hs;
     if (n_miss > 0) {
         size_t mk = A.mark();
         predictor_grads(h->outer_light, g + M_OUTER, h->kout);
@@ -208,25 +238,27 @@ int do_shade_bwd(nero_stage2* h, Arena& A, const float* d_rgb, const float* d_dl
         Bwd ob;
         RC(h->outer_light.backward(A, h->M, h->f_out, n_miss, nullptr, 0, hd, true, false, nullptr, dXm, h->kout, false, false, ob, stream));
         RC(h->outer_light.weight_grads(A, h->M, h->f_out, ob, n_miss, h->Xm, h->kout, nullptr, 0, hd, nullptr, nullptr, partials, stream));
-        A.release(mk);
+        if (!two) A.release(mk);                           // (concurrent branches carve on while these deltas are still read)
         if (hum) {
             predictor_grads(h->human_light, g + M_HUMAN, 24);
             hd[3] = d_hr;
             Bwd hb;
             RC(h->human_light.backward(A, h->M, h->f_hum, n_miss, nullptr, 0, hd, true, false, nullptr, dXhum, 24, false, false, hb, stream));
             RC(h->human_light.weight_grads(A, h->M, h->f_hum, hb, n_miss, h->Xhum, 24, nullptr, 0, hd, nullptr, nullptr, partials, stream));
-            A.release(mk);
+            if (!two) A.release(mk);
         }
     }
     if (n_hit > 0) {
         const size_t mk = A.mark();
         predictor_grads(h->inner_light, g + M_INNER, 123);
-        hd[3] = d_ir;
+        const float* hdh[MAXL] = {};
+        hdh[3] = d_ir;
         Bwd ib;
-        RC(h->inner_light.backward(A, h->M, h->f_in, n_hit, nullptr, 0, hd, true, false, nullptr, dXh, 128, false, false, ib, stream));
-        RC(h->inner_light.weight_grads(A, h->M, h->f_in, ib, n_hit, h->Xh, 128, nullptr, 0, hd, nullptr, nullptr, partials, stream));
-        A.release(mk);
+        RC(h->inner_light.backward(A, h->M, h->f_in, n_hit, nullptr, 0, hdh, true, false, nullptr, dXh, 128, false, false, ib, (void*)side));
+        RC(h->inner_light.weight_grads(A, h->M, h->f_in, ib, n_hit, h->Xh, 128, nullptr, 0, hdh, nullptr, nullptr, partials_h, (void*)side));
+        if (!two) A.release(mk);
     }
+    if (!A.dry) join_side(h, side, hs);
     LAUNCH(nero_mc_dir_bwd(h->pt, h->dirs, h->fnrm, h->slot, h->tab_s, dXm, dXh, d_w, P, Dd, Ds, d_mat5, c.sphere_direction, dXhum, h->poses, stream));
     return nero_check_launch("nero_stage2_shade_bwd");
 }
@@ -247,11 +279,26 @@ int nero_stage2_create(const nero_stage2_cfg* cfg, nero_stage2** out) {
     nero_stage2_weights zero;
     memset(&zero, 0, sizeof(zero));
     build_chains(h, &zero);
+    const char* e = getenv("NERO_STREAMS");
+    h->n_streams = e ? atoi(e) : NERO_STREAMS_DEFAULT;
+    if (h->n_streams >= 2) {
+        if (hipStreamCreateWithFlags(&h->s2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();             // (no device in reach -- the size queries still work -- or out of handles: one stream)
+            h->s2 = nullptr;
+        }
+    }
     *out = h;
     return NERO_OK;
 }
 
-void nero_stage2_destroy(nero_stage2* h) { delete h; }
+void nero_stage2_destroy(nero_stage2* h) {
+    if (!h) return;
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->s2) (void)hipStreamDestroy(h->s2);
+    delete h;
+}
 
 size_t nero_stage2_pack_bytes(nero_stage2* h) { return h ? pack_floats_total(h) * 4 : 0; }
 

@@ -49,7 +49,7 @@ def test_workspace_query_runs_without_a_gpu_and_scales():
     assert w4096 > 7 * w512 > 0
     # the bound covers any actual split; a typical C2 step (73 inner samples per ray) needs less than half of it
     typical = lib.nero_stage1_workspace_bytes_for(h, 4096, 4096 * 73, 4096 * 87, 1)
-    assert typical < 0.6 * w4096
+    assert typical < 0.7 * w4096          # (round 4: the two branches of a step carve side by side -- the typical case keeps more alive, the bound shrank with the injections)
     assert lib.nero_stage1_workspace_bytes_for(h, 4096, 4096 * 160, 0, 1) <= w4096
     # ~90 KB of saved state per inner sample -> tens of GB at 4096 rays, well inside 288 GB
     assert 10e9 < typical < 60e9, typical

@@ -40,7 +40,7 @@ def test_stage2_workspace_query_without_a_gpu():
     w_bell, w_bear = lib.nero_stage2_workspace_bytes(hs[0], 8192, 4096), lib.nero_stage2_workspace_bytes(hs[1], 8192, 4096)
     # 1.05 M light rows x (3 saved layers + 3 deltas + encodings) ~ 10 GB; the human-light MLP adds its share
     assert 4e9 < w_bell < 30e9 and w_bear > w_bell, (w_bell, w_bear)
-    assert lib.nero_stage2_workspace_bytes(hs[0], 1024, 512) < w_bell / 6
+    assert lib.nero_stage2_workspace_bytes(hs[0], 1024, 512) < w_bell / 5          # (fixed part: three 272 MB partial-sum buffers)
     assert lib.nero_stage2_pack_bytes(hs[1]) > lib.nero_stage2_pack_bytes(hs[0]) > 8e6
     bad = S2.Cfg(128, 128, 0, 0, 7, 5.0, 5.0, 2, 2, 2)
     h = C.c_void_p()
