@@ -57,7 +57,7 @@ def hbm_traffic_per_launch(kernel, prefix='hbm_traffic_per_kernel'):
     """average HBM bytes per launch of `kernel` from the newest committed PMC summary (scripts/prof_traffic.sh), or None.
     -> (bytes, description of the source incl. the commit / library hash the counters were taken on and whether that library is
     the one running now)"""
-    for rnd in ('r03', 'r02', 'r01'):
+    for rnd in ('r04', 'r03', 'r02', 'r01'):
         name = f'{rnd}_{prefix}.csv'
         try:
             lines = open(os.path.join(ROOT, 'profiles', name)).read().splitlines()
@@ -95,7 +95,13 @@ def mfma_busy_of(kernel):
                 cyc += n * cycles * 1024.0
     if cyc <= 0:
         return None
-    return {'frac': round(busy / cyc, 4), 'source': os.path.relpath(paths[-1], ROOT) + ' (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES)'}
+    # (the counters describe the build they were taken on: say whether that is the library running now, as for the traffic counters)
+    with open(paths[-1]) as f:
+        stamp = next((ln[1:].strip() for ln in f if ln.startswith('# taken on')), 'taken on: not recorded')
+    cur = lib_sha12()
+    same = cur is not None and cur in stamp
+    return {'frac': round(busy / cyc, 4), 'source': os.path.relpath(paths[-1], ROOT) + ' (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES)',
+            'taken_on': stamp, 'library_now': cur, 'same_build': bool(same)}
 
 
 def cpu_baseline(cfg, variance, step, rays=512, budget_s=15.0, max_steps=10):
