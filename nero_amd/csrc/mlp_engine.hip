@@ -909,13 +909,15 @@ int nero_mlp_backward(const nero_bwd_chain* ch, int n_rows, void* stream) {
 }
 
 // the batching policy of nero_dw_gemm_batch (shared with the workspace query below)
-struct DwBatchPolicy { int rows, big_total, big_group; };
+struct DwBatchPolicy { int rows, big_total, big_group, small_total; };
 static const DwBatchPolicy& dw_batch_policy() {
-    static DwBatchPolicy P = {-1, 256, 8};
+    static DwBatchPolicy P = {-1, 256, 8, 256};
     if (P.rows < 0) {
         const char* e = getenv("NERO_DW_BATCH_ROWS"); P.rows = e ? atoi(e) : DW_BATCH_ROWS;
         e = getenv("NERO_DW_BATCH_TOTAL"); if (e) P.big_total = atoi(e);
         e = getenv("NERO_DW_BATCH_GROUP"); if (e) P.big_group = atoi(e);
+        e = getenv("NERO_DW_SMALL_TOTAL"); if (e) P.small_total = atoi(e);
+        P.small_total = P.small_total < 64 ? 64 : (P.small_total > 1024 ? 1024 : P.small_total);
         P.big_group = P.big_group < 0 ? 0 : (P.big_group > NERO_DW_BATCH_MAX ? NERO_DW_BATCH_MAX : P.big_group);
         P.big_total = P.big_total < 16 ? 16 : (P.big_total > 1024 ? 1024 : P.big_total);
     }
@@ -973,7 +975,10 @@ int nero_dw_gemm_batch(const nero_dw_job* jobs, int n_jobs, int n_rows, float* p
         f16 = f16 && J.gemm_mode == NERO_GEMM_F16X3;
     }
     // Two batching regimes (both: blockIdx.y = job, one reduction launch per group).  Below DW_BATCH_ROWS rows a job alone neither fills
-    // the chip nor amortises its partial matrices: ~1024 slices over groups of up to NERO_DW_BATCH_MAX jobs.  At or above it (round 4) the
+    // the chip nor amortises its partial matrices: groups of up to NERO_DW_BATCH_MAX jobs, and -- round 4 -- 256 slices over the whole
+    // group here too (it was ~1024: at the reference's 512-ray batch the partial matrices and their reduction cost more than the rows they
+    // cover; 6.30 -> 5.95 ms per step at 512 rays, 9.75 -> 8.90 at 1024, Stage II 6.90 -> 6.75; 128 and 64 slices are slower again:
+    // profiles/r04_dw_batch_sweep.txt).  At or above it (round 4) the
     // jobs of a chain still run in groups, of 8, with ONE slice per CU over the whole group (256 slices in all, 32 per job): every
     // workgroup streams ~9 k rows of one job, and the group writes 8 x 32 partial matrices instead of 8 x 256 -- a job alone spent a
     // fifth of its HBM traffic (67 MB written + read back for 610 MB of operands) and ~11 us of dirty-line write-back at the kernel
@@ -983,7 +988,7 @@ int nero_dw_gemm_batch(const nero_dw_job* jobs, int n_jobs, int n_rows, float* p
     const DwBatchPolicy& POL = dw_batch_policy();
     const int batch_rows = POL.rows, big_total = POL.big_total, big_group = POL.big_group;
     const bool big = rows >= batch_rows;
-    const int batch_total = big ? big_total : 1024, batch_group = big ? big_group : NERO_DW_BATCH_MAX;
+    const int batch_total = big ? big_total : POL.small_total, batch_group = big ? big_group : NERO_DW_BATCH_MAX;
     if (!f16 || n_jobs < 2 || batch_group < 1) {                 // the per-job path: one launch (+ reduction) per job
         for (int i = 0; i < n_jobs; ++i) {
             const int rc = nero_dw_gemm(jobs + i, n_rows, partials, stream);
@@ -1002,7 +1007,7 @@ int nero_dw_gemm_batch(const nero_dw_job* jobs, int n_jobs, int n_rows, float* p
             const int ng = n - g0 < batch_group ? n - g0 : batch_group;
             // ~1024 slices over the group's jobs, at least 128 rows (8 chunks) per slice, at most one slice per CU and job
             int target = batch_total / ng;
-            target = target < 16 ? 16 : (target > DW_MAX_SLICES ? DW_MAX_SLICES : target);
+            target = target < 4 ? 4 : (target > DW_MAX_SLICES ? DW_MAX_SLICES : target);
             int rps = (rows + target - 1) / target;
             rps = (rps + 15) / 16 * 16;
             rps = rps < 128 ? 128 : rps;
