@@ -7,6 +7,8 @@
 //           (16 k-steps x [4 weight loads + 4 fragment reads + 12 MFMAs], then ~900 VALU + 32 LDS stores).  Every wave runs the same
 //           sequence GEMM, barrier, epilogue, barrier -- group B one half-step late -- so that in every half-step one wave of a SIMD is in
 //           its GEMM and the other in its epilogue.
+//   MODE 4  "one barrier": MODE 0 with the planes DOUBLE BUFFERED (layer l reads buffer l & 1, its epilogue writes the other) and no
+//           barrier between GEMM and epilogue -- what a block scale known before the GEMM (no row-maximum exchange) would allow.
 //   MODE 2  MODE 1's GEMM alone (no epilogue work): the lone-wave GEMM rate.      MODE 3  MODE 0's GEMM alone.
 // Same arithmetic per tile-layer in all modes (768 MFMAs of v_mfma_f32_32x32x16_f16 per tile and layer: three plane products).
 // hipcc --offload-arch=gfx950 -O3 -o phase_shift_probe phase_shift_probe.hip && ./phase_shift_probe
@@ -89,7 +91,7 @@ template <int MODE>
 __global__ __launch_bounds__(512, 1) void probe(const uint4* W, float* out, int layers) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NF = (MODE == 1 || MODE == 2) ? 2 : 1;
-    constexpr bool EPI = MODE <= 1;
+    constexpr bool EPI = MODE <= 1 || MODE == 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), i = lane & 31, h = lane >> 5;
     for (int idx = tid; idx < 2 * TILE / 16; idx += 512) {          // pseudo-random fp16 planes (realistic toggling)
         unsigned s0 = (blockIdx.x * 9781u + idx) * 2654435761u;
@@ -113,6 +115,12 @@ __global__ __launch_bounds__(512, 1) void probe(const uint4* W, float* out, int 
 #pragma unroll
                 for (int v = 0; v < 16; ++v) { aH[f][r][v] = 0.f; aL[f][r][v] = 0.f; }
         const uint4* wp = W + ((size_t)(l & 7) * 8 + ft0) * 16 * 128 + lane;
+        if (MODE == 4) {
+            gemm<NF>(aH, aL, wp, (size_t)16 * 128, xp + (l & 1) * TILE);
+            s += epilogue(aH[0], aL[0], dst + ((l + 1) & 1) * TILE, 0.01f * l);
+            __syncthreads();
+            continue;
+        }
         gemm<NF>(aH, aL, wp, (size_t)16 * 128, xp);
         __syncthreads();                                           // (lock step: every wave is done reading the planes)
         if (EPI) {
@@ -158,5 +166,6 @@ int main() {
     run<2>("two tiles, GEMM only (4 + 4 waves x 2 feature tiles)", W, out);
     run<0>("lock step: GEMM, epilogue, 2 barriers (today)", W, out);
     run<1>("phase shifted: GEMM || epilogue of the other tile", W, out);
+    run<4>("one barrier per layer, planes double buffered", W, out);
     return 0;
 }
