@@ -66,7 +66,8 @@ def hbm_traffic_per_launch(kernel, prefix='hbm_traffic_per_kernel'):
         stamp = next((ln[1:].strip() for ln in lines if ln.startswith('# taken on')), 'taken on: not recorded (round <= 2 summary)')
         for line in lines:
             f = line.strip().split(',')
-            if len(f) in (5, 6) and f[0] == kernel:      # kernel, launches, fetch_kb_raw, fetch_kb (x2 corrected), write_kb[, gb_per_step]
+            # (round 4 launches the weight-gradient jobs in groups: `dw_f16_kernel`'s counters are under `dw_f16_batch_kernel`)
+            if len(f) in (5, 6) and f[0] in (kernel, kernel.replace('_kernel', '_batch_kernel')):      # kernel, launches, fetch_kb_raw, fetch_kb (x2 corrected), write_kb[, gb_per_step]
                 cur = lib_sha12()
                 same = (cur is not None and cur in stamp)
                 return int((float(f[3]) + float(f[4])) * 1024), (f'profiles/{name}: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, '
@@ -85,7 +86,7 @@ def mfma_busy_of(kernel):
     busy = cyc = 0.0
     with open(paths[-1]) as f:
         for line in f:
-            if line.startswith(kernel):
+            if line.startswith(kernel) or line.startswith(kernel.replace('_kernel', '_batch_kernel')):
                 p = line.rstrip().rsplit(',', 6)
                 try:
                     n, cycles, mb = float(p[1]), float(p[2]), float(p[3])
