@@ -2,9 +2,14 @@
 // 8 waves per workgroup, one workgroup per CU: waves 0-3 (one per SIMD) issue NM back-to-back v_mfma_f32_32x32x16_f16 on four independent
 // accumulators; waves 4-7 (the second wave of each SIMD) issue NV VALU instructions (v_fma_f32 or v_pk_fma_f32 on 8 independent chains).
 // Timed alone and together: together ~ max(alone) = the pipes overlap; together ~ sum = they exclude each other.
-// hipcc --offload-arch=gfx950 -O3 -o coissue_probe coissue_probe.hip && ./coissue_probe
+// CAUTION (found later the same round): under plain -O3 hipcc SLP-packs the eight independent fmaf chains of KIND 0 into v_pk_fma_f32, so
+// rows 0 and 1 both measure the PACKED instruction -- which never overlaps MFMAs -- and at 256 workgroups the MFMA stream alone is already
+// power-limited (51 cycles per MFMA instead of 32).  coissue_kinds_probe.hip pins one instruction per row with inline asm and takes the
+// workgroup count as an argument; read its numbers, not this file's, for "what overlaps".
+// hipcc --offload-arch=gfx950 -O3 -o coissue_probe coissue_probe.hip && ./coissue_probe [workgroups]
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -62,19 +67,22 @@ __global__ __launch_bounds__(512, 1) void k(int nm, int nv, float* out) {
     }
     if (r == 12345.678f) out[threadIdx.x] = r;
 }
+static int g_grid = 256;                         // workgroups = CUs kept busy (argv[1]): 256 = the whole chip (power-limited clocks), 8 = a cold chip
 template <int KIND>
 float timeit(int nm, int nv, float* out) {
     hipFuncSetAttribute((const void*)k<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    k<KIND><<<256, 512, 100 * 1024>>>(nm, nv, out);
+    k<KIND><<<g_grid, 512, 100 * 1024>>>(nm, nv, out);
     hipDeviceSynchronize();
     hipEventRecord(a);
-    k<KIND><<<256, 512, 100 * 1024>>>(nm, nv, out);
+    k<KIND><<<g_grid, 512, 100 * 1024>>>(nm, nv, out);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
     return ms;
 }
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) g_grid = atoi(argv[1]);
+    printf("== %d workgroups (one per CU)\n", g_grid);
     float* out; hipMalloc(&out, 4096);
     const int NM = 200000;                       // MFMAs per wave: 200000 x 32 cycles = 6.4 M cycles
     const char* names[3] = {"v_fma_f32", "v_pk_fma_f32", "cvt_pk_f16 + cvt_f32_f16 + mul + max mix"};

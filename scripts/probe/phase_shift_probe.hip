@@ -14,6 +14,7 @@
 // hipcc --offload-arch=gfx950 -O3 -o phase_shift_probe phase_shift_probe.hip && ./phase_shift_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -135,9 +136,10 @@ __global__ __launch_bounds__(512, 1) void probe(const uint4* W, float* out, int 
     if (NF == 2 && group == 0) __syncthreads();
     if (s == 12345.678f) out[tid] = s;
 }
+static int g_wgs = 1024;                         // workgroups (argv[1]): 1024 = four rounds over all 256 CUs (the loaded chip), 32 = one workgroup on 32 CUs (a cold chip)
 template <int MODE>
 void run(const char* name, const uint4* W, float* out) {
-    const int layers = 64, grid = 256 * 4, lds = 2 * TILE;         // 135 KB: one workgroup per CU in every mode
+    const int layers = 64, grid = g_wgs, lds = 2 * TILE;         // 135 KB: one workgroup per CU in every mode
     hipFuncSetAttribute((const void*)probe<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     probe<MODE><<<grid, 512, lds>>>(W, out, layers);
@@ -147,11 +149,14 @@ void run(const char* name, const uint4* W, float* out) {
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b); ms /= 3;
     const double tile_layers = (double)grid * layers * ((MODE == 1 || MODE == 2) ? 2 : 1);
-    const double us = ms * 1e3 / (tile_layers / 256.0);
+    const double rounds = (g_wgs + 255) / 256;                       // workgroups a CU runs one after the other
+    const double us = ms * 1e3 / (rounds * layers * ((MODE == 1 || MODE == 2) ? 2 : 1));
     printf("%-52s %8.3f ms  %6.2f us per tile-layer per CU  %6.1f TFLOP/s fp32-equivalent (x3 issued)\n", name, ms, us,
            tile_layers * 64.0 * 256 * 256 * 2 / (ms * 1e-3) / 1e12);
 }
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) g_wgs = atoi(argv[1]);
+    printf("== %d workgroups (one per CU at a time)\n", g_wgs);
     uint4* W; float* out;
     const size_t wn = (size_t)8 * 8 * 16 * 128 * 4;      // dwords: 8 layers x 8 feature tiles x 16 k-steps x (64 lanes x 2 planes) uint4
     hipMalloc(&W, wn * 4);
