@@ -380,6 +380,32 @@ int nero_mat_loss_fwd(const nero_mat_loss_cfg* cfg, int P, int has_reg, const fl
                       float* rgb_pr, float* partials, float* loss, void* stream);
 int nero_mat_loss_bwd(const nero_mat_loss_cfg* cfg, int P, int has_reg, const float* mat, const float* rgb_lin, const float* dl, const float* gt,
                       const float* grad_out, float* d_mat, float* d_rgb_lin, float* d_dl, void* stream);
+/* ---- Stage-I training glue (nero_amd/csrc/step_glue.hip): what NeROShapeRenderer.train_step / the trainer do BETWEEN the render calls,
+ *      as a handful of launches and without a second host read-back.  Replaces, per step: near_far_from_sphere
+ *      (network/renderer.py:231-238), the candidate subset of compute_occ_loss (network/renderer.py:528-541: mask -> nonzero ->
+ *      random subset of occ_loss_max_pn), compute_rgb_loss + the means of loss_rgb / loss_eikonal / loss_occ and their sum
+ *      (network/renderer.py:332-343, network/loss.py:8-55, train/trainer.py:127-137) and autograd's seeds for the render backward.
+ * nero_occ_select: flag [n] (nero_occ_candidates) -> counts = (kept = min(total, cap), total); cand [cap] = the sample indices of the
+ *   kept candidates in ascending order, -1 in unused slots.  Above the cap the kept ones are the `cap` smallest keys[ordinal]
+ *   (ordinal = rank of the candidate among the candidates; ties to the lower ordinal): argsort(keys[:total], stable)[:cap], sorted.
+ *   Nothing is read back: every launch covers the worst case n.  ws: nero_occ_select_workspace(n) bytes.
+ * nero_occ_gather: pts / dirs [cap,3] = x4[cand, 0:3] / geo[cand, 4:7] (the reflected direction); unused slots: origin, +z.
+ * nero_shape_loss: losses [4] = (total, mean loss_rgb, eik_weight * mean(gerr) * w[0], L1(occ_prob[cand], gt_occ) * w[1]);
+ *   d_rgb [R,3], d_gerr [n_in], d_occ [n_in] (zero except at the kept candidates) = d total / d (ray_rgb, gradient_error, occ_prob).
+ *   cand = NULL: no occlusion term (d_occ may be NULL).  weights: device [2] (data-parallel count weights) or NULL = (1, 1).
+ *   partials: nero_shape_loss_partials(R, n_in) floats.
+ * nero_var_grad: grad[0] = dsum[0] * 10 * inv_s * [1e-6 <= inv_s <= 1e6], inv_s = exp(10 variance[0])  (std_act 'exp'). */
+enum { NERO_RGB_L2 = 0, NERO_RGB_L1 = 1, NERO_RGB_SMOOTH_L1 = 2, NERO_RGB_CHARBONIER = 3 };
+int nero_near_far_sphere(const float* o, const float* d, int R, float* near, float* far, void* stream);
+size_t nero_occ_select_workspace(int n);
+int nero_occ_select(const unsigned char* flag, int n, const float* keys, int cap, int* cand, int* counts, void* ws, size_t ws_bytes,
+                    void* stream);
+int nero_occ_gather(const float* x4, const float* geo, const int* cand, int cap, float* pts, float* dirs, void* stream);
+int nero_shape_loss_partials(int R, int n_in);
+int nero_shape_loss(int R, int rgb_kind, const float* rgb, const float* gt, int n_in, const float* gerr, float eik_weight,
+                    const float* occ_prob, const int* cand, const int* counts, const float* gt_occ, const float* weights, float* losses,
+                    float* d_rgb, float* d_gerr, float* d_occ, float* partials, void* stream);
+int nero_var_grad(const float* dsum, const float* variance, float* grad, void* stream);
 int nero_mc_dirs(const float* pt, const float* tab_d, const float* tab_s, int P, int Dd, int Ds, float* dirs, float* origins, void* stream);
 /* sphere != 0 ('sphere_direction'): X [rows,144] = [IDE(w,0) | IDE(unit-sphere exit point,0)], else X [rows,72] */
 int nero_mc_encode_miss(const float* dirs, const int* idx, const float* pt, int D, int sphere, int n, float* X, void* stream);

@@ -108,7 +108,11 @@ def device_count_weights(local_counts, world, device, group=None):
     for it on the host (the blocking .tolist() cost one host round trip per step and rank on the DP path)."""
     if world <= 1 and not (group is None and FORCE_COLLECTIVES and dist.is_available() and dist.is_initialized()):
         return torch.ones(len(local_counts), dtype=torch.float32, device=device)
-    loc = torch.tensor([float(c) for c in local_counts], dtype=torch.float64, device=device)
+    if any(torch.is_tensor(c) for c in local_counts):          # (a count that lives on the device -- the occlusion-loss candidates of the HIP-glued step)
+        loc = torch.stack([c.reshape(()).to(device=device, dtype=torch.float64) if torch.is_tensor(c)
+                           else torch.tensor(float(c), dtype=torch.float64, device=device) for c in local_counts])
+    else:
+        loc = torch.tensor([float(c) for c in local_counts], dtype=torch.float64, device=device)
     tot = loc.clone()
     _all_reduce_sum(tot, group)
     w = torch.where(tot > 0, loc * float(world) / tot.clamp(min=1.0), torch.ones_like(loc))
@@ -118,6 +122,11 @@ def device_count_weights(local_counts, world, device, group=None):
 # set by bench.py when it runs as ONE rank under torch.distributed.run: the collectives of the data-parallel path (count weights, the
 # flat gradient all-reduce) are then issued although world == 1, so that the N = 1 point of a scaling run exercises the RCCL code path
 FORCE_COLLECTIVES = False
+
+
+def parallel_forced():
+    """True when the collectives of the data-parallel path are issued although world == 1 (FORCE_COLLECTIVES under an initialised group)"""
+    return bool(FORCE_COLLECTIVES and dist.is_available() and dist.is_initialized())
 
 
 def per_rank_occ_cap(max_pn, world):

@@ -245,3 +245,115 @@ class RenderCoreC(torch.autograd.Function):
         grads = [fresh.get(name) for name in meta['names']]       # None: written in place into the (pre-zeroed) flat bucket
         ctx.keep = None
         return (None, None, None, None, d_var, None, None) + tuple(grads)
+
+
+# ---- the training glue between the driver calls (nero_amd/csrc/step_glue.hip) ---------------------------------------------------------
+_lib.nero_occ_select_workspace.restype = C.c_size_t
+_lib.nero_occ_select_workspace.argtypes = [C.c_int]
+_lib.nero_near_far_sphere.argtypes = [_fp, _fp, C.c_int, _fp, _fp, _fp]
+_lib.nero_occ_select.argtypes = [_fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp, C.c_size_t, _fp]
+_lib.nero_occ_gather.argtypes = [_fp, _fp, _fp, C.c_int, _fp, _fp, _fp]
+_lib.nero_shape_loss_partials.argtypes = [C.c_int, C.c_int]
+_lib.nero_shape_loss.argtypes = [C.c_int, C.c_int, _fp, _fp, C.c_int, _fp, C.c_float] + [_fp] * 11
+_lib.nero_var_grad.argtypes = [_fp, _fp, _fp, _fp]
+_lib.nero_occ_candidates.argtypes = [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_float, C.c_int, _fp, _fp]
+RGB_LOSS_KIND = {'l2': 0, 'l1': 1, 'smooth_l1': 2, 'charbonier': 3}          # include/nero_hip.h NERO_RGB_*
+
+
+class ShapeStepGlue:
+    """One Stage-I training step (world-local part: render forward, the three loss terms, render backward into the flat gradient bucket)
+    with the driver calls glued by nero_amd/csrc/step_glue.hip instead of torch: near / far, the occlusion-loss candidate subset chosen
+    ON THE DEVICE (fixed-capacity march, no read-back of the candidate count), loss + backward seeds in two launches.  Same arithmetic
+    as NeROShapeRenderer.render(is_train=True) + nero_amd.train.shape_training_loss + autograd (network/renderer.py:445-463, 522-606,
+    train/trainer.py:127-137) -- tests/test_step_glue.py compares the two paths gradient by gradient.  The one host synchronisation
+    left is the inner / outer sample count inside nero_stage1_render_fwd."""
+
+    def __init__(self, net, drv, grad_views, names):
+        self.net, self.drv = net, drv
+        self.G = Grads()
+        for i in range(drv.n_lin):
+            dW, db = grad_views[names[2 * i]], grad_views[names[2 * i + 1]]
+            assert dW.is_contiguous() and db.is_contiguous()
+            self.G.lin[i].W, self.G.lin[i].b = dW.data_ptr(), db.data_ptr()
+        self._keep = (grad_views, names)
+        self._bufs = {}
+
+    @staticmethod
+    def supported(net):
+        c = net.cfg
+        return c.get('std_act', 'exp') == 'exp' and c['rgb_loss'] in RGB_LOSS_KIND
+
+    def _buffers(self, R):
+        if R not in self._bufs:
+            dev, T, cap = self.drv.device, self.drv.T, int(self.net.cfg['occ_loss_max_pn'])
+            f32, i32 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.int32, device=dev)
+            n = R * T
+            self._bufs[R] = dict(
+                near=torch.empty((R, 1), **f32), far=torch.empty((R, 1), **f32), rgb=torch.empty((R, 3), **f32), gerr=torch.empty(n, **f32),
+                occ=torch.empty(n, **f32), d_rgb=torch.empty((R, 3), **f32), d_gerr=torch.empty(n, **f32), d_occ=torch.empty(n, **f32),
+                flag=torch.empty(n, dtype=torch.uint8, device=dev), cand=torch.empty(cap, **i32), counts=torch.zeros(2, **i32),
+                losses=torch.zeros(4, **f32), partials=torch.empty(_lib.nero_shape_loss_partials(R, n), **f32),
+                pts=torch.empty((cap, 3), **f32), dirs=torch.empty((cap, 3), **f32), dsum=torch.zeros(1, **f32),
+                sel_ws=torch.empty(_lib.nero_occ_select_workspace(n), dtype=torch.uint8, device=dev))
+        return self._bufs[R]
+
+    def forward_backward(self, o, d, gt, poses, step, variance_param, eik_weight, frozen, weights=None, rands=None):
+        """o, d, gt [R,3] (device, fp32), poses [R,3,4] or None.  weights: device float32 [2] (eikonal, occlusion count weights of the
+        data-parallel step) or a callable (n_in, occ_count_tensor) -> such a tensor, or None.  rands: (rand1 [R,1], rand_bg [R,n_bg],
+        occ_keys [>= #candidates][, near, far]) to inject the random draws (tests).  Gradients land in the bucket views given at construction
+        (the bucket must be zero on entry), d loss / d variance in variance_param.grad unless `frozen`.  -> dict(loss = device
+        tensor [4]: total, rgb, eikonal, occlusion; n_in, n_out; occ_counts = device int32 [2] or None)."""
+        from .shape_step import secondary_occlusion
+        net, drv = self.net, self.drv
+        c = net.cfg
+        R, T = o.shape[0], drv.T
+        B = self._buffers(R)
+        st = L.stream_ptr()
+        o, d, gt = o.contiguous(), d.contiguous(), gt.contiguous()
+        if rands is not None and len(rands) > 3:          # (tests hand over the tensor expression's near / far: it differs from the kernel's in the
+            B['near'].copy_(rands[3])                     #  last bit of some rays, and the hierarchical sampler amplifies that)
+            B['far'].copy_(rands[4])
+        else:
+            L.check(_lib.nero_near_far_sphere(_p(o), _p(d), R, _p(B['near']), _p(B['far']), st))
+        var = variance_param.detach()
+        nb = int(c['n_bg_samples'])
+        if c['perturb'] > 0:
+            if rands is not None:
+                rand1, rand_bg = rands[0].contiguous(), rands[1].contiguous()
+            else:
+                rand1 = torch.rand([R, 1], device=o.device)              # (the same two draws, in the same order, as NeROShapeRenderer.render)
+                rand_bg = torch.rand([R, nb], device=o.device)
+        else:
+            rand1 = rand_bg = None
+        z = drv.sample(o, d, B['near'], B['far'], var, rand1, rand_bg)
+        ws = drv.workspace(R)
+        n_in, n_out = C.c_int(0), C.c_int(0)
+        lut = net.color_network.FG_LUT
+        poses_c = poses.to(torch.float32).contiguous() if poses is not None else None
+        L.check(_lib.nero_stage1_render_fwd(drv.h, R, _p(o), _p(d), _p(z), _p(var), _p(lut), _p(poses_c), float(net.get_anneal_val(step)),
+                                            _p(B['rgb']), _p(B['gerr']), _p(B['occ']), C.byref(n_in), C.byref(n_out), ws.data_ptr(), ws.numel(), st))
+        n_in, n_out = n_in.value, n_out.value
+        occ_on = bool(c['apply_occ_loss']) and step >= c['occ_loss_step'] and n_in > 0
+        cand = counts = gt_occ = None
+        if occ_on:
+            s = drv.state()
+            rpi = row_pad(n_in)
+            x4, geo = drv._view(s.x4, (rpi, 4)), drv._view(s.geo, (rpi, 8))
+            L.check(_lib.nero_occ_candidates(s.x4, s.sdf4, s.normal, s.inner_idx, _p(d), T, float(c['occ_sdf_thresh']), n_in, _p(B['flag']), st))
+            keys = rands[2].to(o.device).contiguous() if (rands is not None and rands[2] is not None) else torch.rand(n_in, dtype=torch.float32, device=o.device)
+            assert keys.numel() >= 1
+            cap = B['cand'].numel()
+            L.check(_lib.nero_occ_select(_p(B['flag']), n_in, _p(keys), cap, _p(B['cand']), _p(B['counts']), B['sel_ws'].data_ptr(), B['sel_ws'].numel(), st))
+            L.check(_lib.nero_occ_gather(_p(x4), _p(geo), _p(B['cand']), cap, _p(B['pts']), _p(B['dirs']), st))
+            gt_occ = secondary_occlusion(_KAdapter(drv), B['pts'], B['dirs'], var, 64, 16)
+            cand, counts = B['cand'], B['counts']
+        if callable(weights):
+            weights = weights(n_in, counts)
+        L.check(_lib.nero_shape_loss(R, RGB_LOSS_KIND[c['rgb_loss']], _p(B['rgb']), _p(gt), n_in, _p(B['gerr']), float(eik_weight), _p(B['occ']),
+                                     _p(cand), _p(counts), _p(gt_occ), _p(weights), _p(B['losses']), _p(B['d_rgb']),
+                                     _p(B['d_gerr']) if n_in > 0 else None, _p(B['d_occ']) if occ_on else None, _p(B['partials']), st))
+        L.check(_lib.nero_stage1_render_bwd(drv.h, _p(B['d_rgb']), _p(B['d_gerr']) if n_in > 0 else None, _p(B['d_occ']) if occ_on else None,
+                                            C.byref(self.G), _p(B['dsum']), st))
+        if n_in > 0 and not frozen:
+            L.check(_lib.nero_var_grad(_p(B['dsum']), _p(var), _p(variance_param.grad), st))
+        return {'loss': B['losses'], 'n_in': n_in, 'n_out': n_out, 'occ_counts': counts}

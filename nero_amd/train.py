@@ -10,7 +10,7 @@ import gc
 import torch
 import torch.distributed as dist  # noqa: F401
 
-from .parallel import GradBucket, device_count_weights, per_rank_occ_cap, rank_slice
+from .parallel import GradBucket, device_count_weights, parallel_forced, per_rank_occ_cap, rank_slice
 
 from .renderer import NeROShapeRenderer
 from .synthetic import perturb_state, synthetic_rays
@@ -221,6 +221,7 @@ class ShapeTrainStep:
         # external optimiser
         self.fused = (device != 'cpu') if fused is None else fused
         self.drv = None
+        self._glue_obj = None
         if self.fused:
             self.fopt = FusedShapeOptimizer(self.net, device)
             self.bucket = self.fopt.bucket
@@ -312,13 +313,38 @@ class ShapeTrainStep:
                              step=min(step, net.cfg['occ_loss_step'] - 1))
         return out['ray_rgb']
 
-    def forward_backward(self, step):
-        """render + loss + backward of this rank's slice of the next global batch; gradients land in the flat bucket"""
+    def _glue(self, step):
+        """the HIP-glued step (nero_amd.stage1.ShapeStepGlue) when the C driver runs the render: default engines, schedule step >= 1000,
+        std_act 'exp', a known rgb_loss; NERO_STEP_GLUE=torch keeps the tensor glue (net.render + shape_training_loss + autograd)"""
+        import os
+        from . import stage1
+        if not (self.fused and self.drv is not None and step >= 1000 and self.drv.matches_current_modes()
+                and stage1.ShapeStepGlue.supported(self.net) and os.environ.get('NERO_STEP_GLUE', 'hip') != 'torch'):
+            return None
+        if self._glue_obj is None:
+            self._glue_obj = stage1.ShapeStepGlue(self.net, self.drv, self.fopt.grad_views, self.fopt.names)
+        return self._glue_obj
+
+    def forward_backward(self, step, rands=None):
+        """render + loss + backward of this rank's slice of the next global batch; gradients land in the flat bucket.
+        rands = (rand1 [R,1], rand_bg [R,n_bg], occ_keys) injects the random draws (tests)."""
         net = self.net
         self.bucket.zero()
         o, d, gt = self._batch()
+        glue = self._glue(step)
+        if glue is not None:
+            self.fopt.reparametrise()
+            self.drv.pack([t.detach() for t in self.fopt.eff])
+            c = net.cfg
+            frozen = c['freeze_inv_s_step'] is not None and step < c['freeze_inv_s_step']
+            # data parallel: the count weights of the eikonal / occlusion means (SURVEY.md 8e) from device-side counts, no host stall
+            wfn = (lambda n_in, counts: device_count_weights([n_in, counts[0] if counts is not None else 0], self.world, self.device)) \
+                if (self.world > 1 or parallel_forced()) else None
+            r = glue.forward_backward(o, d, gt, self._hp, step, net.deviation_network.variance, self.eik_w, frozen, wfn, rands)
+            return {'loss': r['loss'][0], 'n_in': r['n_in'], 'n_out': r['n_out'], 'loss_terms': r['loss']}
         near, far = net.near_far_from_sphere(o, d)
-        out = net.render(o, d, near, far, self._hp, -1, net.get_anneal_val(step), is_train=True, step=step, **self._render_args(step))
+        extra = {} if rands is None else dict(rand1=rands[0], rand_bg=rands[1], occ_keys=rands[2])
+        out = net.render(o, d, near, far, self._hp, -1, net.get_anneal_val(step), is_train=True, step=step, **self._render_args(step), **extra)
         # data parallel: the eikonal mean runs over each rank's own inner samples and the occlusion loss over its own candidate
         # set -> weight both by their global counts so that N ranks reproduce the single-process means (SURVEY.md 8e)
         w_eik, w_occ = device_count_weights([out['_state']['n_in'], out.get('_occ_count', 0)], self.world, self.device)

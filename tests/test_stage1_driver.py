@@ -80,6 +80,9 @@ def test_c_driven_step_equals_python_driven_step_bit_for_bit(kind, rays, monkeyp
     from nero_amd.train import ShapeTrainStep
     cfg = dict(CFG) if kind == 'bell' else {**CFG, 'shader_config': {'human_light': True}}
     res = {}
+    # (the tensor glue on both sides: the HIP glue -- tests/test_step_glue.py -- draws its occlusion keys for every inner sample, the
+    #  tensor glue only when the candidates exceed the cap, so the two consume the generator differently)
+    monkeypatch.setenv('NERO_STEP_GLUE', 'torch')
     for drv in ('py', 'c'):
         monkeypatch.setenv('NERO_STEP_DRIVER', drv)
         torch.manual_seed(0)
