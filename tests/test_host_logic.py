@@ -223,6 +223,9 @@ def test_forced_collectives_run_at_world_one_and_device_count_weights_match_the_
         assert torch.equal(b.flat, want)
         w = parallel.device_count_weights([1234, 0], 1, 'cpu')
         assert w.dtype == torch.float32 and w.tolist() == [1.0, 1.0]
+        # a count that lives on the device (the occlusion-loss candidates of the HIP-glued step, an int32 element) beside a host count
+        w = parallel.device_count_weights([1234, torch.tensor([7, 99], dtype=torch.int32)[0]], 1, 'cpu')
+        assert w.dtype == torch.float32 and w.tolist() == [1.0, 1.0] and parallel.parallel_forced()
         parallel.FORCE_COLLECTIVES = False
         assert parallel.device_count_weights([10, 3], 1, 'cpu').tolist() == parallel.global_count_weights([10, 3], 1, 'cpu')
     finally:
