@@ -341,7 +341,8 @@ class ShapeTrainStep:
             wfn = (lambda n_in, counts: device_count_weights([n_in, counts[0] if counts is not None else 0], self.world, self.device)) \
                 if (self.world > 1 or parallel_forced()) else None
             r = glue.forward_backward(o, d, gt, self._hp, step, net.deviation_network.variance, self.eik_w, frozen, wfn, rands)
-            return {'loss': r['loss'][0], 'n_in': r['n_in'], 'n_out': r['n_out'], 'loss_terms': r['loss']}
+            # ('loss' is a copy: the glue's loss buffer is rewritten by the next step; 'loss_terms' -- total, rgb, eikonal, occlusion -- is that buffer)
+            return {'loss': r['loss'][0].clone(), 'n_in': r['n_in'], 'n_out': r['n_out'], 'loss_terms': r['loss']}
         near, far = net.near_far_from_sphere(o, d)
         extra = {} if rands is None else dict(rand1=rands[0], rand_bg=rands[1], occ_keys=rands[2])
         out = net.render(o, d, near, far, self._hp, -1, net.get_anneal_val(step), is_train=True, step=step, **self._render_args(step), **extra)

@@ -149,3 +149,16 @@ def test_glued_step_matches_the_tensor_glue(case, monkeypatch):
     # and the optimiser takes it from there
     ts.step(step + 1)
     torch.cuda.synchronize()
+
+
+def test_returned_loss_does_not_alias_the_glue_buffer():
+    """two steps: the first step's `loss` keeps its value after the second step rewrote the glue's loss buffer (scripts/soak.py stacks
+    the losses of hundreds of steps)"""
+    from nero_amd.train import ShapeTrainStep
+    ts = ShapeTrainStep({}, rays_per_rank=128, pool_rays=512, device='cuda', variance=0.5, prime_fraction=0.0, prime_passes=0)
+    a = ts.step(25000)
+    va = float(a['loss'])
+    b = ts.step(25001)
+    torch.cuda.synchronize()
+    assert 'loss_terms' in a and float(a['loss']) == va and float(b['loss']) != va
+
