@@ -162,3 +162,31 @@ def test_returned_loss_does_not_alias_the_glue_buffer():
     torch.cuda.synchronize()
     assert 'loss_terms' in a and float(a['loss']) == va and float(b['loss']) != va
 
+
+@pytest.mark.parametrize('case', ['all_rays_miss_the_sphere', 'ragged_65_rays_some_missing'])
+def test_glued_step_edge_batches(case, monkeypatch):
+    """no inner sample at all (every ray passes the unit sphere at distance > 1: no SDF rows, no eikonal term, no occlusion candidates)
+    and a ragged batch mixing such rays with ordinary ones: the glued step equals the tensor-glued step there too"""
+    from nero_amd.train import ShapeTrainStep
+    R = 64 if case.startswith('all') else 65
+    ts = ShapeTrainStep({'occ_loss_max_pn': 50}, rays_per_rank=R, pool_rays=2 * R, device='cuda', variance=0.5, prime_fraction=0.0, prime_passes=0)
+    o, d = ts.pool['o'], ts.pool['d']
+    miss = torch.ones(o.shape[0], dtype=torch.bool, device='cuda') if case.startswith('all') else (torch.arange(o.shape[0], device='cuda') % 3 == 0)
+    # move the origin of the chosen rays sideways by 3: their closest approach to the centre is then > 1
+    side = torch.nn.functional.normalize(torch.cross(d, torch.tensor([[0.3, -0.5, 0.8]], device='cuda').expand_as(d), dim=-1), dim=-1)
+    ts.pool['o'] = torch.where(miss[:, None], o + 3.0 * side, o).contiguous()
+    g = torch.Generator().manual_seed(4)
+    c = ts.net.cfg
+    rands = (torch.rand(R, 1, generator=g).cuda(), torch.rand(R, c['n_bg_samples'], generator=g).cuda(), torch.rand(R * 160, generator=g).cuda())
+    res = {}
+    for mode in ('torch', 'hip'):
+        monkeypatch.setenv('NERO_STEP_GLUE', mode)
+        ts.cursor = 0
+        info = ts.forward_backward(25000, rands)
+        torch.cuda.synchronize()
+        res[mode] = (float(info['loss']), info['n_in'], info['n_out'], ts.bucket.flat.clone())
+    (lt, nit, not_, gt_), (lh, nih, noh, gh) = res['torch'], res['hip']
+    assert (nit, not_) == (nih, noh) and (nit == 0) == case.startswith('all') and not_ > 0
+    assert abs(lt - lh) <= 2e-6 * max(1.0, abs(lt)) and lt == lt
+    assert float((gt_ - gh).abs().max()) <= 1e-5 * float(gt_.abs().max()) + 1e-12
+
