@@ -12,9 +12,11 @@ fused Adam.  Weak scaling: 4096 rays per rank.  Inputs are resident in HBM (devi
 
 Besides the contract fields the line carries: `roofline` (dominant MFMA kernel, live HIP-event timing), `protocol_8d` (SURVEY.md
 8d: median of >= 50 steps after >= 10 warm-up), `forward_only`, `f32_mfma_engine`, `stage2` (BASELINE configs[3]: P = 4096 surface
-points x 128+128 and the YAML default 512+256 MC directions), `torch_gpu_baseline` (the same algorithm as plain PyTorch ops on
-the same MI355X: the ">= 10x reference single-GPU PyTorch" yard-stick of north_star; the reference itself cannot travel to the GPU
-box) and `cpu_baseline` (the oracle on the host cores).  The two baselines are the only places that touch oracle/.
+points x 128+128 and the YAML default 512+256 MC directions), `reference_gpu_baseline` + `x_reference_gpu` (the UNMODIFIED reference
+-- oracle/_ref/, packaged by oracle/make_ref.py -- timed on the same MI355X by oracle/run_ref.py: the ">= 10x reference single-GPU
+PyTorch" yard-stick of north_star), `torch_gpu_baseline` (our torch port of the same algorithm, same GPU), and `cpu_baseline` (kind
+"reference": the unmodified reference on this box's host cores, the port beside it).  The baseline legs are the only places that
+touch oracle/.
 """
 import argparse
 import glob
@@ -137,6 +139,35 @@ def cpu_baseline(cfg, variance, step, rays=512, budget_s=15.0, max_steps=10):
     return {'value': rays * n / dt, 'unit': 'rays/s', 'cores': cores, 'kind': 'port',
             'sample': f'{rays} rays x (64+64+32) samples, oracle (torch-CPU port of the reference path) forward+loss+backward, '
                       f'{n} step(s), {dt:.1f} s'}
+
+
+def run_reference(device, rays, samples, warmup, steps, threads=0, budget_s=0.0, timeout=900):
+    """oracle/run_ref.py in a subprocess: the UNMODIFIED reference (oracle/_ref/, packaged by oracle/make_ref.py in the build container;
+    it rides along to the GPU box like the built .so) timed on this box.  -> its JSON record, {'ok': False, 'error': ...} verbatim when it
+    fails, or None when oracle/_ref/ is not there (then the baselines below fall back to the port and say so)."""
+    ref_dir = os.path.join(ROOT, 'oracle', '_ref')
+    if not os.path.exists(os.path.join(ref_dir, 'nero_ref.zip')):
+        return None
+    cmd = [sys.executable, os.path.join(ROOT, 'oracle', 'run_ref.py'), '--device', device, '--rays', str(rays), '--samples', *map(str, samples),
+           '--warmup', str(warmup), '--steps', str(steps), '--variance', str(VARIANCE)]
+    if threads:
+        cmd += ['--threads', str(threads)]
+    if budget_s:
+        cmd += ['--budget-s', str(budget_s)]
+    env = dict(os.environ, NERO_REFERENCE_ROOT=ref_dir)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'TORCHELASTIC_RUN_ID'):
+        env.pop(k, None)
+    try:
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    except subprocess.TimeoutExpired:
+        return {'ok': False, 'error': f'timeout after {timeout} s', 'cmd': ' '.join(cmd[1:])}
+    for line in reversed(p.stdout.strip().splitlines()):
+        if line.startswith('{'):
+            try:
+                return json.loads(line)
+            except ValueError:
+                break
+    return {'ok': False, 'error': 'no JSON line', 'returncode': p.returncode, 'stderr_tail': p.stderr[-1500:]}
 
 
 def reference_cpu_record():
@@ -474,14 +505,18 @@ def main():
                     'per global batch) and configs[4] (bear Stage II, 16384 points x 256+256) as data-parallel jobs of this world size')
     args = ap.parse_args()
 
-    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    if args.gpus > 1 and not all(k in os.environ for k in ('WORLD_SIZE', 'RANK', 'MASTER_ADDR', 'MASTER_PORT')):
         sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     import torch.distributed as dist
-    under_launcher = 'WORLD_SIZE' in os.environ          # torch.distributed.run set the rendezvous: RCCL is initialised even for ONE rank,
-    if under_launcher:                                   # so that the N = 1 point of a scaling run goes through the same collectives
+    # torch.distributed.run set the FULL rendezvous (a scheduler that merely exports WORLD_SIZE is not a launcher): RCCL is initialised even
+    # for ONE rank, so that the N = 1 point of a scaling run goes through the same collectives
+    under_launcher = all(k in os.environ for k in ('WORLD_SIZE', 'RANK', 'MASTER_ADDR', 'MASTER_PORT'))
+    if not under_launcher:
+        world, rank, local = 1, 0, 0
+    if under_launcher:
         torch.cuda.set_device(local)
         dist.init_process_group('nccl')
         if world == 1:
@@ -739,13 +774,37 @@ def main():
             # (profiles/rNN_ref_vs_port_cpu.json, oracle/ref_vs_port_cpu.py) and is reported BESIDE the ratio, never multiplied in.
             res['x_torch_gpu_baseline'] = round(res['protocol_8d']['rays_per_s_at_median'] / tg['value'], 2)
             res['x_torch_gpu_baseline_is'] = 'vs port (same algorithm as plain PyTorch ops on this GPU); see cpu_baseline.reference for port / reference'
-            refrec = reference_cpu_record()
+            # ---- the UNMODIFIED reference on THIS box (oracle/_ref/, oracle/run_ref.py in a subprocess): GPU denominator of north_star's
+            # ">= 10x the reference single-GPU PyTorch" (same C2 workload, >= 10 warm-up + 50 steps, median) and the host-core baseline
+            rg = run_reference('cuda', args.rays, (64, 64, 32), 10, 50)
+            if rg is not None:
+                res['reference_gpu_baseline'] = rg
+                if rg.get('ok'):
+                    res['x_reference_gpu'] = round(res['protocol_8d']['rays_per_s_at_median'] / rg['rays_per_s'], 2)
+                    res['x_reference_gpu_contract_loop'] = round(res['value'] / rg['rays_per_s'], 2)
+                    res['x_reference_gpu_is'] = ('protocol_8d median rays/s of this framework / median rays/s of the unmodified reference (render + loss + '
+                                                 'backward + torch Adam) on the same MI355X, same 4096 x (64+64+32) workload and schedule step')
             if not args.no_cpu_baseline:
-                res['cpu_baseline'] = cpu_baseline(cfg, VARIANCE, args.train_step)
-                if refrec:
-                    res['cpu_baseline']['reference'] = refrec
-            elif refrec:
-                res['cpu_baseline_reference'] = refrec
+                cores = min(os.cpu_count(), 32)
+                port = cpu_baseline(cfg, VARIANCE, args.train_step)
+                rc = run_reference('cpu', 512, (64, 64, 32), 1, 3, threads=cores, budget_s=25.0)
+                if rc is not None and rc.get('ok'):
+                    # ONE workload on ONE box: 512 rays x (64+64+32) of the benchmarked configuration on this box's host cores
+                    res['cpu_baseline'] = {'value': rc['rays_per_s'], 'unit': 'rays/s', 'cores': rc['cores'], 'kind': 'reference',
+                                           'sample': f"512 rays x (64+64+32) samples, schedule step {args.train_step}: the unmodified reference's render + loss + "
+                                                     f"backward + Adam (oracle/run_ref.py on oracle/_ref), 1 warm-up + {rc['steps']} timed step(s), median "
+                                                     f"{rc['s_per_step_median']:.2f} s/step",
+                                           'port_on_the_same_cores': {'value': round(port['value'], 1), 'sample': port['sample']},
+                                           'record': rc}
+                    c1 = run_reference('cpu', 512, (32, 32, 32), 1, 3, threads=cores, budget_s=15.0)       # BASELINE.md section 3, configs[0]
+                    if c1 is not None:
+                        res['cpu_baseline']['c1_512x96'] = c1
+                else:
+                    res['cpu_baseline'] = port
+                    res['cpu_baseline']['reference_unavailable'] = rc if rc is not None else 'oracle/_ref/ not present (python oracle/make_ref.py in the build container)'
+                    refrec = reference_cpu_record()
+                    if refrec:
+                        res['cpu_baseline']['reference_build_container'] = refrec
         print(json.dumps(res), flush=True)
     if dist.is_initialized():
         dist.barrier()

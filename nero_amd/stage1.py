@@ -281,7 +281,9 @@ class ShapeStepGlue:
     @staticmethod
     def supported(net):
         c = net.cfg
-        return c.get('std_act', 'exp') == 'exp' and c['rgb_loss'] in RGB_LOSS_KIND
+        # nero_occ_select sorts the kept candidates in LDS: cap <= 4096 (PICK_MAX in step_glue.hip); a larger cap keeps the tensor glue
+        return (c.get('std_act', 'exp') == 'exp' and c['rgb_loss'] in RGB_LOSS_KIND
+                and 1 <= int(c['occ_loss_max_pn']) <= 4096)
 
     def _buffers(self, R):
         if R not in self._bufs:
@@ -310,9 +312,9 @@ class ShapeStepGlue:
         B = self._buffers(R)
         st = L.stream_ptr()
         o, d, gt = o.contiguous(), d.contiguous(), gt.contiguous()
-        if rands is not None and len(rands) > 3:          # (tests hand over the tensor expression's near / far: it differs from the kernel's in the
-            B['near'].copy_(rands[3])                     #  last bit of some rays, and the hierarchical sampler amplifies that)
-            B['far'].copy_(rands[4])
+        if rands is not None and len(rands) > 3:          # (tests may hand over near / far: for unit directions the kernel's are bit-identical
+            B['near'].copy_(rands[3])                     #  to the tensor expression's (tests/test_step_glue.py); for |d| != 1 they can differ
+            B['far'].copy_(rands[4])                      #  in the last bit, which the hierarchical sampler amplifies)
         else:
             L.check(_lib.nero_near_far_sphere(_p(o), _p(d), R, _p(B['near']), _p(B['far']), st))
         var = variance_param.detach()
@@ -341,7 +343,10 @@ class ShapeStepGlue:
             x4, geo = drv._view(s.x4, (rpi, 4)), drv._view(s.geo, (rpi, 8))
             L.check(_lib.nero_occ_candidates(s.x4, s.sdf4, s.normal, s.inner_idx, _p(d), T, float(c['occ_sdf_thresh']), n_in, _p(B['flag']), st))
             keys = rands[2].to(o.device).contiguous() if (rands is not None and rands[2] is not None) else torch.rand(n_in, dtype=torch.float32, device=o.device)
-            assert keys.numel() >= 1
+            # RNG note: this path draws rand(n_in) keys every step >= occ_loss_step; the tensor glue draws rand(Pn) only when the
+            # candidates exceed the cap, so NERO_STEP_GLUE=torch|hip runs are not seed-comparable from that step on.
+            if keys.numel() < n_in:                       # occ_records_kernel reads keys[ordinal among the candidates], ordinal < n_in
+                keys = torch.cat([keys, torch.full((n_in - keys.numel(),), float('inf'), dtype=torch.float32, device=o.device)])
             cap = B['cand'].numel()
             L.check(_lib.nero_occ_select(_p(B['flag']), n_in, _p(keys), cap, _p(B['cand']), _p(B['counts']), B['sel_ws'].data_ptr(), B['sel_ws'].numel(), st))
             L.check(_lib.nero_occ_gather(_p(x4), _p(geo), _p(B['cand']), cap, _p(B['pts']), _p(B['dirs']), st))

@@ -197,6 +197,12 @@ class FusedMaterialOptimizer(FusedOptimizer):
             out += [(f'{pn}.{i}', getattr(sn, pn)[k]) for i, k in enumerate((0, 2, 4, 6))]
         return out
 
+    def _after_step(self):
+        # same reason as FusedShapeOptimizer._after_step: NeROMaterialRenderer._kernels keys its no-grad cache on torch's version
+        # counters, which raw-kernel updates do not move
+        self.net._param_epoch = getattr(self.net, '_param_epoch', 0) + 1
+        self.net._kern_cache = None
+
 
 class ShapeTrainStep:
     """one process = one GPU.  Every rank holds the same weights and a disjoint slice of each global ray batch

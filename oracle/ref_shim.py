@@ -13,6 +13,11 @@ What it does:
   4. CPU only: Tensor.cuda / Module.cuda -> identity, torch.randperm drops device='cuda'
      (network/renderer.py:537);
   5. chdir to the reference root so assets/bsdf_256_256.bin resolves (network/field.py:510).
+
+Round 5: the reference root may also be oracle/_ref/ (oracle/make_ref.py: the same files, byte for byte, as an importable zip
++ the FG asset), which is what oracle/run_ref.py uses to TIME the unmodified reference on the GPU box (bench.py's `cpu_baseline`
+kind "reference" and `reference_gpu_baseline`).  install(force_cpu=True) applies the CPU-only patches of item 4 even when a GPU
+is visible (the host-core timing on the GPU box).
 """
 import importlib.abc
 import importlib.machinery
@@ -24,7 +29,8 @@ import types
 import numpy as np
 import torch
 
-REF_ROOT = os.environ.get('NERO_REFERENCE_ROOT', '/root/reference')
+_PACKED = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_ref')
+REF_ROOT = os.environ.get('NERO_REFERENCE_ROOT') or ('/root/reference' if os.path.isdir('/root/reference/network') else _PACKED)
 
 _STUBS = ('mcubes', 'cv2', 'open3d', 'trimesh', 'raytracing', 'h5py', 'plyfile', 'skimage',
           'transforms3d', 'tensorboardX', 'nvdiffrast', 'xatlas')
@@ -84,11 +90,14 @@ def texture_bilinear_clamp(tex, uv, filter_mode='linear', boundary_mode='clamp')
 _installed = False
 
 
-def install():
+def install(force_cpu=False):
     global _installed
     if _installed:
         return
     _installed = True
+    global _STUBS
+    if not os.path.isdir(os.path.join(REF_ROOT, 'colmap')):      # the packaged reference (oracle/_ref) carries network/, utils/, dataset/ only:
+        _STUBS = _STUBS + ('colmap',)                            # dataset/database.py:11-12 imports COLMAP model IO, never used on the render path
     sys.meta_path.insert(0, _Finder())
     import nvdiffrast.torch as dr  # stub
     dr.texture = texture_bilinear_clamp
@@ -96,7 +105,7 @@ def install():
         np.math = math
     if not hasattr(np, 'bool'):
         np.bool = bool
-    if not torch.cuda.is_available():
+    if force_cpu or not torch.cuda.is_available():
         torch.Tensor.cuda = lambda self, *a, **k: self
         torch.nn.Module.cuda = lambda self, *a, **k: self
         _randperm = torch.randperm
@@ -105,14 +114,16 @@ def install():
             k.pop('device', None)
             return _randperm(n, *a, **k)
         torch.randperm = randperm
-    if REF_ROOT not in sys.path:
-        sys.path.insert(0, REF_ROOT)
+    packed = os.path.join(REF_ROOT, 'nero_ref.zip')
+    src = packed if os.path.exists(packed) else REF_ROOT
+    if src not in sys.path:
+        sys.path.insert(0, src)
     os.chdir(REF_ROOT)
 
 
-def load_reference():
+def load_reference(force_cpu=False):
     """Returns (network.renderer, network.field) modules of the unmodified reference."""
-    install()
+    install(force_cpu)
     import warnings
     warnings.filterwarnings('ignore')
     import network.field as field

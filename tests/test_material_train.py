@@ -65,6 +65,30 @@ def test_fused_material_step_matches_the_torch_path():
     assert n == 96                                                  # every tensor of the bear material model
 
 
+def test_no_grad_cache_follows_the_fused_material_optimiser():
+    """FusedMaterialOptimizer updates the parameters with raw kernels, which torch's version counters do not see; the
+    renderer's no-grad cache of packed operand images must be dropped by the optimiser (a material extraction after fused steps
+    must see the new weights)."""
+    from nero_amd.train import MaterialTrainStep
+    ts = MaterialTrainStep({'shader_cfg': SCFG, 'database_name': 'real/bear'}, _mesh(), points_per_rank=P, pool_points=4 * P, device='cuda:0',
+                           fused=True)
+    g = torch.Generator().manual_seed(5)
+    pts = (torch.nn.functional.normalize(torch.randn(500, 3, generator=g), dim=-1) * 0.45).cuda()
+    with torch.no_grad():
+        k0 = ts.net._kernels()
+        before = [t.clone() for t in ts.net.predict_materials(pts, k0)]
+        assert ts.net._kernels()[2] is k0[2]                         # unchanged weights: the cached pack is served
+    for i in range(2):
+        ts.forward_backward(5000 + i, _rands(P, 0, P, 'cuda:0'))
+        ts.fopt.step(1e-2, 1)
+    assert ts.net._kern_cache is None                                # dropped by FusedMaterialOptimizer._after_step
+    with torch.no_grad():
+        k1 = ts.net._kernels()
+        assert k1[2] is not k0[2]
+        after = ts.net.predict_materials(pts, k1)
+    assert max(float((a - b).abs().max()) for a, b in zip(after, before)) > 1e-5
+
+
 BELL_SCFG = dict(diffuse_sample_num=64, specular_sample_num=32, human_lights=False, outer_light_version='direction', geometry_type='ggx_smith')
 
 
