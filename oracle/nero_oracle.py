@@ -197,6 +197,7 @@ def sdf_value_and_normal(P, x):
 # h * gate instead of relu(h).  Keys: '<predictor prefix>@<call index>/<layer>' (call index: outer_light is evaluated twice, diffuse
 # then specular), 'outer_nerf/pts<i>', 'outer_nerf/views'.  Outside the context manager nothing changes.
 _FORCED = None
+_CAPTURE = None
 _CALLS = {}
 
 
@@ -218,7 +219,29 @@ class forced_relu_gates:
         _CALLS.clear()
 
 
+class capture_relu_gates(forced_relu_gates):
+    """records the decisions instead of forcing them: after the `with` block `.gates` maps every key to the 0/1 gate (ReLU) or the sign
+    (L1 terms) THIS evaluation took -- e.g. a float64 run, whose decisions a float32 run is then handed through forced_relu_gates
+    (tests/test_oracle_golden.py: float32 ARITHMETIC against float64 without the tie-breaking noise)"""
+
+    def __init__(self):
+        super().__init__({})
+
+    def __enter__(self):
+        global _CAPTURE
+        r = super().__enter__()
+        _CAPTURE = self.gates
+        return r
+
+    def __exit__(self, *a):
+        global _CAPTURE
+        _CAPTURE = None
+        super().__exit__(*a)
+
+
 def _relu(h, key):
+    if _CAPTURE is not None:
+        _CAPTURE[key] = (h.detach() > 0).to(torch.float32)
     if _FORCED is None or key not in _FORCED:
         return F.relu(h)
     g = _FORCED[key]
@@ -231,6 +254,8 @@ def _abs(x, key):
     """|x| -- or, inside forced_relu_gates with `key` present, x * sign taken from another evaluation (an L1 term whose argument sits
     within rounding of zero is the same kind of tie as a ReLU at zero: one flipped sign of the diffuse-light neutrality term of ONE
     surface point of 4096 moves every outer-light gradient by 1e-4, scripts/r04/diag_outer_light.py)"""
+    if _CAPTURE is not None:
+        _CAPTURE[key] = torch.where(x.detach() >= 0, 1.0, -1.0).to(torch.float32)
     if _FORCED is None or key not in _FORCED:
         return torch.abs(x)
     g = _FORCED[key]
