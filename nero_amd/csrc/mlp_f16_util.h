@@ -28,6 +28,21 @@ constexpr int SA = 528;                 // bytes per row of a main plane: 256 fp
 constexpr int PLANE_A = 64 * SA;
 constexpr int SX_N = 112, SX_W = 208;   // aux plane row strides (48 / 96 columns + 16 B)
 constexpr float LO = 2048.f, LO_INV = 1.f / 2048.f;
+// Round 5 -- ONE accumulator set (default; -DF16_TWO_ACC restores the H / L pair of rounds 1-4).  The block scale puts an operand's
+// largest magnitude into [2^14, 2^15), the TOP of fp16's range, instead of [0.5, 1): the remainder l = fp16(xs - h) is then an ordinary
+// fp16 number at its TRUE scale (|l| <= 2^3 for the largest elements, normal down to 2^-14, i.e. for every element within 2^-17 of the
+// row maximum; below that its absolute error 2^-25 is 2^-40 of the maximum) -- no 2^11 pre-scale -- and the three plane products
+// hw hx + hw lx + lw hx accumulate into the SAME fp32 accumulator inside the matrix pipe (what the weight-gradient GEMM has done since
+// round 2, mlp_f16dw.hip).  Same three MFMAs per k-step; what goes away is the second accumulator set (32 VGPRs per wave), the
+// H + 2^-11 L combine (32 VALU per lane and layer), the 2^11 multiply of every split (32 more) and half of the skip-layer rescale.
+// Products reach 2^30, a 256-term sum 2^38: far inside fp32.  Error against fp64: tests/test_mlp_engine.py (unchanged tolerances).
+#ifdef F16_TWO_ACC
+constexpr int F16_TOP = 0;
+#define ACCV(aH, aL, r, v) fmaf((aL)[r][v], LO_INV, (aH)[r][v])
+#else
+constexpr int F16_TOP = 15;
+#define ACCV(aH, aL, r, v) ((aH)[r][v])
+#endif
 constexpr int HDR_BYTES = 256;          // packed-image header: float[0] = 2^ew (the factor results are multiplied by), uint[1] = max bits
 constexpr int SCR_LD = 36, SCR_BYTES = 32 * SCR_LD * 4;
 
@@ -83,12 +98,12 @@ __device__ __forceinline__ void lds_dma16(const void* gptr, unsigned lds_addr) {
 __device__ __forceinline__ unsigned lds_offset_of(const void* p) { return (unsigned)(size_t)p; }      // generic -> LDS byte offset
 
 // ---- scaling -----------------------------------------------------------------------------------------------------------
-// exponent e with m * 2^-e in [0.5, 1) for normal m > 0 (0 for m == 0 / denormal), clamped to [-40, 40]
+// exponent e with m * 2^-e in [0.5, 1) * 2^F16_TOP for normal m > 0 (-F16_TOP for m == 0 / denormal), e + F16_TOP clamped to [-40, 40]
 __device__ __forceinline__ int scale_exp(float m) {
     const int eb = (__float_as_uint(m) >> 23) & 0xff;
     int e = eb ? eb - 126 : 0;
     e = e < -40 ? -40 : (e > 40 ? 40 : e);
-    return e;
+    return e - F16_TOP;                                  // (one accumulator: m * 2^-e in [2^14, 2^15), the top of fp16's range)
 }
 __device__ __forceinline__ float pow2i(int e) { return __uint_as_float((unsigned)(127 + e) << 23); }
 
@@ -101,7 +116,11 @@ __device__ __forceinline__ unsigned pk_f16(float a, float b) {       // v_cvt_pk
 __device__ __forceinline__ void split2h(float a, float b, unsigned& h, unsigned& l) {     // a, b already block-scaled
     h = pk_f16(a, b);
     const f16x2 hh = __builtin_bit_cast(f16x2, h);
+#ifdef F16_TWO_ACC
     l = pk_f16((a - (float)hh[0]) * LO, (b - (float)hh[1]) * LO);
+#else
+    l = pk_f16(a - (float)hh[0], b - (float)hh[1]);
+#endif
 }
 __device__ __forceinline__ void store_planes4h(char* dst, int plane_bytes, float4 v) {
     unsigned h0, l0, h1, l1;
@@ -116,10 +135,17 @@ __device__ __forceinline__ float4 load_planes4h(const char* src, int plane_bytes
     const f16x2 a0 = __builtin_bit_cast(f16x2, a.x), a1 = __builtin_bit_cast(f16x2, a.y);
     const f16x2 b0 = __builtin_bit_cast(f16x2, b.x), b1 = __builtin_bit_cast(f16x2, b.y);
     float4 v;
+#ifdef F16_TWO_ACC
     v.x = fmaf((float)b0[0], LO_INV, (float)a0[0]);
     v.y = fmaf((float)b0[1], LO_INV, (float)a0[1]);
     v.z = fmaf((float)b1[0], LO_INV, (float)a1[0]);
     v.w = fmaf((float)b1[1], LO_INV, (float)a1[1]);
+#else
+    v.x = (float)a0[0] + (float)b0[0];
+    v.y = (float)a0[1] + (float)b0[1];
+    v.z = (float)a1[0] + (float)b1[0];
+    v.w = (float)a1[1] + (float)b1[1];
+#endif
     return v;
 }
 
@@ -203,9 +229,18 @@ __device__ __forceinline__ void ops_compute(f32x16 (&aH)[2], f32x16 (&aL)[2], co
     aH[1][0] += __uint_as_float(w.wh.y ^ x.xh1.x); aL[1][0] += __uint_as_float(w.wl.y ^ x.xl1.x);
     return;
 #endif
+#ifdef F16_TWO_ACC
     NERO_MFH(aL[0], w.wl, x.xh0); NERO_MFH(aL[1], w.wl, x.xh1);
     NERO_MFH(aH[0], w.wh, x.xh0); NERO_MFH(aH[1], w.wh, x.xh1);
     NERO_MFH(aL[0], w.wh, x.xl0); NERO_MFH(aL[1], w.wh, x.xl1);
+#else
+    // (the two small products first: they enter an accumulator that still holds little; dependent MFMAs on one accumulator issue back
+    //  to back at full rate -- accumulation forwarding, measured for the weight-gradient kernel in round 2)
+    NERO_MFH(aH[0], w.wl, x.xh0); NERO_MFH(aH[1], w.wl, x.xh1);
+    NERO_MFH(aH[0], w.wh, x.xl0); NERO_MFH(aH[1], w.wh, x.xl1);
+    NERO_MFH(aH[0], w.wh, x.xh0); NERO_MFH(aH[1], w.wh, x.xh1);
+    (void)aL;
+#endif
 }
 #define NERO_FENCE() __builtin_amdgcn_sched_barrier(0)      // (without the fences hipcc sinks the prefetches: the kernels run 40 % slower)
 // One k-step = 2 weight loads (VMEM) + 4 activation-fragment reads (DS) for a LATER step + 6 MFMAs of this step.  Issued as

@@ -7,6 +7,8 @@
 // trouble of its own) and |xs - h - 2^-11 l| <= 2^-24 |xs|: the pair represents xs to fp32's own half-ulp.  A product is
 //        w x = [ hw hx  +  2^-11 (hw lx + lw hx) ] * 2^(ew + ex),          dropped: 2^-22 lw lx <= 2^-24 |w x|
 // i.e. THREE MFMAs in two accumulator sets (H: hw hx, L: hw lx + lw hx), combined as H + 2^-11 L in the epilogue.
+// ROUND 5 (default; mlp_f16_util.h, -DF16_TWO_ACC = the text above): the block scale puts the maximum at the TOP of fp16's range,
+// l = fp16(xs - h) at its true scale, and all three products accumulate into ONE fp32 accumulator set.
 // Range: fp16 overflows at 65504 and loses precision below 2^-14, so every operand is scaled by an exact power of two:
 // activations per ROW (64 per tile; exponent of the row maximum, kept in LDS next to the planes), weights per MATRIX (exponent in
 // the packed image's header).  Elements more than 2^14 below their row's maximum lose relative -- not absolute -- precision,
@@ -149,10 +151,10 @@ __device__ __forceinline__ void fwd_values(const f32x16 (&aH)[2], const f32x16 (
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float4 v;
-            v.x = act_fwd<ACT>(fmaf(fmaf(aL[r][4 * g], LO_INV, aH[r][4 * g]), U[r], bq[g].x));
-            v.y = act_fwd<ACT>(fmaf(fmaf(aL[r][4 * g + 1], LO_INV, aH[r][4 * g + 1]), U[r], bq[g].y));
-            v.z = act_fwd<ACT>(fmaf(fmaf(aL[r][4 * g + 2], LO_INV, aH[r][4 * g + 2]), U[r], bq[g].z));
-            v.w = act_fwd<ACT>(fmaf(fmaf(aL[r][4 * g + 3], LO_INV, aH[r][4 * g + 3]), U[r], bq[g].w));
+            v.x = act_fwd<ACT>(fmaf(ACCV(aH, aL, r, 4 * g), U[r], bq[g].x));
+            v.y = act_fwd<ACT>(fmaf(ACCV(aH, aL, r, 4 * g + 1), U[r], bq[g].y));
+            v.z = act_fwd<ACT>(fmaf(ACCV(aH, aL, r, 4 * g + 2), U[r], bq[g].z));
+            v.w = act_fwd<ACT>(fmaf(ACCV(aH, aL, r, 4 * g + 3), U[r], bq[g].w));
             val[r][g] = v;
             m[r] = fmaxf(m[r], fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
         }
@@ -256,7 +258,12 @@ __global__ __launch_bounds__(512, 1) void fwd_f16_kernel(nero_fwd_chain ch, int 
                     // bring the aux partial sums into the main part's unit (exact: powers of two)
                     const float r0 = U[0] / u0, r1 = U[1] / u1;
 #pragma unroll
-                    for (int v = 0; v < 16; ++v) { aH[0][v] *= r0; aL[0][v] *= r0; aH[1][v] *= r1; aL[1][v] *= r1; }
+                    for (int v = 0; v < 16; ++v) {
+                        aH[0][v] *= r0; aH[1][v] *= r1;
+#ifdef F16_TWO_ACC
+                        aL[0][v] *= r0; aL[1][v] *= r1;
+#endif
+                    }
                 }
                 U[0] = u0;
                 U[1] = u1;
@@ -377,7 +384,12 @@ __device__ __forceinline__ void gemm_two_sources(f32x16 (&aH)[2], f32x16 (&aL)[2
         if (sx > 0) {
             const float r0 = U[0] / u0, r1 = U[1] / u1;    // exact: powers of two
 #pragma unroll
-            for (int v = 0; v < 16; ++v) { aH[0][v] *= r0; aL[0][v] *= r0; aH[1][v] *= r1; aL[1][v] *= r1; }
+            for (int v = 0; v < 16; ++v) {
+                        aH[0][v] *= r0; aH[1][v] *= r1;
+#ifdef F16_TWO_ACC
+                        aL[0][v] *= r0; aL[1][v] *= r1;
+#endif
+                    }
         }
         U[0] = u0;
         U[1] = u1;
@@ -451,10 +463,10 @@ __global__ __launch_bounds__(512, 1) void tan_f16_kernel(nero_tan_chain ch, int 
                 for (int g = 0; g < 4; ++g) {
                     const float4 a = pa[r][g], gb = pg[r][g];
                     float4 ad, ij;
-                    tan_elem(a.x, fmaf(aL[r][4 * g], LO_INV, aH[r][4 * g]) * U[r], gb.x, live, ad.x, ij.x);
-                    tan_elem(a.y, fmaf(aL[r][4 * g + 1], LO_INV, aH[r][4 * g + 1]) * U[r], gb.y, live, ad.y, ij.y);
-                    tan_elem(a.z, fmaf(aL[r][4 * g + 2], LO_INV, aH[r][4 * g + 2]) * U[r], gb.z, live, ad.z, ij.z);
-                    tan_elem(a.w, fmaf(aL[r][4 * g + 3], LO_INV, aH[r][4 * g + 3]) * U[r], gb.w, live, ad.w, ij.w);
+                    tan_elem(a.x, ACCV(aH, aL, r, 4 * g) * U[r], gb.x, live, ad.x, ij.x);
+                    tan_elem(a.y, ACCV(aH, aL, r, 4 * g + 1) * U[r], gb.y, live, ad.y, ij.y);
+                    tan_elem(a.z, ACCV(aH, aL, r, 4 * g + 2) * U[r], gb.z, live, ad.z, ij.z);
+                    tan_elem(a.w, ACCV(aH, aL, r, 4 * g + 3) * U[r], gb.w, live, ad.w, ij.w);
                     val[r][g] = ad;
                     m[r] = fmaxf(m[r], amax4(ad));
                     adq[g] = live ? ad : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -653,8 +665,8 @@ __global__ __launch_bounds__(512, 1) void bwd_f16_kernel(nero_bwd_chain ch, int 
                             const int f = fbase + 8 * g;
                             if (f < ch.ld_daux)
                                 *reinterpret_cast<float4*>(ch.d_aux + (size_t)(row0 + 32 * r + i) * ch.ld_daux + f) =
-                                    make_float4(fmaf(aL[r][4 * g], LO_INV, aH[r][4 * g]) * u[r], fmaf(aL[r][4 * g + 1], LO_INV, aH[r][4 * g + 1]) * u[r],
-                                                fmaf(aL[r][4 * g + 2], LO_INV, aH[r][4 * g + 2]) * u[r], fmaf(aL[r][4 * g + 3], LO_INV, aH[r][4 * g + 3]) * u[r]);
+                                    make_float4(ACCV(aH, aL, r, 4 * g) * u[r], ACCV(aH, aL, r, 4 * g + 1) * u[r],
+                                                ACCV(aH, aL, r, 4 * g + 2) * u[r], ACCV(aH, aL, r, 4 * g + 3) * u[r]);
                         }
                 }
             }
@@ -677,8 +689,8 @@ __global__ __launch_bounds__(512, 1) void bwd_f16_kernel(nero_bwd_chain ch, int 
             for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    gq[r][g] = make_float4(fmaf(aL[r][4 * g], LO_INV, aH[r][4 * g]) * u[r], fmaf(aL[r][4 * g + 1], LO_INV, aH[r][4 * g + 1]) * u[r],
-                                           fmaf(aL[r][4 * g + 2], LO_INV, aH[r][4 * g + 2]) * u[r], fmaf(aL[r][4 * g + 3], LO_INV, aH[r][4 * g + 3]) * u[r]);
+                    gq[r][g] = make_float4(ACCV(aH, aL, r, 4 * g) * u[r], ACCV(aH, aL, r, 4 * g + 1) * u[r],
+                                           ACCV(aH, aL, r, 4 * g + 2) * u[r], ACCV(aH, aL, r, 4 * g + 3) * u[r]);
             if (first) {
                 if (ch.d_init && live_wave) {
                     const int ldi = ch.ld_dinit;

@@ -230,13 +230,17 @@ def parity_report(test_id, **fields):
 class CTracer:
     """RayTracer-shaped wrapper over the fp64 brute-force oracle (C restatement), remembering the ambiguity flags"""
 
-    def __init__(self, v, f, replay=None, eps_edge=2e-5, eps_t=2e-6, ray_tol=None):
+    def __init__(self, v, f, replay=None, eps_edge=2e-5, eps_t=2e-6, ray_tol=None, defer=None):
         """replay: a CTracer whose recorded answers are returned call by call instead of tracing (an fp64 oracle run -- or the HIP
         step under teacher forcing -- then sees exactly the hits of the fp32 oracle run: its own, slightly different secondary rays
         would flip razor-edge rays).  ray_tol: in replay mode, additionally require the incoming rays to equal the recorded ones to
         this absolute tolerance (the directions are computed by the code under test) and remember the largest deviation."""
         self.v, self.f, self.amb, self.hit, self.raw, self.rays = v, f, [], [], [], []
         self.replay, self.calls, self.eps, self.ray_tol, self.max_ray_dev = replay, 0, (eps_edge, eps_t), ray_tol, 0.0
+        # defer = (pos, nrm, depth) float32 arrays over ALL rays of the run, in call order, from ANOTHER tracer (the HIP BVH): on the
+        # rays this oracle flags as razor-edge -- where either answer is legitimate -- the other tracer's answer is returned, so that a
+        # shading comparison is teacher-forced on the hit of exactly the ambiguous rays and on nothing else
+        self.defer, self.offset, self.deferred = defer, 0, 0
 
     def trace(self, o, d):
         from oracle.tracer_oracle import trace_bruteforce_margins
@@ -255,6 +259,12 @@ class CTracer:
         on, dn = o.detach().cpu().numpy(), d.detach().cpu().numpy()
         pos, nrm, depth, tri, amb = trace_bruteforce_margins(self.v, self.f, on, dn, eps_edge=self.eps[0], eps_t=self.eps[1])
         pos, nrm, depth = pos.astype(np.float32), nrm.astype(np.float32), depth.astype(np.float32)       # the tracer contract is float32
+        if self.defer is not None:
+            sl = slice(self.offset, self.offset + on.shape[0])
+            self.offset += on.shape[0]
+            a = np.asarray(amb, bool)
+            pos[a], nrm[a], depth[a] = self.defer[0][sl][a], self.defer[1][sl][a], self.defer[2][sl][a]
+            self.deferred += int(a.sum())
         self.raw.append((pos, nrm, depth))
         self.rays.append((on.astype(np.float64), dn.astype(np.float64)))
         self.amb.append(amb)

@@ -277,11 +277,13 @@ def test_c2_end_to_end_without_teacher_forcing_statistics():
 # ----------------------------------------------------------------------------------------------------------------------
 class _Recording:
     def __init__(self, inner):
-        self.inner, self.depth, self.o, self.d = inner, [], [], []
+        self.inner, self.depth, self.o, self.d, self.pos, self.nrm = inner, [], [], [], [], []
 
     def trace(self, o, d):
         out = self.inner.trace(o, d)
         self.depth.append(out[2].detach().cpu().numpy().reshape(-1))
+        self.pos.append(out[0].detach().cpu().numpy())
+        self.nrm.append(out[1].detach().cpu().numpy())
         self.o.append(o.detach().cpu().numpy())
         self.d.append(d.detach().cpu().numpy())
         return out
@@ -385,7 +387,15 @@ def _stage2_teacher_forced(test_id, Pn, shader_cfg, step=5000, inputs=None, mesh
     assert rec['errs']['rgb_pr'] < 1e-4, rec
     for k in ('albedo', 'roughness', 'metallic', 'diffuse_light', 'specular_light', 'specular_color'):
         assert rec['errs'][k] < 1e-4, (k, rec)
-    assert rec['errs']['loss_mat_reg'] < 1e-3, rec
+    # loss_mat_reg is |m(p) - m(p + eps)| of two nearly equal predictions: a cancellation that amplifies the 1e-6 of the predictions
+    # themselves.  It is held to the plain 1e-4 against the FLOAT64 oracle, or to 3 x the distance the float32 oracle itself has from
+    # float64 (VERDICT r4 'weak' 3: rounds 3-4 compared against the float32 oracle and had to allow 1e-3)
+    reg_hip = out['loss_mat_reg'].detach().cpu()
+    o64 = oracle(torch.float64)
+    reg64 = o64[0]['loss_mat_reg']
+    rec['loss_mat_reg_vs_fp64'] = dict(hip=rel_err(reg_hip, reg64), oracle_fp32=rel_err(oo['loss_mat_reg'], reg64))
+    parity_report(test_id, **rec)
+    assert rec['loss_mat_reg_vs_fp64']['hip'] <= max(1e-4, 3.0 * rec['loss_mat_reg_vs_fp64']['oracle_fp32']), rec
     loss = out['loss_rgb'].mean() + out['loss_mat_reg'].mean() + out['loss_diffuse_light'].mean()
     assert abs(float(loss) - loss_o) < 2e-5, (float(loss), loss_o)
     if not check_grads:
@@ -396,7 +406,7 @@ def _stage2_teacher_forced(test_id, Pn, shader_cfg, step=5000, inputs=None, mesh
     gates = {**forced_gates_from_capture(capture, 2, Pn), **signs}
     del net, out, loss, capture
     _free()
-    g64 = oracle(torch.float64)[2]
+    g64 = o64[2]
     if not small_batch:                                            # gate-teacher-forced (see _run_shape): plain 1e-4 for every tensor
         rec['forced_gates'] = _forced_gate_errors(g_hip, oracle(torch.float32, gates)[2], oracle(torch.float64, gates)[2])
     del gates
@@ -450,8 +460,10 @@ def test_c4_shaped_stage2_hip_tracer_with_explicit_edge_exclusion():
     only on rays the oracle itself flags as razor-edge (a triangle edge within 1e-4 barycentric units of deciding the closest hit, or
     a candidate intersection within 5e-6 of the ray origin -- the rays start 1e-5 off the surface, so the triangle they left sits at
     t = -1e-5 exactly and is never such a candidate).  So:
-    (1) every ray on which the two tracers disagree is such a ray; (2) the points that own no flagged ray -- counted, reported,
-    and required to be the large majority -- match the oracle shading to 1e-4."""
+    (1) every ray on which the two tracers disagree is such a ray;
+    (2) round 5 (VERDICT r4 'weak' 2): the comparison is teacher-forced PER RAY, not by dropping points -- the oracle shades with its
+        own fp64 hits everywhere except on the flagged rays (0.09 % of them), where it takes the HIP tracer's answer (both answers are
+        legitimate there).  EVERY point is kept and compared; round 4 dropped the 117 of 512 points that owned a flagged ray."""
     from nero_amd.renderer import NeROMaterialRenderer
     from nero_amd.renderer import NeROShapeRenderer
     shader_cfg = dict(diffuse_sample_num=128, specular_sample_num=128, human_lights=False, outer_light_version='direction')
@@ -459,13 +471,8 @@ def test_c4_shaped_stage2_hip_tracer_with_explicit_edge_exclusion():
     I = _material_inputs(Pn)
     ref = _material_pair(shader_cfg)
     sd = {k: v.detach() for k, v in ref.state_dict().items()}
-    tr = _CTracer(*golden_mesh(), eps_edge=1e-4, eps_t=5e-6)
     hp = NeROShapeRenderer.get_human_coordinate_poses(type('c', (), {'cfg': {'fixed_camera': False}})(), I['poses'])
-    with torch.no_grad():
-        rgb_o, oo = M.mc_shade(O.effective_params(sd), {**M.DEFAULT_SHADER_CFG, **shader_cfg}, _contract(tr), I['pts'], I['view'], I['normals'],
-                               hp, I['rand_d'], I['rand_s'])
-    amb, hit_o = np.concatenate(tr.amb), np.concatenate(tr.hit)
-    assert amb.shape[0] == Pn * D
+    # the HIP side first: its answers are what the oracle defers to on the rays it finds ambiguous
     net = NeROMaterialRenderer({'shader_cfg': shader_cfg, 'database_name': 'syn/bell'}, mesh=golden_mesh())
     net.load_state_dict(ref.state_dict())
     net = net.cuda()
@@ -474,8 +481,19 @@ def test_c4_shaped_stage2_hip_tracer_with_explicit_edge_exclusion():
     c = lambda k: I[k].cuda()
     with torch.no_grad():
         out = net.shade(c('pts'), c('view'), c('normals'), hp.cuda(), True, step, c('rand_d'), c('rand_s'))
-    hit_h = np.concatenate(rec.depth) < 10.0
-    assert hit_h.shape == hit_o.shape
+    hip = (np.concatenate(rec.pos).astype(np.float32), np.concatenate(rec.nrm).astype(np.float32), np.concatenate(rec.depth).astype(np.float32))
+    assert hip[2].shape[0] == Pn * D
+
+    def oracle_shade(defer):
+        tr = _CTracer(*golden_mesh(), eps_edge=1e-4, eps_t=5e-6, defer=defer)
+        with torch.no_grad():
+            rgb, _ = M.mc_shade(O.effective_params(sd), {**M.DEFAULT_SHADER_CFG, **shader_cfg}, _contract(tr), I['pts'], I['view'], I['normals'],
+                                hp, I['rand_d'], I['rand_s'])
+        return rgb, tr
+    rgb_own, tr = oracle_shade(None)                            # the oracle on its own hits: who is flagged, who differs
+    amb, hit_o = np.concatenate(tr.amb), np.concatenate(tr.hit)
+    assert amb.shape[0] == Pn * D
+    hit_h = hip[2] < 10.0
     differ = hit_h != hit_o
     if (differ & ~amb).any():                                   # say what the unexplained rays look like before failing
         from oracle.tracer_oracle import trace_bruteforce_margins
@@ -484,27 +502,31 @@ def test_c4_shaped_stage2_hip_tracer_with_explicit_edge_exclusion():
         loose = trace_bruteforce_margins(*golden_mesh(), ro, rd, eps_edge=1e-3, eps_t=9e-6)
         raise AssertionError(f'{int((differ & ~amb).sum())} rays differ between the HIP BVH and the fp64 oracle without being razor-edge: rows '
                              f'{idx}, oracle depth on the HIP rays {loose[2]}, flagged at (1e-3, 9e-6): {loose[4]}, hip depth '
-                             f'{np.concatenate(rec.depth)[idx]}, oracle depth on its own rays {np.concatenate([r[2] for r in tr.raw])[idx]}')
-    pt_amb = amb.reshape(Pn, D).any(axis=1)
-    ok = torch.from_numpy(~pt_amb)
+                             f'{hip[2][idx]}, oracle depth on its own rays {np.concatenate([r[2] for r in tr.raw])[idx]}')
+    rgb_o, tr2 = oracle_shade(hip)                              # ... and deferring to the HIP tracer on exactly the flagged rays
+    assert tr2.deferred == int(amb.sum()) and tr2.offset == Pn * D
+    # hit POSITIONS of the rays both tracers answer alike: float32 BVH against the fp64 brute force
+    both = hit_h & hit_o & ~amb
+    dpos = float(np.abs(hip[0][both] - np.concatenate([r[0] for r in tr.raw])[both]).max()) if both.any() else 0.0
     scale = float(rgb_o.abs().max())
     perr = (out['rgb_pr'].cpu() - rgb_o).abs().max(-1)[0] / scale
-    good = perr[ok]
-    frac_kept, frac_good, worst = float(ok.float().mean()), float((good < 1e-4).float().mean()), float(good.max())
+    perr_own = (out['rgb_pr'].cpu() - rgb_own).abs().max(-1)[0] / scale
+    pt_amb = torch.from_numpy(amb.reshape(Pn, D).any(axis=1))
+    frac_good, worst = float((perr < 1e-4).float().mean()), float(perr.max())
+    offenders = [dict(point=int(i), err=float(perr[i]), owns_flagged_ray=bool(pt_amb[i])) for i in torch.nonzero(perr >= 1e-4)[:, 0][:16]]
     parity_report('c4_bell_P512_D256_hip_bvh', points=Pn, directions=D, razor_edge_rays=int(amb.sum()), rays=Pn * D,
-                  rays_answered_differently=int(differ.sum()), points_excluded=int(pt_amb.sum()), fraction_points_kept=frac_kept,
-                  fraction_kept_points_within_1e4=frac_good, worst_kept_point=worst,
-                  worst_excluded_point=float(perr[~ok].max()) if pt_amb.any() else 0.0, hit_fraction=float(hit_o.mean()))
-    # Hit / miss patterns agree on every non-flagged ray (asserted above), so what remains on the non-excluded points is the float32
-    # vs float64 hit POSITION (|dx| ~ 1e-7, amplified 2^7-fold by PE-8 into the inner-light MLP) and, on rays that graze a shared
-    # edge, the choice between two coplanar-depth triangles with different normals: a handful of points at the 1e-3 level.
-    # Bounds = the measured values of this deterministic case plus margin (see STAGE2_BVH_BOUNDS).
-    assert frac_kept > STAGE2_BVH_BOUNDS['min_fraction_points_kept'], frac_kept
-    assert frac_good > STAGE2_BVH_BOUNDS['min_fraction_within_1e4'], frac_good
-    assert worst < STAGE2_BVH_BOUNDS['max_worst_kept_point'], worst
+                  rays_answered_differently=int(differ.sum()), points_owning_a_flagged_ray=int(pt_amb.sum()), fraction_points_kept=1.0,
+                  fraction_points_within_1e4=frac_good, worst_point=worst, points_beyond_1e4=offenders,
+                  worst_point_without_per_ray_forcing=float(perr_own.max()), max_hit_position_difference=dpos, hit_fraction=float(hit_o.mean()))
+    # every point is compared.  What can remain beyond 1e-4 is the float32 hit POSITION (|dx| <= max_hit_position_difference, amplified
+    # 2^7-fold by PE-8 in front of the inner-light MLP) on single rays of a point; STAGE2_BVH_BOUNDS holds the measured values.
+    assert frac_good >= STAGE2_BVH_BOUNDS['min_fraction_within_1e4'], (frac_good, offenders)
+    assert worst < STAGE2_BVH_BOUNDS['max_worst_point'], (worst, offenders)
+    assert dpos < 2e-6, dpos
 
 
 # measured on MI355X for this deterministic case (gpurun_out/parity_at_size.json, round 3): 120 razor-edge rays of 131 072 (2 answered
 # differently), 117 of 512 points excluded (0.7715 kept), 99.24 % of the kept points within 1e-4, worst kept point 2.19e-3.
 # (round 2 asserted 0.6 / 0.97 / 1e-2.)
-STAGE2_BVH_BOUNDS = {'min_fraction_points_kept': 0.75, 'min_fraction_within_1e4': 0.985, 'max_worst_kept_point': 4e-3}
+# round 5, per-ray forcing, all 512 points kept: see profiles/r05_parity_at_size.json
+STAGE2_BVH_BOUNDS = {'min_fraction_within_1e4': 0.99, 'max_worst_point': 1e-3}
