@@ -30,12 +30,13 @@ def _eff(lin):
 
 
 class SDFNetwork(nn.Module):
-    """PE-6 -> 9 weight-normed layers (skip into layer 4), softplus(beta=100); geometric (sphere) initialisation."""
-    N_FREQ = 6
-    D_PE = 3 + 3 * 2 * 6        # 39
+    """PE-f -> n_layers + 1 weight-normed layers (the input re-injected in front of layer n_layers // 2), softplus(beta=100);
+    geometric (sphere) initialisation.  Every shipped YAML: f = 6 (39 input columns), n_layers = 8."""
 
-    def __init__(self, d_out=257, d_hidden=256, n_layers=8, bias=0.5, geometric_init=True):
+    def __init__(self, d_out=257, d_hidden=256, n_layers=8, bias=0.5, geometric_init=True, n_freq=6):
         super().__init__()
+        self.N_FREQ = n_freq
+        self.D_PE = 3 + 3 * 2 * n_freq          # 39 at the YAMLs' sdf_freq = 6
         dims = [self.D_PE] + [d_hidden] * n_layers + [d_out]
         self.n_lin = len(dims) - 1
         self.skip = n_layers // 2
@@ -153,7 +154,7 @@ def build_shape_fields(cfg):
     """-> (sdf_network, deviation_network, outer_nerf, color_network) in the reference's construction order
     (network/renderer.py:117-130)."""
     sdf = SDFNetwork(d_out=cfg['sdf_d_out'], n_layers=cfg['sdf_n_layers'], bias=cfg['sdf_bias'],
-                     geometric_init=cfg['geometry_init'])
+                     geometric_init=cfg['geometry_init'], n_freq=cfg['sdf_freq'])
     dev = SingleVarianceNetwork(cfg['inv_s_init'], cfg['std_act'])
     nerf = NeRFNetwork()
     nn.init.constant_(nerf.rgb_linear.bias, math.log(0.5))

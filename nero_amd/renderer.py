@@ -30,14 +30,21 @@ class NeROShapeRenderer(nn.Module):
         c = self.cfg
         if c['std_act'] not in ('exp', 'linear', 'square'):
             raise NotImplementedError(f"std_act {c['std_act']!r}")      # (as the reference: network/field.py:197)
-        if c['sdf_activation'] != 'none' or c['sdf_freq'] != 6 or c['sdf_n_layers'] != 8 or c['sdf_d_out'] != 257:
-            # the SDF chain kernels, their packed operand images and the second-order backward are laid out for the 8 x 256 network with a
-            # PE-6 input and 257 outputs that every shipped YAML uses (INTEGRATION.md lists the keys that raise)
-            raise NotImplementedError('sdf_activation / sdf_freq / sdf_n_layers / sdf_d_out other than none / 6 / 8 / 257 are not implemented in HIP')
+        # network-shape keys (network/renderer.py:73-76,118-124).  Round 5: sdf_n_layers, sdf_freq and shader_config.light_pos_freq are free
+        # (the chain descriptors take any depth / input width; non-YAML values run on the Python-sequenced chains, the C step driver stays
+        # laid out for the YAML shapes).  sdf_activation is accepted and ignored, exactly as the reference does: SDFNetwork.__init__ takes
+        # the argument and never reads it (network/field.py:72, 130-147).  What raises, and why:
+        if c['sdf_d_out'] != 257:
+            # AppShadingNetwork hard-codes feats_dim = 256 (network/field.py:499): the reference itself fails in its first forward
+            raise NotImplementedError('sdf_d_out must be 257: the shading network consumes exactly 256 SDF features (network/field.py:499)')
+        if not 2 <= int(c['sdf_n_layers']) <= 9:
+            raise NotImplementedError('sdf_n_layers must be in [2, 9]: a chain descriptor holds NERO_MAX_LAYERS = 10 layers (include/nero_hip.h)')
+        if not 1 <= int(c['sdf_freq']) <= 7:
+            # sdf_freq 0 builds a different network in the reference (no embedding, another initialisation: network/field.py:80-107)
+            raise NotImplementedError('sdf_freq must be in [1, 7]: the skip layer re-reads the PE input from a 48-column aux tile (3 + 6 f <= 48)')
         sc = c['shader_config']
-        if sc.get('light_pos_freq', 8) != 8:
-            # the HIP encoders (shade_encode / mc_encode_hit) hard-wire PE-8 for the light-MLP position input
-            raise NotImplementedError('shader_config.light_pos_freq != 8 is not implemented in HIP')
+        if not 1 <= int(sc.get('light_pos_freq', 8)) <= 10:
+            raise NotImplementedError('shader_config.light_pos_freq must be in [1, 10]')
         if c['n_importance'] % c['up_sample_steps'] != 0:
             raise NotImplementedError('n_importance must be a multiple of up_sample_steps')
         self.sdf_network, self.deviation_network, self.outer_nerf, self.color_network = build_shape_fields(c)
@@ -166,7 +173,7 @@ class NeROShapeRenderer(nn.Module):
         if eff[0].device.type != 'cuda':
             return None
         from . import stage1
-        if not stage1.supported():
+        if not stage1.supported(self.cfg, self.color_network.cfg):
             return None
         drv = getattr(self, '_infer_drv', None)
         if drv is None or not drv.matches_current_modes():

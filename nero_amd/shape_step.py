@@ -54,9 +54,24 @@ class ShapeKernels:
         self.sphere = int(bool(shader_cfg.get('sphere_direction', False)))
         self.ld_outer = 144 if self.sphere else 72          # [IDE(v) | IDE(sphere exit point)] with shader_config.sphere_direction
         self.outer_light = Chain(predictor_entries(eff['outer_light'], self.ld_outer), k_init=self.ld_outer, device=device)
-        self.inner_light = Chain(predictor_entries(eff['inner_light'], 123), k_init=128, device=device)
-        self.inner_weight = Chain(predictor_entries(eff['inner_weight'], 90), k_init=96, device=device)
+        self.pos_freq = int(shader_cfg.get('light_pos_freq', 8))
+        self.pos_dim = 3 + 6 * self.pos_freq                 # network/field.py:515: get_embedder(light_pos_freq, 3)
+        r8 = lambda k: (k + 7) // 8 * 8
+        self.ld_xi, self.ld_xo = r8(self.pos_dim + 72), r8(self.pos_dim + 39)       # 128 / 96 at the YAMLs' PE-8
+        self.inner_light = Chain(predictor_entries(eff['inner_light'], self.pos_dim + 72), k_init=self.ld_xi, device=device)
+        self.inner_weight = Chain(predictor_entries(eff['inner_weight'], self.pos_dim + 39), k_init=self.ld_xo, device=device)
         self.human_light = Chain(predictor_entries(eff['human'], 24), k_init=24, device=device) if self.human else None
+
+    def recode_positions(self, x4, n_in, Xi8, Xo8):
+        """[PE-8(p) | IDE(refl, rough)] [rows,128] and [PE-8(p) | PE-6(refl)] [rows,96] -> the same rows with PE-f(p), f = light_pos_freq"""
+        from .sdf import encode_pe
+        rp, pd = Xi8.shape[0], self.pos_dim
+        pe = encode_pe(x4, n_in, 3, self.pos_freq, (pd + 7) // 8 * 8)
+        Xi = torch.zeros((rp, self.ld_xi), dtype=torch.float32, device=Xi8.device)
+        Xo = torch.zeros((rp, self.ld_xo), dtype=torch.float32, device=Xi8.device)
+        Xi[:, :pd], Xi[:, pd:pd + 72] = pe[:, :pd], Xi8[:, 51:123]
+        Xo[:, :pd], Xo[:, pd:pd + 39] = pe[:, :pd], Xo8[:, 51:90]
+        return Xi, Xo
 
     def pack(self):
         """(re)pack the operand images of all ten networks: ONE zero-filled flat buffer (kept and re-used while its size fits) and
@@ -109,7 +124,7 @@ def unflatten_effective(names, ts):
 
     def wb(prefix):
         return d[prefix + '.weight'], d[prefix + '.bias']
-    eff = {'sdf': [wb(f'sdf.{l}') for l in range(9)],
+    eff = {'sdf': [wb(f'sdf.{l}') for l in range(sum(1 for k in d if k.startswith('sdf.') and k.endswith('.weight')))],
            'nerf': {'pts': [wb(f'nerf.pts.{i}') for i in range(8)], 'views': wb('nerf.views'), 'feature': wb('nerf.feature'),
                     'alpha': wb('nerf.alpha'), 'rgb': wb('nerf.rgb')}}
     for short, pn in (('metallic', 'metallic_predictor'), ('roughness', 'roughness_predictor'), ('albedo', 'albedo_predictor'),
@@ -137,13 +152,11 @@ def sample_ray(K, cfg, o, d, near, far, variance, rand1=None, rand_bg=None, trac
     st = _st()
     lib = L.lib
     L.check(lib.nero_coarse_z(_p(near), _p(far), _p(rand1), R, ns, _p(z), T, st))
-    pe = torch.empty((row_pad(R * ns), 40), dtype=torch.float32, device=dev)
-    L.check(lib.nero_ray_points_pe(_p(o), _p(d), _p(z), T, 0, ns, R, _p(pe), st))
+    pe = K.sdf.pe_of_rays(o, d, z, 0, ns)
     s4 = K.sdf.sdf_from_pe(pe, R * ns)
     L.check(lib.nero_scatter_sdf(_p(s4), 4, R, ns, _p(tab), n_in, st))
     n = ns
     z_new = torch.empty((R, m), dtype=torch.float32, device=dev)
-    pe_new = torch.empty((row_pad(R * m), 40), dtype=torch.float32, device=dev)
     var_ptr = variance if cfg['clip_sample_variance'] else None
     for i in range(up):
         w_out = inds = index = None
@@ -157,8 +170,7 @@ def sample_ray(K, cfg, o, d, near, far, variance, rand1=None, rand_bg=None, trac
                                   _p(z_new), _p(w_out), _p(inds), st))
         last = (i + 1 == up)
         if not last:
-            L.check(lib.nero_ray_points_pe(_p(o), _p(d), _p(z_new), m, 0, m, R, _p(pe_new), st))
-            s4 = K.sdf.sdf_from_pe(pe_new, R * m)
+            s4 = K.sdf.sdf_from_pe(K.sdf.pe_of_rays(o, d, z_new, 0, m), R * m)
             L.check(lib.nero_merge_sorted(_p(z), T, n, _p(tab), n_in, _p(z_new), m, _p(s4), 4, R, _p(index), st))
         else:
             L.check(lib.nero_merge_sorted(_p(z), T, n, _p(None), 0, _p(z_new), m, _p(None), 0, R, _p(index), st))
@@ -218,7 +230,7 @@ class RenderCore(torch.autograd.Function):
         if n_in > 0:
             x4, pe40 = torch.empty((rpi, 4), **f32), torch.empty((rpi, 40), **f32)
             L.check(lib.nero_gather_inner(_p(pts4), _p(inner_idx), n_in, _p(x4), _p(pe40), st))
-            sctx = K.sdf.forward_normal(x4, n_in, pe40)
+            sctx = K.sdf.forward_normal(x4, n_in, pe40 if K.sdf.default_pe else None)     # (another sdf_freq: nero_encode_pe inside)
             alpha_i, geo = torch.empty(rpi, **f32), torch.empty((rpi, 8), **f32)
             L.check(lib.nero_sdf_alpha_fwd(_p(sctx['sdf4']), _p(sctx['normal']), _p(x4), _p(inner_idx), _p(d), T, _p(variance),
                                            C.c_float(meta['anneal']), n_in, _p(alpha_i), _p(geo), _p(gerr), st))
@@ -231,6 +243,11 @@ class RenderCore(torch.autograd.Function):
             Xi, Xo = torch.empty((rpi, 128), **f32), torch.empty((rpi, 96), **f32)
             L.check(lib.nero_shade_encode(_p(x4), _p(geo), _p(mats[0]['heads'][3]), _p(mats[1]['heads'][3]), _p(mats[2]['heads'][3]),
                                           n_in, _p(mat), _p(Xo2[:rpi]), _p(Xo2[rpi:]), _p(Xi), _p(Xo), K.sphere, st))
+            if K.pos_freq != 8:
+                # shader_config.light_pos_freq other than the YAMLs' 8: the encoder kernel writes [PE-8(p) | IDE] and [PE-8(p) | PE-6(refl)];
+                # the position part is re-encoded at the requested frequency count, the direction parts are kept (network/field.py:515,
+                # 556-571: pos_enc only ever sees the detached points)
+                Xi, Xo = K.recode_positions(x4, n_in, Xi, Xo)
             f_out = K.outer_light.forward(Xo2, None, rpi + n_in)
             f_in = K.inner_light.forward(Xi, None, n_in)
             f_w = K.inner_weight.forward(Xo, None, n_in)
@@ -338,7 +355,12 @@ class RenderCore(torch.autograd.Function):
                                                   _p(hb['d_init']), _p(extra), st))
             dmr, drr, dar = (torch.empty((rpi, 4), **f32) for _ in range(3))
             dX = ob['d_init']
-            L.check(lib.nero_shade_encode_bwd(_p(geo), _p(mat), _p(dX[:rpi]), _p(dX[rpi:]), _p(ib['d_init']), _p(dmat), n_in,
+            dXi = ib['d_init']
+            if K.pos_freq != 8:                      # the IDE columns of d Xi back at 51..122, where nero_shade_encode_bwd reads them
+                dXi128 = torch.zeros((rpi, 128), **f32)
+                dXi128[:, 51:123] = dXi[:, K.pos_dim:K.pos_dim + 72]
+                dXi = dXi128
+            L.check(lib.nero_shade_encode_bwd(_p(geo), _p(mat), _p(dX[:rpi]), _p(dX[rpi:]), _p(dXi), _p(dmat), n_in,
                                               _p(d_geo), _p(dmr), _p(drr), _p(dar), _p(extra), _p(S['x4']), K.sphere, st))
             d_feat = torch.empty((rpi, 256), **f32)
             feat = S['sctx']['feat']
@@ -350,8 +372,8 @@ class RenderCore(torch.autograd.Function):
             L.check(lib.nero_sdf_alpha_bwd(_p(S['sctx']['sdf4']), _p(S['sctx']['normal']), _p(S['x4']), _p(S['inner_idx']), _p(S['d']), T,
                                            _p(S['variance']), C.c_float(meta['anneal']), n_in, _p(d_ai), _p(d_gerr_c), _p(d_geo),
                                            _p(d_sdf4), _p(d_grad), _p(dinv), st))
-            sg = K.sdf.backward(S['sctx'], d_sdf4, d_feat, d_grad, workspace=ws, outs=outs_of('sdf', range(8)))
-            for l in range(9):
+            sg = K.sdf.backward(S['sctx'], d_sdf4, d_feat, d_grad, workspace=ws, outs=outs_of('sdf', range(K.sdf.last)))
+            for l in range(K.sdf.n_lin):
                 G[f'sdf.{l}.weight'], G[f'sdf.{l}.bias'] = sg[l]
             if not meta['freeze_inv_s']:
                 v = S['variance'].detach()
@@ -381,13 +403,13 @@ class SDFValue(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, K, x, *params):
-        from .sdf import encode_pe, N_FREQ, LD_PE
+        from .sdf import encode_pe
         n = x.shape[0]
-        pe = encode_pe(x.contiguous(), n, 3, N_FREQ, LD_PE)
+        pe = encode_pe(x.contiguous(), n, 3, K.sdf.n_freq, K.sdf.ld_pe)
         fwd = K.sdf.value_only.forward(pe, pe, n, save=True)
         ctx.K, ctx.pe, ctx.fwd, ctx.n = K, pe, fwd, n
         ctx.shapes = [tuple(p.shape) for p in params]
-        return fwd['heads'][8][:n, 0].clone()
+        return fwd['heads'][K.sdf.last][:n, 0].clone()
 
     @staticmethod
     def backward(ctx, d_sdf):
@@ -396,15 +418,16 @@ class SDFValue(torch.autograd.Function):
         rp = row_pad(n)
         dy = torch.zeros((rp, 4), dtype=torch.float32, device=d_sdf.device)
         dy[:n, 0] = d_sdf
-        bwd = ch.backward(fwd, n, head_dys={8: dy})
-        gr = ch.weight_grads(fwd, bwd, n, pe, pe, head_dys={8: dy})
+        last = K.sdf.last
+        bwd = ch.backward(fwd, n, head_dys={last: dy})
+        gr = ch.weight_grads(fwd, bwd, n, pe, pe, head_dys={last: dy})
         out = []
-        for l in range(8):
+        for l in range(last):
             out += [gr[l]['dW'], gr[l]['db']]
-        dW8 = torch.zeros(ctx.shapes[16], dtype=torch.float32, device=d_sdf.device)
-        db8 = torch.zeros(ctx.shapes[17], dtype=torch.float32, device=d_sdf.device)
-        dW8[0:1] = gr[8]['dWh']
-        db8[0:1] = gr[8]['dbh']
+        dW8 = torch.zeros(ctx.shapes[2 * last], dtype=torch.float32, device=d_sdf.device)
+        db8 = torch.zeros(ctx.shapes[2 * last + 1], dtype=torch.float32, device=d_sdf.device)
+        dW8[0:1] = gr[last]['dWh']
+        db8[0:1] = gr[last]['dbh']
         out += [dW8, db8]
         return (None, None) + tuple(out)
 
@@ -418,16 +441,12 @@ def secondary_occlusion(K, o, dr, variance, sn0, sn1):
     Pn = o.shape[0]
     z = torch.empty((Pn, sn0), **f32)
     L.check(lib.nero_occ_z(_p(o), _p(dr), Pn, sn0, _p(z), st))
-    pe = torch.empty((row_pad(Pn * sn0), 40), **f32)
-    L.check(lib.nero_ray_points_pe(_p(o), _p(dr), _p(z), sn0, 0, sn0, Pn, _p(pe), st))
-    s4 = K.sdf.sdf_from_pe(pe, Pn * sn0)
+    s4 = K.sdf.sdf_from_pe(K.sdf.pe_of_rays(o, dr, z, 0, sn0), Pn * sn0)
     w = torch.empty((Pn, sn0 - 1), **f32)
     L.check(lib.nero_section_weights(_p(z), _p(s4), 4, sn0, _p(variance), Pn, _p(w), _p(None), st))
     z_new = torch.empty((Pn, sn1), **f32)
     L.check(lib.nero_sample_pdf(_p(z), sn0, _p(w), sn0 - 1, sn0, sn1, Pn, _p(z_new), _p(None), st))
-    pe2 = torch.empty((row_pad(Pn * sn1), 40), **f32)
-    L.check(lib.nero_ray_points_pe(_p(o), _p(dr), _p(z_new), sn1, 0, sn1, Pn, _p(pe2), st))
-    s4b = K.sdf.sdf_from_pe(pe2, Pn * sn1)
+    s4b = K.sdf.sdf_from_pe(K.sdf.pe_of_rays(o, dr, z_new, 0, sn1), Pn * sn1)
     gt = torch.empty(Pn, **f32)
     L.check(lib.nero_section_weights(_p(z_new), _p(s4b), 4, sn1, _p(variance), Pn, _p(None), _p(gt), st))
     return gt

@@ -58,9 +58,16 @@ _lib.nero_stage1_get_state.argtypes = [_fp, C.POINTER(State)]
 _lib.nero_stage1_destroy.argtypes = [_fp]
 
 
-def supported():
-    """the C driver packs fp16 two-plane operands only (the default engines)"""
-    return all(GEMM_MODE[k] == L.GEMM_F16X3 for k in ('fwd', 'tan', 'bwd', 'dw'))
+def supported(cfg=None, shader_cfg=None):
+    """the C driver packs fp16 two-plane operands only (the default engines) and is laid out for the network shapes of the shipped
+    YAMLs: 8 x 256 SDF layers on a PE-6 input, PE-8 positions in front of the light MLPs.  Other values of sdf_n_layers / sdf_freq /
+    shader_config.light_pos_freq run on the Python-sequenced chains (nero_amd/shape_step.py), which take any of them."""
+    ok = all(GEMM_MODE[k] == L.GEMM_F16X3 for k in ('fwd', 'tan', 'bwd', 'dw'))
+    if cfg is not None:
+        ok = ok and int(cfg.get('sdf_n_layers', 8)) == 8 and int(cfg.get('sdf_freq', 6)) == 6
+    if shader_cfg is not None:
+        ok = ok and int(shader_cfg.get('light_pos_freq', 8)) == 8
+    return ok
 
 
 def current_modes():

@@ -235,7 +235,7 @@ class ShapeTrainStep:
             # keeps the Python-sequenced launches of nero_amd/shape_step.py (identical kernels, identical results)
             import os
             from . import stage1
-            if os.environ.get('NERO_STEP_DRIVER', 'c') != 'py' and stage1.supported():
+            if os.environ.get('NERO_STEP_DRIVER', 'c') != 'py' and stage1.supported(self.net.cfg, self.net.color_network.cfg):
                 self.drv = stage1.Stage1Driver(self.net.cfg, self.net.color_network.cfg, device)
         else:
             self.bucket = GradBucket(self.params)                # p.grad = views of one flat buffer, for the whole run

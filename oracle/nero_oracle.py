@@ -166,14 +166,19 @@ def softplus100(x):
 
 
 def sdf_network(P, x, prefix='sdf_network'):
-    """9-layer softplus(beta=100) MLP, PE-6 input, skip into layer 4   (network/field.py:130-147).  -> [N,257]"""
-    e = pos_enc(x, 6)
+    """softplus(beta=100) MLP of sdf_n_layers + 1 linear layers on a PE-f input, the input re-injected in front of layer
+    sdf_n_layers // 2   (network/field.py:75-101, 130-147; network/renderer.py:118-124).  Every shipped YAML: 9 layers, PE-6, skip into
+    layer 4; the shape is read off the weights.  -> [N,257]"""
+    n_lin = sum(1 for k in P if k.startswith(f'{prefix}.lin') and k.endswith('.weight'))
+    n_freq = (P[f'{prefix}.lin0.weight'].shape[1] - 3) // 6
+    skip = (n_lin - 1) // 2
+    e = pos_enc(x, n_freq)
     h = e
-    for l in range(9):
-        if l == 4:
+    for l in range(n_lin):
+        if l == skip:
             h = torch.cat([h, e], -1) / math.sqrt(2)
         h = F.linear(h, P[f'{prefix}.lin{l}.weight'], P[f'{prefix}.lin{l}.bias'])
-        if l < 8:
+        if l < n_lin - 1:
             h = softplus100(h)
     return h
 

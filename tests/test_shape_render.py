@@ -11,6 +11,9 @@ from tests.helpers import T, assert_grads_fp32_grade, build_case_model, load_gol
 pytestmark = pytest.mark.gpu
 
 CASES = ['bell_s25000', 'bell_s5000_sharp', 'bell_c1', 'bear_s25000', 'bell_sphdir', 'bell_noclip_l1', 'bell_l2', 'bell_smoothl1']
+# non-YAML network-shape keys (round 5; oracle/gen_golden_r5.py): sdf_n_layers 6 / sdf_freq 4 / light_pos_freq 6 and 9 / 7 / 10 --
+# the Python-sequenced chains (the C step driver keeps the YAML shapes, nero_amd.stage1.supported)
+SHAPE_KEY_CASES = ['bell_shape_keys', 'bell_deep_sdf']
 
 
 def rel(a, b):
@@ -81,7 +84,7 @@ def test_sampler_stagewise_teacher_forced(name):
         assert torch.equal(zt.cpu(), t['z_out'])
 
 
-@pytest.mark.parametrize('name', CASES)
+@pytest.mark.parametrize('name', CASES + SHAPE_KEY_CASES)
 def test_sampler_end_to_end(name):
     z, meta = load_golden(name)
     net = build_case_model(meta).cuda()
@@ -95,7 +98,7 @@ def test_sampler_end_to_end(name):
     assert (zg[:, -nb:] / zo[:, -nb:] - 1).abs().max() < 1e-6
 
 
-@pytest.mark.parametrize('name', CASES)
+@pytest.mark.parametrize('name', CASES + SHAPE_KEY_CASES)
 def test_render_core_outputs_and_grads(name):
     """teacher-forced on the golden z_vals: ray_rgb / gradient_error / occ_prob and every parameter gradient vs the oracle"""
     z, meta = load_golden(name)
@@ -157,7 +160,8 @@ def test_std_act_linear_and_square_render_and_variance_gradient(act, variance):
     assert abs(gvo) > 1e-9 and abs(gv - gvo) < 2e-4 * abs(gvo), (gv, gvo)
 
 
-@pytest.mark.parametrize('name', ['bell_s25000', 'bell_occcap', 'bell_s500', 'bear_s25000', 'bell_sphdir', 'bell_noclip_l1', 'bell_l2', 'bell_smoothl1'])
+@pytest.mark.parametrize('name', ['bell_s25000', 'bell_occcap', 'bell_s500', 'bear_s25000', 'bell_sphdir', 'bell_noclip_l1', 'bell_l2', 'bell_smoothl1']
+                         + SHAPE_KEY_CASES)
 def test_full_training_loss_with_occ_and_init_reg(name):
     """trainer loss incl. the occlusion loss (step >= 20000, with and without the random cap) and the InitSDFRegLoss inputs
     (step < 1000), teacher-forced on the golden z_vals; loss, loss_occ and gradients vs the oracle"""
@@ -187,6 +191,24 @@ def test_full_training_loss_with_occ_and_init_reg(name):
     loss.backward()
     g64 = _oracle_grads(meta, z, torch.float64, occ=True, keys=keys)
     assert_grads_fp32_grade(named_grads(net), named_grads(ref), g64, where=name)
+
+
+def test_non_yaml_network_shape_keys_on_the_fused_trainer():
+    """sdf_n_layers / sdf_freq / light_pos_freq away from the YAML values: the fused training step runs (Python-sequenced chains, fused
+    weight-norm + Adam kernels over the 7-layer SDF network), its first loss equals the drop-in renderer's on the same batch, and
+    training reduces it; sdf_d_out != 257 raises like the reference's first forward would"""
+    from nero_amd.renderer import NeROShapeRenderer
+    from nero_amd.train import ShapeTrainStep
+    cfg = dict(n_samples=16, n_importance=16, n_bg_samples=8, up_sample_steps=4, sdf_n_layers=6, sdf_freq=4, sdf_activation='sigmoid',
+               shader_config={'light_pos_freq': 6}, freeze_inv_s_step=15000, apply_occ_loss=True, occ_loss_step=20000)
+    ts = ShapeTrainStep(cfg, rays_per_rank=256, pool_rays=2048, device='cuda:0', variance=0.4, prime_fraction=0.0)
+    assert ts.drv is None and ts.net.sdf_network.n_lin == 7 and ts.net.sdf_network.lin0.weight_v.shape[1] == 27
+    losses = [float(ts.step(25000 + i)['loss']) for i in range(12)]
+    assert all(np.isfinite(losses)) and min(losses[-3:]) < losses[0], losses
+    with pytest.raises(NotImplementedError):
+        NeROShapeRenderer({'sdf_d_out': 129}, training=False)
+    with pytest.raises(NotImplementedError):
+        NeROShapeRenderer({'sdf_freq': 9}, training=False)
 
 
 def test_trainer_entry_point_with_database_object():
