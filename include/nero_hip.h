@@ -333,6 +333,13 @@ int nero_gather_sample_grads(const float* d_alphaRT, const float* d_colorRT, con
 int nero_bvh_create(const float* verts, int nV, const int* tris, int nT, void** handle);
 int nero_bvh_trace(void* handle, const float* rays_o, const float* rays_d, int n, float* positions, float* face_normals, float* depth,
                    void* stream);
+/* nero_bvh_trace with a LAUNCH-ORDER hint (round 5): the rays come in groups of `group` (Stage II: the D = Dd + Ds secondary rays of a
+ * surface point, field.py:856-880) whose entries [heavy_from, group) are the expensive ones (the GGX specular directions: the only rays
+ * that can point below the surface and cross the inside of the mesh); their 64-ray chunks are started first, so that the launch ends
+ * with short rays.  Outputs identical to nero_bvh_trace's.  group, heavy_from multiples of 64, 0 < heavy_from < group, n % group == 0;
+ * otherwise the natural order. */
+int nero_bvh_trace_grouped(void* handle, const float* rays_o, const float* rays_d, int n, float* positions, float* face_normals, float* depth,
+                           int group, int heavy_from, void* stream);
 int nero_bvh_destroy(void* handle);
 /* which kernel nero_bvh_trace launches: 1 = memory requests of a traversal step overlapped, stack in LDS (default when the tree is no
  * deeper than the 24-entry LDS stack), 0 = private stack, one request after the other.  Same visit order and arithmetic per ray:

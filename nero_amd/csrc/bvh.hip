@@ -232,12 +232,26 @@ __device__ __forceinline__ void leaf_test_batched(const Tri* __restrict__ tris, 
 constexpr int PL_THREADS = 64;
 constexpr int PL_STACK = 24;               // LDS stack entries per ray (6 KB per workgroup); deeper trees take trace_kernel
 
+// LAUNCH ORDER (round 5, nero_bvh_trace_grouped): the secondary rays of Stage II come as [point][direction] with the cosine-weighted
+// diffuse directions first and the GGX specular ones behind them.  Every ray that points below the geometric surface -- it crosses the
+// inside of the mesh to its far side: hundreds of dependent node steps -- is a specular one, so the 64-ray chunks of a point fall into
+// light ones (diffuse: above the horizon, most of them miss) and heavy ones, and in ray order the launch ends with whatever heavy chunks the
+// last points own: 2.1 resident waves per SIMD on average (tracer).  With `gchunks` > 0 workgroup b takes the HEAVY chunks of
+// all groups first ([heavy0, gchunks) of every group of gchunks chunks), then the light ones: the tail of the launch is made of short rays.
+// Same rays, same arithmetic, same outputs at the same addresses -- only the order in which workgroups start changes.
 __global__ __launch_bounds__(PL_THREADS) void trace_overlap_kernel(const Node* __restrict__ nodes, const Tri* __restrict__ tris, int root,
                                                                    const float* __restrict__ ro, const float* __restrict__ rd, int n,
-                                                                   float* __restrict__ pos, float* __restrict__ nrm, float* __restrict__ depth) {
+                                                                   float* __restrict__ pos, float* __restrict__ nrm, float* __restrict__ depth,
+                                                                   int gchunks, int heavy0, int n_groups) {
     __shared__ int lds_stack[PL_STACK * PL_THREADS];
     int* const st = lds_stack + threadIdx.x;                                   // entry s of this lane: st[s * PL_THREADS]
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    int chunk = blockIdx.x;
+    if (gchunks > 0 && chunk < n_groups * gchunks) {
+        const int nh = gchunks - heavy0, heavy_total = n_groups * nh;
+        if (chunk < heavy_total) chunk = (chunk / nh) * gchunks + heavy0 + chunk % nh;
+        else { const int b = chunk - heavy_total; chunk = (b / heavy0) * gchunks + b % heavy0; }
+    }
+    const int r = chunk * blockDim.x + threadIdx.x;
     if (r >= n) return;
     const float o[3] = {ro[r * 3], ro[r * 3 + 1], ro[r * 3 + 2]};
     const float d[3] = {rd[r * 3], rd[r * 3 + 1], rd[r * 3 + 2]};
@@ -363,8 +377,24 @@ int nero_bvh_trace(void* handle, const float* rays_o, const float* rays_d, int n
         return nero_check_launch("nero_bvh_trace");
     }
     hipLaunchKernelGGL(trace_overlap_kernel, dim3((n + PL_THREADS - 1) / PL_THREADS), dim3(PL_THREADS), 0, (hipStream_t)stream, h->b.d_nodes, h->b.d_tris,
-                       h->root, rays_o, rays_d, n, positions, face_normals, depth);
+                       h->root, rays_o, rays_d, n, positions, face_normals, depth, 0, 0, 0);
     return nero_check_launch("nero_bvh_trace");
+}
+
+// nero_bvh_trace with a launch-order hint for rays that come in groups of `group` (Stage II: the D = Dd + Ds directions of a surface
+// point) whose entries [heavy_from, group) are the expensive ones (the specular directions): those chunks are started first.  Outputs
+// are identical to nero_bvh_trace's.  group and heavy_from must be multiples of 64 (the chunk size) with 0 < heavy_from < group, and n a
+// multiple of group; anything else takes the natural order.
+int nero_bvh_trace_grouped(void* handle, const float* rays_o, const float* rays_d, int n, float* positions, float* face_normals, float* depth,
+                           int group, int heavy_from, void* stream) {
+    if (!handle || !rays_o || !rays_d || !positions || !face_normals || !depth) return nero_fail(NERO_ERR_ARG, "nero_bvh_trace_grouped: bad argument");
+    Handle* h = (Handle*)handle;
+    const bool ok = h->mode != 0 && group > 0 && heavy_from > 0 && heavy_from < group && group % PL_THREADS == 0 && heavy_from % PL_THREADS == 0 &&
+                    n > 0 && n % group == 0;
+    if (!ok) return nero_bvh_trace(handle, rays_o, rays_d, n, positions, face_normals, depth, stream);
+    hipLaunchKernelGGL(trace_overlap_kernel, dim3(n / PL_THREADS), dim3(PL_THREADS), 0, (hipStream_t)stream, h->b.d_nodes, h->b.d_tris, h->root,
+                       rays_o, rays_d, n, positions, face_normals, depth, group / PL_THREADS, heavy_from / PL_THREADS, n / group);
+    return nero_check_launch("nero_bvh_trace_grouped");
 }
 
 int nero_bvh_set_traversal(void* handle, int mode) {

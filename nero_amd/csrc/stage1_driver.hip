@@ -45,6 +45,13 @@ struct nero_stage1 {
     int n_streams = 1;
     hipStream_t s2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // ---- a third stream for the weight-gradient jobs of the SDF / shading branch (round 5, NERO_STREAMS=3): the jobs of a chain depend on
+    // that chain's reverse pass only and nothing in the step depends on them, so they run BESIDE the next chain's reverse pass.  The two
+    // kernel classes are bound by different things -- the weight-gradient GEMM streams its operands from HBM (4.9 TB/s), the chain kernels
+    // issue MFMA + VALU -- and their workgroups interleave over the CUs: fewer weight-gradient workgroups at a time compete for HBM.  The
+    // price is memory: a chain's deltas cannot be released while its jobs may still read them (no arena release in this mode).
+    hipStream_t s3 = nullptr;
+    hipEvent_t ev_dw = nullptr, ev_dw_done = nullptr;
 };
 
 namespace {
@@ -60,6 +67,19 @@ void join_side(nero_stage1* h, hipStream_t side, hipStream_t main) {
     if (side == main) return;
     (void)hipEventRecord(h->ev_join, side);
     (void)hipStreamWaitEvent(main, h->ev_join, 0);
+}
+
+// the stream of the weight-gradient jobs: s3 behind everything `main` holds so far (the reverse pass that produced their operands)
+hipStream_t fork_dw(nero_stage1* h, const Arena& A, hipStream_t main) {
+    if (A.dry || h->n_streams < 3 || !h->s3 || nero_prof_is_on()) return main;
+    (void)hipEventRecord(h->ev_dw, main);
+    (void)hipStreamWaitEvent(h->s3, h->ev_dw, 0);
+    return h->s3;
+}
+void join_dw(nero_stage1* h, const Arena& A, hipStream_t main) {
+    if (A.dry || h->n_streams < 3 || !h->s3 || nero_prof_is_on()) return;
+    (void)hipEventRecord(h->ev_dw_done, h->s3);
+    (void)hipStreamWaitEvent(main, h->ev_dw_done, 0);
 }
 
 void build_chains(nero_stage1* h, const nero_stage1_weights* w) {
@@ -288,6 +308,7 @@ int do_backward(nero_stage1* h, Arena& A, const float* d_rgb, const float* d_ger
     const int ws_rows = (n_in + rpi) > n_out ? (n_in + rpi) : n_out;
     float* partials = A.f32((size_t)nero_dw_workspace_floats(ws_rows > 1 ? ws_rows : 1));
     const bool two = h->n_streams >= 2;
+    const bool three = h->n_streams >= 3;              // (weight-gradient jobs of the inner branch on their own stream: no delta is released)
     float* partials_o = two ? A.f32((size_t)nero_dw_workspace_floats(n_out > 1 ? n_out : 1)) : partials;      // (the side branch's own partial sums)
     if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_bwd: workspace too small");
     LAUNCH(nero_composite_bwd(h->alphaRT, h->colorRT, S.weights, d_rgb, R, T, d_aRT, d_cRT, stream));
@@ -362,27 +383,27 @@ int do_backward(nero_stage1* h, Arena& A, const float* d_rgb, const float* d_ger
             hd[3] = dLh;
             Bwd ob;
             RC(h->outer_light.backward(A, M, h->f_out, n2, nullptr, 0, hd, true, false, nullptr, dxo, h->ld_outer, false, false, ob, stream));
-            RC(h->outer_light.weight_grads(A, M, h->f_out, ob, n2, h->Xo2, h->ld_outer, nullptr, 0, hd, nullptr, nullptr, partials, stream));
-            A.release(mk);
+            RC(h->outer_light.weight_grads(A, M, h->f_out, ob, n2, h->Xo2, h->ld_outer, nullptr, 0, hd, nullptr, nullptr, partials, (void*)fork_dw(h, A, hs)));
+            if (!three) A.release(mk);
             predictor_grads(h->inner_light, g + L_INNER, 123);
             hd[3] = dLi;
             Bwd ib;
             RC(h->inner_light.backward(A, M, h->f_in, n_in, nullptr, 0, hd, true, false, nullptr, dxi, 128, false, false, ib, stream));
-            RC(h->inner_light.weight_grads(A, M, h->f_in, ib, n_in, h->Xi, 128, nullptr, 0, hd, nullptr, nullptr, partials, stream));
-            A.release(mk);
+            RC(h->inner_light.weight_grads(A, M, h->f_in, ib, n_in, h->Xi, 128, nullptr, 0, hd, nullptr, nullptr, partials, (void*)fork_dw(h, A, hs)));
+            if (!three) A.release(mk);
             predictor_grads(h->inner_weight, g + L_WEIGHT, 90);
             hd[3] = dLo;
             Bwd wb;
             RC(h->inner_weight.backward(A, M, h->f_w, n_in, nullptr, 0, hd, false, false, nullptr, nullptr, 0, false, false, wb, stream));
-            RC(h->inner_weight.weight_grads(A, M, h->f_w, wb, n_in, h->Xo, 96, nullptr, 0, hd, nullptr, nullptr, partials, stream));
-            A.release(mk);
+            RC(h->inner_weight.weight_grads(A, M, h->f_w, wb, n_in, h->Xo, 96, nullptr, 0, hd, nullptr, nullptr, partials, (void*)fork_dw(h, A, hs)));
+            if (!three) A.release(mk);
             if (h->cfg.human_light) {
                 predictor_grads(h->human_light, g + L_HUMAN, 24);
                 hd[3] = dLhum;
                 Bwd hb;
                 RC(h->human_light.backward(A, M, h->f_h, n_in, nullptr, 0, hd, true, false, nullptr, dxh, 24, false, false, hb, stream));
-                RC(h->human_light.weight_grads(A, M, h->f_h, hb, n_in, h->Xh, 24, nullptr, 0, hd, nullptr, nullptr, partials, stream));
-                A.release(mk);
+                RC(h->human_light.weight_grads(A, M, h->f_h, hb, n_in, h->Xh, 24, nullptr, 0, hd, nullptr, nullptr, partials, (void*)fork_dw(h, A, hs)));
+                if (!three) A.release(mk);
                 LAUNCH(nero_human_encode_bwd(S.x4, S.geo, h->mat8, S.inner_idx, T, h->poses, n_in, dxh, extra, stream));
             }
             dX_outer = dxo; ld_dxo = h->ld_outer; dX_inner = dxi;
@@ -398,8 +419,8 @@ int do_backward(nero_stage1* h, Arena& A, const float* d_rgb, const float* d_ger
             hd[3] = dhs[j];
             Bwd mb;
             RC(h->mat[j].backward(A, M, h->f_mat[j], n_in, nullptr, 0, hd, true, false, nullptr, d_feat, NERO_HID, j > 0, false, mb, stream));
-            RC(h->mat[j].weight_grads(A, M, h->f_mat[j], mb, n_in, S.feat, NERO_HID, h->x8, 8, hd, nullptr, nullptr, partials, stream));
-            A.release(mk);
+            RC(h->mat[j].weight_grads(A, M, h->f_mat[j], mb, n_in, S.feat, NERO_HID, h->x8, 8, hd, nullptr, nullptr, partials, (void*)fork_dw(h, A, hs)));
+            if (!three) A.release(mk);
         }
         float* d_sdf4 = A.f32((size_t)rpi * 4);
         float* d_grad = A.f32((size_t)rpi * 3);
@@ -450,7 +471,8 @@ int do_backward(nero_stage1* h, Arena& A, const float* d_rgb, const float* d_ger
         sd[8] = d_sdf4;
         Bwd sb;
         RC(sc.backward(A, M, h->f_sdf, n_in, d_feat, NERO_HID, sd, false, false, injs, nullptr, 0, false, false, sb, stream, adots));
-        RC(sc.weight_grads(A, M, h->f_sdf, sb, n_in, h->pe40, LD_PE, h->pe40, LD_PE, sd, second, head_extra, partials, stream));
+        RC(sc.weight_grads(A, M, h->f_sdf, sb, n_in, h->pe40, LD_PE, h->pe40, LD_PE, sd, second, head_extra, partials, (void*)fork_dw(h, A, hs)));
+        join_dw(h, A, hs);
         float* part = A.f32(128);
         if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_bwd: workspace too small");
         if (d_inv_s_sum && !A.dry) {
@@ -492,6 +514,13 @@ int nero_stage1_create(const nero_stage1_cfg* cfg, nero_stage1** out) {
             h->s2 = nullptr;
         }
     }
+    if (h->n_streams >= 3) {
+        if (hipStreamCreateWithFlags(&h->s3, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_dw, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_dw_done, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            h->s3 = nullptr;
+        }
+    }
     *out = h;
     return NERO_OK;
 }
@@ -501,6 +530,9 @@ void nero_stage1_destroy(nero_stage1* h) {
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->s2) (void)hipStreamDestroy(h->s2);
+    if (h->ev_dw) (void)hipEventDestroy(h->ev_dw);
+    if (h->ev_dw_done) (void)hipEventDestroy(h->ev_dw_done);
+    if (h->s3) (void)hipStreamDestroy(h->s3);
     delete h;
 }
 

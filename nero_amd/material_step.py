@@ -3,6 +3,7 @@ the Monte-Carlo shader (secondary rays through the BVH tracer, light MLPs on com
 Mirrors MCShadingNetwork.forward / shade_mixed / get_lights / material_regularization (network/field.py:856-1087) and
 NeROMaterialRenderer.shade / train_step (network/renderer.py:810-848)."""
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -177,7 +178,13 @@ class MCShade(torch.autograd.Function):
         L.check(lib.nero_mc_point_setup(_p(pts), _p(view), _p(normals), _p(mat5), _p(rd), _p(rs), Pn, _p(pt), st))
         dirs, orig = torch.empty((Pn * D, 3), **f32), torch.empty((Pn * D, 3), **f32)
         L.check(lib.nero_mc_dirs(_p(pt), _p(K.tab_d), _p(K.tab_s), Pn, Dd, Ds, _p(dirs), _p(orig), st))
-        pos, fnrm, depth = tracer.trace(orig, dirs)                       # closest hit, depth >= 10 <=> miss
+        # closest hit, depth >= 10 <=> miss.  A tracer that takes a launch-order hint starts the specular chunks of every point first
+        # (nero_bvh_trace_grouped: same outputs); any other RayTracer-shaped object (tests, a reference-side tracer) gets the plain call
+        tg = getattr(tracer, 'trace_grouped', None)
+        if tg is not None and os.environ.get('NERO_TRACE_ORDER', 'grouped') == 'grouped':
+            pos, fnrm, depth = tg(orig, dirs, D, Dd)
+        else:
+            pos, fnrm, depth = tracer.trace(orig, dirs)
         # hit / miss split on the device (ordered compaction, nero_mc_split): the index lists torch.nonzero would give + the slot map
         N = Pn * D
         depth = depth.contiguous().reshape(-1)

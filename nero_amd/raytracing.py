@@ -35,7 +35,12 @@ class RayTracer:
         except Exception:
             pass
 
-    def trace(self, rays_o, rays_d, inplace=False):
+    def trace_grouped(self, rays_o, rays_d, group, heavy_from, inplace=False):
+        """trace() with a launch-order hint (nero_bvh_trace_grouped): rays in groups of `group`, entries [heavy_from, group) of every
+        group started first (Stage II: the specular directions of a surface point).  Same outputs as trace()."""
+        return self.trace(rays_o, rays_d, inplace, _order=(int(group), int(heavy_from)))
+
+    def trace(self, rays_o, rays_d, inplace=False, _order=None):
         rays_o = rays_o.float().contiguous()
         rays_d = rays_d.float().contiguous()
         if not rays_o.is_cuda:
@@ -51,7 +56,12 @@ class RayTracer:
         depth = torch.empty(n, dtype=torch.float32, device=rays_o.device)
         if inplace:                      # the kernel reads o/d before it writes: each thread owns its ray
             pass
-        L.check(L.lib.nero_bvh_trace(self._handle(), C.c_void_p(rays_o.data_ptr()), C.c_void_p(rays_d.data_ptr()), n,
-                                     C.c_void_p(positions.data_ptr()), C.c_void_p(face_normals.data_ptr()),
-                                     C.c_void_p(depth.data_ptr()), L.stream_ptr()))
+        if _order is not None:
+            L.check(L.lib.nero_bvh_trace_grouped(self._handle(), C.c_void_p(rays_o.data_ptr()), C.c_void_p(rays_d.data_ptr()), n,
+                                                 C.c_void_p(positions.data_ptr()), C.c_void_p(face_normals.data_ptr()),
+                                                 C.c_void_p(depth.data_ptr()), _order[0], _order[1], L.stream_ptr()))
+        else:
+            L.check(L.lib.nero_bvh_trace(self._handle(), C.c_void_p(rays_o.data_ptr()), C.c_void_p(rays_d.data_ptr()), n,
+                                         C.c_void_p(positions.data_ptr()), C.c_void_p(face_normals.data_ptr()),
+                                         C.c_void_p(depth.data_ptr()), L.stream_ptr()))
         return positions.view(*prefix, 3), face_normals.view(*prefix, 3), depth.view(*prefix)

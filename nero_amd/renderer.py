@@ -39,9 +39,10 @@ class NeROShapeRenderer(nn.Module):
             raise NotImplementedError('sdf_d_out must be 257: the shading network consumes exactly 256 SDF features (network/field.py:499)')
         if not 2 <= int(c['sdf_n_layers']) <= 9:
             raise NotImplementedError('sdf_n_layers must be in [2, 9]: a chain descriptor holds NERO_MAX_LAYERS = 10 layers (include/nero_hip.h)')
-        if not 1 <= int(c['sdf_freq']) <= 7:
+        if not 1 <= int(c['sdf_freq']) <= 6:
             # sdf_freq 0 builds a different network in the reference (no embedding, another initialisation: network/field.py:80-107)
-            raise NotImplementedError('sdf_freq must be in [1, 7]: the skip layer re-reads the PE input from a 48-column aux tile (3 + 6 f <= 48)')
+            raise NotImplementedError('sdf_freq must be in [1, 6]: the PE input (3 + 6 f columns) is re-read by the skip layer from a 40-column '
+                                      'aux tile and its Jacobian kernels (nero_pe_vjp / nero_pe_jvp) stage rows of <= 40 floats')
         sc = c['shader_config']
         if not 1 <= int(sc.get('light_pos_freq', 8)) <= 10:
             raise NotImplementedError('shader_config.light_pos_freq must be in [1, 10]')

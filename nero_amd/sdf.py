@@ -19,7 +19,7 @@ from . import _lib as L
 from .chain import Chain, Dense, Head, row_pad, _r8, _r16, _tiles, GEMM_MODE
 
 N_FREQ, D_PE, LD_PE = 6, 39, 40                        # the shipped YAMLs: sdf_freq 6 (network/renderer.py:75)
-MAX_SDF_FREQ = 7                                        # the chain kernels' narrow aux tile holds 48 columns: 3 + 6 f <= 48
+MAX_SDF_FREQ = 6                                        # the chain kernels' narrow aux tile and nero_pe_vjp / _jvp hold 40 columns: 3 + 6 f <= 40
 
 
 def sdf_shape(eff):

@@ -182,6 +182,14 @@ class _SdfAdapter:
     def sdf_from_pe(self, pe, n):
         return self._drv.sdf_from_pe(pe, n)
 
+    def pe_of_rays(self, o, d, z, col0, ncols):
+        """PE-6 rows of the points o + z[:, col0 : col0 + ncols] d (the C driver exists for the YAML shapes only: stage1.supported)"""
+        R = o.shape[0]
+        pe = torch.empty((row_pad(R * ncols), 40), dtype=torch.float32, device=o.device)
+        P = C.c_void_p                                   # (no argtypes are declared for this entry point here: hand over real pointers)
+        L.check(_lib.nero_ray_points_pe(P(o.data_ptr()), P(d.data_ptr()), P(z.data_ptr()), z.stride(0), col0, ncols, R, P(pe.data_ptr()), L.stream_ptr()))
+        return pe
+
 
 class _KAdapter:
     """what nero_amd.shape_step.occ_loss / secondary_occlusion need of a ShapeKernels object"""

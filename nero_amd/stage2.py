@@ -3,6 +3,7 @@ predict_materials and the Monte-Carlo shader (MCShadingNetwork.shade_mixed / get
 calls instead of the ~120 launches nero_amd/material_step.py sequences from Python.  The mesh tracer stays a Python-visible call between
 nero_stage2_rays and nero_stage2_shade_fwd (nero_amd.raytracing.RayTracer in production, the oracle tracer in teacher-forced tests)."""
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -160,7 +161,13 @@ class MCShadeC(torch.autograd.Function):
         orig, dirs = torch.empty((Pn * D, 3), **f32), torch.empty((Pn * D, 3), **f32)
         L.check(_lib.nero_stage2_rays(drv.h, Pn, _p(pts), _p(view), _p(normals), _p(mat5), _p(rd), _p(rs), _p(drv.tab_d), _p(drv.tab_s), _p(orig),
                                       _p(dirs), L.stream_ptr()))
-        pos, fnrm, depth = tracer.trace(orig, dirs)                       # closest hit, depth >= 10 <=> miss
+        # closest hit, depth >= 10 <=> miss.  A tracer that takes a launch-order hint starts the specular chunks of every point first
+        # (nero_bvh_trace_grouped: same outputs); any other RayTracer-shaped object (tests, a reference-side tracer) gets the plain call
+        tg = getattr(tracer, 'trace_grouped', None)
+        if tg is not None and os.environ.get('NERO_TRACE_ORDER', 'grouped') == 'grouped':
+            pos, fnrm, depth = tg(orig, dirs, D, drv.Dd)
+        else:
+            pos, fnrm, depth = tracer.trace(orig, dirs)
         pos, fnrm, depth = pos.contiguous(), fnrm.contiguous(), depth.contiguous().reshape(-1)
         rgb, dl, sl, sp = (torch.empty((Pn, 3), **f32) for _ in range(4))
         n_miss, n_hit = C.c_int(0), C.c_int(0)

@@ -6,7 +6,7 @@
                                sdf_freq 4 (27 input columns), shader_config.light_pos_freq 6 (39 position columns in front of the indirect-light
                                and occlusion MLPs), sdf_activation 'sigmoid' (accepted and never read by the reference: network/field.py:72) --
                                for network/renderer.py:73-76,118-124 and network/field.py:515 (VERDICT r4 'missing' 4)
-  tests/golden/bell_deep_sdf.npz                    sdf_n_layers 9 (the deepest a chain descriptor holds), sdf_freq 7 (the widest skip input)
+  tests/golden/bell_deep_sdf.npz                    sdf_n_layers 9 (the deepest a chain descriptor holds), sdf_freq 5, light_pos_freq 10
 
 TEST INFRASTRUCTURE ONLY: /root/reference does not exist on the GPU box; the committed fixtures are what travels.
 """
@@ -21,6 +21,6 @@ if __name__ == '__main__':
     small = dict(n_samples=16, n_importance=16, n_bg_samples=8, up_sample_steps=4)
     run_case('bell_shape_keys', dict(small, sdf_n_layers=6, sdf_freq=4, sdf_activation='sigmoid', shader_config={'light_pos_freq': 6}),
              R=48, step=25000, variance=0.4)
-    run_case('bell_deep_sdf', dict(small, sdf_n_layers=9, sdf_freq=7, shader_config={'light_pos_freq': 10}), R=48, step=25000, variance=0.4)
+    run_case('bell_deep_sdf', dict(small, sdf_n_layers=9, sdf_freq=5, shader_config={'light_pos_freq': 10}), R=48, step=25000, variance=0.4)
     from oracle import gen_golden_grads as G
     G.dump('bell_shape_keys', G.shape_case('bell_shape_keys'))

@@ -230,7 +230,7 @@ def parity_report(test_id, **fields):
 class CTracer:
     """RayTracer-shaped wrapper over the fp64 brute-force oracle (C restatement), remembering the ambiguity flags"""
 
-    def __init__(self, v, f, replay=None, eps_edge=2e-5, eps_t=2e-6, ray_tol=None, defer=None):
+    def __init__(self, v, f, replay=None, eps_edge=2e-5, eps_t=2e-6, ray_tol=None, defer=None, rays_from=None):
         """replay: a CTracer whose recorded answers are returned call by call instead of tracing (an fp64 oracle run -- or the HIP
         step under teacher forcing -- then sees exactly the hits of the fp32 oracle run: its own, slightly different secondary rays
         would flip razor-edge rays).  ray_tol: in replay mode, additionally require the incoming rays to equal the recorded ones to
@@ -241,6 +241,10 @@ class CTracer:
         # rays this oracle flags as razor-edge -- where either answer is legitimate -- the other tracer's answer is returned, so that a
         # shading comparison is teacher-forced on the hit of exactly the ambiguous rays and on nothing else
         self.defer, self.offset, self.deferred = defer, 0, 0
+        # rays_from = (o, d) float arrays over ALL rays of the run, in call order: the rays ANOTHER implementation generated for the same
+        # (point, direction) slots.  They are traced instead of the caller's own (which must agree with them to ray_tol): two tracers
+        # are then compared on the SAME rays -- a direction that differs by 1e-6 moves a grazing hit by 1e-5 and can carry it across an edge
+        self.rays_from, self.roff = rays_from, 0
 
     def trace(self, o, d):
         from oracle.tracer_oracle import trace_bruteforce_margins
@@ -257,6 +261,14 @@ class CTracer:
             f = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(o.dtype).to(o.device)
             return f(pos), f(nrm), f(depth)
         on, dn = o.detach().cpu().numpy(), d.detach().cpu().numpy()
+        if self.rays_from is not None:
+            sl = slice(self.roff, self.roff + on.shape[0])
+            self.roff += on.shape[0]
+            ro, rd = self.rays_from[0][sl], self.rays_from[1][sl]
+            dev = max(float(np.abs(on.astype(np.float64) - ro).max()), float(np.abs(dn.astype(np.float64) - rd).max()))
+            self.max_ray_dev = max(self.max_ray_dev, dev)
+            assert self.ray_tol is None or dev <= self.ray_tol, f'the substituted rays deviate from the caller\'s own by {dev:.3e} > {self.ray_tol:.1e}'
+            on, dn = np.ascontiguousarray(ro, dtype=on.dtype), np.ascontiguousarray(rd, dtype=dn.dtype)
         pos, nrm, depth, tri, amb = trace_bruteforce_margins(self.v, self.f, on, dn, eps_edge=self.eps[0], eps_t=self.eps[1])
         pos, nrm, depth = pos.astype(np.float32), nrm.astype(np.float32), depth.astype(np.float32)       # the tracer contract is float32
         if self.defer is not None:
@@ -285,7 +297,7 @@ def tracer_contract(tr):
 # ----------------------------------------------------------------------------------------------------------------------
 # gate-teacher-forced gradient parity: the ReLU decisions of the HIP forward, as keys of oracle.nero_oracle.forced_relu_gates
 # ----------------------------------------------------------------------------------------------------------------------
-def forced_gates_from_capture(capture, stage, n_primary, human=False):
+def forced_gates_from_capture(capture, stage, n_primary, human=False, k_inner_light=128, k_inner_weight=96):
     """capture: nero_amd.chain.MASK_CAPTURE after ONE forward of the Python-sequenced HIP step (records in launch order).
     stage 1: n_primary = n_in (inner rows); stage 2: n_primary = P (surface points; predict_materials may run on [pts; reg_pts]).
     -> {oracle gate key: bool [rows, n_out]} (on the device of the masks)."""
@@ -324,9 +336,9 @@ def forced_gates_from_capture(capture, stage, n_primary, human=False):
                 put_pred(f'{pre}.outer_light', rec, [(0, n_primary), (row_pad(n_primary), n_primary)])
             else:
                 put_pred(f'{pre}.outer_light', rec, [(0, n)])
-        elif k == 128:
+        elif k == k_inner_light:
             put_pred(f'{pre}.inner_light', rec, [(0, n)])
-        elif k == 96 and stage == 1:
+        elif k == k_inner_weight and stage == 1:
             put_pred(f'{pre}.inner_weight', rec, [(0, n)])
         elif k == 24:
             put_pred(f'{pre}.human_light_predictor' if stage == 1 else f'{pre}.human_light', rec, [(0, n)])

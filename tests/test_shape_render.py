@@ -11,7 +11,7 @@ from tests.helpers import T, assert_grads_fp32_grade, build_case_model, load_gol
 pytestmark = pytest.mark.gpu
 
 CASES = ['bell_s25000', 'bell_s5000_sharp', 'bell_c1', 'bear_s25000', 'bell_sphdir', 'bell_noclip_l1', 'bell_l2', 'bell_smoothl1']
-# non-YAML network-shape keys (round 5; oracle/gen_golden_r5.py): sdf_n_layers 6 / sdf_freq 4 / light_pos_freq 6 and 9 / 7 / 10 --
+# non-YAML network-shape keys (round 5; oracle/gen_golden_r5.py): sdf_n_layers 6 / sdf_freq 4 / light_pos_freq 6 and 9 / 5 / 10 --
 # the Python-sequenced chains (the C step driver keeps the YAML shapes, nero_amd.stage1.supported)
 SHAPE_KEY_CASES = ['bell_shape_keys', 'bell_deep_sdf']
 
@@ -21,8 +21,14 @@ def rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
-def _oracle_grads(meta, z, dtype, occ, keys=None):
-    """parameter gradients of the oracle evaluated in `dtype` on the golden case (teacher-forced on its z_vals)"""
+def _oracle_grads(meta, z, dtype, occ, keys=None, gates=None):
+    """parameter gradients of the oracle evaluated in `dtype` on the golden case (teacher-forced on its z_vals); gates: ReLU decisions
+    to force (oracle.nero_oracle.forced_relu_gates)"""
+    if gates is not None:
+        with O.forced_relu_gates(gates) as fg:
+            res = _oracle_grads(meta, z, dtype, occ, keys)
+            assert fg.used == set(gates), sorted(set(gates) - fg.used)[:5]
+        return res
     ref = build_case_model(meta).to(dtype)
     sd = {k: v for k, v in ref.named_parameters()}
     sd.update({k: v for k, v in ref.named_buffers()})
@@ -37,6 +43,31 @@ def _oracle_grads(meta, z, dtype, occ, keys=None):
         oo = O.render_core(P, cfg, f('o'), f('d'), f('z_vals'), f('human_poses'), meta['anneal'], meta['step'])
         (O.rgb_loss(cfg, oo['ray_rgb'], f('gt')).mean() + (oo['gradient_error'] * 0.1).mean()).backward()
     return named_grads(ref)
+
+
+def _check_grads(name, net, ref, meta, z, occ, keys, capture, n_in):
+    """HIP parameter gradients against the fp64 oracle: the ungated criterion of tests/helpers.py first (1e-4, or fp32 torch equally far,
+    or 1e-4 of the MLP's gradient scale).  A ReLU unit within rounding of zero may fall on the other side in the HIP forward than in BOTH
+    torch evaluations -- with 48 rays one flipped unit moves a bias gradient by 1e-3 of its maximum, and which evaluation flips depends on
+    the last bit of a 256-term sum (the one-accumulator chain kernels of round 5 round differently from rounds 1-4: bell_smoothl1 then
+    failed on exactly one outer-light bias).  Such a case is decided by ARITHMETIC: the oracle in fp64 and fp32 is handed the HIP
+    forward's own gate decisions (its saved sign masks) and the plain 1e-4 must hold for every tensor -- no escape clause beyond the two
+    NeRF++ density-head tensors whose fp32 floor tests/test_parity_at_size.py documents."""
+    from tests.helpers import forced_gates_from_capture
+    from tests.test_parity_at_size import STAGE1_FLOOR_TENSORS, _forced_gate_errors
+    g_hip = {k: v.cpu() for k, v in named_grads(net).items()}
+    g64 = _oracle_grads(meta, z, torch.float64, occ, keys)
+    try:
+        assert_grads_fp32_grade(g_hip, named_grads(ref), g64, where=name)
+        return
+    except AssertionError as e:
+        ungated = str(e)
+    sc = {**{'light_pos_freq': 8}, **meta['cfg'].get('shader_config', {})}
+    pd = 3 + 6 * int(sc['light_pos_freq'])
+    r8 = lambda k: (k + 7) // 8 * 8
+    gates = forced_gates_from_capture(capture, 1, n_in, k_inner_light=r8(pd + 72), k_inner_weight=r8(pd + 39))
+    fe = _forced_gate_errors(g_hip, _oracle_grads(meta, z, torch.float32, occ, keys, gates), _oracle_grads(meta, z, torch.float64, occ, keys, gates))
+    assert fe['n_unexplained'] == 0 and set(fe['fp32_floor']) <= STAGE1_FLOOR_TENSORS, (ungated[:400], fe)
 
 
 def _oracle_P(net):
@@ -111,17 +142,22 @@ def test_render_core_outputs_and_grads(name):
     oo = O.render_core(P, cfg, T(z, 'o'), T(z, 'd'), T(z, 'z_vals'), T(z, 'human_poses'), meta['anneal'], meta['step'])
     loss_o = O.rgb_loss(cfg, oo['ray_rgb'], T(z, 'gt')).mean() + (oo['gradient_error'] * 0.1).mean()
     loss_o.backward()
-    out = net.render(T(z, 'o', 'cuda'), T(z, 'd', 'cuda'), T(z, 'near', 'cuda'), T(z, 'far', 'cuda'), T(z, 'human_poses', 'cuda'),
-                     -1, meta['anneal'], is_train=True, step=meta['step'], z_vals=T(z, 'z_vals', 'cuda'))
+    from nero_amd import chain as CH
+    CH.MASK_CAPTURE = []
+    try:
+        out = net.render(T(z, 'o', 'cuda'), T(z, 'd', 'cuda'), T(z, 'near', 'cuda'), T(z, 'far', 'cuda'), T(z, 'human_poses', 'cuda'),
+                         -1, meta['anneal'], is_train=True, step=meta['step'], z_vals=T(z, 'z_vals', 'cuda'))
+        capture = CH.MASK_CAPTURE
+    finally:
+        CH.MASK_CAPTURE = None
     assert out['gradient_error'].shape == oo['gradient_error'].shape
     assert rel(out['ray_rgb'], oo['ray_rgb']) < 1e-4
     assert rel(out['gradient_error'], oo['gradient_error']) < 1e-4
     loss = net.compute_rgb_loss(out['ray_rgb'], T(z, 'gt', 'cuda')).mean() + (out['gradient_error'] * 0.1).mean()
     assert abs(float(loss) - float(loss_o)) < 1e-5
     loss.backward()
-    # gradients: within 1e-4 of the fp64 oracle unless torch-fp32 itself is equally off (tests/helpers.py)
-    g64 = _oracle_grads(meta, z, torch.float64, occ=False)
-    assert_grads_fp32_grade(named_grads(net), named_grads(ref), g64, where=name)
+    # gradients: within 1e-4 of the fp64 oracle unless torch-fp32 itself is equally off (tests/helpers.py); else under forced gates
+    _check_grads(name, net, ref, meta, z, False, None, capture, out['_state']['n_in'])
 
 
 @pytest.mark.parametrize('act,variance', [('linear', 2.0), ('square', 0.45)])
@@ -177,8 +213,14 @@ def test_full_training_loss_with_occ_and_init_reg(name):
     oo = O.render_core(P, cfg, T(z, 'o'), T(z, 'd'), T(z, 'z_vals'), T(z, 'human_poses'), meta['anneal'], meta['step'], keys)
     loss_o = O.training_loss(cfg, oo, T(z, 'gt'), meta['step'])
     loss_o.backward()
-    out = net.render(T(z, 'o', 'cuda'), T(z, 'd', 'cuda'), T(z, 'near', 'cuda'), T(z, 'far', 'cuda'), T(z, 'human_poses', 'cuda'),
-                     -1, meta['anneal'], is_train=True, step=meta['step'], z_vals=T(z, 'z_vals', 'cuda'), occ_keys=keys)
+    from nero_amd import chain as CH
+    CH.MASK_CAPTURE = []
+    try:
+        out = net.render(T(z, 'o', 'cuda'), T(z, 'd', 'cuda'), T(z, 'near', 'cuda'), T(z, 'far', 'cuda'), T(z, 'human_poses', 'cuda'),
+                         -1, meta['anneal'], is_train=True, step=meta['step'], z_vals=T(z, 'z_vals', 'cuda'), occ_keys=keys)
+        capture = CH.MASK_CAPTURE
+    finally:
+        CH.MASK_CAPTURE = None
     if meta['step'] >= 20000:
         assert out['_occ_count'] == oo['occ_count'] > 0
         assert abs(float(out['loss_occ']) - float(oo['loss_occ'])) < 1e-5
@@ -189,8 +231,7 @@ def test_full_training_loss_with_occ_and_init_reg(name):
     assert abs(float(loss) - float(loss_o)) < 2e-5
     assert abs(float(loss) - float(z['loss'])) < 5e-5            # and the unmodified reference's own loss value
     loss.backward()
-    g64 = _oracle_grads(meta, z, torch.float64, occ=True, keys=keys)
-    assert_grads_fp32_grade(named_grads(net), named_grads(ref), g64, where=name)
+    _check_grads(name, net, ref, meta, z, True, keys, capture, out['_state']['n_in'])
 
 
 def test_non_yaml_network_shape_keys_on_the_fused_trainer():
@@ -208,7 +249,7 @@ def test_non_yaml_network_shape_keys_on_the_fused_trainer():
     with pytest.raises(NotImplementedError):
         NeROShapeRenderer({'sdf_d_out': 129}, training=False)
     with pytest.raises(NotImplementedError):
-        NeROShapeRenderer({'sdf_freq': 9}, training=False)
+        NeROShapeRenderer({'sdf_freq': 7}, training=False)
 
 
 def test_trainer_entry_point_with_database_object():

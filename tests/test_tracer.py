@@ -83,3 +83,26 @@ def test_both_traversal_kernels_agree_bit_for_bit(subdiv, n_pts, n_dir):
         assert torch.equal(a, b), int((a != b).sum())
     with pytest.raises(RuntimeError):
         L.check(L.lib.nero_bvh_set_traversal(h, 2))
+
+
+@pytest.mark.parametrize('n_pts,group,heavy_from', [(300, 256, 128), (97, 768, 512), (64, 128, 64), (10, 192, 64)])
+def test_grouped_launch_order_is_bit_identical_to_the_natural_order(n_pts, group, heavy_from):
+    """nero_bvh_trace_grouped (round 5): the heavy chunks of every group of rays are STARTED first -- same rays, same arithmetic, same
+    outputs at the same addresses as nero_bvh_trace; arguments that do not fit the chunking fall back to the natural order"""
+    from nero_amd.raytracing import RayTracer
+    from nero_amd.synthetic import icosphere, secondary_rays
+    v, f = icosphere(5, 0.5, 0.2)
+    f = np.ascontiguousarray(f[:, ::-1])
+    rt = RayTracer(v, f)
+    o, d = secondary_rays(v, f, n_pts, group, seed=n_pts)
+    assert o.shape[0] == n_pts * group
+    plain = [x.clone() for x in rt.trace(o, d)]
+    grouped = [x.clone() for x in rt.trace_grouped(o, d, group, heavy_from)]
+    assert 0.05 < float((plain[2] < 10).float().mean()) < 0.95
+    for a, b in zip(plain, grouped):
+        assert torch.equal(a, b), int((a != b).sum())
+    # a group size that is not a multiple of the 64-ray chunk, and a ray count that is not a multiple of the group: natural order, same result
+    for g, hf, n in ((100, 50, o.shape[0]), (group, heavy_from, o.shape[0] - 64)):
+        odd = rt.trace_grouped(o[:n], d[:n], g, hf)
+        for a, b in zip(plain, odd):
+            assert torch.equal(a[:n], b)
