@@ -267,12 +267,16 @@ def stage2_step_bench(dev, kind, P_, Dd, Ds, mesh, rank=0, world=1, warmup=5, st
     rec = {'n': 0, 'hit': 0, 'ms': 0.0, 'on': False}
 
     class Timed:                                            # times nero_bvh_trace on the secondary rays of one untimed extra step
-        def trace(self, ro, rd):
+        def trace_grouped(self, ro, rd, group, heavy_from):
+            return self.trace(ro, rd, (group, heavy_from))
+
+        def trace(self, ro, rd, order=None):
+            run = (lambda: tracer.trace_grouped(ro, rd, *order)) if order is not None else (lambda: tracer.trace(ro, rd))
             if not rec['on']:
-                return tracer.trace(ro, rd)
+                return run()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            r = tracer.trace(ro, rd)
+            r = run()
             e1.record()
             torch.cuda.synchronize()
             rec['ms'] += e0.elapsed_time(e1)

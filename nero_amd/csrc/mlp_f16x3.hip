@@ -589,8 +589,8 @@ inline int bwd_lds_bytes() { return 2 * PLANE_A + (64 + 64 + 512) * 4 + BWD_PA_B
 // no spill -- instead of reading them in the epilogue: the second-order reverse pass went from 1.74 to 2.69 ms.  vmcnt retires in
 // order, so the weight stream of the next GEMM queued behind eight 1 KB HBM loads per wave, exactly what the LDS-DMA of the saved
 // activations had been introduced to avoid; there is no LDS left for a second DMA target: 135.7 of 160 KB.)
-template <bool FIXED>
-__global__ __launch_bounds__(512, 1) void bwd_f16_kernel(nero_bwd_chain ch, int n_rows) {
+template <bool FIXED, bool WALK>
+__global__ __launch_bounds__(512, 1) void bwd_f16_kernel(nero_bwd_chain ch, int n_rows, int n_tiles_total) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Lds S;
     S.actp = smem;
@@ -602,9 +602,12 @@ __global__ __launch_bounds__(512, 1) void bwd_f16_kernel(nero_bwd_chain ch, int 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
-    const int row0 = blockIdx.x * 64;
     char* pa_lds = reinterpret_cast<char*>(S.rmax + 64 * 8) + wave * 8192;
     const unsigned pa_addr = __builtin_amdgcn_readfirstlane(lds_offset_of(pa_lds));
+    // PERSISTENT walk (round 5; NERO_F16_PERSIST bit 1): with the second accumulator set gone (mlp_f16_util.h) the tile loop fits the
+    // register budget -- round 4 measured it 2-5 % SLOWER because it spilled 12-20 VGPRs.  n_tiles_total = 0: one tile per workgroup.
+    for (int tile = blockIdx.x; tile < (WALK ? n_tiles_total : (int)gridDim.x); tile += gridDim.x) {
+    const int row0 = tile * 64;
     const size_t goff = (size_t)(row0 + i) * NERO_HID + 32 * wave + 4 * h;
     unsigned mbits[2] = {0u, 0u};                      // ReLU sign masks of the layer being processed
     // request what the epilogue of layer `Ln` needs of its input activation: the sign words (registers) or the fp32 tile (LDS-DMA)
@@ -761,6 +764,9 @@ __global__ __launch_bounds__(512, 1) void bwd_f16_kernel(nero_bwd_chain ch, int 
         PH(6);
     }
     PH_END;
+    if (!WALK) break;
+    __syncthreads();                                       // (the next tile's dy overwrites the planes every wave has just read)
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -908,9 +914,18 @@ int nero_f16_backward(const nero_bwd_chain* ch, int n_rows, hipStream_t stream) 
     if (ch->d_init && (ch->ld_dinit & 3)) return nero_fail(NERO_ERR_ARG, "nero_mlp_backward(f16x3): ld_dinit must be a multiple of 4");
     bool fixed = true;
     for (int l = 0; l < ch->n_layers; ++l) fixed = fixed && (ch->layer[l].n_out == 0 || ch->layer[l].n_out == 256);
-    NERO_ONCE(hipFuncSetAttribute((const void*)bwd_f16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bwd_lds_bytes()));
-    NERO_ONCE(hipFuncSetAttribute((const void*)bwd_f16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bwd_lds_bytes()));
-    if (fixed) hipLaunchKernelGGL(bwd_f16_kernel<true>, grid, block, bwd_lds_bytes(), stream, *ch, n_rows);
-    else hipLaunchKernelGGL(bwd_f16_kernel<false>, grid, block, bwd_lds_bytes(), stream, *ch, n_rows);
+    NERO_ONCE(hipFuncSetAttribute((const void*)bwd_f16_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bwd_lds_bytes()));
+    NERO_ONCE(hipFuncSetAttribute((const void*)bwd_f16_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bwd_lds_bytes()));
+    NERO_ONCE(hipFuncSetAttribute((const void*)bwd_f16_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bwd_lds_bytes()));
+    NERO_ONCE(hipFuncSetAttribute((const void*)bwd_f16_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bwd_lds_bytes()));
+    const int n_tiles = (n_rows + 63) / 64;
+    const dim3 pgrid(nero_chain_grid(n_tiles, 1));
+    if ((int)pgrid.x < n_tiles) {
+        if (fixed) hipLaunchKernelGGL((bwd_f16_kernel<true, true>), pgrid, block, bwd_lds_bytes(), stream, *ch, n_rows, n_tiles);
+        else hipLaunchKernelGGL((bwd_f16_kernel<false, true>), pgrid, block, bwd_lds_bytes(), stream, *ch, n_rows, n_tiles);
+    } else {
+        if (fixed) hipLaunchKernelGGL((bwd_f16_kernel<true, false>), grid, block, bwd_lds_bytes(), stream, *ch, n_rows, n_tiles);
+        else hipLaunchKernelGGL((bwd_f16_kernel<false, false>), grid, block, bwd_lds_bytes(), stream, *ch, n_rows, n_tiles);
+    }
     return NERO_OK;
 }

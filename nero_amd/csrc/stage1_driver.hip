@@ -12,7 +12,7 @@
 #include "chain_host.h"
 #include <stdlib.h>
 #ifndef NERO_STREAMS_DEFAULT
-#define NERO_STREAMS_DEFAULT 2
+#define NERO_STREAMS_DEFAULT 3
 #endif
 
 

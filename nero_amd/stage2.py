@@ -164,7 +164,7 @@ class MCShadeC(torch.autograd.Function):
         # closest hit, depth >= 10 <=> miss.  A tracer that takes a launch-order hint starts the specular chunks of every point first
         # (nero_bvh_trace_grouped: same outputs); any other RayTracer-shaped object (tests, a reference-side tracer) gets the plain call
         tg = getattr(tracer, 'trace_grouped', None)
-        if tg is not None and os.environ.get('NERO_TRACE_ORDER', 'grouped') == 'grouped':
+        if tg is not None and os.environ.get('NERO_TRACE_ORDER', 'natural') == 'grouped':
             pos, fnrm, depth = tg(orig, dirs, D, drv.Dd)
         else:
             pos, fnrm, depth = tracer.trace(orig, dirs)

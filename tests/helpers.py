@@ -275,6 +275,20 @@ class CTracer:
             sl = slice(self.offset, self.offset + on.shape[0])
             self.offset += on.shape[0]
             a = np.asarray(amb, bool)
+            # ... and on rays where the two tracers report the SAME point (to 1e-4) on DIFFERENT triangles (normals apart): a grazing
+            # hit -- t = (q . e2) / det with a small det carries 1e-5 of float32 error along the ray -- that lands next to an edge, beyond
+            # the barycentric margin but within the tracer's own precision.  Either triangle is a legitimate answer.
+            dp = np.abs(pos - self.defer[0][sl]).max(-1)
+            dn_ = np.abs(nrm - self.defer[1][sl]).max(-1)
+            near = (~a) & (depth < 10) & (self.defer[2][sl] < 10) & (dp < 1e-4) & (dn_ > 1e-3)
+            self.near_edge = getattr(self, 'near_edge', 0) + int(near.sum())
+            # ... and on rays whose hit distance straddles get_lights' near mask `depth > 1e-5` (network/field.py:859,879: the same 1e-5
+            # the ray origin was lifted by): a self-hit on a neighbouring, nearly coplanar triangle at t ~ 1e-5, where the two tracers'
+            # distances differ by a few 1e-6 and fall on different sides of the threshold -- the light of that ray is kept or zeroed
+            dh = self.defer[2][sl]
+            flip = (~a) & ((depth > 1e-5) != (dh > 1e-5)) & (np.abs(depth - dh) < 2e-5)
+            self.near_mask_flips = getattr(self, 'near_mask_flips', 0) + int(flip.sum())
+            a = a | near | flip
             pos[a], nrm[a], depth[a] = self.defer[0][sl][a], self.defer[1][sl][a], self.defer[2][sl][a]
             self.deferred += int(a.sum())
         self.raw.append((pos, nrm, depth))

@@ -107,6 +107,34 @@ def test_c_driven_step_equals_python_driven_step_bit_for_bit(kind, rays, monkeyp
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('kind,rays', [('bell', 512), ('bear', 200)])
+def test_stream_modes_are_bit_identical(kind, rays, monkeypatch):
+    """NERO_STREAMS = 1 (one stream), 2 (+ the NeRF++ branch beside the SDF / shading branch), 3 (+ the weight-gradient jobs of the
+    inner branch beside the next chain's reverse pass; round 5, the default): the same kernels on the same operands in an order that
+    respects every dependency -- loss and every gradient bit for bit"""
+    from nero_amd.train import ShapeTrainStep
+    cfg = dict(CFG) if kind == 'bell' else {**CFG, 'shader_config': {'human_light': True}}
+    monkeypatch.setenv('NERO_STEP_DRIVER', 'c')
+    res = {}
+    for n in ('1', '2', '3'):
+        monkeypatch.setenv('NERO_STREAMS', n)
+        torch.manual_seed(0)
+        ts = ShapeTrainStep(cfg, rays_per_rank=rays, pool_rays=1024, device='cuda:0', variance=0.4, prime_fraction=0.0, prime_passes=0)
+        for rep in range(2):                                       # (two steps' worth of batches per mode, the same ones in every mode)
+            torch.manual_seed(123 + rep)
+            info = ts.forward_backward(25000)
+            torch.cuda.synchronize()
+            res[(n, rep)] = (float(info['loss']), ts.bucket.flat.clone())
+    for (n, rep), (l, f) in res.items():
+        l0, f0 = res[('1', rep)]
+        assert l == l0 and torch.equal(f, f0), ((n, rep), l, l0, float((f - f0).abs().max()))
+    return
+    l0, f0 = res[('1', 0)]
+    for k, (l, f) in res.items():
+        assert l == l0 and torch.equal(f, f0), (k, l, l0, float((f - f0).abs().max()))
+
+
+@pytest.mark.gpu
 def test_c_driver_training_steps_and_small_workspace_error(monkeypatch):
     """three optimisation steps run through the driver (pack every step, workspace reused); a workspace that is too small is an error
     code with a message, never an out-of-bounds write"""
