@@ -297,6 +297,8 @@ int nero_shade_encode(const float* x4, const float* geo, const float* m_raw, con
 int nero_shade_combine_fwd(const float* geo, const float* mat, const float* Ld, const float* Ls, const float* Li, const float* Lo,
                            const float* lut /*[256,256,2]*/, float exp_max, int n, float* color /*[n,3]*/, float* occ_prob,
                            const float* Lh, const float* hmask, void* stream);
+/* dmat[k] = { d_metallic, d_rough (LUT part), d_albedo(3), d_NoV (LUT part), 0, 0 }: whole rows.  d_geo is NOT written here (round 5: the
+ * argument is kept for the ABI); nero_shade_encode_bwd writes every row of d_geo once: { d_nhat(3), d_NoV = dmat[k][5], d_refl(3), 0 } */
 int nero_shade_combine_bwd(const float* geo, const float* mat, const float* Ld, const float* Ls, const float* Li, const float* Lo,
                            const float* lut, float exp_max, int n, const float* d_color, const float* d_occ /*or NULL*/, float* dLd,
                            float* dLs, float* dLi, float* dLo, float* dmat /*[rows,8]*/, float* d_geo /*[rows,8]*/,
@@ -483,6 +485,9 @@ size_t nero_stage1_workspace_bytes(nero_stage1* h, int R);
 size_t nero_stage1_workspace_bytes_for(nero_stage1* h, int R, int n_in, int n_out, int with_sampler);
 /* sampler + render forward only (inference chunks: no nero_stage1_render_bwd on this workspace), worst case over the split */
 size_t nero_stage1_workspace_bytes_fwd(nero_stage1* h, int R);
+/* debug: (device pointer, bytes) of nine intermediates of the last nero_stage1_render_bwd -- d_geo, d_feat, d_sdf4, d_grad, dinv, ehat, adot,
+ * d_alpha_inner, d_metallic_raw -- for run-to-run comparisons (scripts/r05/dbg_streams.py) */
+int nero_stage1_debug_buffers(nero_stage1* h, const void** ptrs, size_t* bytes);
 /* z_vals [R, n_samples + n_importance + n_bg_samples]; rand1 [R] / rand_bg [R, n_bg] uniform draws or NULL (no perturbation) */
 int nero_stage1_sample(nero_stage1* h, int R, const float* o, const float* d, const float* near, const float* far, const float* variance,
                        const float* rand1, const float* rand_bg, float* z_vals, void* ws, size_t ws_bytes, void* stream);

@@ -200,7 +200,8 @@ __device__ __forceinline__ void dw_f16_body(const nero_dw_job& job, int n_rows, 
         float m = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            v[j] *= cmask;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[j][c] *= cmask[c];   // (component-wise: no v_pk_mul_f32 -- see the note on packed fp32 in common.h)
             m = fmaxf(m, fmaxf(fmaxf(fabsf(v[j][0]), fabsf(v[j][1])), fmaxf(fabsf(v[j][2]), fabsf(v[j][3]))));
         }
         m = wave_max(m);
@@ -239,7 +240,9 @@ __device__ __forceinline__ void dw_f16_body(const nero_dw_job& job, int n_rows, 
         fetch(av, 0);
         publish(av, 0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bsum += av[j];
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bsum[c] += av[j][c];
         if (total > 1) fetch(cv, 1);
     }
     __syncthreads();                                     // maxima of chunk 0 visible
@@ -268,7 +271,9 @@ __device__ __forceinline__ void dw_f16_body(const nero_dw_job& job, int n_rows, 
         auto convert_next = [&]() {
             const float keep = (q + 1 < nch) ? 1.f : 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bsum += av[j] * keep;
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) bsum[c] = fmaf(av[j][c], keep, bsum[c]);
             // chunk q+1 -> the other stage, in the unit it leaves E at
             put(av, (q + 1) & 1, smem + ((q + 1) & 1) * DWH_STAGE, q + 1 < total);
             resc_next = resc;

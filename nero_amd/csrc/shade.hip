@@ -168,10 +168,21 @@ __global__ void sdf_alpha_bwd_kernel(const float* __restrict__ sdf4, const float
     const float gd = fmaxf(gn, 1e-12f);
     const float nh[3] = {g[0] / gd, g[1] / gd, g[2] / gd};
     // eikonal: (|g|-1)^2
+#ifdef NERO_DBG_COHERENT_LOADS                        // (race hunt, round 5: device-scope loads of the two inputs only d_grad depends on)
+    auto cl = [](const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+    const float de = d_gerr ? cl(d_gerr + k) * 2.f * (gn - 1.0f) : 0.f;
+    float qv[8];
+    if (d_geo) for (int c = 0; c < 8; ++c) qv[c] = cl(d_geo + (size_t)k * 8 + c);
+#else
     const float de = d_gerr ? d_gerr[k] * 2.f * (gn - 1.0f) : 0.f;
+#endif
     for (int c = 0; c < 3; ++c) dg[c] += de * nh[c];
     if (d_geo) {
+#ifdef NERO_DBG_COHERENT_LOADS
+        const float* q = qv;
+#else
         const float* q = d_geo + (size_t)k * 8;
+#endif
         const float v[3] = {-dh[0], -dh[1], -dh[2]};
         const float nov = nh[0] * v[0] + nh[1] * v[1] + nh[2] * v[2];
         const float drn = q[4] * nh[0] + q[5] * nh[1] + q[6] * nh[2];
@@ -470,7 +481,7 @@ __global__ void shade_inter_kernel(const float* __restrict__ geo, const float* _
 }
 
 // backward of combine: writes the gradients of the RAW head outputs (dLd, dLs, dLi, dLo [rows,4]), the partial
-// material grads dmat[k] = { d_metallic, d_rough(LUT part), d_albedo(3) } and d_geo[k][3] = d_NoV (LUT part)
+// material grads dmat[k] = { d_metallic, d_rough(LUT part), d_albedo(3), d_NoV (LUT part: handed to shade_encode_bwd, which writes d_geo) }
 __global__ void shade_combine_bwd_kernel(const float* __restrict__ geo, const float* __restrict__ mat, const float* __restrict__ Ld,
                                          const float* __restrict__ Ls, const float* __restrict__ Li, const float* __restrict__ Lo,
                                          const float* __restrict__ lut, float exp_max, int n, int n_pad,
@@ -545,13 +556,20 @@ __global__ void shade_combine_bwd_kernel(const float* __restrict__ geo, const fl
     reinterpret_cast<float4*>(dLo)[k] = make_float4(0.5f * d_occ_tot, 0.f, 0.f, 0.f);
     const float d_u = (nov >= 0.f && nov <= 1.f) ? d_f0 * df0du + d_f1 * df1du : 0.f;
     const float d_v = (r >= 0.f && r <= 1.f) ? d_f0 * df0dv + d_f1 * df1dv : 0.f;
-    float* dm = dmat + (size_t)k * 8;
-    dm[0] = d_m; dm[1] = d_v; dm[2] = da_out[0]; dm[3] = da_out[1]; dm[4] = da_out[2];
-    d_geo[(size_t)k * 8 + 3] = d_u;
+    // Whole 32-byte rows, and d_NoV travels in dmat[k][5] (round 5): rounds 1-4 dropped it into d_geo[k][3] here, a 4-byte store per
+    // 32-byte row into a buffer a memset had zeroed and shade_encode_bwd then completed with seven more scalar stores -- three kernels
+    // building the same cache lines from byte-masked pieces.  With a second stream's kernels running beside the step (NERO_STREAMS=3)
+    // sdf_alpha_bwd then occasionally read 16-row blocks of d_geo WITHOUT shade_encode_bwd's part (scripts/r05/dbg_streams.py: d_grad off by
+    // exactly the size of those terms, the buffer itself final and identical afterwards).  Now every row of d_geo is written once, by
+    // one kernel, as two float4 stores.
+    float4* dm = reinterpret_cast<float4*>(dmat + (size_t)k * 8);
+    dm[0] = make_float4(d_m, d_v, da_out[0], da_out[1]);
+    dm[1] = make_float4(da_out[2], d_u, 0.f, 0.f);
+    (void)d_geo;
 }
 
-// backward of the encodings: dXd, dXs [rows,72], dXi [rows,128] (cols 51..122 = IDE part) -> d_geo (d_nhat, d_refl; d_NoV
-// already there), total roughness gradient; then the RAW material head gradients dm_raw/dr_raw/da_raw [rows,4]
+// backward of the encodings: dXd, dXs [rows,72], dXi [rows,128] (cols 51..122 = IDE part) -> d_geo (d_nhat, d_NoV from dmat[k][5],
+// d_refl: whole rows), total roughness gradient; then the RAW material head gradients dm_raw/dr_raw/da_raw [rows,4]
 // (Measured and dropped: bringing the gradient rows in through LDS like the forward encoders' stores (rows_load, rows.h) -- 95 -> 234 us:
 // four staged loads mean eight barriers, the LDS reads sit inside the unrolled IDE chains, and at 274 VGPRs one wave per SIMD hides none of it.)
 __global__ __launch_bounds__(128) void shade_encode_bwd_kernel(const float* __restrict__ geo, const float* __restrict__ mat, const float* __restrict__ dXd,
@@ -564,6 +582,7 @@ __global__ __launch_bounds__(128) void shade_encode_bwd_kernel(const float* __re
     float4 z4 = make_float4(0, 0, 0, 0);
     if (k >= n) {
         reinterpret_cast<float4*>(dm_raw)[k] = z4; reinterpret_cast<float4*>(dr_raw)[k] = z4; reinterpret_cast<float4*>(da_raw)[k] = z4;
+        reinterpret_cast<float4*>(d_geo)[2 * k] = z4; reinterpret_cast<float4*>(d_geo)[2 * k + 1] = z4;
         return;
     }
     const float* q = geo + (size_t)k * 8;
@@ -600,9 +619,8 @@ __global__ __launch_bounds__(128) void shade_encode_bwd_kernel(const float* __re
         const float* ex = extra + (size_t)k * 4;
         drx += ex[0]; dry += ex[1]; drz += ex[2]; d_r += ex[3];
     }
-    float* o = d_geo + (size_t)k * 8;
-    o[0] = dnx; o[1] = dny; o[2] = dnz;
-    o[4] = drx; o[5] = dry; o[6] = drz; o[7] = 0.f;
+    reinterpret_cast<float4*>(d_geo)[2 * k] = make_float4(dnx, dny, dnz, dm[5]);         // (d_NoV from shade_combine_bwd: dmat[k][5])
+    reinterpret_cast<float4*>(d_geo)[2 * k + 1] = make_float4(drx, dry, drz, 0.f);
     reinterpret_cast<float4*>(dm_raw)[k] = make_float4(dm[0] * m * (1.f - m), 0.f, 0.f, 0.f);
     reinterpret_cast<float4*>(dr_raw)[k] = make_float4(d_r * r * (1.f - r), 0.f, 0.f, 0.f);
     reinterpret_cast<float4*>(da_raw)[k] = make_float4(dm[2] * mo[2] * (1.f - mo[2]), dm[3] * mo[3] * (1.f - mo[3]), dm[4] * mo[4] * (1.f - mo[4]), 0.f);

@@ -50,6 +50,10 @@ struct nero_stage1 {
     // kernel classes are bound by different things -- the weight-gradient GEMM streams its operands from HBM (4.9 TB/s), the chain kernels
     // issue MFMA + VALU -- and their workgroups interleave over the CUs: fewer weight-gradient workgroups at a time compete for HBM.  The
     // price is memory: a chain's deltas cannot be released while its jobs may still read them (no arena release in this mode).
+    // debug: (pointer, bytes) of the backward's intermediates of the last step, for scripts/r05/dbg_streams.py (nero_stage1_debug_buffers)
+    const void* dbg_ptr[12] = {};
+    size_t dbg_bytes[12] = {};
+    float *dbg_c0 = nullptr, *dbg_c1 = nullptr;
     hipStream_t s3 = nullptr;
     static constexpr int N_DW_EV = 12;                     // one event per fork of a step (never re-recorded while a wait on it may be pending)
     hipEvent_t ev_dw[N_DW_EV] = {}, ev_dw_done = nullptr;
@@ -432,14 +436,28 @@ int do_backward(nero_stage1* h, Arena& A, const float* d_rgb, const float* d_ger
         // covered by an event, the light / material chains beside the same jobs are bit-reproducible, and the mechanism is as unexplained as
         // the co-residency fault of round 3 (docs/experiments.md 3i).  Until it is understood the SDF passes run with nothing beside them
         // but the NeRF++ branch, as in rounds 3-4.
-        static const bool late_join = [] { const char* e = getenv("NERO_DW_JOIN"); return e && e[0] == 'l'; }();
-        if (!late_join) join_dw(h, A, hs);
+        // NERO_DW_JOIN (race hunt): e(arly, default) | j (in front of the tangent chain) | t (behind the tangent launch) | b (behind the SDF reverse launch) | l(ate: behind the SDF jobs)
+        static const char join_at = [] { const char* e = getenv("NERO_DW_JOIN"); return e ? e[0] : 'e'; }();
+        const bool late_join = join_at == 'l';
+        if (join_at == 'e') join_dw(h, A, hs);
+        static const bool dbg_sync = getenv("NERO_DBG_SYNC") != nullptr;   // (race hunt: host-side wait for the main stream only)
+        if (dbg_sync && !A.dry) (void)hipStreamSynchronize(hs);
         float* d_sdf4 = A.f32((size_t)rpi * 4);
         float* d_grad = A.f32((size_t)rpi * 3);
         float* dinv = A.f32(rpi);
         if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_bwd: workspace too small");
+        static const bool dbg_copy = getenv("NERO_DBG_COPY") != nullptr;     // (race hunt: d_grad / d_geo as they are right behind sdf_alpha_bwd)
+        float* c0 = dbg_copy ? A.f32((size_t)rpi * 3) : nullptr;
+        float* c1 = dbg_copy ? A.f32((size_t)rpi * 8) : nullptr;
+        if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_bwd: workspace too small");
         LAUNCH(nero_sdf_alpha_bwd(S.sdf4, S.normal, S.x4, S.inner_idx, h->d, T, h->variance, h->anneal, n_in, d_ai, d_gerr, d_geo, d_sdf4, d_grad,
                                   dinv, stream));
+        if (dbg_copy && !A.dry) {
+            (void)hipMemcpyAsync(c0, d_grad, (size_t)n_in * 12, hipMemcpyDeviceToDevice, hs);
+            (void)hipMemcpyAsync(c1, d_geo, (size_t)rpi * 32, hipMemcpyDeviceToDevice, hs);
+            (void)hipStreamSynchronize(hs);
+            h->dbg_c0 = c0; h->dbg_c1 = c1;
+        }
         // ---- SDFField.backward: tangent chain, reverse chain with the sigma'' injections, weight gradients with two operand pairs ----
         Chain& sc = h->sdf_full;
         for (int l = 0; l < 8; ++l) set_dense_grad(sc.e[l], g[L_SDF + l], l == 0 ? D_PE : 256);
@@ -451,7 +469,16 @@ int do_backward(nero_stage1* h, Arena& A, const float* d_rgb, const float* d_ger
         float* ehat = A.f32((size_t)rpi * LD_PE);
         float* tbuf = A.f32((size_t)8 * rpi * NERO_HID);               // adot_0..7 (the injections are formed inside the reverse kernel)
         if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_bwd: workspace too small");
+        if (!A.dry) {
+            const void* ps[9] = {d_geo, d_feat, d_sdf4, d_grad, dinv, ehat, tbuf, d_ai, dmr};
+            const size_t bs[9] = {(size_t)rpi * 32, (size_t)rpi * NERO_HID * 4, (size_t)rpi * 16, (size_t)n_in * 12, (size_t)n_in * 4, (size_t)rpi * LD_PE * 4,
+                                  (size_t)8 * rpi * NERO_HID * 4, (size_t)n_in * 4, (size_t)rpi * 16};
+            for (int i = 0; i < 9; ++i) { h->dbg_ptr[i] = ps[i]; h->dbg_bytes[i] = bs[i]; }
+            h->dbg_ptr[9] = h->dbg_c0; h->dbg_bytes[9] = h->dbg_c0 ? (size_t)n_in * 12 : 0;
+            h->dbg_ptr[10] = h->dbg_c1; h->dbg_bytes[10] = h->dbg_c1 ? (size_t)rpi * 32 : 0;
+        }
         LAUNCH(nero_pe_jvp(S.x4, 4, d_grad, 3, N_FREQ, n_in, ehat, LD_PE, stream));
+        if (join_at == 'j') join_dw(h, A, hs);                 // (behind sdf_alpha_bwd + pe_jvp, in front of the tangent chain)
         nero_tan_chain tc;
         memset(&tc, 0, sizeof(tc));
         tc.init = ehat; tc.ld_init = LD_PE; tc.k_init = LD_PE; tc.aux = ehat; tc.ld_aux = LD_PE; tc.k_aux = LD_PE;
@@ -479,10 +506,12 @@ int do_backward(nero_stage1* h, Arena& A, const float* d_rgb, const float* d_ger
         tc.macs_per_row = macs;
         head_extra[8] = tbuf + (size_t)7 * rpi * NERO_HID;
         LAUNCH(nero_mlp_tangent(&tc, n_in, stream));
+        if (join_at == 't') join_dw(h, A, hs);
         const float* sd[MAXL] = {};
         sd[8] = d_sdf4;
         Bwd sb;
         RC(sc.backward(A, M, h->f_sdf, n_in, d_feat, NERO_HID, sd, false, false, injs, nullptr, 0, false, false, sb, stream, adots));
+        if (join_at == 'b') join_dw(h, A, hs);
         RC(sc.weight_grads(A, M, h->f_sdf, sb, n_in, h->pe40, LD_PE, h->pe40, LD_PE, sd, second, head_extra, partials,
                            late_join ? (void*)fork_dw(h, A, hs) : stream));
         if (late_join) join_dw(h, A, hs);
@@ -679,6 +708,14 @@ int nero_stage1_render_bwd(nero_stage1* h, const float* d_rgb, const float* d_ge
     if (!h || !h->A.base || !d_rgb || !grads) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_bwd: bad argument (no forward state)");
     h->A.release(h->step_mark);
     return do_backward(h, h->A, d_rgb, d_gerr, d_occ, grads, d_inv_s_sum, stream);
+}
+
+// debug (scripts/r05/dbg_streams.py): device pointers + sizes of nine intermediates of the last render_bwd, in the order
+// d_geo, d_feat, d_sdf4, d_grad, dinv, ehat, adot (8 layers), d_alpha_inner, d_metallic_raw
+int nero_stage1_debug_buffers(nero_stage1* h, const void** ptrs, size_t* bytes) {
+    if (!h || !ptrs || !bytes) return nero_fail(NERO_ERR_ARG, "nero_stage1_debug_buffers: bad argument");
+    for (int i = 0; i < 11; ++i) { ptrs[i] = h->dbg_ptr[i]; bytes[i] = h->dbg_bytes[i]; }
+    return NERO_OK;
 }
 
 int nero_stage1_get_state(nero_stage1* h, nero_stage1_state* out) {

@@ -1,7 +1,7 @@
 #!/bin/bash
 # VGPRs / spills / scratch of every kernel of one translation unit:  scripts/kernel_regs.sh <unit, e.g. mlp_f16x3> ["<extra flags>"]
 cd "$(dirname "$0")/.."
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed $2 -Rpass-analysis=kernel-resource-usage -c nero_amd/csrc/$1.hip -o /tmp/kr_$$.o 2>&1 |
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -Wno-pass-failed $2 -Rpass-analysis=kernel-resource-usage -c nero_amd/csrc/$1.hip -o /tmp/kr_$$.o 2>&1 |
   python3 -c "
 import re,sys,subprocess
 cur=None;rows={}
