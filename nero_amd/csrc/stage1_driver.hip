@@ -53,7 +53,6 @@ struct nero_stage1 {
     // debug: (pointer, bytes) of the backward's intermediates of the last step, for scripts/r05/dbg_streams.py (nero_stage1_debug_buffers)
     const void* dbg_ptr[12] = {};
     size_t dbg_bytes[12] = {};
-    float *dbg_c0 = nullptr, *dbg_c1 = nullptr;
     hipStream_t s3 = nullptr;
     static constexpr int N_DW_EV = 12;                     // one event per fork of a step (never re-recorded while a wait on it may be pending)
     hipEvent_t ev_dw[N_DW_EV] = {}, ev_dw_done = nullptr;
@@ -430,34 +429,22 @@ int do_backward(nero_stage1* h, Arena& A, const float* d_rgb, const float* d_ger
             RC(h->mat[j].weight_grads(A, M, h->f_mat[j], mb, n_in, S.feat, NERO_HID, h->x8, 8, hd, nullptr, nullptr, partials, (void*)fork_dw(h, A, hs)));
             if (!three) A.release(mk);
         }
-        // The weight-gradient stream is joined HERE, in front of the SDF passes (NERO_DW_JOIN=late moves the join behind them): with the
-        // tangent / second-order reverse kernels running beside the material MLPs' weight-gradient jobs, repeats of the same step differed
-        // in the SDF gradients (and only there) by 1e-7 ... 1e-5 in two of nine repeats (scripts/r05/dbg_streams.py) -- every dependency is
-        // covered by an event, the light / material chains beside the same jobs are bit-reproducible, and the mechanism is as unexplained as
-        // the co-residency fault of round 3 (docs/experiments.md 3i).  Until it is understood the SDF passes run with nothing beside them
-        // but the NeRF++ branch, as in rounds 3-4.
-        // NERO_DW_JOIN (race hunt): e(arly, default) | j (in front of the tangent chain) | t (behind the tangent launch) | b (behind the SDF reverse launch) | l(ate: behind the SDF jobs)
-        static const char join_at = [] { const char* e = getenv("NERO_DW_JOIN"); return e ? e[0] : 'e'; }();
+        // Where the weight-gradient stream is joined: behind the SDF network's own jobs (default), i.e. the tangent / second-order reverse
+        // passes run beside the material MLPs' jobs.  HISTORY (round 5): the first version of this did not reproduce its SDF gradients bit for
+        // bit (2 repeats of 9 differed by 1e-7 ... 1e-5).  scripts/r05/dbg_streams.py narrowed it to ONE kernel: sdf_alpha_bwd, with identical
+        // inputs, returned 16-row blocks of d_grad a few ulp off whenever the narrow weight-gradient kernel shared its SIMDs -- packed fp32
+        // VALU instructions next to another wave's MFMAs (common.h).  With the library built without them every join position is
+        // bit-reproducible (8 x 9 repeats each).  NERO_DW_JOIN = e | j | t | b | l moves the join for experiments (early: in front of
+        // sdf_alpha_bwd; j: in front of the tangent chain; t / b: behind the tangent / reverse launch; l: late, the default).
+        static const char join_at = [] { const char* e = getenv("NERO_DW_JOIN"); return e ? e[0] : 'l'; }();
         const bool late_join = join_at == 'l';
         if (join_at == 'e') join_dw(h, A, hs);
-        static const bool dbg_sync = getenv("NERO_DBG_SYNC") != nullptr;   // (race hunt: host-side wait for the main stream only)
-        if (dbg_sync && !A.dry) (void)hipStreamSynchronize(hs);
         float* d_sdf4 = A.f32((size_t)rpi * 4);
         float* d_grad = A.f32((size_t)rpi * 3);
         float* dinv = A.f32(rpi);
         if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_bwd: workspace too small");
-        static const bool dbg_copy = getenv("NERO_DBG_COPY") != nullptr;     // (race hunt: d_grad / d_geo as they are right behind sdf_alpha_bwd)
-        float* c0 = dbg_copy ? A.f32((size_t)rpi * 3) : nullptr;
-        float* c1 = dbg_copy ? A.f32((size_t)rpi * 8) : nullptr;
-        if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_bwd: workspace too small");
         LAUNCH(nero_sdf_alpha_bwd(S.sdf4, S.normal, S.x4, S.inner_idx, h->d, T, h->variance, h->anneal, n_in, d_ai, d_gerr, d_geo, d_sdf4, d_grad,
                                   dinv, stream));
-        if (dbg_copy && !A.dry) {
-            (void)hipMemcpyAsync(c0, d_grad, (size_t)n_in * 12, hipMemcpyDeviceToDevice, hs);
-            (void)hipMemcpyAsync(c1, d_geo, (size_t)rpi * 32, hipMemcpyDeviceToDevice, hs);
-            (void)hipStreamSynchronize(hs);
-            h->dbg_c0 = c0; h->dbg_c1 = c1;
-        }
         // ---- SDFField.backward: tangent chain, reverse chain with the sigma'' injections, weight gradients with two operand pairs ----
         Chain& sc = h->sdf_full;
         for (int l = 0; l < 8; ++l) set_dense_grad(sc.e[l], g[L_SDF + l], l == 0 ? D_PE : 256);
@@ -474,8 +461,6 @@ int do_backward(nero_stage1* h, Arena& A, const float* d_rgb, const float* d_ger
             const size_t bs[9] = {(size_t)rpi * 32, (size_t)rpi * NERO_HID * 4, (size_t)rpi * 16, (size_t)n_in * 12, (size_t)n_in * 4, (size_t)rpi * LD_PE * 4,
                                   (size_t)8 * rpi * NERO_HID * 4, (size_t)n_in * 4, (size_t)rpi * 16};
             for (int i = 0; i < 9; ++i) { h->dbg_ptr[i] = ps[i]; h->dbg_bytes[i] = bs[i]; }
-            h->dbg_ptr[9] = h->dbg_c0; h->dbg_bytes[9] = h->dbg_c0 ? (size_t)n_in * 12 : 0;
-            h->dbg_ptr[10] = h->dbg_c1; h->dbg_bytes[10] = h->dbg_c1 ? (size_t)rpi * 32 : 0;
         }
         LAUNCH(nero_pe_jvp(S.x4, 4, d_grad, 3, N_FREQ, n_in, ehat, LD_PE, stream));
         if (join_at == 'j') join_dw(h, A, hs);                 // (behind sdf_alpha_bwd + pe_jvp, in front of the tangent chain)
@@ -714,7 +699,7 @@ int nero_stage1_render_bwd(nero_stage1* h, const float* d_rgb, const float* d_ge
 // d_geo, d_feat, d_sdf4, d_grad, dinv, ehat, adot (8 layers), d_alpha_inner, d_metallic_raw
 int nero_stage1_debug_buffers(nero_stage1* h, const void** ptrs, size_t* bytes) {
     if (!h || !ptrs || !bytes) return nero_fail(NERO_ERR_ARG, "nero_stage1_debug_buffers: bad argument");
-    for (int i = 0; i < 11; ++i) { ptrs[i] = h->dbg_ptr[i]; bytes[i] = h->dbg_bytes[i]; }
+    for (int i = 0; i < 9; ++i) { ptrs[i] = h->dbg_ptr[i]; bytes[i] = h->dbg_bytes[i]; }
     return NERO_OK;
 }
 

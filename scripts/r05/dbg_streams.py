@@ -1,4 +1,9 @@
-"""which gradient tensors differ between repeats of the same Stage-I step (NERO_STREAMS=3 race hunt)"""
+"""Run-to-run comparison of the Stage-I training step, tensor by tensor and intermediate by intermediate (round 5).
+usage: [NERO_STREAMS=3 NERO_DW_JOIN=e|j|t|b|l] python scripts/r05/dbg_streams.py [bell|bear] [rays]
+Ten repeats of the same batch with the same draws; prints which gradient tensors, which of nine intermediates of the backward
+(nero_stage1_debug_buffers), which pieces of the forward state and which glue buffers differ from the first repeat, and for d_grad the rows.
+This is the script that traced the 3-stream nondeterminism to sdf_alpha_bwd's packed fp32 instructions: with a library built
+WITH them (scripts/build_variant.sh slp shade -fslp-vectorize; NERO_HIP_LIB=...) two of nine repeats differ in 16-row blocks of d_grad."""
 import os, sys
 sys.path.insert(0, '.')
 import torch
@@ -11,11 +16,11 @@ ts = ShapeTrainStep(cfg, rays_per_rank=rays, pool_rays=4 * rays, device='cuda:0'
 names = ts.fopt.names + ['variance']
 import ctypes as C
 from nero_amd import stage1 as S1
-LBL = ['d_geo', 'd_feat', 'd_sdf4', 'd_grad', 'dinv', 'ehat', 'adot', 'd_alpha_inner', 'd_metallic_raw', 'd_grad_copy', 'd_geo_copy']
+LBL = ['d_geo', 'd_feat', 'd_sdf4', 'd_grad', 'dinv', 'ehat', 'adot', 'd_alpha_inner', 'd_metallic_raw']
 
 
 def snapshot():
-    ptrs, nb = (C.c_void_p * 11)(), (C.c_size_t * 11)()
+    ptrs, nb = (C.c_void_p * 9)(), (C.c_size_t * 9)()
     S1._lib.nero_stage1_debug_buffers(ts.drv.h, ptrs, nb)
     out = {}
     ws = ts.drv.workspace(rays)
