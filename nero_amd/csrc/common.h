@@ -7,6 +7,13 @@
 // arithmetic on ext_vector_type(float) values component by component; tests/test_no_packed_fp32.py scans the compiled ISA.
 #include <hip/hip_runtime.h>
 
+// x * y rounded to fp32 and NEVER contracted into a neighbouring add / subtract (HIP compiles with -ffp-contract=fast, and __fmul_rn is a
+// plain product in its headers): the operand packers split fl(W * scale) into planes whose sum must be that fp32 value exactly.
+__device__ __forceinline__ float nero_mul_rn(float x, float y) {
+#pragma clang fp contract(off)
+    return x * y;
+}
+
 int nero_fail(int code, const char* msg);          // records msg for nero_last_error(), returns code
 int nero_check_launch(const char* what);           // hipGetLastError() -> NERO_OK / NERO_ERR_LAUNCH
 

@@ -806,7 +806,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ W, int nrows, int l
     float v = 0.f;
     if (!transpose) { if (k < ncols && n < nrows) v = W[(size_t)n * ld + col0 + k]; }
     else            { if (k < nrows && n < ncols) v = W[(size_t)k * ld + col0 + n]; }
-    out[idx] = v * scale;
+    out[idx] = nero_mul_rn(v, scale);
 }
 
 constexpr int DW_MAX_SLICES = 256;          // one row slice per CU

@@ -781,7 +781,7 @@ __device__ __forceinline__ float pack_elem(const nero_pack_job& J, int m, int k)
     float x = 0.f;
     if (!J.transpose) { if (m < J.nrows && k < J.ncols) x = J.W[(size_t)m * J.ld + J.col0 + k]; }
     else              { if (m < J.ncols && k < J.nrows) x = J.W[(size_t)k * J.ld + J.col0 + m]; }
-    return x * J.scale;
+    return nero_mul_rn(x, J.scale);                    // (the fp32 value of the scaled weight: not contracted into the split's remainder)
 }
 
 __global__ __launch_bounds__(256) void pack_max_kernel(PackBatchH B) {

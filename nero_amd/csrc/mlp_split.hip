@@ -741,7 +741,7 @@ __global__ void pack_split_kernel(const float* __restrict__ W, int nrows, int ld
         float x = 0.f;
         if (!transpose) { if (m < nrows && k < ncols) x = W[(size_t)m * ld + col0 + k]; }
         else            { if (m < ncols && k < nrows) x = W[(size_t)k * ld + col0 + m]; }
-        v[j] = x * scale;
+        v[j] = nero_mul_rn(x, scale);                   // (rounded product: never contracted into the split's x - x0, which must see the fp32 value)
     }
     unsigned p[3][4];
 #pragma unroll
@@ -767,7 +767,7 @@ __device__ __forceinline__ void pack_split_one(const nero_pack_job& J, int idx) 
         float x = 0.f;
         if (!J.transpose) { if (m < J.nrows && k < J.ncols) x = W[(size_t)m * J.ld + J.col0 + k]; }
         else              { if (m < J.ncols && k < J.nrows) x = W[(size_t)k * J.ld + J.col0 + m]; }
-        v[j] = x * J.scale;
+        v[j] = nero_mul_rn(x, J.scale);
     }
     unsigned p[3][4];
 #pragma unroll
@@ -786,7 +786,7 @@ __device__ __forceinline__ void pack_f32_one(const nero_pack_job& J, int idx) {
     float x = 0.f;
     if (!J.transpose) { if (n < J.nrows && k < J.ncols) x = J.W[(size_t)n * J.ld + J.col0 + k]; }
     else              { if (k < J.nrows && n < J.ncols) x = J.W[(size_t)k * J.ld + J.col0 + n]; }
-    reinterpret_cast<float*>(J.out)[idx] = x * J.scale;
+    reinterpret_cast<float*>(J.out)[idx] = nero_mul_rn(x, J.scale);
 }
 __global__ __launch_bounds__(256) void pack_batch_kernel(PackBatch B) {
     const nero_pack_job& J = B.job[blockIdx.y];
