@@ -648,16 +648,17 @@ def main():
             ts.step(args.train_step + 100 + i)
         torch.cuda.synchronize()
         L.lib.nero_prof_enable(0)
-        rep = (C.c_double * 12)()
-        L.lib.nero_prof_report(rep)
+        rep = (C.c_double * 24)()
+        L.lib.nero_prof_report_kernels(rep)             # per KERNEL: 0-3 the 512-thread chain kernels + the weight-gradient GEMM, 4-6 mlp_f16p.hip's
         kname = {'fwd': ('mlp_fwd_kernel', 'fwd_split_kernel', 'fwd_f16_kernel'),
                  'tan': ('mlp_tan_kernel', 'tan_split_kernel', 'tan_f16_kernel'),
                  'bwd': ('mlp_bwd_kernel', 'bwd_split_kernel', 'bwd_f16_kernel'),
                  'dw': ('dw_gemm_kernel', 'dw_split_kernel', 'dw_f16_kernel')}
         passes = ('fwd', 'tan', 'bwd', 'dw')
-        kinds = [kname[m][CH.GEMM_MODE[m]] for m in passes]
-        peaks = [PEAK_OF_MODE[CH.GEMM_MODE[m]] for m in passes]
-        rows = [(kinds[k], rep[3 * k], rep[3 * k + 1], rep[3 * k + 2], peaks[k], CH.GEMM_MODE[passes[k]]) for k in range(4)]
+        kinds = [kname[m][CH.GEMM_MODE[m]] for m in passes] + ['fwd_p_kernel', 'tan_p_kernel', 'bwd_p_kernel']
+        peaks = [PEAK_OF_MODE[CH.GEMM_MODE[m]] for m in passes + passes[:3]]
+        modes_k = [CH.GEMM_MODE[m] for m in passes + passes[:3]]
+        rows = [(kinds[k], rep[3 * k], rep[3 * k + 1], rep[3 * k + 2], peaks[k], modes_k[k]) for k in range(7) if rep[3 * k] > 0]
         dom = max(rows, key=lambda r: r[2])
         ach = dom[3] / (dom[2] * 1e-3) / 1e12 if dom[2] > 0 else 0.0
         peak = dom[4] / 1e12

@@ -46,6 +46,9 @@ int nero_version(void);
  * report fills out[kind*3 + {0,1,2}] = {launches, total ms, total algorithmic flops} (host array of 12 doubles). */
 int nero_prof_enable(int on);
 int nero_prof_report(double* out);
+/* the same per kernel, 24 doubles: classes 0-3 = the 512-thread chain kernels and the weight-gradient GEMM alone, 4 / 5 / 6 = the forward /
+ * tangent / reverse launches that ran on the two-workgroups-per-CU kernels (nero_f16_paired), 7 unused */
+int nero_prof_report_kernels(double* out);
 
 /* ---- weight packing -------------------------------------------------------------------------------------------
  * Packs (a column window of) an effective weight matrix W[rows, ld] into the MFMA B-operand order used by the chain
@@ -173,6 +176,13 @@ typedef struct {
 } nero_bwd_chain;
 
 int nero_mlp_backward(const nero_bwd_chain* chain /*host*/, int n_rows, void* stream);
+/* Workgroup organisation of the F16X3 chain passes: bit 0 / 1 / 2 of `mask` = the forward / tangent / reverse pass runs with TWO 256-thread
+ * workgroups per CU (mlp_f16p.hip: one's epilogue, barriers and HBM waits under the other's MFMAs) instead of one 512-thread workgroup
+ * (mlp_f16x3.hip) on launches of more than 4 tiles of 64 rows per CU; bit 3 = on launches of every size.  Same packed operands, same
+ * descriptors, the same results bit for bit (tests/test_paired_engine.py).  mask < 0 only queries; returns the previous selection.
+ * Initial value: NERO_F16_PAIRED in the environment, default 3.  Process-wide, not thread-safe against concurrent launches.
+ * (No reference counterpart: an execution detail of network/field.py's nn.Linear stacks.) */
+int nero_f16_paired(int mask);
 
 /* ---- weight-gradient GEMM ------------------------------------------------------------------------------------
  * dW[n][k] (+)= sum_r D0[r][n] * B0[r][k] (+ sum_r D1[r][n] * B1[r][k]),  db[n] (+)= sum_r D0[r][n]

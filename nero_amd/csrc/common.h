@@ -26,5 +26,7 @@ int nero_check_launch(const char* what);           // hipGetLastError() -> NERO_
 // optional per-launch timing of the four MFMA kernel classes with HIP events on the launch stream (bench.py roofline leg)
 enum { NERO_K_FWD = 0, NERO_K_TAN = 1, NERO_K_BWD = 2, NERO_K_DW = 3, NERO_K_COUNT = 4 };
 void nero_prof_begin(int kind, double flops, hipStream_t s);
+void nero_prof_mark_paired();                      // the record just opened is a launch of mlp_f16p.hip's kernels (class + NERO_K_COUNT)
+void nero_prof_note(long long rows, unsigned sig);  // annotates the record just opened (NERO_PROF_DUMP lines)
 void nero_prof_end(int kind, hipStream_t s);
 bool nero_prof_is_on();                            // (the step drivers keep ONE stream while launches are being timed)

@@ -26,14 +26,14 @@ extern "C" int nero_version(void) { return 100; }
 #include <cstdlib>
 #include <vector>
 namespace {
-struct ProfRec { hipEvent_t a, b; int kind; double flops; };
+struct ProfRec { hipEvent_t a, b; int kind; double flops; long long rows; unsigned sig; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_recs;
 hipEvent_t g_cur_a;
 }
 void nero_prof_begin(int kind, double flops, hipStream_t s) {
     if (!g_prof_on) return;
-    ProfRec r; r.kind = kind; r.flops = flops;
+    ProfRec r; r.kind = kind; r.flops = flops; r.rows = 0; r.sig = 0u;
     (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b);
     (void)hipEventRecord(r.a, s);
     g_recs.push_back(r);
@@ -43,23 +43,39 @@ void nero_prof_end(int kind, hipStream_t s) {
     (void)kind;
     (void)hipEventRecord(g_recs.back().b, s);
 }
+// annotate the record just opened (NERO_PROF_DUMP only): rows of the launch and a caller-defined signature word
+void nero_prof_note(long long rows, unsigned sig) {
+    if (!g_prof_on || g_recs.empty()) return;
+    g_recs.back().rows = rows; g_recs.back().sig = sig;
+}
 bool nero_prof_is_on() { return g_prof_on; }
 extern "C" int nero_prof_enable(int on) {
     g_prof_on = on != 0;
     return 0;
 }
-// out[kind*3 + {0,1,2}] = {launches, total milliseconds, total algorithmic flops}; clears the records
-extern "C" int nero_prof_report(double* out /*host, 12 doubles*/) {
-    for (int i = 0; i < NERO_K_COUNT * 3; ++i) out[i] = 0.0;
-    // NERO_PROF_DUMP=<file>: additionally append one "kind ms flops" line per launch (tuning aid)
+// annotate the record just opened as a launch of the two-workgroups-per-CU kernels (mlp_f16p.hip): reported as its own class
+void nero_prof_mark_paired() {
+    if (!g_prof_on || g_recs.empty() || g_recs.back().kind >= NERO_K_COUNT) return;
+    g_recs.back().kind += NERO_K_COUNT;
+}
+static int prof_report(double* out, int n_kinds);
+// out[kind*3 + {0,1,2}] = {launches, total milliseconds, total algorithmic flops}; clears the records.  Four classes (forward, tangent,
+// reverse, weight gradient): the paired-kernel launches are counted with their pass
+extern "C" int nero_prof_report(double* out /*host, 12 doubles*/) { return prof_report(out, NERO_K_COUNT); }
+// the same per KERNEL: classes 0-3 as above but only the 512-thread / weight-gradient kernels, 4-6 = fwd_p / tan_p / bwd_p kernel, 7 unused
+extern "C" int nero_prof_report_kernels(double* out /*host, 24 doubles*/) { return prof_report(out, 2 * NERO_K_COUNT); }
+static int prof_report(double* out, int n_kinds) {
+    for (int i = 0; i < n_kinds * 3; ++i) out[i] = 0.0;
+    // NERO_PROF_DUMP=<file>: additionally append one "kind ms flops rows signature" line per launch (tuning aid)
     const char* dump = getenv("NERO_PROF_DUMP");
     FILE* df = dump ? fopen(dump, "a") : nullptr;
     for (auto& r : g_recs) {
         (void)hipEventSynchronize(r.b);
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, r.a, r.b);
-        out[r.kind * 3 + 0] += 1.0; out[r.kind * 3 + 1] += ms; out[r.kind * 3 + 2] += r.flops;
-        if (df) fprintf(df, "%d %.4f %.0f\n", r.kind, ms, r.flops);
+        const int k = r.kind % n_kinds;
+        out[k * 3 + 0] += 1.0; out[k * 3 + 1] += ms; out[k * 3 + 2] += r.flops;
+        if (df) fprintf(df, "%d %.4f %.0f %lld 0x%x\n", r.kind, ms, r.flops, r.rows, r.sig);
         (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
     }
     if (df) fclose(df);

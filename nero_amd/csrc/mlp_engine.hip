@@ -852,6 +852,7 @@ int nero_mlp_forward(const nero_fwd_chain* ch, int n_rows, void* stream) {
         return nero_fail(NERO_ERR_ARG, "nero_mlp_forward: init/aux width out of range");
     const dim3 grid((n_rows + 63) / 64), block(256);
     nero_prof_begin(NERO_K_FWD, 2.0 * ch->macs_per_row * n_rows, (hipStream_t)stream);
+    nero_prof_note(n_rows, (unsigned)ch->n_layers | (ch->aux_wide ? 1u : 0u) << 8 | (unsigned)ch->k_init << 16);
     if (ch->gemm_mode == NERO_GEMM_BF16X6 || ch->gemm_mode == NERO_GEMM_F16X3) {
         const int rc = ch->gemm_mode == NERO_GEMM_F16X3 ? nero_f16_forward(ch, n_rows, (hipStream_t)stream)
                                                         : nero_split_forward(ch, n_rows, (hipStream_t)stream);
@@ -897,6 +898,16 @@ int nero_mlp_backward(const nero_bwd_chain* ch, int n_rows, void* stream) {
     const dim3 grid((n_rows + 63) / 64), block(256);
     NERO_ONCE(hipFuncSetAttribute((const void*)mlp_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(0)));
     nero_prof_begin(NERO_K_BWD, 2.0 * ch->macs_per_row * n_rows, (hipStream_t)stream);
+    if (nero_prof_is_on()) {                           // signature: layers | inj 8 | mask 9 | softplus 10 | dy 11 | d_aux 12 | heads 13 | saves 14 | d_init 15
+        unsigned sig = (unsigned)ch->n_layers;
+        for (int l = 0; l < ch->n_layers; ++l) {
+            const nero_bwd_layer& Lr = ch->layer[l];
+            sig |= (Lr.inj ? 1u : 0u) << 8 | (Lr.mask_prev ? 1u : 0u) << 9 | (Lr.act_prev == NERO_ACT_SOFTPLUS100 ? 1u : 0u) << 10;
+            sig |= (Lr.n_head > 0 ? 1u : 0u) << 13 | (Lr.delta_prev ? 1u : 0u) << 14;
+        }
+        sig |= (ch->dy ? 1u : 0u) << 11 | (ch->d_aux ? 1u : 0u) << 12 | (ch->d_init ? 1u : 0u) << 15;
+        nero_prof_note(n_rows, sig);
+    }
     if (ch->gemm_mode == NERO_GEMM_BF16X6 || ch->gemm_mode == NERO_GEMM_F16X3) {
         const int rc = ch->gemm_mode == NERO_GEMM_F16X3 ? nero_f16_backward(ch, n_rows, (hipStream_t)stream)
                                                         : nero_split_backward(ch, n_rows, (hipStream_t)stream);

@@ -379,3 +379,90 @@ __device__ __forceinline__ float row_max8(const float* rmax, int row) {
     return fmaxf(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)));
 }
 
+// ---- epilogue of a reverse layer (shared by mlp_f16x3.hip and mlp_f16p.hip) ---------------------------------------------------------
+// PRE: the injections were requested inside the GEMM (ijp, bwd_f16_kernel<true>); otherwise they are read here
+template <int ACT, bool HEAD, bool PRE>
+__device__ __forceinline__ void bwd_values(const float4 (&gq)[2][4], const float4 (&pa)[2][4], size_t goff, bool has_inj,
+                                           const nero_bwd_layer& L, int row0, int i, int fbase, int n_rows, float4 (&val)[2][4],
+                                           float (&m)[2], const float4 (&ijp)[2][4]) {
+    // the global operands of the epilogue are requested in branch-free batches ahead of their use: with the loads inside
+    // `if (has_inj)` / `if (j < nh)` hipcc waited for each of them separately (147 of the reverse kernel's 240 loads were followed by
+    // s_waitcnt vmcnt(0)) -- eight serial HBM round trips per layer-tile for the injections of the second-order pass, up to 32 serial
+    // L2 round trips for the head weights of a chain's first step.  Now: four head-weight rows per request group, and the four
+    // injection vectors of a row half together (both halves at once costs 32 more registers: 255 + spills).
+    const int nh = L.n_head;
+    float4 gs[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gs[r][g] = gq[r][g];
+    if (HEAD) {
+        float dj[2][4];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const float4 dyh = *reinterpret_cast<const float4*>(L.head_dy + (size_t)(row0 + 32 * r + i) * 4);
+            dj[r][0] = dyh.x; dj[r][1] = dyh.y; dj[r][2] = dyh.z; dj[r][3] = dyh.w;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 hw[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hw[j] = *reinterpret_cast<const float4*>(L.head_w + (j < nh ? j : 0) * NERO_HID + fbase + 8 * g);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < nh) {
+                        gs[r][g].x = fmaf(dj[r][j], hw[j].x, gs[r][g].x); gs[r][g].y = fmaf(dj[r][j], hw[j].y, gs[r][g].y);
+                        gs[r][g].z = fmaf(dj[r][j], hw[j].z, gs[r][g].z); gs[r][g].w = fmaf(dj[r][j], hw[j].w, gs[r][g].w);
+                    }
+            __builtin_amdgcn_sched_barrier(0);         // (one request group at a time: all sixteen hoisted cost 40 registers and spills)
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const bool live = (row0 + 32 * r + i) < n_rows;
+        float4 ij[4];
+        if (PRE) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ij[g] = ijp[r][g];
+        } else if (has_inj) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ij[g] = *reinterpret_cast<const float4*>(L.inj + goff + (size_t)r * 32 * NERO_HID + 8 * g);
+            if (ACT == NERO_ACT_SOFTPLUS100 && L.inj_adot) {
+                // `inj` is gbar and inj_adot the tangent: the sigma'' injection gbar beta (1 - s) zdot with zdot = adot / s is formed here
+                // (s = sigma'(a_prev) is in hand anyway), so the tangent pass neither reads gbar nor writes a finished term
+                float4 ad[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) ad[g] = *reinterpret_cast<const float4*>(L.inj_adot + goff + (size_t)r * 32 * NERO_HID + 8 * g);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 a = pa[r][g];
+                    ij[g].x = inj_elem(a.x, ij[g].x, ad[g].x); ij[g].y = inj_elem(a.y, ij[g].y, ad[g].y);
+                    ij[g].z = inj_elem(a.z, ij[g].z, ad[g].z); ij[g].w = inj_elem(a.w, ij[g].w, ad[g].w);
+                }
+            }
+        }
+        m[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 a = pa[r][g];
+            float4 d;
+            d.x = act_grad<ACT>(a.x, gs[r][g].x); d.y = act_grad<ACT>(a.y, gs[r][g].y);
+            d.z = act_grad<ACT>(a.z, gs[r][g].z); d.w = act_grad<ACT>(a.w, gs[r][g].w);
+            if (has_inj) { d.x += ij[g].x; d.y += ij[g].y; d.z += ij[g].z; d.w += ij[g].w; }
+            if (!live) d = make_float4(0.f, 0.f, 0.f, 0.f);
+            val[r][g] = d;
+            m[r] = fmaxf(m[r], amax4(d));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+template <int ACT, bool PRE>
+__device__ __forceinline__ void bwd_values_h(const float4 (&gq)[2][4], const float4 (&pa)[2][4], size_t goff, bool has_inj,
+                                             const nero_bwd_layer& L, int row0, int i, int fbase, int n_rows, float4 (&val)[2][4],
+                                             float (&m)[2], const float4 (&ijp)[2][4]) {
+    if (L.n_head > 0) bwd_values<ACT, true, PRE>(gq, pa, goff, has_inj, L, row0, i, fbase, n_rows, val, m, ijp);
+    else bwd_values<ACT, false, PRE>(gq, pa, goff, has_inj, L, row0, i, fbase, n_rows, val, m, ijp);
+}
+

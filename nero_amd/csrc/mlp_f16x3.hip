@@ -487,92 +487,7 @@ __global__ __launch_bounds__(512, 1) void tan_f16_kernel(nero_tan_chain ch, int 
 // ---------------------------------------------------------------------------------------------------------------------
 // reverse chain:  delta_{l-1} = (delta_l W_l [+ dy_head W_head]) * act'(a_{l-1}) [+ inj_{l-1}]
 // ---------------------------------------------------------------------------------------------------------------------
-// PRE: the injections were requested inside the GEMM (ijp, bwd_f16_kernel<true>); otherwise they are read here
-template <int ACT, bool HEAD, bool PRE>
-__device__ __forceinline__ void bwd_values(const float4 (&gq)[2][4], const float4 (&pa)[2][4], size_t goff, bool has_inj,
-                                           const nero_bwd_layer& L, int row0, int i, int fbase, int n_rows, float4 (&val)[2][4],
-                                           float (&m)[2], const float4 (&ijp)[2][4]) {
-    // the global operands of the epilogue are requested in branch-free batches ahead of their use: with the loads inside
-    // `if (has_inj)` / `if (j < nh)` hipcc waited for each of them separately (147 of the reverse kernel's 240 loads were followed by
-    // s_waitcnt vmcnt(0)) -- eight serial HBM round trips per layer-tile for the injections of the second-order pass, up to 32 serial
-    // L2 round trips for the head weights of a chain's first step.  Now: four head-weight rows per request group, and the four
-    // injection vectors of a row half together (both halves at once costs 32 more registers: 255 + spills).
-    const int nh = L.n_head;
-    float4 gs[2][4];
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) gs[r][g] = gq[r][g];
-    if (HEAD) {
-        float dj[2][4];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const float4 dyh = *reinterpret_cast<const float4*>(L.head_dy + (size_t)(row0 + 32 * r + i) * 4);
-            dj[r][0] = dyh.x; dj[r][1] = dyh.y; dj[r][2] = dyh.z; dj[r][3] = dyh.w;
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float4 hw[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) hw[j] = *reinterpret_cast<const float4*>(L.head_w + (j < nh ? j : 0) * NERO_HID + fbase + 8 * g);
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (j < nh) {
-                        gs[r][g].x = fmaf(dj[r][j], hw[j].x, gs[r][g].x); gs[r][g].y = fmaf(dj[r][j], hw[j].y, gs[r][g].y);
-                        gs[r][g].z = fmaf(dj[r][j], hw[j].z, gs[r][g].z); gs[r][g].w = fmaf(dj[r][j], hw[j].w, gs[r][g].w);
-                    }
-            __builtin_amdgcn_sched_barrier(0);         // (one request group at a time: all sixteen hoisted cost 40 registers and spills)
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const bool live = (row0 + 32 * r + i) < n_rows;
-        float4 ij[4];
-        if (PRE) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) ij[g] = ijp[r][g];
-        } else if (has_inj) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) ij[g] = *reinterpret_cast<const float4*>(L.inj + goff + (size_t)r * 32 * NERO_HID + 8 * g);
-            if (ACT == NERO_ACT_SOFTPLUS100 && L.inj_adot) {
-                // `inj` is gbar and inj_adot the tangent: the sigma'' injection gbar beta (1 - s) zdot with zdot = adot / s is formed here
-                // (s = sigma'(a_prev) is in hand anyway), so the tangent pass neither reads gbar nor writes a finished term
-                float4 ad[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) ad[g] = *reinterpret_cast<const float4*>(L.inj_adot + goff + (size_t)r * 32 * NERO_HID + 8 * g);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 a = pa[r][g];
-                    ij[g].x = inj_elem(a.x, ij[g].x, ad[g].x); ij[g].y = inj_elem(a.y, ij[g].y, ad[g].y);
-                    ij[g].z = inj_elem(a.z, ij[g].z, ad[g].z); ij[g].w = inj_elem(a.w, ij[g].w, ad[g].w);
-                }
-            }
-        }
-        m[r] = 0.f;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 a = pa[r][g];
-            float4 d;
-            d.x = act_grad<ACT>(a.x, gs[r][g].x); d.y = act_grad<ACT>(a.y, gs[r][g].y);
-            d.z = act_grad<ACT>(a.z, gs[r][g].z); d.w = act_grad<ACT>(a.w, gs[r][g].w);
-            if (has_inj) { d.x += ij[g].x; d.y += ij[g].y; d.z += ij[g].z; d.w += ij[g].w; }
-            if (!live) d = make_float4(0.f, 0.f, 0.f, 0.f);
-            val[r][g] = d;
-            m[r] = fmaxf(m[r], amax4(d));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-template <int ACT, bool PRE>
-__device__ __forceinline__ void bwd_values_h(const float4 (&gq)[2][4], const float4 (&pa)[2][4], size_t goff, bool has_inj,
-                                             const nero_bwd_layer& L, int row0, int i, int fbase, int n_rows, float4 (&val)[2][4],
-                                             float (&m)[2], const float4 (&ijp)[2][4]) {
-    if (L.n_head > 0) bwd_values<ACT, true, PRE>(gq, pa, goff, has_inj, L, row0, i, fbase, n_rows, val, m, ijp);
-    else bwd_values<ACT, false, PRE>(gq, pa, goff, has_inj, L, row0, i, fbase, n_rows, val, m, ijp);
-}
-
+// (bwd_values / bwd_values_h: mlp_f16_util.h, shared with mlp_f16p.hip)
 // LDS of the reverse kernel: planes | row scales, row maxima | PA: the saved activations of the layer the walk reaches NEXT,
 // 8 KB per wave in this lane's fragment order [r][g][lane] x 16 B, brought in by LDS-DMA (global_load_lds_dwordx4) while the
 // current layer computes; between its read-out and the next request the same 8 KB serve as the wave's store-transposition scratch.  Without it the 64 KB per tile and layer were requested in front of
@@ -874,6 +789,31 @@ static int nero_chain_grid(int n_tiles, int kind_bit) {
     return ((mask >> kind_bit) & 1) && n_tiles > cus ? cus : n_tiles;
 }
 
+// NERO_F16_PAIRED: bit 0 / 1 / 2 = the forward / tangent / reverse pass runs on the two-workgroups-per-CU kernels of mlp_f16p.hip when the
+// launch is large enough to keep two of them on every CU for several rounds (more than 4 tiles per CU: below that the 4-wave workgroup's
+// longer walk through a tile is the critical path -- 512 rays: forward 1.95 -> 2.12 ms); bit 3 = whatever the size (tests).  Narrow-aux
+// chains only: the wide aux operand would be converted from global memory inside its k-steps, which costs more than it hides.
+// Measured (profiles/r05_paired_ab.txt, 4096 rays, same box): forward 9.19 -> 8.80 ms, tangent 1.61 -> 1.45 ms, reverse 8.88 -> 9.46 ms
+// (-> 8.8 with the batched epilogue loads, still no gain: its epilogue wants the saved activations the 512-thread kernel brings in by
+// LDS-DMA under the GEMM, for which two workgroups leave no LDS) => default 3.
+#ifndef NERO_F16_PAIRED_DEFAULT
+#define NERO_F16_PAIRED_DEFAULT 3
+#endif
+static int g_paired_mask = -1;
+static int nero_paired_mask() {
+    if (g_paired_mask < 0) { const char* e = getenv("NERO_F16_PAIRED"); g_paired_mask = (e ? atoi(e) : NERO_F16_PAIRED_DEFAULT) & 15; }
+    return g_paired_mask;
+}
+static bool nero_paired(int kind_bit, int n_rows) {
+    const int m = nero_paired_mask();
+    return ((m >> kind_bit) & 1) && ((m & 8) || (n_rows + 63) / 64 > 4 * nero_cu_count());
+}
+extern "C" int nero_f16_paired(int mask) {           // mask >= 0: select; returns the previous selection (include/nero_hip.h)
+    const int prev = nero_paired_mask();
+    if (mask >= 0) g_paired_mask = mask & 15;
+    return prev;
+}
+
 template <bool WIDE, int NVI>
 static void launch_fwd(const nero_fwd_chain* ch, int n_rows, int n_tiles, dim3 grid, hipStream_t stream) {
     NERO_ONCE(hipFuncSetAttribute((const void*)fwd_f16_kernel<WIDE, NVI>, hipFuncAttributeMaxDynamicSharedMemorySize, f16_lds_bytes(WIDE ? 1 : 0)));
@@ -881,6 +821,7 @@ static void launch_fwd(const nero_fwd_chain* ch, int n_rows, int n_tiles, dim3 g
 }
 
 int nero_f16_forward(const nero_fwd_chain* ch, int n_rows, hipStream_t stream) {
+    if (nero_paired(0, n_rows) && !ch->aux_wide) return nero_f16p_forward(ch, n_rows, stream);
     const int n_tiles = (n_rows + 63) / 64, cus = nero_cu_count();
     const dim3 grid(nero_chain_grid(n_tiles, 0));
     for (int l = 0; l < ch->n_layers; ++l)
@@ -896,6 +837,7 @@ int nero_f16_forward(const nero_fwd_chain* ch, int n_rows, hipStream_t stream) {
 }
 
 int nero_f16_tangent(const nero_tan_chain* ch, int n_rows, hipStream_t stream) {
+    if (nero_paired(1, n_rows) && !ch->aux_wide) return nero_f16p_tangent(ch, n_rows, stream);
     const dim3 grid((n_rows + 63) / 64), block(512);
     for (int l = 0; l < ch->n_layers; ++l)
         if ((ch->layer[l].k_main | ch->layer[l].k_aux) & 15)
@@ -907,6 +849,7 @@ int nero_f16_tangent(const nero_tan_chain* ch, int n_rows, hipStream_t stream) {
 }
 
 int nero_f16_backward(const nero_bwd_chain* ch, int n_rows, hipStream_t stream) {
+    if (nero_paired(2, n_rows)) return nero_f16p_backward(ch, n_rows, stream);
     const dim3 grid((n_rows + 63) / 64), block(512);
     for (int l = 0; l < ch->n_layers; ++l)
         if (ch->layer[l].n_out & 15) return nero_fail(NERO_ERR_ARG, "nero_mlp_backward(f16x3): n_out must be a multiple of 16");

@@ -17,6 +17,11 @@ int nero_f16_pack_batch(const nero_pack_job* jobs, int n_jobs, hipStream_t strea
 int nero_f16_forward(const nero_fwd_chain* ch, int n_rows, hipStream_t stream);
 int nero_f16_tangent(const nero_tan_chain* ch, int n_rows, hipStream_t stream);
 int nero_f16_backward(const nero_bwd_chain* ch, int n_rows, hipStream_t stream);
+// the same passes with two 256-thread workgroups per CU (mlp_f16p.hip): same operands, same results bit for bit; chosen per pass by
+// NERO_F16_PAIRED (bit 0 forward, 1 tangent, 2 reverse) inside nero_f16_forward / _tangent / _backward
+int nero_f16p_forward(const nero_fwd_chain* ch, int n_rows, hipStream_t stream);
+int nero_f16p_tangent(const nero_tan_chain* ch, int n_rows, hipStream_t stream);
+int nero_f16p_backward(const nero_bwd_chain* ch, int n_rows, hipStream_t stream);
 int nero_f16_dw(const nero_dw_job* job, int n_rows, int rows_per_slice, int slices, float* partials, int n_pad, int k_pad,
                 hipStream_t stream);                                                    // mlp_f16dw.hip
 // several weight-gradient jobs over the SAME rows in one launch (grid.y = job): kernel argument of dw_f16_batch_kernel / dw_reduce_batch_kernel

@@ -22,8 +22,8 @@ L.lib.nero_prof_report(rep)
 names = {0: 'fwd', 1: 'tan', 2: 'bwd', 3: 'dw'}
 tot = {}
 for i, line in enumerate(open(dump)):
-    k, ms, fl = line.split()
+    k, ms, fl, rows, sig = (line.split() + ['0', '0x0'])[:5]
     k, ms, fl = int(k), float(ms), float(fl)
     tot[k] = tot.get(k, 0.0) + ms
-    print(f'{i:3d} {names[k]:3s} {ms:8.4f} ms {fl / 1e9:10.2f} GFLOP {fl / ms / 1e9:8.1f} TFLOP/s')
+    print(f'{i:3d} {names[k]:3s} {ms:8.4f} ms {fl / 1e9:10.2f} GFLOP {fl / ms / 1e9:8.1f} TFLOP/s rows {rows} sig {sig}')
 print({names[k]: round(v, 3) for k, v in tot.items()})

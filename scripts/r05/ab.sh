@@ -12,7 +12,7 @@ run() {
   env $envs timeout 300 python bench.py --quick --steps ${STEPS:-16} --warmup 4 ${BENCH_ARGS} 2>&1 | tail -1 | python -c "
 import sys,json
 try:
-    d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], {k[:3]: v['ms_per_step'] for k, v in d.get('roofline',{}).get('per_kernel',{}).items()})
+    d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], {k.replace('_kernel','').replace('_f16',''): v['ms_per_step'] for k, v in d.get('roofline',{}).get('per_kernel',{}).items()})
 except Exception as e: print('FAILED', e)" | tee -a $OUT
 }
 for rep in 1 2; do for s in "$@"; do run $s; done; done
