@@ -34,9 +34,9 @@ enum { NERO_ACT_NONE = 0, NERO_ACT_RELU = 1, NERO_ACT_SOFTPLUS100 = 2 };
 /* F16X3: operands as two fp16 planes (h, l*2^11) of their block-scaled value (per activation row / per weight matrix, exact
  * powers of two), three plane products in two accumulator sets -- half the MFMA count of BF16X6 at the same error class
  * (representation error <= 2^-24 of the block maximum, dropped term <= 2^-24 of the product). */
-/* (value 3 was NERO_GEMM_F16X3P, the two-workgroups-per-CU forward engine of rounds 2-3: removed in round 4 -- it returned a wrong
- * partial sum in one launch of three at size and the mechanism was never identified; every entry point now answers
- * NERO_ERR_UNSUPPORTED / NERO_ERR_ARG to it.) */
+/* (value 3 was NERO_GEMM_F16X3P, the two-workgroups-per-CU forward engine of rounds 2-3, removed in round 4 for a wrong partial sum in one
+ * launch of three at size.  Round 5 found the mechanism -- packed fp32 beside another wave's MFMAs, DESIGN.md 9.3 -- and the kernels are
+ * back as an execution detail of F16X3, nero_f16_paired below: not a mode, the value 3 stays refused.) */
 enum { NERO_GEMM_F32 = 0, NERO_GEMM_BF16X6 = 1, NERO_GEMM_F16X3 = 2 };
 enum { NERO_OK = 0, NERO_ERR_ARG = -1, NERO_ERR_LAUNCH = -2, NERO_ERR_UNSUPPORTED = -3 };
 

@@ -17,8 +17,10 @@ from . import _lib as L
 #   'f16x3'  (default) two block-scaled fp16 planes, 3 MFMA products: per activation row / weight matrix in the chain kernels
 #            (mlp_f16x3.hip), per 16-row chunk with a running accumulator unit in the weight-gradient GEMM (mlp_f16dw.hip)
 #   'bf16x6' three bf16 planes, 6 products (mlp_split.hip)
-#   ('f16x3p', the two-workgroups-per-CU forward engine of rounds 2-3, is gone: it sporadically returned a wrong partial sum at size
-#            and the mechanism was never identified; asking for it raises)
+#            -- the chain passes of large launches run as two 256-thread workgroups per CU (mlp_f16p.hip; NERO_F16_PAIRED /
+#            nero_f16_paired, default forward + tangent): an execution detail, same images, same results bit for bit.  (Rounds 2-3 had it
+#            as a fourth arithmetic 'f16x3p', removed in round 4 for a sporadic wrong partial sum; round 5 found the cause -- packed fp32
+#            beside MFMAs, DESIGN.md 9.3 -- and brought the kernels back; the MODE name still raises.)
 #   'f32'    the f32-input MFMA, an exact fmaf chain
 # NERO_GEMM=<mode> selects all passes, NERO_GEMM_FWD / _TAN / _BWD / _DW one pass.
 _MODE_NAMES = {'f32': L.GEMM_F32, 'bf16x6': L.GEMM_BF16X6, 'f16x3': L.GEMM_F16X3}
@@ -28,8 +30,8 @@ _DEFAULT = {'fwd': 'f16x3', 'tan': 'f16x3', 'bwd': 'f16x3', 'dw': 'f16x3'}
 
 def _resolve(mode, k):
     if mode not in _MODE_NAMES:
-        raise ValueError(f"NERO_GEMM{'_' + k.upper()}: unknown arithmetic {mode!r} (one of {sorted(_MODE_NAMES)}; 'f16x3p' was removed in "
-                         "round 4, DESIGN.md 3i)")
+        raise ValueError(f"NERO_GEMM{'_' + k.upper()}: unknown arithmetic {mode!r} (one of {sorted(_MODE_NAMES)}; 'f16x3p' is not an arithmetic any more: "
+                         "NERO_F16_PAIRED selects the workgroup organisation, DESIGN.md 9.3)")
     return _MODE_NAMES[mode]
 
 

@@ -792,7 +792,8 @@ static int nero_chain_grid(int n_tiles, int kind_bit) {
 // NERO_F16_PAIRED: bit 0 / 1 / 2 = the forward / tangent / reverse pass runs on the two-workgroups-per-CU kernels of mlp_f16p.hip when the
 // launch is large enough to keep two of them on every CU for several rounds (more than 4 tiles per CU: below that the 4-wave workgroup's
 // longer walk through a tile is the critical path -- 512 rays: forward 1.95 -> 2.12 ms); bit 3 = whatever the size (tests).  Narrow-aux
-// chains only: the wide aux operand would be converted from global memory inside its k-steps, which costs more than it hides.
+// chains only: the wide aux operand would be converted from global memory inside its k-steps, which costs more than it hides
+// (measured: forward classes 9.32 -> 9.54 ms with the wide-aux SDF chain on the paired kernel, gpurun_out/r05/paired_wide_ab.txt).
 // Measured (profiles/r05_paired_ab.txt, 4096 rays, same box): forward 9.19 -> 8.80 ms, tangent 1.61 -> 1.45 ms, reverse 8.88 -> 9.46 ms
 // (-> 8.8 with the batched epilogue loads, still no gain: its epilogue wants the saved activations the 512-thread kernel brings in by
 // LDS-DMA under the GEMM, for which two workgroups leave no LDS) => default 3.

@@ -1,7 +1,7 @@
 """Bit-reproducibility of ONE forward chain launch: records the NeRF++ head chain (256 -> 256 -> 128 (+27 aux) -> 3, ~390 k rows) of a
 4096-ray render, takes the 512-thread engine's result as the reference and replays the chain 60 times on the engine named in
 the forward engine, counting the launches whose first saved activation differs.
-It was the reproducer of the fault of the removed two-workgroups-per-CU kernel and stays as a determinism probe.  usage: python scripts/replay_fwd_chain.py"""
+It was the reproducer of the round-3 fault of the two-workgroups-per-CU kernel (packed fp32 beside MFMAs) and stays as a determinism probe.  usage: python scripts/replay_fwd_chain.py"""
 import sys
 sys.path.insert(0, '.')
 import numpy as np, torch

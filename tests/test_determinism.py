@@ -1,8 +1,10 @@
 """GPU tier: run-to-run bit reproducibility.  No kernel of the path uses floating-point atomics and every reduction has a fixed order,
 so the same batch with the same random draws must give the same loss and the same gradients BIT FOR BIT, however the workgroups are
-scheduled.  This is the test that found the fault of the two-workgroups-per-CU forward kernel (`f16x3p`, removed in round 4: DESIGN.md 3i):
-one launch in three returned one column of 16 rows with another partial sum -- 1e-7 of a gradient, below every parity tolerance, and
-invisible to a comparison of single runs."""
+scheduled.  This is the test that found the fault of the two-workgroups-per-CU forward kernel in round 3 (one launch in three returned one column
+of 16 rows with another partial sum -- 1e-7 of a gradient, below every parity tolerance, invisible to a comparison of single runs) and
+the same fault in `sdf_alpha_bwd` in round 5, where it was traced to packed fp32 arithmetic beside another wave's MFMAs.
+With no packed fp32 left in the library the two-workgroup kernels are back and these tests run on them (tests/test_paired_engine.py
+compares them with the 512-thread kernels bit for bit)."""
 import numpy as np
 import pytest
 import torch
@@ -57,12 +59,12 @@ def test_stage2_training_step_is_bit_reproducible():
 
 def test_forward_chain_launches_are_bit_reproducible():
     """a NeRF++-head shaped chain (256 -> 256 -> 128 with a 27-column aux operand -> 3) over 300 k rows, forty launches on the default
-    forward engine: every saved activation and the head identical to the first launch (the shape and size at which the removed f16x3p kernel
-    failed in a third of its launches)"""
+    forward engine (at this size the two-workgroups-per-CU kernel): every saved activation and the head identical to the first launch
+    (the shape and size at which the round-3 build of that kernel failed in a third of its launches)"""
     from nero_amd import _lib as L
     from nero_amd import chain as CH
     from nero_amd.chain import Chain, Dense, Head
-    assert CH.GEMM_MODE['fwd'] == L.GEMM_F16X3, 'the default forward engine is the bit-reproducible 512-thread kernel (nero_amd/chain.py)'
+    assert CH.GEMM_MODE['fwd'] == L.GEMM_F16X3, 'the default forward arithmetic is f16x3 (nero_amd/chain.py)'
     g = torch.Generator(device='cuda').manual_seed(2)
     rn = lambda *s: torch.randn(*s, device='cuda', generator=g)
     n = 300000
