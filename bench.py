@@ -319,15 +319,14 @@ def stage2_step_bench(dev, kind, P_, Dd, Ds, mesh, rank=0, world=1, warmup=5, st
             ts.step(7000 + i)
         torch.cuda.synchronize()
         L.lib.nero_prof_enable(0)
-        rep = (C.c_double * 12)()
-        L.lib.nero_prof_report(rep)
-        names = ('fwd', 'tan', 'bwd', 'dw')
-        rows = {names[k]: (rep[3 * k], rep[3 * k + 1], rep[3 * k + 2]) for k in range(4) if rep[3 * k] > 0}
+        rep = (C.c_double * 24)()
+        L.lib.nero_prof_report_kernels(rep)             # per KERNEL: 0-3 the 512-thread chain kernels + the weight-gradient GEMM, 4-6 mlp_f16p.hip's
+        names = ('fwd_f16_kernel', 'tan_f16_kernel', 'bwd_f16_kernel', 'dw_f16_kernel', 'fwd_p_kernel', 'tan_p_kernel', 'bwd_p_kernel')
+        rows = {names[k]: (rep[3 * k], rep[3 * k + 1], rep[3 * k + 2]) for k in range(7) if rep[3 * k] > 0}
         if rows:
             dom = max(rows, key=lambda k: rows[k][1])
             n_l, ms_l, fl = rows[dom]
-            kern = {'fwd': 'fwd_f16_kernel', 'bwd': 'bwd_f16_kernel', 'dw': 'dw_f16_kernel',
-                    'tan': 'tan_f16_kernel'}[dom]
+            kern = dom
             traffic, tsrc = hbm_traffic_per_launch(kern, 'stage2_hbm_traffic_per_kernel')
             out['roofline'] = {'bound': 'mfma', 'kernel': kern, 'achieved': round(fl / (ms_l * 1e-3) / 1e12, 2), 'peak': round(peak / 1e12, 1),
                                'unit': 'TFLOP/s', 'frac': round(fl / (ms_l * 1e-3) / peak, 4), 'avg_launch_ms': round(ms_l / max(n_l, 1), 4),
