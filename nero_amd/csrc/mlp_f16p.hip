@@ -27,6 +27,13 @@ namespace {
 #include "mlp_f16_util.h"
 
 constexpr int PW = 4;                                  // waves per workgroup
+// reverse kernel: the saved activations of a wave's first / second feature tile are requested in front of (true) or behind (false) its GEMM
+#ifndef P_PA_EARLY_A
+#define P_PA_EARLY_A true
+#endif
+#ifndef P_PA_EARLY_B
+#define P_PA_EARLY_B true
+#endif
 
 struct LdsP { char* actp; float* rs_main; float* rs_aux; float* rmax; char* scr; };
 __device__ __forceinline__ LdsP carve_p(char* smem) {
@@ -419,6 +426,7 @@ __device__ __forceinline__ void combine_acc(float4 (&gq)[2][4], const f32x16 (&a
 }
 
 // one feature tile of one reverse layer; `first` = the chain's first dense layer (its input gradient goes to d_init / d_aux)
+template <bool PA_EARLY>
 __device__ __forceinline__ void bwd_tile(const nero_bwd_chain& ch, const nero_bwd_layer& L, const Ctx& c, int t, bool first, float rs0, float rs1,
                                          float4 (&val)[2][4], float (&m)[2]) {
     m[0] = m[1] = 0.f;
@@ -429,6 +437,27 @@ __device__ __forceinline__ void bwd_tile(const nero_bwd_chain& ch, const nero_bw
     const int steps = L.n_out >> 4;
     const bool has_inj = !first && L.inj != nullptr;
     const char* xp = c.S.actp + c.i * SA + 16 * c.h;
+    // saved activations of this lane's outputs (ReLU: 1 / 0 from the sign words).  PA_EARLY: requested in FRONT of the main GEMM (32
+    // registers through the k-loop, the HBM round trip under it); default: behind it (the round trip under the sibling workgroup's MFMAs)
+    float4 pa[2][4];
+    auto load_pa = [&]() {
+        if (first || !live_t) return;
+        if (L.mask_prev && L.act_prev == NERO_ACT_RELU) {   // 4 bytes per (row, tile) instead of 128: only the sign is needed
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const unsigned bits = L.mask_prev[(size_t)(c.row0 + 32 * r + c.i) * 8 + t] >> (16 * c.h);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    pa[r][g] = make_float4((bits >> (4 * g)) & 1u ? 1.f : 0.f, (bits >> (4 * g + 1)) & 1u ? 1.f : 0.f,
+                                           (bits >> (4 * g + 2)) & 1u ? 1.f : 0.f, (bits >> (4 * g + 3)) & 1u ? 1.f : 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) pa[r][g] = *reinterpret_cast<const float4*>(L.a_prev + goff + (size_t)r * 32 * NERO_HID + 8 * g);
+        }
+    };
     float4 gq[2][4];                                   // incoming gradient of this lane's outputs, true units
     if (L.n_out > 0) {
         f32x16 aH[2], aL[2];
@@ -449,6 +478,10 @@ __device__ __forceinline__ void bwd_tile(const nero_bwd_chain& ch, const nero_bw
                 }
         }
         if (!live_t || (first && !ch.d_init)) { publish_rowmax(c.S.rmax, 0.f, 0.f, t, c.i, c.h); return; }
+        if (PA_EARLY) {
+            load_pa();
+            NERO_FENCE();
+        }
         zero2(aH);
         zero2(aL);
         const float wsc = *L.w_main_t;
@@ -477,30 +510,16 @@ __device__ __forceinline__ void bwd_tile(const nero_bwd_chain& ch, const nero_bw
     } else {
         // head-only pseudo layer: the incoming gradient is the current content of the planes
         if (!live_t) { publish_rowmax(c.S.rmax, 0.f, 0.f, t, c.i, c.h); return; }
+        if (PA_EARLY) load_pa();
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             gq[0][g] = scale4(load_planes4h(c.S.actp + c.i * SA + (fbase + 8 * g) * 2, PLANE_A), rs0);
             gq[1][g] = scale4(load_planes4h(c.S.actp + (32 + c.i) * SA + (fbase + 8 * g) * 2, PLANE_A), rs1);
         }
     }
-    float4 pa[2][4];                                   // saved activations of this lane's outputs, requested BEHIND the GEMM (as tan_tile: no room for 32 more registers in front of it)
-    NERO_FENCE();
-    if (!first && live_t) {
-        if (L.mask_prev && L.act_prev == NERO_ACT_RELU) {   // 4 bytes per (row, tile) instead of 128: only the sign is needed
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const unsigned bits = L.mask_prev[(size_t)(c.row0 + 32 * r + c.i) * 8 + t] >> (16 * c.h);
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    pa[r][g] = make_float4((bits >> (4 * g)) & 1u ? 1.f : 0.f, (bits >> (4 * g + 1)) & 1u ? 1.f : 0.f,
-                                           (bits >> (4 * g + 2)) & 1u ? 1.f : 0.f, (bits >> (4 * g + 3)) & 1u ? 1.f : 0.f);
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) pa[r][g] = *reinterpret_cast<const float4*>(L.a_prev + goff + (size_t)r * 32 * NERO_HID + 8 * g);
-        }
+    if (!PA_EARLY) {
+        NERO_FENCE();
+        load_pa();
     }
     float4 ijp[2][4];                                  // (unused: PRE = false)
 #pragma unroll
@@ -536,8 +555,8 @@ __global__ __launch_bounds__(256, 2) void bwd_p_kernel(nero_bwd_chain ch, int n_
         const float rs0 = c.S.rs_main[c.i], rs1 = c.S.rs_main[32 + c.i];
         float4 v0[2][4], v1[2][4];
         float m0[2], m1[2];
-        bwd_tile(ch, L, c, c.wave, first, rs0, rs1, v0, m0);
-        bwd_tile(ch, L, c, c.wave + PW, first, rs0, rs1, v1, m1);
+        bwd_tile<P_PA_EARLY_A>(ch, L, c, c.wave, first, rs0, rs1, v0, m0);
+        bwd_tile<P_PA_EARLY_B>(ch, L, c, c.wave + PW, first, rs0, rs1, v1, m1);
         if (first) break;
         commit_planes_p(c, v0, v1, c.wave < L.k_main_tiles, c.wave + PW < L.k_main_tiles);
     }

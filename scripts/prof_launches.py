@@ -19,7 +19,7 @@ torch.cuda.synchronize()
 L.lib.nero_prof_enable(0)
 rep = (C.c_double * 12)()
 L.lib.nero_prof_report(rep)
-names = {0: 'fwd', 1: 'tan', 2: 'bwd', 3: 'dw'}
+names = {0: 'fwd', 1: 'tan', 2: 'bwd', 3: 'dw', 4: 'fwP', 5: 'taP', 6: 'bwP'}      # 4-6: the two-workgroups-per-CU kernels (mlp_f16p.hip)
 tot = {}
 for i, line in enumerate(open(dump)):
     k, ms, fl, rows, sig = (line.split() + ['0', '0x0'])[:5]
