@@ -1,11 +1,14 @@
 // mlp_f16p.hip -- the fused MLP-chain passes of the fp16 two-plane arithmetic (mlp_f16x3.hip: three MFMAs per fp32 multiply-add,
-// per-row block scaling) organised for TWO resident workgroups per CU (gemm_mode NERO_GEMM_F16X3P).
+// per-row block scaling) organised for TWO resident workgroups per CU.  Not a gemm_mode: an execution detail of NERO_GEMM_F16X3, chosen
+// per pass and launch size by nero_f16_forward / _tangent / _backward (mlp_f16x3.hip: NERO_F16_PAIRED, nero_f16_paired).
 //
 // HISTORY.  Built in round 2 (forward default of rounds 2-3: -3 % on the training step), REMOVED in round 4 because one launch in three
 // returned a wrong partial sum in a quarter of the lanes of one accumulator pair (docs/experiments.md 3i) and the mechanism was not
 // found.  Round 5 found it: packed fp32 VALU instructions -- the epilogue's v_pk_fma_f32 -- next to the OTHER
 // workgroup's MFMAs on the same SIMD.  The library is built without packed fp32 now (common.h), so the engine is back, ported to the
-// one-accumulator plane format, behind the same bit-reproducibility tests that caught it.
+// one-accumulator plane format and the fused-injection protocol of the second-order pass, behind the bit-reproducibility tests that caught
+// it (tests/test_determinism.py) and a bit-for-bit comparison with the 512-thread kernels (tests/test_paired_engine.py).  Measured
+// (profiles/r05_paired_ab.txt): forward -4 %, tangent -10 %, reverse +-0 => forward + tangent of large launches by default.
 //
 // Why: the 512-thread kernels of mlp_f16x3.hip hold one workgroup per CU, whose 8 waves walk the phases of a layer in lock step
 // (GEMM -> activation / saves -> row-maximum exchange -> plane conversion, two barriers), so the matrix pipe idles through every
