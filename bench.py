@@ -705,7 +705,8 @@ def main():
                                    f'(64+64+32) samples per GPU, training-schedule step {args.train_step}', 'rays_per_gpu': args.rays,
                        'parallelism': f'dp{world}', 'optimizer': 'adam(fused)', 'inv_s': 'exp(10*0.5)',
                        'streams': int(os.environ.get('NERO_STREAMS', '3')),
-                       'arithmetic': 'fp16 two-plane operands, 3 MFMA products into ONE fp32 accumulator; no packed fp32 VALU (DESIGN.md 9.3)'},
+                       'arithmetic': 'fp16 two-plane operands, 3 MFMA products into ONE fp32 accumulator; no packed fp32 VALU (DESIGN.md 9.3)',
+                       'f16_paired_mask': CH.f16_paired()},
             'step_mlp_flop_frac': round(flop_step / (dt / args.steps) / PEAK_OF_MODE[CH.GEMM_MODE['fwd']], 4),
             'step_mlp_flop_frac_of_f32_mfma_peak': round(flop_step / (dt / args.steps) / PEAK_F32_MFMA, 4),
             'inner_samples_per_ray': round(n_in / args.steps / args.rays, 2),

@@ -46,6 +46,15 @@ def set_gemm_mode(mode, passes=('fwd', 'tan', 'bwd', 'dw')):
         GEMM_MODE[k] = _resolve(_DEFAULT[k] if mode == 'default' else mode, k)
 
 
+def f16_paired(mask=-1):
+    """workgroup organisation of the f16x3 chain passes (include/nero_hip.h::nero_f16_paired): bit 0 / 1 / 2 = forward / tangent / reverse on
+    the two-workgroups-per-CU kernels for launches of more than 4 tiles per CU, bit 3 = for launches of every size; mask < 0 only queries.
+    Returns the previous mask.  Results are bit-identical in every setting (tests/test_paired_engine.py)."""
+    L.lib.nero_f16_paired.argtypes = [C.c_int]
+    L.lib.nero_f16_paired.restype = C.c_int
+    return int(L.lib.nero_f16_paired(int(mask)))
+
+
 # test hook (tests/test_parity_at_size.py, gate-teacher-forced gradient parity): when a list, every saving forward launch appends the
 # ReLU sign masks its kernel wrote (nero_fwd_layer.relu_mask: one word per (row, 32-column tile)) with the chain's signature
 MASK_CAPTURE = None

@@ -42,3 +42,20 @@ def test_dw_workspace_is_worst_case_sized():
     for n in (0, 1, 100, 8000, 8192, 8193, 300000, 1 << 22):
         assert lib.nero_dw_workspace_floats(n) >= base
     assert lib.nero_dw_workspace_floats(1 << 22) >= ((1 << 22) // 128) * 1028
+
+
+def test_f16_paired_selector_round_trip():
+    """nero_f16_paired (no GPU needed: a host-side selection): a negative mask only queries, a mask is kept modulo its four bits, the call
+    returns the previous selection; the default is forward + tangent (3) unless NERO_F16_PAIRED says otherwise"""
+    from nero_amd import chain as CH
+    prev = CH.f16_paired()
+    try:
+        if 'NERO_F16_PAIRED' not in os.environ:
+            assert prev == 3
+        assert CH.f16_paired(8 | 5) == prev
+        assert CH.f16_paired() == 13
+        assert CH.f16_paired(0x47) == 13              # only bits 0-3 are kept
+        assert CH.f16_paired(-1) == 7
+    finally:
+        CH.f16_paired(prev)
+    assert CH.f16_paired() == prev

@@ -2,8 +2,6 @@
 512-thread kernels (mlp_f16x3.hip): same operands, same descriptors, identical results BIT FOR BIT, and identical from launch to launch
 at the size and shape at which the round-2 version of this engine failed in a third of its launches (the fault traced in round 5 to packed
 fp32 arithmetic beside another wave's MFMAs: DESIGN.md 9.3; the library holds no packed fp32 now, tests/test_no_packed_fp32.py)."""
-import ctypes as C
-
 import pytest
 import torch
 
@@ -12,13 +10,10 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture
 def paired():
-    from nero_amd import _lib as L
-    lib = L.lib
-    lib.nero_f16_paired.argtypes = [C.c_int]
-    lib.nero_f16_paired.restype = C.c_int
-    prev = lib.nero_f16_paired(-1)
-    yield lib.nero_f16_paired
-    lib.nero_f16_paired(prev)
+    from nero_amd import chain as CH
+    prev = CH.f16_paired()
+    yield CH.f16_paired
+    CH.f16_paired(prev)
 
 
 def _head_chain(n):
