@@ -9,6 +9,9 @@
 // one-accumulator plane format and the fused-injection protocol of the second-order pass, behind the bit-reproducibility tests that caught
 // it (tests/test_determinism.py) and a bit-for-bit comparison with the 512-thread kernels (tests/test_paired_engine.py).  Measured
 // (profiles/r05_paired_ab.txt): forward -4 %, tangent -10 %, reverse +-0 => forward + tangent of large launches by default.
+// Measured and dropped here: the next tile's / next layer's first weight fragments requested behind the running GEMM (prefetch_layer of
+// the 512-thread forward kernel): 242 instead of 224 VGPRs, forward class 6.82 -> 6.90 ms in 4 of 4 interleaved runs -- the sibling
+// workgroup already covers that L2 round trip.
 //
 // Why: the 512-thread kernels of mlp_f16x3.hip hold one workgroup per CU, whose 8 waves walk the phases of a layer in lock step
 // (GEMM -> activation / saves -> row-maximum exchange -> plane conversion, two barriers), so the matrix pipe idles through every
