@@ -43,6 +43,7 @@ struct nero_stage1 {
     // two run concurrently: one branch's partial last rounds of workgroups and its ~300 kernel boundaries are filled by the other's
     // work.  NERO_STREAMS=1 restores the single-stream order (also used while launches are timed: nero_prof_enable).
     int n_streams = 1;
+    int device = -1;                                   // the device the private streams / events were created on (nero_stage1_create)
     hipStream_t s2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // ---- a third stream for the weight-gradient jobs of the SDF / shading branch (round 5, NERO_STREAMS=3): the jobs of a chain depend on
@@ -87,6 +88,22 @@ void join_dw(nero_stage1* h, const Arena& A, hipStream_t main) {
     (void)hipEventRecord(h->ev_dw_done, h->s3);
     (void)hipStreamWaitEvent(main, h->ev_dw_done, 0);
     h->dw_fork = 0;
+}
+
+// A call that fails between a fork and its join would leave work queued on the private streams with nothing ordering it in front of
+// whatever the caller does next with the workspace: every failing exit of the entry points drains them (host-blocking, error path only).
+int drain_on_error(nero_stage1* h, int rc) {
+    if (rc == NERO_OK) return rc;
+    if (h->s2) (void)hipStreamSynchronize(h->s2);
+    if (h->s3) (void)hipStreamSynchronize(h->s3);
+    h->dw_fork = 0;
+    (void)hipGetLastError();
+    return rc;
+}
+// the private streams belong to the device that was current at create time: a call under another current device would fork onto it
+bool wrong_device(const nero_stage1* h) {
+    int dev = -1;
+    return (h->s2 || h->s3) && hipGetDevice(&dev) == hipSuccess && h->device >= 0 && dev != h->device;
 }
 
 void build_chains(nero_stage1* h, const nero_stage1_weights* w) {
@@ -534,6 +551,7 @@ int nero_stage1_create(const nero_stage1_cfg* cfg, nero_stage1** out) {
     make_value_chain(h);
     const char* e = getenv("NERO_STREAMS");
     h->n_streams = e ? atoi(e) : NERO_STREAMS_DEFAULT;
+    if (hipGetDevice(&h->device) != hipSuccess) { h->device = -1; (void)hipGetLastError(); }
     if (h->n_streams >= 2) {
         if (hipStreamCreateWithFlags(&h->s2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
@@ -660,6 +678,7 @@ int nero_stage1_render_fwd(nero_stage1* h, int R, const float* o, const float* d
     if (!h || !h->packed || !o || !d || !z_vals || !variance || !lut || !rgb || !gerr || !occ_prob || !ws || R <= 0)
         return nero_fail(NERO_ERR_ARG, "nero_stage1_render_fwd: bad argument (pack the weights first)");
     if (h->cfg.human_light && !poses) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_fwd: human_light needs poses [R,3,4]");
+    if (wrong_device(h)) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_fwd: the current device is not the one the handle was created on");
     const nero_stage1_cfg& c = h->cfg;
     const int T = c.n_samples + c.n_importance + c.n_bg_samples;
     Arena& A = h->A;
@@ -683,7 +702,7 @@ int nero_stage1_render_fwd(nero_stage1* h, int R, const float* o, const float* d
         (void)hipMemsetAsync(gerr, 0, 4, (hipStream_t)stream);
         (void)hipMemsetAsync(occ_prob, 0, 4, (hipStream_t)stream);
     }
-    RC(do_forward(h, A, R, T, S.n_in, S.n_out, d, variance, lut, poses, anneal, rgb, gerr, occ_prob, stream));
+    RC(drain_on_error(h, do_forward(h, A, R, T, S.n_in, S.n_out, d, variance, lut, poses, anneal, rgb, gerr, occ_prob, stream)));
     h->step_mark = A.mark();
     return nero_check_launch("nero_stage1_render_fwd");
 }
@@ -691,8 +710,9 @@ int nero_stage1_render_fwd(nero_stage1* h, int R, const float* o, const float* d
 int nero_stage1_render_bwd(nero_stage1* h, const float* d_rgb, const float* d_gerr, const float* d_occ, const nero_stage1_grads* grads,
                            float* d_inv_s_sum, void* stream) {
     if (!h || !h->A.base || !d_rgb || !grads) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_bwd: bad argument (no forward state)");
+    if (wrong_device(h)) return nero_fail(NERO_ERR_ARG, "nero_stage1_render_bwd: the current device is not the one the handle was created on");
     h->A.release(h->step_mark);
-    return do_backward(h, h->A, d_rgb, d_gerr, d_occ, grads, d_inv_s_sum, stream);
+    return drain_on_error(h, do_backward(h, h->A, d_rgb, d_gerr, d_occ, grads, d_inv_s_sum, stream));
 }
 
 // debug (scripts/r05/dbg_streams.py): device pointers + sizes of nine intermediates of the last render_bwd, in the order

@@ -52,6 +52,7 @@ struct nero_stage2 {
     int kout = 72;
     bool packed = false;
     Chain feats, mat[3], outer_light, inner_light, human_light;
+    int device = -1;                                   // the device the private stream / events were created on (nero_stage2_create)
     Arena A;
     size_t predict_mark = 0, shade_mark = 0;
     // predict state
@@ -73,6 +74,17 @@ struct nero_stage2 {
 
 namespace {
 
+// (as stage1_driver.hip) a failing exit between a fork and its join drains the private stream; calls under another current device are refused
+int drain_on_error(nero_stage2* h, int rc) {
+    if (rc == NERO_OK) return rc;
+    if (h->s2) (void)hipStreamSynchronize(h->s2);
+    (void)hipGetLastError();
+    return rc;
+}
+bool wrong_device(const nero_stage2* h) {
+    int dev = -1;
+    return h->s2 && hipGetDevice(&dev) == hipSuccess && h->device >= 0 && dev != h->device;
+}
 hipStream_t fork_side(nero_stage2* h, const Arena& A, hipStream_t main) {
     if (A.dry || h->n_streams < 2 || !h->s2 || nero_prof_is_on()) return main;
     (void)hipEventRecord(h->ev_fork, main);
@@ -281,6 +293,7 @@ int nero_stage2_create(const nero_stage2_cfg* cfg, nero_stage2** out) {
     build_chains(h, &zero);
     const char* e = getenv("NERO_STREAMS");
     h->n_streams = e ? atoi(e) : NERO_STREAMS_DEFAULT;
+    if (hipGetDevice(&h->device) != hipSuccess) { h->device = -1; (void)hipGetLastError(); }
     if (h->n_streams >= 2) {
         if (hipStreamCreateWithFlags(&h->s2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
@@ -386,6 +399,7 @@ int nero_stage2_shade_fwd(nero_stage2* h, const float* pos, const float* face_no
                           float* dl, float* sl, float* sp, int* n_miss_out, int* n_hit_out, void* stream) {
     if (!h || !h->P || !pos || !face_normals || !depth || !rgb || !dl || !sl || !sp) return nero_fail(NERO_ERR_ARG, "nero_stage2_shade_fwd: bad argument (nero_stage2_rays first)");
     if (h->cfg.human_lights && !poses) return nero_fail(NERO_ERR_ARG, "nero_stage2_shade_fwd: human_lights needs poses [P,3,4]");
+    if (wrong_device(h)) return nero_fail(NERO_ERR_ARG, "nero_stage2_shade_fwd: the current device is not the one the handle was created on");
     Arena& A = h->A;
     A.release(h->shade_mark);
     const int N = h->P * (h->cfg.diffuse_sample_num + h->cfg.specular_sample_num);
@@ -399,7 +413,7 @@ int nero_stage2_shade_fwd(nero_stage2* h, const float* pos, const float* face_no
     if (n_miss_out) *n_miss_out = counts[0];
     if (n_hit_out) *n_hit_out = counts[1];
     h->depth = depth; h->fnrm = face_normals; h->poses = poses;
-    RC(do_shade_lights(h, A, pos, rgb, dl, sl, sp, stream));
+    RC(drain_on_error(h, do_shade_lights(h, A, pos, rgb, dl, sl, sp, stream)));
     h->shade_mark = A.mark();
     return nero_check_launch("nero_stage2_shade_fwd");
 }
@@ -409,7 +423,8 @@ int nero_stage2_shade_bwd(nero_stage2* h, const float* d_rgb, const float* d_dl,
     Arena& A = h->A;
     const size_t mk = h->shade_mark;
     A.release(mk);
-    const int rc = do_shade_bwd(h, A, d_rgb, d_dl, grads, d_mat5, stream);
+    if (wrong_device(h)) return nero_fail(NERO_ERR_ARG, "nero_stage2_shade_bwd: the current device is not the one the handle was created on");
+    const int rc = drain_on_error(h, do_shade_bwd(h, A, d_rgb, d_dl, grads, d_mat5, stream));
     A.release(mk);
     return rc;
 }

@@ -156,3 +156,33 @@ def test_c_driver_training_steps_and_small_workspace_error(monkeypatch):
                                         ts.net.color_network.FG_LUT.data_ptr(), None, 0.5, rgb.data_ptr(), ge.data_ptr(), oc.data_ptr(),
                                         C.byref(n1), C.byref(n2), tiny.data_ptr(), tiny.numel(), L.stream_ptr())
     assert rc == -1 and b'workspace too small' in L.lib.nero_last_error()
+    # a workspace that runs out AFTER the side streams were forked (the NeRF++ branch / the weight-gradient stream): the failing call drains
+    # its private streams before it returns (stage1_driver.hip::drain_on_error), so the caller may reuse or free the workspace at once,
+    # and the handle keeps working
+    full = drv.workspace(128)
+    rc = S1._lib.nero_stage1_render_fwd(drv.h, 128, o.data_ptr(), d.data_ptr(), z.data_ptr(), ts.net.deviation_network.variance.data_ptr(),
+                                        ts.net.color_network.FG_LUT.data_ptr(), None, 0.5, rgb.data_ptr(), ge.data_ptr(), oc.data_ptr(),
+                                        C.byref(n1), C.byref(n2), full.data_ptr(), full.numel(), L.stream_ptr())
+    assert rc == 0 and n1.value > 0 and n2.value > 0
+    need = S1._lib.nero_stage1_workspace_bytes_for(drv.h, 128, n1.value, n2.value, 0)      # forward + backward of THIS batch: the forward alone takes a fraction
+    failed = 0
+    for frac in (0.5, 0.35, 0.25, 0.18, 0.12, 0.08, 0.05, 0.03, 0.02):
+        mid = torch.empty(int(need * frac) // 256 * 256, dtype=torch.uint8, device='cuda')
+        rc = S1._lib.nero_stage1_render_fwd(drv.h, 128, o.data_ptr(), d.data_ptr(), z.data_ptr(), ts.net.deviation_network.variance.data_ptr(),
+                                            ts.net.color_network.FG_LUT.data_ptr(), None, 0.5, rgb.data_ptr(), ge.data_ptr(), oc.data_ptr(),
+                                            C.byref(n1), C.byref(n2), mid.data_ptr(), mid.numel(), L.stream_ptr())
+        assert rc in (0, -1), rc
+        if rc == -1:
+            failed += 1
+            assert b'workspace too small' in L.lib.nero_last_error(), L.lib.nero_last_error()
+        del mid                                          # (freed at once: the failing call has drained its streams)
+    assert 2 <= failed <= 8, failed                      # (some sizes hold the forward, the small ones run out somewhere inside it)
+    runs = []
+    for k in range(2):
+        ts.cursor = 0
+        torch.manual_seed(7)
+        info = ts.forward_backward(25010)
+        torch.cuda.synchronize()
+        runs.append((float(info['loss']), ts.bucket.flat.clone()))
+    assert runs[0][0] == runs[0][0] and runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
+    assert float(runs[0][1].abs().max()) > 0
