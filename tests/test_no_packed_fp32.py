@@ -41,3 +41,27 @@ def test_no_packed_fp32_instructions_in_any_kernel():
         res = dict(ex.map(_scan, units))
     bad = {u: h for u, h in res.items() if h}
     assert not bad, bad
+
+
+def test_paired_chain_kernels_fit_two_workgroups_per_cu():
+    """the two-workgroups-per-CU forward / tangent kernels (mlp_f16p.hip, the default on large launches) only pay while two of them share a
+    CU: 256 threads each = two waves per SIMD = at most 256 VGPRs per wave, and a spill would put scratch traffic into their epilogues.  The
+    code object's own metadata: <= 256 VGPRs, no spilled VGPR, no scratch for fwd_p_kernel and tan_p_kernel (the opt-in bwd_p_kernel is
+    allowed its 14 spills: DESIGN.md section 3)."""
+    path = os.path.join(ROOT, 'nero_amd', 'csrc', 'mlp_f16p.hip')
+    p = subprocess.run(['hipcc'] + _flags() + ['-S', '--cuda-device-only', '-o', '-', path], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    meta, cur = {}, None
+    for line in p.stdout.splitlines():
+        m = re.match(r'\s*\.name:\s+(\S+)', line)
+        if m and 'kernel' in m.group(1):
+            cur = m.group(1)
+            meta[cur] = {}
+        m = re.match(r'\s*\.(vgpr_count|vgpr_spill_count|private_segment_fixed_size|max_flat_workgroup_size):\s+(\d+)', line)
+        if m and cur:
+            meta[cur][m.group(1)] = int(m.group(2))
+    for k in ('fwd_p_kernel', 'tan_p_kernel'):
+        hit = [v for n, v in meta.items() if k in n]
+        assert len(hit) == 1, (k, list(meta))
+        v = hit[0]
+        assert v['vgpr_count'] <= 256 and v['vgpr_spill_count'] == 0 and v['private_segment_fixed_size'] == 0 and v['max_flat_workgroup_size'] == 256, (k, v)
