@@ -267,6 +267,11 @@ __global__ __launch_bounds__(512, 1) void fwd_f16_kernel(nero_fwd_chain ch, int 
                 }
                 U[0] = u0;
                 U[1] = u1;
+#ifdef FWD_FIXED16
+                if (sm == 16) gemm_f16x3_fixed<16>(aH, aL, reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(L.w_main) + HDR_BYTES) + (size_t)wave * sm * 128 + lane,
+                                                   S.actp + i * SA + 16 * h, 32 * SA, PLANE_A);
+                else
+#endif
                 gemm_f16x3_loop(aH, aL, reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(L.w_main) + HDR_BYTES) + (size_t)wave * sm * 128 + lane,
                                 S.actp + i * SA + 16 * h, 32 * SA, PLANE_A, sm, F16_W_PRE && sx == 0, pw0, pw1, pw2);
             }
