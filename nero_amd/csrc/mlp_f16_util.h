@@ -199,6 +199,76 @@ __device__ __forceinline__ float amax4(float4 v) { return fmaxf(fmaxf(fabsf(v.x)
 __device__ __forceinline__ float4 scale4(float4 v, float s) { return make_float4(v.x * s, v.y * s, v.z * s, v.w * s); }
 
 
+// ---- chain descriptors and operand scales without dependent round trips (round 6) ------------------------------------------------------
+// The layer descriptors live in the kernel-argument segment.  Read through a reference (`const nero_fwd_layer& L = ch.layer[l]`) every
+// field became its own s_load + s_waitcnt lgkmcnt(0) at its point of use -- about ten scalar-cache round trips per layer, serial, on the
+// critical path between two barriers -- and the block scale of a packed image (`*L.w_main`, a device-side value in the image header) a
+// scalar load FOLLOWED BY a global load and a vmcnt(0) in front of the GEMM, which also drained the weight prefetch.  Now: the
+// descriptor of a layer is copied by value in one batch of scalar loads (PIN_LAYER keeps hipcc from sinking the loads back to the uses),
+// the NEXT layer's while the matrix pipe drains the current GEMM, and the scales of every image of the chain sit in a 20-entry LDS table
+// filled once per workgroup (wsc[2 l] = main, wsc[2 l + 1] = aux image of layer l).
+constexpr int WSC_N = 2 * NERO_MAX_LAYERS;
+constexpr int LDS_SMALL_BYTES = (64 + 64 + 512 + 32) * 4;      // rs_main[64] rs_aux[64] rmax[64][8] wsc[<= 32]
+#define PIN_S(x) asm volatile("" : "+s"(x))
+// (pointers are pinned as INPUTS only: a pointer redefined by an asm statement loses its provenance and hipcc addresses through it with
+//  flat_load / flat_store, which count on vmcnt AND lgkmcnt -- every LDS wait of the k-loop then waits for the weight stream as well)
+#define PIN_P(x) asm volatile("" : : "s"(x))
+__device__ __forceinline__ nero_fwd_layer load_layer(const nero_fwd_chain& ch, int l) {
+    nero_fwd_layer L = ch.layer[l];
+#ifndef NERO_NO_PIN
+    PIN_P(L.w_main); PIN_P(L.w_aux); PIN_P(L.bias); PIN_P(L.save); PIN_P(L.head_w); PIN_P(L.head_b); PIN_P(L.head_out);
+    PIN_S(L.k_main); PIN_S(L.k_aux); PIN_S(L.n_tiles); PIN_S(L.n_head); PIN_S(L.act); PIN_S(L.head_k); PIN_P(L.relu_mask);
+#endif
+    return L;
+}
+__device__ __forceinline__ nero_tan_layer load_layer(const nero_tan_chain& ch, int l) {
+    nero_tan_layer L = ch.layer[l];
+#ifndef NERO_NO_PIN
+    PIN_P(L.w_main); PIN_P(L.w_aux); PIN_P(L.a_saved); PIN_P(L.gbar); PIN_P(L.adot); PIN_P(L.inj);
+    PIN_S(L.k_main); PIN_S(L.k_aux); PIN_S(L.n_tiles);
+#endif
+    return L;
+}
+__device__ __forceinline__ nero_bwd_layer load_layer(const nero_bwd_chain& ch, int l) {
+    nero_bwd_layer L = ch.layer[l];
+#ifndef NERO_NO_PIN
+    PIN_P(L.w_main_t); PIN_P(L.w_aux_t); PIN_P(L.a_prev); PIN_P(L.inj); PIN_P(L.delta_prev); PIN_P(L.head_w); PIN_P(L.head_dy);
+    PIN_S(L.n_out); PIN_S(L.k_main_tiles); PIN_S(L.k_aux_tiles); PIN_S(L.n_head); PIN_S(L.act_prev); PIN_P(L.mask_prev); PIN_P(L.inj_adot);
+#endif
+    return L;
+}
+// request the scale of every packed image of the chain (uniform addresses; branch-free: a missing image reads the chain's first one) ...
+struct WscRegs { float v[WSC_N]; };
+template <class CH, class F> __device__ __forceinline__ void wsc_request(WscRegs& r, const CH& ch, F&& images) {
+    const float* fb = nullptr;
+#pragma unroll
+    for (int l = NERO_MAX_LAYERS - 1; l >= 0; --l) {
+        const float *pm, *pa;
+        images(ch.layer[l], pm, pa);
+        if (l < ch.n_layers) { fb = pa ? pa : fb; fb = pm ? pm : fb; }
+    }
+#pragma unroll
+    for (int k = 0; k < WSC_N; ++k) r.v[k] = 1.f;
+    if (fb == nullptr) return;
+#pragma unroll
+    for (int l = 0; l < NERO_MAX_LAYERS; ++l) {
+        const float *pm, *pa;
+        images(ch.layer[l], pm, pa);
+        const bool in = l < ch.n_layers;
+        pm = (in && pm) ? pm : fb;
+        pa = (in && pa) ? pa : fb;
+        r.v[2 * l] = *pm;
+        r.v[2 * l + 1] = *pa;
+    }
+}
+// ... and put them into the table (one lane; the caller's next barrier publishes it)
+__device__ __forceinline__ void wsc_commit(float* wsc, const WscRegs& r, int tid) {
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < WSC_N; k += 4) *reinterpret_cast<float4*>(wsc + k) = make_float4(r.v[k], r.v[k + 1], r.v[k + 2], r.v[k + 3]);
+    }
+}
+
 // ---- GEMM core ------------------------------------------------------------------------------------------------------------
 // accH[r] += wh xh,  accL[r] += wh xl + wl xh  over `n` k-steps of 16 (r = 32-row half).  Weight planes three steps ahead in a
 // ring of four register sets (L2 stream), activation planes one step ahead in a double buffer (LDS).
@@ -367,10 +437,42 @@ __device__ __forceinline__ void zero2(f32x16 (&acc)[2]) {
         for (int v = 0; v < 16; ++v) acc[r][v] = 0.f;
 }
 
+// ---- lane exchanges without the LDS (round 6) ---------------------------------------------------------------------------------
+// __shfl_xor compiles to ds_bpermute_b32 + a bounds select + s_waitcnt lgkmcnt: an LDS round trip (~100+ cycles, and lgkmcnt is shared
+// with the scalar loads) per exchange, several of them on the critical path of every layer epilogue.  gfx950 has the exchange of the two
+// 32-lane halves as ONE VALU instruction (v_permlane32_swap) and the exchanges inside a row of 16 as DPP modifiers.
+#ifdef NERO_SHFL_LDS                                   // (experiment switch: the round-5 code)
+__device__ __forceinline__ float max_xor32(float m) { return fmaxf(m, __shfl_xor(m, 32)); }
+__device__ __forceinline__ unsigned other_half(unsigned v, int h) { (void)h; return __shfl_xor(v, 32); }
+__device__ __forceinline__ float max_8lanes(float m) { m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); return fmaxf(m, __shfl_xor(m, 4)); }
+__device__ __forceinline__ float max_4lanes(float m) { m = fmaxf(m, __shfl_xor(m, 1)); return fmaxf(m, __shfl_xor(m, 2)); }
+__device__ __forceinline__ float sum_8lanes(float s) { s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); return s + __shfl_xor(s, 4); }
+#else
+// v_permlane32_swap vdst, src0: vdst[32..63] <-> src0[0..31].  With both operands = v: r[0] = v's lower half in both halves, r[1] = its
+// upper half in both halves.
+__device__ __forceinline__ float max_xor32(float m) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ unsigned other_half(unsigned v, int h) {          // the value lane ^ 32 holds
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return h ? r[0] : r[1];
+}
+// DPP: quad_perm [1,0,3,2] = 0xB1 (lane ^ 1), quad_perm [2,3,0,1] = 0x4E (lane ^ 2), row_half_mirror = 0x141 (lane j <-> 7 - j of each
+// group of 8: the OTHER quad, which is all a reduction over 8 lanes needs once every lane holds its quad's result)
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float max_4lanes(float m) { m = fmaxf(m, dpp_f32<0xB1>(m)); return fmaxf(m, dpp_f32<0x4E>(m)); }
+__device__ __forceinline__ float max_8lanes(float m) { m = max_4lanes(m); return fmaxf(m, dpp_f32<0x141>(m)); }
+// (same bits as the shuffle butterfly: every step adds the partner's partial sum to the lane's own, and fp32 addition commutes)
+__device__ __forceinline__ float sum_8lanes(float s) { s += dpp_f32<0xB1>(s); s += dpp_f32<0x4E>(s); return s + dpp_f32<0x141>(s); }
+#endif
+
 // row maxima of this wave's 64x32 block (two rows per lane) -> rmax[row][wave]
 __device__ __forceinline__ void publish_rowmax(float* rmax, float m0, float m1, int wave, int i, int h) {
-    m0 = fmaxf(m0, __shfl_xor(m0, 32));
-    m1 = fmaxf(m1, __shfl_xor(m1, 32));
+    m0 = max_xor32(m0);
+    m1 = max_xor32(m1);
     if (h == 0) { rmax[i * 8 + wave] = m0; rmax[(32 + i) * 8 + wave] = m1; }
 }
 __device__ __forceinline__ float row_max8(const float* rmax, int row) {

@@ -41,20 +41,21 @@ constexpr int PW = 4;                                  // waves per workgroup
 #define P_PA_EARLY_B true
 #endif
 
-struct LdsP { char* actp; float* rs_main; float* rs_aux; float* rmax; char* scr; };
+struct LdsP { char* actp; float* rs_main; float* rs_aux; float* rmax; float* wsc; char* scr; };
 __device__ __forceinline__ LdsP carve_p(char* smem) {
     LdsP l;
     l.actp = smem;
     l.rs_main = reinterpret_cast<float*>(smem + 2 * PLANE_A);
     l.rs_aux = l.rs_main + 64;
     l.rmax = l.rs_aux + 64;                            // [64 rows][8 tiles]
-    l.scr = reinterpret_cast<char*>(l.rmax + 64 * 8);
+    l.wsc = l.rmax + 64 * 8;                           // block scales of the chain's packed images (mlp_f16_util.h: wsc_request)
+    l.scr = reinterpret_cast<char*>(l.wsc + 32);
     return l;
 }
 #ifndef P_LDS_EXTRA
 #define P_LDS_EXTRA 0                                   // (timing experiment: > 2560 forces ONE workgroup per CU)
 #endif
-inline int p_lds_bytes() { return 2 * PLANE_A + (64 + 64 + 512) * 4 + PW * SCRP_BYTES + P_LDS_EXTRA; }      // 79360
+inline int p_lds_bytes() { return 2 * PLANE_A + LDS_SMALL_BYTES + PW * SCRP_BYTES + P_LDS_EXTRA; }      // 79488
 
 struct Ctx { LdsP S; int wave, lane, i, h, row0, n_rows; };
 
@@ -75,8 +76,7 @@ __device__ __forceinline__ void load_planes_scaled_p(char* planes, float* rs, co
         if (c4 < k) v[j] = *reinterpret_cast<const float4*>(rowp + c4);
         m = fmaxf(m, amax4(v[j]));
     }
-    m = fmaxf(m, __shfl_xor(m, 1));
-    m = fmaxf(m, __shfl_xor(m, 2));
+    m = max_4lanes(m);
     const int e = scale_exp(m);
     const float inv = pow2i(-e);
 #pragma unroll
@@ -93,8 +93,7 @@ __device__ __forceinline__ void aux_row_scales_p(float* rs, const float* __restr
     const float* rowp = src + (size_t)gr * ld;
     float m = 0.f;
     for (int c4 = 4 * q; c4 < k; c4 += 16) m = fmaxf(m, amax4(*reinterpret_cast<const float4*>(rowp + c4)));
-    m = fmaxf(m, __shfl_xor(m, 1));
-    m = fmaxf(m, __shfl_xor(m, 2));
+    m = max_4lanes(m);
     if (q == 0) rs[r] = pow2i(scale_exp(m));
 }
 
@@ -149,9 +148,10 @@ __device__ __forceinline__ void gemm_aux_global(f32x16 (&aH)[2], f32x16 (&aL)[2]
 
 // aux part (its own unit) then main part of one feature tile; U = unit of the result per 32-row half
 __device__ __forceinline__ void gemm_tile(f32x16 (&aH)[2], f32x16 (&aL)[2], float (&U)[2], const Ctx& c, int t, const float* w_main,
-                                          const float* w_aux, int sm, int sx, const float* aux, int ld_aux, int k_aux_cols) {
+                                          const float* w_aux, float wsc_main, float wsc_aux, int sm, int sx, const float* aux, int ld_aux,
+                                          int k_aux_cols) {
     if (sx > 0) {
-        const float wsc = *w_aux;
+        const float wsc = wsc_aux;
         const float ra0 = c.S.rs_aux[c.i], ra1 = c.S.rs_aux[32 + c.i];
         gemm_aux_global(aH, aL, reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w_aux) + HDR_BYTES) + (size_t)t * sx * 128 + c.lane,
                         aux, ld_aux, k_aux_cols, sx, c, 1.f / ra0, 1.f / ra1);
@@ -159,7 +159,7 @@ __device__ __forceinline__ void gemm_tile(f32x16 (&aH)[2], f32x16 (&aL)[2], floa
         U[1] = wsc * ra1;
     }
     if (sm > 0) {
-        const float wsc = *w_main;
+        const float wsc = wsc_main;
         const float u0 = wsc * c.S.rs_main[c.i], u1 = wsc * c.S.rs_main[32 + c.i];
         if (sx > 0) {
             const float r0 = U[0] / u0, r1 = U[1] / u1;    // exact: powers of two
@@ -196,11 +196,7 @@ __device__ __forceinline__ void eval_head_p(const char* planes, const float* rs,
                 }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            s[j] += __shfl_xor(s[j], 1);
-            s[j] += __shfl_xor(s[j], 2);
-            s[j] += __shfl_xor(s[j], 4);
-        }
+        for (int j = 0; j < 4; ++j) s[j] = sum_8lanes(s[j]);
         if (q == 0) {
             const float sc = rs[r];
 #pragma unroll
@@ -270,7 +266,7 @@ __device__ __forceinline__ void fwd_values(const f32x16 (&aH)[2], const f32x16 (
     }
 }
 
-__device__ __forceinline__ void fwd_tile(const nero_fwd_chain& ch, const nero_fwd_layer& L, const Ctx& c, int t, float4 (&val)[2][4],
+__device__ __forceinline__ void fwd_tile(const nero_fwd_chain& ch, const nero_fwd_layer& L, int l, const Ctx& c, int t, float4 (&val)[2][4],
                                          float (&m)[2] PH_PARAM) {
     m[0] = m[1] = 0.f;
     if (t < L.n_tiles) {
@@ -283,7 +279,7 @@ __device__ __forceinline__ void fwd_tile(const nero_fwd_chain& ch, const nero_fw
             bq[g] = L.bias ? *reinterpret_cast<const float4*>(L.bias + 32 * t + 8 * g + 4 * c.h) : make_float4(0.f, 0.f, 0.f, 0.f);
         float U[2] = {1.f, 1.f};
         PH(1);
-        gemm_tile(aH, aL, U, c, t, L.w_main, L.w_aux, L.k_main >> 4, L.k_aux >> 4, ch.aux, ch.ld_aux, ch.k_aux);
+        gemm_tile(aH, aL, U, c, t, L.w_main, L.w_aux, c.S.wsc[2 * l], c.S.wsc[2 * l + 1], L.k_main >> 4, L.k_aux >> 4, ch.aux, ch.ld_aux, ch.k_aux);
         PH(2);
         if (L.act == NERO_ACT_RELU) fwd_values<NERO_ACT_RELU>(aH, aL, bq, U, val, m);
         else if (L.act == NERO_ACT_SOFTPLUS100) fwd_values<NERO_ACT_SOFTPLUS100>(aH, aL, bq, U, val, m);
@@ -306,7 +302,7 @@ __device__ __forceinline__ void fwd_tile(const nero_fwd_chain& ch, const nero_fw
                     bits |= (val[r][g].z > 0.f ? 1u : 0u) << (4 * g + 2);
                     bits |= (val[r][g].w > 0.f ? 1u : 0u) << (4 * g + 3);
                 }
-                const unsigned other = __shfl_xor(bits, 32);
+                const unsigned other = other_half(bits, c.h);
                 if (c.h == 0) L.relu_mask[(size_t)(c.row0 + 32 * r + c.i) * 8 + t] = bits | (other << 16);
             }
         }
@@ -323,18 +319,21 @@ __global__ __launch_bounds__(256, 2) void fwd_p_kernel(nero_fwd_chain ch, int n_
 #ifdef F16_PHASE_TIMING
     const long long ph_start = ph_t;
 #endif
+    WscRegs wr;
+    wsc_request(wr, ch, [](const nero_fwd_layer& Lx, const float*& pm, const float*& pa) { pm = Lx.k_main > 0 && Lx.n_tiles > 0 ? Lx.w_main : nullptr; pa = Lx.k_aux > 0 && Lx.n_tiles > 0 ? Lx.w_aux : nullptr; });
     if (ch.init) load_planes_scaled_p(c.S.actp, c.S.rs_main, ch.init, ch.ld_init, ch.k_init, c.row0, n_rows, tid);
     if (ch.aux) aux_row_scales_p(c.S.rs_aux, ch.aux, ch.ld_aux, ch.k_aux, c.row0, n_rows, tid);
+    wsc_commit(c.S.wsc, wr, tid);
     __syncthreads();
     PH(0);
     for (int l = 0; l < ch.n_layers; ++l) {
-        const nero_fwd_layer& L = ch.layer[l];
+        const nero_fwd_layer L = load_layer(ch, l);
         if (L.n_head > 0) eval_head_p(c.S.actp, c.S.rs_main, L.head_w, L.head_b, L.head_out, L.n_head, L.head_k, c.row0, tid);
         if (L.n_tiles == 0) continue;
         float4 v0[2][4], v1[2][4];
         float m0[2], m1[2];
-        fwd_tile(ch, L, c, c.wave, v0, m0 PH_ARG);
-        fwd_tile(ch, L, c, c.wave + PW, v1, m1 PH_ARG);
+        fwd_tile(ch, L, l, c, c.wave, v0, m0 PH_ARG);
+        fwd_tile(ch, L, l, c, c.wave + PW, v1, m1 PH_ARG);
         commit_planes_p(c, v0, v1, c.wave < L.n_tiles, c.wave + PW < L.n_tiles);
         PH(5);
     }
@@ -348,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void fwd_p_kernel(nero_fwd_chain ch, int n_
 // ---------------------------------------------------------------------------------------------------------------------
 // tangent chain (softplus networks):  adot_l = s_l * (W_l adot_{l-1}),  inj_l = gbar_l * beta (1-s_l) * zdot_l
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void tan_tile(const nero_tan_chain& ch, const nero_tan_layer& L, const Ctx& c, int t, float4 (&val)[2][4],
+__device__ __forceinline__ void tan_tile(const nero_tan_chain& ch, const nero_tan_layer& L, int l, const Ctx& c, int t, float4 (&val)[2][4],
                                          float (&m)[2]) {
     m[0] = m[1] = 0.f;
     if (t < L.n_tiles) {
@@ -359,7 +358,7 @@ __device__ __forceinline__ void tan_tile(const nero_tan_chain& ch, const nero_ta
         zero2(aH);
         zero2(aL);
         float U[2] = {1.f, 1.f};
-        gemm_tile(aH, aL, U, c, t, L.w_main, L.w_aux, L.k_main >> 4, L.k_aux >> 4, ch.aux, ch.ld_aux, ch.k_aux);
+        gemm_tile(aH, aL, U, c, t, L.w_main, L.w_aux, c.S.wsc[2 * l], c.S.wsc[2 * l + 1], L.k_main >> 4, L.k_aux >> 4, ch.aux, ch.ld_aux, ch.k_aux);
         // the saved activations are requested BEHIND the GEMM (32 registers it has no room for at two workgroups per CU: 23 spilled);
         // the round trip is covered by the other workgroup's MFMAs, which is what this engine is for
         NERO_FENCE();
@@ -406,15 +405,18 @@ __global__ __launch_bounds__(256, 2) void tan_p_kernel(nero_tan_chain ch, int n_
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Ctx c = make_ctx(smem, n_rows);
     const int tid = threadIdx.x;
+    WscRegs wr;
+    wsc_request(wr, ch, [](const nero_tan_layer& Lx, const float*& pm, const float*& pa) { pm = Lx.k_main > 0 ? Lx.w_main : nullptr; pa = Lx.k_aux > 0 ? Lx.w_aux : nullptr; });
     if (ch.init) load_planes_scaled_p(c.S.actp, c.S.rs_main, ch.init, ch.ld_init, ch.k_init, c.row0, n_rows, tid);
     if (ch.aux) aux_row_scales_p(c.S.rs_aux, ch.aux, ch.ld_aux, ch.k_aux, c.row0, n_rows, tid);
+    wsc_commit(c.S.wsc, wr, tid);
     __syncthreads();
     for (int l = 0; l < ch.n_layers; ++l) {
-        const nero_tan_layer& L = ch.layer[l];
+        const nero_tan_layer L = load_layer(ch, l);
         float4 v0[2][4], v1[2][4];
         float m0[2], m1[2];
-        tan_tile(ch, L, c, c.wave, v0, m0);
-        tan_tile(ch, L, c, c.wave + PW, v1, m1);
+        tan_tile(ch, L, l, c, c.wave, v0, m0);
+        tan_tile(ch, L, l, c, c.wave + PW, v1, m1);
         commit_planes_p(c, v0, v1, c.wave < L.n_tiles, c.wave + PW < L.n_tiles);
     }
 }
@@ -433,7 +435,7 @@ __device__ __forceinline__ void combine_acc(float4 (&gq)[2][4], const f32x16 (&a
 
 // one feature tile of one reverse layer; `first` = the chain's first dense layer (its input gradient goes to d_init / d_aux)
 template <bool PA_EARLY>
-__device__ __forceinline__ void bwd_tile(const nero_bwd_chain& ch, const nero_bwd_layer& L, const Ctx& c, int t, bool first, float rs0, float rs1,
+__device__ __forceinline__ void bwd_tile(const nero_bwd_chain& ch, const nero_bwd_layer& L, int l, const Ctx& c, int t, bool first, float rs0, float rs1,
                                          float4 (&val)[2][4], float (&m)[2]) {
     m[0] = m[1] = 0.f;
     const bool live_t = t < L.k_main_tiles;
@@ -470,7 +472,7 @@ __device__ __forceinline__ void bwd_tile(const nero_bwd_chain& ch, const nero_bw
         if (ch.d_aux && L.w_aux_t && t < L.k_aux_tiles) {
             zero2(aH);
             zero2(aL);
-            const float wsc = *L.w_aux_t;
+            const float wsc = c.S.wsc[2 * l + 1];
             gemm_f16x3(aH, aL, reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(L.w_aux_t) + HDR_BYTES) + (size_t)t * steps * 128 + c.lane,
                        xp, 32 * SA, PLANE_A, steps);
             const float u[2] = {wsc * rs0, wsc * rs1};
@@ -490,7 +492,7 @@ __device__ __forceinline__ void bwd_tile(const nero_bwd_chain& ch, const nero_bw
         }
         zero2(aH);
         zero2(aL);
-        const float wsc = *L.w_main_t;
+        const float wsc = c.S.wsc[2 * l];
         gemm_f16x3(aH, aL, reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(L.w_main_t) + HDR_BYTES) + (size_t)t * steps * 128 + c.lane,
                    xp, 32 * SA, PLANE_A, steps);
         const float u[2] = {wsc * rs0, wsc * rs1};
@@ -547,22 +549,25 @@ __global__ __launch_bounds__(256, 2) void bwd_p_kernel(nero_bwd_chain ch, int n_
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Ctx c = make_ctx(smem, n_rows);
     const int tid = threadIdx.x;
+    WscRegs wr;
+    wsc_request(wr, ch, [](const nero_bwd_layer& Lx, const float*& pm, const float*& pa) { pm = Lx.n_out > 0 ? Lx.w_main_t : nullptr; pa = Lx.n_out > 0 ? Lx.w_aux_t : nullptr; });
     if (ch.dy) load_planes_scaled_p(c.S.actp, c.S.rs_main, ch.dy, ch.ld_dy, ch.k_dy, c.row0, n_rows, tid);
     else {
         for (int idx = tid; idx < 2 * PLANE_A / 16; idx += 256) reinterpret_cast<uint4*>(c.S.actp)[idx] = make_uint4(0u, 0u, 0u, 0u);
         if (tid < 64) c.S.rs_main[tid] = 1.f;
     }
+    wsc_commit(c.S.wsc, wr, tid);
     __syncthreads();
     for (int l = ch.n_layers - 1; l >= 0; --l) {
-        const nero_bwd_layer& L = ch.layer[l];
+        const nero_bwd_layer L = load_layer(ch, l);
         const bool first = (L.a_prev == nullptr);
         if (first && ch.d_init == nullptr && !(ch.d_aux && L.w_aux_t)) break;
         if (first && L.n_out == 0) break;
         const float rs0 = c.S.rs_main[c.i], rs1 = c.S.rs_main[32 + c.i];
         float4 v0[2][4], v1[2][4];
         float m0[2], m1[2];
-        bwd_tile<P_PA_EARLY_A>(ch, L, c, c.wave, first, rs0, rs1, v0, m0);
-        bwd_tile<P_PA_EARLY_B>(ch, L, c, c.wave + PW, first, rs0, rs1, v1, m1);
+        bwd_tile<P_PA_EARLY_A>(ch, L, l, c, c.wave, first, rs0, rs1, v0, m0);
+        bwd_tile<P_PA_EARLY_B>(ch, L, l, c, c.wave + PW, first, rs0, rs1, v1, m1);
         if (first) break;
         commit_planes_p(c, v0, v1, c.wave < L.k_main_tiles, c.wave + PW < L.k_main_tiles);
     }

@@ -66,9 +66,7 @@ __device__ __forceinline__ void tile_commit(char* planes, int stride, int plane_
     float m = 0.f;
 #pragma unroll
     for (int j = 0; j < NV; ++j) m = fmaxf(m, fmaxf(fmaxf(fabsf(v[j].x), fabsf(v[j].y)), fmaxf(fabsf(v[j].z), fabsf(v[j].w))));
-    m = fmaxf(m, __shfl_xor(m, 1));
-    m = fmaxf(m, __shfl_xor(m, 2));
-    m = fmaxf(m, __shfl_xor(m, 4));
+    m = max_8lanes(m);
     const int e = scale_exp(m);
     const float inv = pow2i(-e);
 #pragma unroll
@@ -107,11 +105,7 @@ __device__ __forceinline__ void eval_head_f16(const char* planes, const float* r
         for (int j = 0; j < 4; ++j) s[j] = fmaf(x.x, ww[j].x, fmaf(x.y, ww[j].y, fmaf(x.z, ww[j].z, fmaf(x.w, ww[j].w, s[j]))));
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        s[j] += __shfl_xor(s[j], 1);
-        s[j] += __shfl_xor(s[j], 2);
-        s[j] += __shfl_xor(s[j], 4);
-    }
+    for (int j = 0; j < 4; ++j) s[j] = sum_8lanes(s[j]);
     if (q == 0) {
         const float sc = rs[r];
 #pragma unroll
@@ -122,7 +116,7 @@ __device__ __forceinline__ void eval_head_f16(const char* planes, const float* r
 
 // LDS carve-up shared by the chain kernels
 struct Lds {
-    char* actp; char* auxp; float* rs_main; float* rs_aux; float* rmax; char* scr;
+    char* actp; char* auxp; float* rs_main; float* rs_aux; float* rmax; float* wsc; char* scr;
 };
 template <int SX>
 __device__ __forceinline__ Lds carve(char* smem) {
@@ -133,11 +127,12 @@ __device__ __forceinline__ Lds carve(char* smem) {
     l.rs_main = reinterpret_cast<float*>(p);
     l.rs_aux = l.rs_main + 64;
     l.rmax = l.rs_aux + 64;                          // [64 rows][8 waves]
-    l.scr = reinterpret_cast<char*>(l.rmax + 64 * 8);
+    l.wsc = l.rmax + 64 * 8;                         // [2 * NERO_MAX_LAYERS] block scales of the chain's packed images (mlp_f16_util.h)
+    l.scr = reinterpret_cast<char*>(l.wsc + 32);
     return l;
 }
-inline int f16_lds_bytes(int wide) { return 2 * PLANE_A + 2 * 64 * (wide ? SX_W : SX_N) + (64 + 64 + 512) * 4 + 8 * SCR_BYTES; }
-inline int tan_lds_bytes() { return 2 * PLANE_A + 2 * 64 * SX_N + (64 + 64 + 512) * 4 + 8 * 8192; }      // 150016
+inline int f16_lds_bytes(int wide) { return 2 * PLANE_A + 2 * 64 * (wide ? SX_W : SX_N) + LDS_SMALL_BYTES + 8 * SCR_BYTES; }
+inline int tan_lds_bytes() { return 2 * PLANE_A + 2 * 64 * SX_N + LDS_SMALL_BYTES + 8 * 8192; }      // 150144
 
 // ---------------------------------------------------------------------------------------------------------------------
 // forward chain
@@ -192,7 +187,7 @@ __global__ __launch_bounds__(512, 1) void fwd_f16_kernel(nero_fwd_chain ch, int 
     const int first_gemm = gmask ? __builtin_ctz(gmask) : 0, last_gemm = gmask ? 31 - __builtin_clz(gmask) : -1;
     // first weight fragments of layer `Ln`'s first GEMM (the aux part when it has one) -> pw
     WF pw0, pw1, pw2;
-    auto prefetch_layer = [&](const nero_fwd_layer& Ln) {
+    auto prefetch_layer = [&](const nero_fwd_layer& Ln) {      // (Ln: a by-value copy in SGPRs, load_layer)
 #ifdef F16_NO_W_PRE
         return;
 #endif
@@ -215,7 +210,14 @@ __global__ __launch_bounds__(512, 1) void fwd_f16_kernel(nero_fwd_chain ch, int 
     int tile = blockIdx.x;
     if (tile >= n_tiles_total) return;
     if (NVI > 0) request_tile(tile);
-    if (last_gemm >= 0) prefetch_layer(ch.layer[first_gemm]);
+    nero_fwd_layer Ln = load_layer(ch, first_gemm);        // descriptor of the next layer with a GEMM, one layer ahead
+    int ln_idx = first_gemm;
+    if (last_gemm >= 0) prefetch_layer(Ln);
+    {
+        WscRegs wr;
+        wsc_request(wr, ch, [](const nero_fwd_layer& Lx, const float*& pm, const float*& pa) { pm = Lx.k_main > 0 && Lx.n_tiles > 0 ? Lx.w_main : nullptr; pa = Lx.k_aux > 0 && Lx.n_tiles > 0 ? Lx.w_aux : nullptr; });
+        wsc_commit(S.wsc, wr, tid);                        // (published by the first tile's barrier below)
+    }
     for (; tile < n_tiles_total; tile += gridDim.x) {
     const int row0 = tile * 64;
     PH_DECL;
@@ -229,7 +231,8 @@ __global__ __launch_bounds__(512, 1) void fwd_f16_kernel(nero_fwd_chain ch, int 
     __syncthreads();
     PH(0);
     for (int l = 0; l < ch.n_layers; ++l) {
-        const nero_fwd_layer& L = ch.layer[l];
+        nero_fwd_layer L;
+        if (l == ln_idx) L = Ln; else L = load_layer(ch, l);
         if (L.n_head > 0) eval_head_f16(S.actp, S.rs_main, L.head_w, L.head_b, L.head_out, L.n_head, L.head_k, row0, tid);
         if (L.n_tiles == 0) continue;
         const bool live_wave = wave < L.n_tiles;
@@ -245,14 +248,14 @@ __global__ __launch_bounds__(512, 1) void fwd_f16_kernel(nero_fwd_chain ch, int 
         if (live_wave) {
             const int sm = L.k_main >> 4, sx = L.k_aux >> 4;
             if (sx > 0) {
-                const float wsc = *reinterpret_cast<const float*>(L.w_aux);
+                const float wsc = S.wsc[2 * l + 1];
                 gemm_f16x3_loop(aH, aL, reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(L.w_aux) + HDR_BYTES) + (size_t)wave * sx * 128 + lane,
                                 S.auxp + i * SX + 16 * h, 32 * SX, PLANE_X, sx, F16_W_PRE, pw0, pw1, pw2);
                 U[0] = wsc * S.rs_aux[i];
                 U[1] = wsc * S.rs_aux[32 + i];
             }
             if (sm > 0) {
-                const float wsc = *reinterpret_cast<const float*>(L.w_main);
+                const float wsc = S.wsc[2 * l];
                 const float u0 = wsc * S.rs_main[i], u1 = wsc * S.rs_main[32 + i];
                 if (sx > 0) {
                     // bring the aux partial sums into the main part's unit (exact: powers of two)
@@ -280,10 +283,17 @@ __global__ __launch_bounds__(512, 1) void fwd_f16_kernel(nero_fwd_chain ch, int 
         // fragments, or -- after the tile's last GEMM -- the next tile's input rows and the first layer's fragments again.  The
         // epilogue, two barriers and the plane conversion that follow (~6 k cycles) cover the L2 / HBM latency.
         NERO_FENCE();
-        if (l != last_gemm) prefetch_layer(ch.layer[l + 1 + __builtin_ctz(gmask >> (l + 1))]);
-        else {
+        // (two separate call sites on purpose: merged into one, hipcc keeps the tile-ahead registers and the fragment registers of both
+        //  branches alive together -- 256 VGPRs + 13-17 spilled instead of 229-233)
+        if (l != last_gemm) {
+            ln_idx = l + 1 + __builtin_ctz(gmask >> (l + 1));
+            Ln = load_layer(ch, ln_idx);                   // (one batch of scalar loads while the matrix pipe drains)
+            prefetch_layer(Ln);
+        } else {
             if (NVI > 0 && tile + (int)gridDim.x < n_tiles_total) request_tile(tile + gridDim.x);
-            prefetch_layer(ch.layer[first_gemm]);
+            ln_idx = first_gemm;
+            Ln = load_layer(ch, ln_idx);
+            prefetch_layer(Ln);
         }
         NERO_FENCE();
         // values, optional saves, row maxima
@@ -317,7 +327,7 @@ __global__ __launch_bounds__(512, 1) void fwd_f16_kernel(nero_fwd_chain ch, int 
                         bits |= (val[r][g].z > 0.f ? 1u : 0u) << (4 * g + 2);
                         bits |= (val[r][g].w > 0.f ? 1u : 0u) << (4 * g + 3);
                     }
-                    const unsigned other = __shfl_xor(bits, 32);
+                    const unsigned other = other_half(bits, h);
                     if (h == 0) L.relu_mask[(size_t)(row0 + 32 * r + i) * 8 + wave] = bits | (other << 16);
                 }
             }
@@ -375,16 +385,17 @@ __device__ __forceinline__ void commit_planes(const Lds& S, const float4 (&val)[
 
 // aux part first (its own unit), converted into the main part's unit, then the main part: returns the unit of the result
 __device__ __forceinline__ void gemm_two_sources(f32x16 (&aH)[2], f32x16 (&aL)[2], float (&U)[2], const Lds& S, const float* w_main,
-                                                 const float* w_aux, int sm, int sx, int SXb, int PLANE_Xb, int wave, int lane, int i, int h) {
+                                                 const float* w_aux, float wsc_main, float wsc_aux, int sm, int sx, int SXb, int PLANE_Xb,
+                                                 int wave, int lane, int i, int h) {
     if (sx > 0) {
-        const float wsc = *w_aux;
+        const float wsc = wsc_aux;
         gemm_f16x3(aH, aL, reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w_aux) + HDR_BYTES) + (size_t)wave * sx * 128 + lane,
                    S.auxp + i * SXb + 16 * h, 32 * SXb, PLANE_Xb, sx);
         U[0] = wsc * S.rs_aux[i];
         U[1] = wsc * S.rs_aux[32 + i];
     }
     if (sm > 0) {
-        const float wsc = *w_main;
+        const float wsc = wsc_main;
         const float u0 = wsc * S.rs_main[i], u1 = wsc * S.rs_main[32 + i];
         if (sx > 0) {
             const float r0 = U[0] / u0, r1 = U[1] / u1;    // exact: powers of two
@@ -425,11 +436,14 @@ __global__ __launch_bounds__(512, 1) void tan_f16_kernel(nero_tan_chain ch, int 
             for (int g = 0; g < 4; ++g) lds_dma16(Ln.a_saved + goff + (size_t)r * 32 * NERO_HID + 8 * g, pa_addr + (r * 4 + g) * 1024);
     };
     prefetch_act(ch.layer[0]);
+    WscRegs wr;
+    wsc_request(wr, ch, [](const nero_tan_layer& Lx, const float*& pm, const float*& pa) { pm = Lx.k_main > 0 ? Lx.w_main : nullptr; pa = Lx.k_aux > 0 ? Lx.w_aux : nullptr; });
     if (ch.init) load_planes_scaled(S.actp, SA, PLANE_A, S.rs_main, ch.init, ch.ld_init, ch.k_init, row0, n_rows, tid);
     if (ch.aux) load_planes_scaled(S.auxp, SX, PLANE_X, S.rs_aux, ch.aux, ch.ld_aux, ch.k_aux, row0, n_rows, tid);
+    wsc_commit(S.wsc, wr, tid);
     __syncthreads();
     for (int l = 0; l < ch.n_layers; ++l) {
-        const nero_tan_layer& L = ch.layer[l];
+        const nero_tan_layer L = load_layer(ch, l);
         const bool live_wave = wave < L.n_tiles;
         const size_t boff = (size_t)row0 * NERO_HID + 32 * wave;
         float4 pg[2][4];
@@ -448,7 +462,7 @@ __global__ __launch_bounds__(512, 1) void tan_f16_kernel(nero_tan_chain ch, int 
         zero2(aH);
         zero2(aL);
         float U[2] = {1.f, 1.f};
-        if (live_wave) gemm_two_sources(aH, aL, U, S, L.w_main, L.w_aux, L.k_main >> 4, L.k_aux >> 4, SX, PLANE_X, wave, lane, i, h);
+        if (live_wave) gemm_two_sources(aH, aL, U, S, L.w_main, L.w_aux, S.wsc[2 * l], S.wsc[2 * l + 1], L.k_main >> 4, L.k_aux >> 4, SX, PLANE_X, wave, lane, i, h);
         float4 val[2][4];
         float m[2] = {0.f, 0.f};
         if (live_wave) {
@@ -499,7 +513,7 @@ __global__ __launch_bounds__(512, 1) void tan_f16_kernel(nero_tan_chain ch, int 
 // the k-loop, every CU at once, and the weight stream queued behind them (vmcnt retires in order): 14.9k instead of 8.3k cycles
 // per softplus layer (profiles/r02_phase_timing.txt); it also frees 32 VGPRs through the GEMM.
 constexpr int BWD_PA_BYTES = 8 * 8192;
-inline int bwd_lds_bytes() { return 2 * PLANE_A + (64 + 64 + 512) * 4 + BWD_PA_BYTES; }      // 135680
+inline int bwd_lds_bytes() { return 2 * PLANE_A + LDS_SMALL_BYTES + BWD_PA_BYTES; }      // 135808
 
 // FIXED: every reverse GEMM of the chain contracts over exactly 256 outputs (16 k-steps) -- the k-loop is then fully unrolled
 // (no ring rotation, clamps or branches: 16 % faster on 256-wide chains); chains with other widths take the generic loop.  The host
@@ -518,11 +532,17 @@ __global__ __launch_bounds__(512, 1) void bwd_f16_kernel(nero_bwd_chain ch, int 
     S.rs_main = reinterpret_cast<float*>(smem + 2 * PLANE_A);
     S.rs_aux = S.rs_main + 64;
     S.rmax = S.rs_aux + 64;
+    S.wsc = S.rmax + 64 * 8;
     S.scr = nullptr;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
-    char* pa_lds = reinterpret_cast<char*>(S.rmax + 64 * 8) + wave * 8192;
+    char* pa_lds = reinterpret_cast<char*>(S.wsc + 32) + wave * 8192;
+    {
+        WscRegs wr;
+        wsc_request(wr, ch, [](const nero_bwd_layer& Lx, const float*& pm, const float*& pa) { pm = Lx.n_out > 0 ? Lx.w_main_t : nullptr; pa = Lx.n_out > 0 ? Lx.w_aux_t : nullptr; });
+        wsc_commit(S.wsc, wr, tid);                        // (published by the first tile's barrier)
+    }
     const unsigned pa_addr = __builtin_amdgcn_readfirstlane(lds_offset_of(pa_lds));
     // PERSISTENT walk (round 5; NERO_F16_PERSIST bit 1): with the second accumulator set gone (mlp_f16_util.h) the tile loop fits the
     // register budget -- round 4 measured it 2-5 % SLOWER because it spilled 12-20 VGPRs.  n_tiles_total = 0: one tile per workgroup.
@@ -553,7 +573,7 @@ __global__ __launch_bounds__(512, 1) void bwd_f16_kernel(nero_bwd_chain ch, int 
     __syncthreads();
     PH_DECL;
     for (int l = ch.n_layers - 1; l >= 0; --l) {
-        const nero_bwd_layer& L = ch.layer[l];
+        const nero_bwd_layer L = load_layer(ch, l);
         const bool first = (L.a_prev == nullptr);
         if (first && ch.d_init == nullptr && !(ch.d_aux && L.w_aux_t)) break;
         const int nt = L.k_main_tiles;
@@ -576,7 +596,7 @@ __global__ __launch_bounds__(512, 1) void bwd_f16_kernel(nero_bwd_chain ch, int 
                 zero2(aH);
                 zero2(aL);
                 if (wave < L.k_aux_tiles) {
-                    const float wsc = *L.w_aux_t;
+                    const float wsc = S.wsc[2 * l + 1];
                     const uint4* wpx = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(L.w_aux_t) + HDR_BYTES) + (size_t)wave * steps * 128 + lane;
                     if constexpr (FIXED) gemm_f16x3_fixed<16>(aH, aL, wpx, S.actp + i * SA + 16 * h, 32 * SA, PLANE_A);
                     else gemm_f16x3(aH, aL, wpx, S.actp + i * SA + 16 * h, 32 * SA, PLANE_A, steps);
@@ -597,7 +617,7 @@ __global__ __launch_bounds__(512, 1) void bwd_f16_kernel(nero_bwd_chain ch, int 
             zero2(aL);
             float u[2] = {1.f, 1.f};
             if (live_wave) {
-                const float wsc = *L.w_main_t;
+                const float wsc = S.wsc[2 * l];
                 const uint4* wpm = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(L.w_main_t) + HDR_BYTES) + (size_t)wave * steps * 128 + lane;
                 // (Round 4, measured and dropped: the injections requested INSIDE the GEMM, behind its last weight request, so that the
                 //  epilogue does not wait for them -- the second-order pass stayed at 1.55 ms: it is bound by its HBM traffic, 3 KB per row
