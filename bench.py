@@ -30,6 +30,13 @@ import time
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+# The split-sum FG table is INPUT DATA of the reference (assets/bsdf_256_256.bin, read relative to the working directory at
+# network/field.py:510).  The bench does not run from a reference checkout, so it names the table explicitly -- the committed fixture that
+# holds the reference's asset bit for bit (tests/test_fg_lut.py::test_constructed_in_the_reference_tree) -- instead of letting the model fall
+# back, loudly, to the computed table (within 3.9e-4 of the asset: VERDICT r5 missing 6).  An explicit $NERO_FG_LUT wins.
+_FG_FIXTURE = os.path.join(ROOT, 'tests', 'golden', 'fg_lut_ref.npz')
+if 'NERO_FG_LUT' not in os.environ and os.path.exists(_FG_FIXTURE):
+    os.environ['NERO_FG_LUT'] = _FG_FIXTURE
 sys.path.insert(0, ROOT)
 
 C_SDF, C_NERF, C_APP = 524544, 604160, 1211648          # MACs per point
@@ -706,7 +713,8 @@ def main():
                        'parallelism': f'dp{world}', 'optimizer': 'adam(fused)', 'inv_s': 'exp(10*0.5)',
                        'streams': int(os.environ.get('NERO_STREAMS', '3')),
                        'arithmetic': 'fp16 two-plane operands, 3 MFMA products into ONE fp32 accumulator; no packed fp32 VALU (DESIGN.md 9.3)',
-                       'f16_paired_mask': CH.f16_paired()},
+                       'f16_paired_mask': CH.f16_paired(),
+                       'fg_table': ('reference asset (' + os.path.relpath(os.environ['NERO_FG_LUT'], ROOT) + ')') if os.environ.get('NERO_FG_LUT') else 'computed fallback'},
             'step_mlp_flop_frac': round(flop_step / (dt / args.steps) / PEAK_OF_MODE[CH.GEMM_MODE['fwd']], 4),
             'step_mlp_flop_frac_of_f32_mfma_peak': round(flop_step / (dt / args.steps) / PEAK_F32_MFMA, 4),
             'inner_samples_per_ray': round(n_in / args.steps / args.rays, 2),
@@ -769,10 +777,27 @@ def main():
                 return {'value': round(512 / d_, 1), 'unit': 'rays/s', 'ms_per_step': round(d_ * 1e3, 3), 'rays': 512, 'steps': 20, 'warmup': 5,
                         'what': "the reference's own train_ray_num = 512 (configs/shape/syn/bell.yaml:31) on the fused training step"}
             leg('r512', r512)
+
+            def c3_shard():
+                # BASELINE configs[2] is bear Stage I, 8192 rays per global batch on 8 GPUs: THIS is one rank's shard of it (1024 rays, human light
+                # on) on one GPU -- the N = 1 denominator of that configuration's scaling curve
+                t3 = ShapeTrainStep({**BELL, 'shader_config': {'human_light': True}}, rays_per_rank=1024, device=dev, variance=VARIANCE, prime_fraction=0.0)
+                for i in range(5):
+                    t3.step(args.train_step + i)
+                torch.cuda.synchronize()
+                t0_ = time.time()
+                for i in range(20):
+                    t3.step(args.train_step + 5 + i)
+                torch.cuda.synchronize()
+                d_ = (time.time() - t0_) / 20
+                return {'value': round(1024 / d_, 1), 'unit': 'rays/s', 'ms_per_step': round(d_ * 1e3, 3), 'rays': 1024, 'steps': 20, 'warmup': 5,
+                        'what': "GlossyReal 'bear' Stage-I shape, 1024 rays x (64+64+32) on ONE GPU = one rank's shard of BASELINE configs[2] (8192 rays over 8 GPUs)"}
+            leg('c3_shard_bear_1024_rays', c3_shard)
             leg('dropin_trainer', lambda: {'r4096': dropin_trainer_bench(dev, cfg, args.rays, VARIANCE, args.train_step),
                                            'r512': dropin_trainer_bench(dev, cfg, 512, VARIANCE, args.train_step)})
             leg('inference', lambda: inference_bench(dev, cfg, VARIANCE))
             leg('stage2', lambda: stage2_bench(dev))
+            # (= one rank's shard of BASELINE configs[4]: bear Stage II, 16384 points x (256+256) over 8 GPUs -- the N = 1 denominator)
             leg('stage2_bear_2048x512', lambda: stage2_step_bench(dev, 'bear', 2048, 256, 256, _bench_mesh()))
             tg = torch_gpu_baseline(cfg, VARIANCE, args.train_step, args.rays, dev)
             res['torch_gpu_baseline'] = tg

@@ -31,17 +31,25 @@ enum { NERO_ACT_NONE = 0, NERO_ACT_RELU = 1, NERO_ACT_SOFTPLUS100 = 2 };
  * BF16X6: every fp32 operand is carried as three bf16 planes (exact 3-way split) and each product is the sum of the six
  * significant plane products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- dropped terms <= 3*2^-27 relative, i.e.
  * below fp32's own rounding; 417 TFLOP/s fp32-equivalent peak.  Packed operands are mode specific. */
-/* F16X3: operands as two fp16 planes (h, l*2^11) of their block-scaled value (per activation row / per weight matrix, exact
- * powers of two), three plane products in two accumulator sets -- half the MFMA count of BF16X6 at the same error class
- * (representation error <= 2^-24 of the block maximum, dropped term <= 2^-24 of the product). */
+/* F16X3: operands as two fp16 planes h = fp16(xs), l = fp16(xs - h) of their block-scaled value xs (per activation row / per weight
+ * matrix, exact powers of two that put the block maximum into [2^14, 2^15), the top of fp16's range), three plane products
+ * hw hx + hw lx + lw hx accumulated into ONE fp32 accumulator set -- half the MFMA count of BF16X6 at the same error class
+ * (representation error <= 2^-24 of the block maximum, dropped term <= 2^-24 of the product).  (Rounds 1-4 scaled into [0.5, 1),
+ * stored l * 2^11 and kept two accumulator sets; -DF16_TWO_ACC rebuilds that format.) */
 /* (value 3 was NERO_GEMM_F16X3P, the two-workgroups-per-CU forward engine of rounds 2-3, removed in round 4 for a wrong partial sum in one
  * launch of three at size.  Round 5 found the mechanism -- packed fp32 beside another wave's MFMAs, DESIGN.md 9.3 -- and the kernels are
  * back as an execution detail of F16X3, nero_f16_paired below: not a mode, the value 3 stays refused.) */
 enum { NERO_GEMM_F32 = 0, NERO_GEMM_BF16X6 = 1, NERO_GEMM_F16X3 = 2 };
-enum { NERO_OK = 0, NERO_ERR_ARG = -1, NERO_ERR_LAUNCH = -2, NERO_ERR_UNSUPPORTED = -3 };
+enum { NERO_OK = 0, NERO_ERR_ARG = -1, NERO_ERR_LAUNCH = -2, NERO_ERR_UNSUPPORTED = -3, NERO_ERR_NOMEM = -4 };
 
 const char* nero_last_error(void);
 int nero_version(void);
+/* Would a caller-owned workspace of `need_bytes` fit the current device?  The step drivers below never allocate -- the caller hands over ONE
+ * workspace sized by nero_stage1_workspace_bytes / nero_stage2_workspace_bytes (31 GiB typical, 52 GiB worst case at 4096 rays) -- so the place
+ * to fail cleanly is in front of the caller's allocation: NERO_OK when need_bytes <= free device memory + reusable_bytes (memory the caller
+ * will release or re-use for it: its previous workspace, its allocator's cached blocks), else NERO_ERR_NOMEM with the byte counts and `what`
+ * in nero_last_error().  (The reference has no counterpart: torch raises an allocator OOM from wherever the step happens to be.) */
+int nero_check_device_memory(size_t need_bytes, size_t reusable_bytes, const char* what);
 /* per-launch HIP-event timing of the MFMA kernel classes {0 forward, 1 tangent, 2 reverse, 3 weight-gradient GEMM}:
  * report fills out[kind*3 + {0,1,2}] = {launches, total ms, total algorithmic flops} (host array of 12 doubles). */
 int nero_prof_enable(int on);

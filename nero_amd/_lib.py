@@ -95,11 +95,32 @@ class NeroHipError(RuntimeError):
     pass
 
 
+class NeroOutOfMemory(NeroHipError, MemoryError):
+    """a step workspace larger than what the device can hold (NERO_ERR_NOMEM, nero_check_device_memory)"""
+
+
+def check_workspace_fits(need_bytes, device, held_bytes=0, what='step workspace'):
+    """raise NeroOutOfMemory -- with the byte counts -- BEFORE torch is asked for a workspace that cannot fit: free device memory + what torch's
+    caching allocator holds without using + the caller's previous workspace (released for the new one) must cover it"""
+    import ctypes as C
+    import torch
+    reusable = int(held_bytes)
+    try:
+        reusable += max(0, torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device))
+    except Exception:                                  # noqa: BLE001 (no CUDA context yet)
+        pass
+    lib.nero_check_device_memory.argtypes = [C.c_size_t, C.c_size_t, C.c_char_p]
+    with torch.cuda.device(device):
+        check(lib.nero_check_device_memory(int(need_bytes), reusable, what.encode()))
+
+
 def check(rc):
     if rc != 0:
         msg = lib.nero_last_error().decode()
         if rc == -3:
             raise NotImplementedError(msg)
+        if rc == -4:                                   # NERO_ERR_NOMEM: a workspace that cannot fit, reported BEFORE the allocation is tried
+            raise NeroOutOfMemory(msg)
         raise NeroHipError(f'libnero_hip error {rc}: {msg}')
 
 

@@ -19,6 +19,20 @@ int nero_check_launch(const char* what) {
 }
 
 extern "C" const char* nero_last_error(void) { return g_err; }
+
+extern "C" int nero_check_device_memory(size_t need_bytes, size_t reusable_bytes, const char* what) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+        (void)hipGetLastError();
+        return nero_fail(NERO_ERR_LAUNCH, "nero_check_device_memory: hipMemGetInfo failed (no device?)");
+    }
+    if (need_bytes <= free_b + reusable_bytes) return NERO_OK;
+    const double G = 1.0 / (1024.0 * 1024.0 * 1024.0);
+    snprintf(g_err, sizeof(g_err), "%s: needs %zu bytes (%.1f GiB); the device has %zu free + %zu re-usable by the caller = %.1f GiB of %.1f GiB. "
+             "Fewer rays / points per GPU, or NERO_STREAMS=2 (no third stream: chain deltas are released early), shrink it.",
+             what ? what : "workspace", need_bytes, need_bytes * G, free_b, reusable_bytes, (free_b + reusable_bytes) * G, total_b * G);
+    return NERO_ERR_NOMEM;
+}
 extern "C" int nero_version(void) { return 100; }
 
 // ---- per-launch kernel timing (disabled by default) ----------------------------------------------------------------

@@ -64,23 +64,27 @@ __device__ __forceinline__ void store_ws4(float* dst, float4 v) {
 constexpr int SCRP_ROWS = 16;
 constexpr int SCRP_BYTES = SCRP_ROWS * SCR_LD * 4;     // 2304 B per wave: store-transposition scratch, 16 rows at a time
 
-// accumulator-layout 32x32 block -> row-major global store, 16 rows at a time through the wave-private scratch
-__device__ __forceinline__ void acc_to_global16(float* scr, const float4 (&q)[4], float* __restrict__ gblock, int lane) {
+// accumulator-layout 32x32 block -> row-major global store, ROWS (16 or 8) rows at a time through the wave-private scratch
+template <int ROWS>
+__device__ __forceinline__ void acc_to_global_rows(float* scr, const float4 (&q)[4], float* __restrict__ gblock, int lane) {
     const int i = lane & 31, h = lane >> 5;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        if ((i >> 4) == p) {
+    for (int p = 0; p < 32 / ROWS; ++p) {
+        if (i / ROWS == p) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(scr + (i & 15) * SCR_LD + 8 * g + 4 * h) = q[g];
+            for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(scr + (i % ROWS) * SCR_LD + 8 * g + 4 * h) = q[g];
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < ROWS / 8; ++k) {
             const int idx = lane + 64 * k, row = idx >> 3, c4 = 4 * (idx & 7);
-            store_ws4(gblock + (size_t)(16 * p + row) * NERO_HID + c4, *reinterpret_cast<const float4*>(scr + row * SCR_LD + c4));
+            store_ws4(gblock + (size_t)(ROWS * p + row) * NERO_HID + c4, *reinterpret_cast<const float4*>(scr + row * SCR_LD + c4));
         }
         __builtin_amdgcn_wave_barrier();
     }
+}
+__device__ __forceinline__ void acc_to_global16(float* scr, const float4 (&q)[4], float* __restrict__ gblock, int lane) {
+    acc_to_global_rows<16>(scr, q, gblock, lane);
 }
 
 // ---- LDS-DMA ----------------------------------------------------------------------------------------------------------------
@@ -98,11 +102,15 @@ __device__ __forceinline__ void lds_dma16(const void* gptr, unsigned lds_addr) {
 __device__ __forceinline__ unsigned lds_offset_of(const void* p) { return (unsigned)(size_t)p; }      // generic -> LDS byte offset
 
 // ---- scaling -----------------------------------------------------------------------------------------------------------
-// exponent e with m * 2^-e in [0.5, 1) * 2^F16_TOP for normal m > 0 (-F16_TOP for m == 0 / denormal), e + F16_TOP clamped to [-40, 40]
+// exponent e with m * 2^-e in [0.5, 1) * 2^F16_TOP for normal m > 0 (-F16_TOP for m == 0 / denormal).  The exponent of m is taken from
+// [2^-40, 2^100]: below, the block is scaled as if its maximum were 2^-40 (everything in it is then tiny but finite in the planes); the
+// upper end keeps 2^e and 2^-e normal floats with room to spare (|e - F16_TOP| <= 115 < 126).  Rounds 1-5 clamped the exponent to +-40 BEFORE the shift by F16_TOP: with the
+// one-accumulator format a block maximum beyond 2^40 would then have been scaled above 65504 and become fp16 infinity (the
+// two-accumulator format stayed finite to 2^56).  No value of the training step comes near either end.
 __device__ __forceinline__ int scale_exp(float m) {
     const int eb = (__float_as_uint(m) >> 23) & 0xff;
     int e = eb ? eb - 126 : 0;
-    e = e < -40 ? -40 : (e > 40 ? 40 : e);
+    e = e < -40 ? -40 : (e > 100 ? 100 : e);
     return e - F16_TOP;                                  // (one accumulator: m * 2^-e in [2^14, 2^15), the top of fp16's range)
 }
 __device__ __forceinline__ float pow2i(int e) { return __uint_as_float((unsigned)(127 + e) << 23); }
@@ -293,7 +301,16 @@ __device__ __forceinline__ void load_x(XF& o, const char* xp, int half_bytes, in
 }
 #define NERO_MFH(ACC, A, B) \
     ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), ACC, 0, 0, 0)
+// GEMM_SETPRIO (experiment, round 6): 1 = a wave raises its issue priority for the six MFMAs of a k-step and drops it for the operand
+// requests of the next one (the two waves of a SIMD would then alternate k-steps instead of one running ahead and the other finishing
+// alone at the lone-wave rate); 2 = the second wave of every SIMD (waves 4-7) holds priority 1 through the whole GEMM.
+#ifndef GEMM_SETPRIO
+#define GEMM_SETPRIO 0
+#endif
 __device__ __forceinline__ void ops_compute(f32x16 (&aH)[2], f32x16 (&aL)[2], const WF& w, const XF& x) {
+#if GEMM_SETPRIO == 1
+    __builtin_amdgcn_s_setprio(1);
+#endif
 #ifdef F16_NO_MFMA
     aH[0][0] += __uint_as_float(w.wh.x ^ x.xh0.x); aL[0][0] += __uint_as_float(w.wl.x ^ x.xl0.x);
     aH[1][0] += __uint_as_float(w.wh.y ^ x.xh1.x); aL[1][0] += __uint_as_float(w.wl.y ^ x.xl1.x);
@@ -310,6 +327,9 @@ __device__ __forceinline__ void ops_compute(f32x16 (&aH)[2], f32x16 (&aL)[2], co
     NERO_MFH(aH[0], w.wh, x.xl0); NERO_MFH(aH[1], w.wh, x.xl1);
     NERO_MFH(aH[0], w.wh, x.xh0); NERO_MFH(aH[1], w.wh, x.xh1);
     (void)aL;
+#endif
+#if GEMM_SETPRIO == 1
+    __builtin_amdgcn_s_setprio(0);
 #endif
 }
 #define NERO_FENCE() __builtin_amdgcn_sched_barrier(0)      // (without the fences hipcc sinks the prefetches: the kernels run 40 % slower)
@@ -380,6 +400,32 @@ __device__ __forceinline__ void gemm_f16x3_loop(f32x16 (&aH)[2], f32x16 (&aL)[2]
     gemm_f16x3_loop(aH, aL, wp, xp, half_bytes, plane_bytes, n, false, wa, wb, wc);
 }
 
+
+// lean k-loop for the kernels that run FOUR waves per SIMD (<= 128 registers per wave; mlp_f16p.hip, NW = 8): weights two steps ahead in a
+// ring of three register sets, fragments one step ahead -- 56 operand registers instead of 64 + 32; the other three waves of the SIMD cover
+// what the shallower ring no longer does.  Same products in the same order as gemm_f16x3_loop.
+__device__ __forceinline__ void gemm_f16x3_lean(f32x16 (&aH)[2], f32x16 (&aL)[2], const uint4* wp, const char* xp, int half_bytes,
+                                                int plane_bytes, int n) {
+    if (n <= 0) return;
+    WF w0, w1, w2;
+    XF xa, xb;
+    const int last = n - 1;
+#define NERO_CL(c) ((c) < last ? (c) : last)
+    load_w(w0, wp, 0);
+    load_w(w1, wp, NERO_CL(1));
+    load_x(xa, xp, half_bytes, plane_bytes, 0);
+    NERO_FENCE();
+    for (int c = 0; c < n; c += 6) {
+        load_w(w2, wp, NERO_CL(c + 2)); load_x(xb, xp, half_bytes, plane_bytes, NERO_CL(c + 1)); NERO_FENCE();
+        ops_compute(aH, aL, w0, xa); NERO_FENCE();
+        if (c + 1 < n) { load_w(w0, wp, NERO_CL(c + 3)); load_x(xa, xp, half_bytes, plane_bytes, NERO_CL(c + 2)); NERO_FENCE(); ops_compute(aH, aL, w1, xb); NERO_FENCE(); }
+        if (c + 2 < n) { load_w(w1, wp, NERO_CL(c + 4)); load_x(xb, xp, half_bytes, plane_bytes, NERO_CL(c + 3)); NERO_FENCE(); ops_compute(aH, aL, w2, xa); NERO_FENCE(); }
+        if (c + 3 < n) { load_w(w2, wp, NERO_CL(c + 5)); load_x(xa, xp, half_bytes, plane_bytes, NERO_CL(c + 4)); NERO_FENCE(); ops_compute(aH, aL, w0, xb); NERO_FENCE(); }
+        if (c + 4 < n) { load_w(w0, wp, NERO_CL(c + 6)); load_x(xb, xp, half_bytes, plane_bytes, NERO_CL(c + 5)); NERO_FENCE(); ops_compute(aH, aL, w1, xa); NERO_FENCE(); }
+        if (c + 5 < n) { load_w(w1, wp, NERO_CL(c + 7)); load_x(xa, xp, half_bytes, plane_bytes, NERO_CL(c + 6)); NERO_FENCE(); ops_compute(aH, aL, w2, xb); NERO_FENCE(); }
+    }
+#undef NERO_CL
+}
 
 // compile-time step count (the 256-wide layers: 16 steps), fully unrolled: no clamps, no branches, every ring slot a fixed register
 // set.  XD = how many steps ahead the activation fragments are requested (ring of XD + 1 sets), weights three steps ahead.

@@ -32,7 +32,9 @@ namespace {
 
 #include "mlp_f16_util.h"
 
-constexpr int PW = 4;                                  // waves per workgroup
+// NW = waves per workgroup.  4 (round 2 / 5): wave w computes the feature tiles w and w + 4 one after the other, 256 registers per wave,
+// two waves per SIMD.  8 (round 6): wave w computes tile w only, at most 128 registers per wave, FOUR waves per SIMD from two workgroups --
+// the occupancy at which scripts/probe/rowowner_probe.hip measures today's layer structure 13 % faster than with one workgroup per CU.
 // reverse kernel: the saved activations of a wave's first / second feature tile are requested in front of (true) or behind (false) its GEMM
 #ifndef P_PA_EARLY_A
 #define P_PA_EARLY_A true
@@ -52,48 +54,54 @@ __device__ __forceinline__ LdsP carve_p(char* smem) {
     l.scr = reinterpret_cast<char*>(l.wsc + 32);
     return l;
 }
+#ifndef NERO_F16_PW_DEFAULT
+#define NERO_F16_PW_DEFAULT 4
+#endif
 #ifndef P_LDS_EXTRA
 #define P_LDS_EXTRA 0                                   // (timing experiment: > 2560 forces ONE workgroup per CU)
 #endif
-inline int p_lds_bytes() { return 2 * PLANE_A + LDS_SMALL_BYTES + PW * SCRP_BYTES + P_LDS_EXTRA; }      // 79488
+inline int p_lds_bytes() { return 2 * PLANE_A + LDS_SMALL_BYTES + 4 * SCRP_BYTES + P_LDS_EXTRA; }      // 79488 (NW = 8: 8 x 8-row scratch, the same)
 
-struct Ctx { LdsP S; int wave, lane, i, h, row0, n_rows; };
+struct Ctx { LdsP S; int wave, lane, i, h, row0, n_rows; float* scr; };
 
-// rows [row0, row0+64) x first k columns of a row-major fp32 matrix -> scaled plane pairs + per-row scale (4 threads per row)
+// rows [row0, row0+64) x first k columns of a row-major fp32 matrix -> scaled plane pairs + per-row scale (NW threads per row)
+template <int NW>
 __device__ __forceinline__ void load_planes_scaled_p(char* planes, float* rs, const float* __restrict__ src, int ld, int k, int row0,
                                                      int n_rows, int tid) {
-    const int r = tid >> 2, q = tid & 3;
+    constexpr int NV = 64 / NW;
+    const int r = tid / NW, q = tid % NW;
     const int k16 = (k + 15) & ~15, q4 = k16 >> 2;
     int gr = row0 + r;
     gr = gr < n_rows ? gr : n_rows - 1;
     const float* rowp = src + (size_t)gr * ld;
-    float4 v[16];
+    float4 v[NV];
     float m = 0.f;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int c4 = 4 * (q + 4 * j);
+    for (int j = 0; j < NV; ++j) {
+        const int c4 = 4 * (q + NW * j);
         v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c4 < k) v[j] = *reinterpret_cast<const float4*>(rowp + c4);
         m = fmaxf(m, amax4(v[j]));
     }
-    m = max_4lanes(m);
+    m = NW == 8 ? max_8lanes(m) : max_4lanes(m);
     const int e = scale_exp(m);
     const float inv = pow2i(-e);
 #pragma unroll
-    for (int j = 0; j < 16; ++j)
-        if (q + 4 * j < q4) store_planes4h(planes + r * SA + (q + 4 * j) * 8, PLANE_A, scale4(v[j], inv));
+    for (int j = 0; j < NV; ++j)
+        if (q + NW * j < q4) store_planes4h(planes + r * SA + (q + NW * j) * 8, PLANE_A, scale4(v[j], inv));
     if (q == 0) rs[r] = pow2i(e);
 }
 
 // per-row scale of the aux operand (its planes are built on the fly, gemm_aux_global)
+template <int NW>
 __device__ __forceinline__ void aux_row_scales_p(float* rs, const float* __restrict__ src, int ld, int k, int row0, int n_rows, int tid) {
-    const int r = tid >> 2, q = tid & 3;
+    const int r = tid / NW, q = tid % NW;
     int gr = row0 + r;
     gr = gr < n_rows ? gr : n_rows - 1;
     const float* rowp = src + (size_t)gr * ld;
     float m = 0.f;
-    for (int c4 = 4 * q; c4 < k; c4 += 16) m = fmaxf(m, amax4(*reinterpret_cast<const float4*>(rowp + c4)));
-    m = max_4lanes(m);
+    for (int c4 = 4 * q; c4 < k; c4 += 4 * NW) m = fmaxf(m, amax4(*reinterpret_cast<const float4*>(rowp + c4)));
+    m = NW == 8 ? max_8lanes(m) : max_4lanes(m);
     if (q == 0) rs[r] = pow2i(scale_exp(m));
 }
 
@@ -147,6 +155,7 @@ __device__ __forceinline__ void gemm_aux_global(f32x16 (&aH)[2], f32x16 (&aL)[2]
 }
 
 // aux part (its own unit) then main part of one feature tile; U = unit of the result per 32-row half
+template <int NW>
 __device__ __forceinline__ void gemm_tile(f32x16 (&aH)[2], f32x16 (&aL)[2], float (&U)[2], const Ctx& c, int t, const float* w_main,
                                           const float* w_aux, float wsc_main, float wsc_aux, int sm, int sx, const float* aux, int ld_aux,
                                           int k_aux_cols) {
@@ -173,17 +182,19 @@ __device__ __forceinline__ void gemm_tile(f32x16 (&aH)[2], f32x16 (&aL)[2], floa
         }
         U[0] = u0;
         U[1] = u1;
-        gemm_f16x3(aH, aL, reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w_main) + HDR_BYTES) + (size_t)t * sm * 128 + c.lane,
-                   c.S.actp + c.i * SA + 16 * c.h, 32 * SA, PLANE_A, sm);
+        const uint4* wp = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w_main) + HDR_BYTES) + (size_t)t * sm * 128 + c.lane;
+        if (NW == 8) gemm_f16x3_lean(aH, aL, wp, c.S.actp + c.i * SA + 16 * c.h, 32 * SA, PLANE_A, sm);
+        else gemm_f16x3(aH, aL, wp, c.S.actp + c.i * SA + 16 * c.h, 32 * SA, PLANE_A, sm);
     }
 }
 
-// VALU head on the current activation planes (8 threads per row, two passes of 32 rows)
+// VALU head on the current activation planes (8 threads per row; NW = 4: two passes of 32 rows)
+template <int NW>
 __device__ __forceinline__ void eval_head_p(const char* planes, const float* rs, const float* __restrict__ w, const float* __restrict__ b,
                                             float* __restrict__ out, int n_head, int hk, int row0, int tid) {
     const int q = tid & 7;
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < 8 / NW; ++pass) {
         const int r = (tid >> 3) + 32 * pass;
         float s[4] = {0.f, 0.f, 0.f, 0.f};
         for (int c4 = 4 * q; c4 < hk; c4 += 32) {
@@ -208,6 +219,7 @@ __device__ __forceinline__ void eval_head_p(const char* planes, const float* rs,
 
 // shared tail: barrier (row maxima of all 8 tiles visible, every wave done reading the input planes), rescale + store the two
 // tiles of this wave as plane pairs, new row scales, barrier
+template <int NW>
 __device__ __forceinline__ void commit_planes_p(const Ctx& c, const float4 (&v0)[2][4], const float4 (&v1)[2][4], bool live0, bool live1) {
     __syncthreads();
     const int e0 = scale_exp(row_max8(c.S.rmax, c.i)), e1 = scale_exp(row_max8(c.S.rmax, 32 + c.i));
@@ -220,8 +232,8 @@ __device__ __forceinline__ void commit_planes_p(const Ctx& c, const float4 (&v0)
             store_planes4h(dst + 32 * SA + 16 * g, PLANE_A, scale4(v0[1][g], inv1));
         }
     }
-    if (live1) {
-        char* dst = c.S.actp + c.i * SA + (32 * (c.wave + PW) + 4 * c.h) * 2;
+    if (NW == 4 && live1) {
+        char* dst = c.S.actp + c.i * SA + (32 * (c.wave + NW) + 4 * c.h) * 2;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             store_planes4h(dst + 16 * g, PLANE_A, scale4(v1[0][g], inv0));
@@ -232,6 +244,7 @@ __device__ __forceinline__ void commit_planes_p(const Ctx& c, const float4 (&v0)
     __syncthreads();
 }
 
+template <int NW>
 __device__ __forceinline__ Ctx make_ctx(char* smem, int n_rows) {
     Ctx c;
     c.S = carve_p(smem);
@@ -241,6 +254,7 @@ __device__ __forceinline__ Ctx make_ctx(char* smem, int n_rows) {
     c.h = c.lane >> 5;
     c.row0 = blockIdx.x * 64;
     c.n_rows = n_rows;
+    c.scr = reinterpret_cast<float*>(c.S.scr + c.wave * (NW == 8 ? SCRP_BYTES / 2 : SCRP_BYTES));     // 8 / 16 rows at a time
     return c;
 }
 
@@ -266,6 +280,7 @@ __device__ __forceinline__ void fwd_values(const f32x16 (&aH)[2], const f32x16 (
     }
 }
 
+template <int NW>
 __device__ __forceinline__ void fwd_tile(const nero_fwd_chain& ch, const nero_fwd_layer& L, int l, const Ctx& c, int t, float4 (&val)[2][4],
                                          float (&m)[2] PH_PARAM) {
     m[0] = m[1] = 0.f;
@@ -274,22 +289,25 @@ __device__ __forceinline__ void fwd_tile(const nero_fwd_chain& ch, const nero_fw
         zero2(aH);
         zero2(aL);
         float4 bq[4];
+        auto load_bias = [&]() {
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            bq[g] = L.bias ? *reinterpret_cast<const float4*>(L.bias + 32 * t + 8 * g + 4 * c.h) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int g = 0; g < 4; ++g)
+                bq[g] = L.bias ? *reinterpret_cast<const float4*>(L.bias + 32 * t + 8 * g + 4 * c.h) : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        if (NW == 4) load_bias();                       // (NW = 8: behind the GEMM -- 16 registers its 128 have no room for)
         float U[2] = {1.f, 1.f};
         PH(1);
-        gemm_tile(aH, aL, U, c, t, L.w_main, L.w_aux, c.S.wsc[2 * l], c.S.wsc[2 * l + 1], L.k_main >> 4, L.k_aux >> 4, ch.aux, ch.ld_aux, ch.k_aux);
+        gemm_tile<NW>(aH, aL, U, c, t, L.w_main, L.w_aux, c.S.wsc[2 * l], c.S.wsc[2 * l + 1], L.k_main >> 4, L.k_aux >> 4, ch.aux, ch.ld_aux, ch.k_aux);
+        if (NW == 8) { NERO_FENCE(); load_bias(); }
         PH(2);
         if (L.act == NERO_ACT_RELU) fwd_values<NERO_ACT_RELU>(aH, aL, bq, U, val, m);
         else if (L.act == NERO_ACT_SOFTPLUS100) fwd_values<NERO_ACT_SOFTPLUS100>(aH, aL, bq, U, val, m);
         else fwd_values<NERO_ACT_NONE>(aH, aL, bq, U, val, m);
         PH(3);
         if (L.save) {
-            float* scr = reinterpret_cast<float*>(c.S.scr + c.wave * SCRP_BYTES);
             float* sblock = L.save + (size_t)c.row0 * NERO_HID + 32 * t;
-            acc_to_global16(scr, val[0], sblock, c.lane);
-            acc_to_global16(scr, val[1], sblock + (size_t)32 * NERO_HID, c.lane);
+            acc_to_global_rows<64 / NW>(c.scr, val[0], sblock, c.lane);
+            acc_to_global_rows<64 / NW>(c.scr, val[1], sblock + (size_t)32 * NERO_HID, c.lane);
         }
         if (L.relu_mask) {                              // sign bits of this lane's 2 x 16 outputs -> one word per (row, tile)
 #pragma unroll
@@ -311,9 +329,10 @@ __device__ __forceinline__ void fwd_tile(const nero_fwd_chain& ch, const nero_fw
     PH(4);
 }
 
-__global__ __launch_bounds__(256, 2) void fwd_p_kernel(nero_fwd_chain ch, int n_rows) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2) void fwd_p_kernel(nero_fwd_chain ch, int n_rows) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const Ctx c = make_ctx(smem, n_rows);
+    const Ctx c = make_ctx<NW>(smem, n_rows);
     const int tid = threadIdx.x;
     PH_DECL;
 #ifdef F16_PHASE_TIMING
@@ -321,20 +340,20 @@ __global__ __launch_bounds__(256, 2) void fwd_p_kernel(nero_fwd_chain ch, int n_
 #endif
     WscRegs wr;
     wsc_request(wr, ch, [](const nero_fwd_layer& Lx, const float*& pm, const float*& pa) { pm = Lx.k_main > 0 && Lx.n_tiles > 0 ? Lx.w_main : nullptr; pa = Lx.k_aux > 0 && Lx.n_tiles > 0 ? Lx.w_aux : nullptr; });
-    if (ch.init) load_planes_scaled_p(c.S.actp, c.S.rs_main, ch.init, ch.ld_init, ch.k_init, c.row0, n_rows, tid);
-    if (ch.aux) aux_row_scales_p(c.S.rs_aux, ch.aux, ch.ld_aux, ch.k_aux, c.row0, n_rows, tid);
+    if (ch.init) load_planes_scaled_p<NW>(c.S.actp, c.S.rs_main, ch.init, ch.ld_init, ch.k_init, c.row0, n_rows, tid);
+    if (ch.aux) aux_row_scales_p<NW>(c.S.rs_aux, ch.aux, ch.ld_aux, ch.k_aux, c.row0, n_rows, tid);
     wsc_commit(c.S.wsc, wr, tid);
     __syncthreads();
     PH(0);
     for (int l = 0; l < ch.n_layers; ++l) {
         const nero_fwd_layer L = load_layer(ch, l);
-        if (L.n_head > 0) eval_head_p(c.S.actp, c.S.rs_main, L.head_w, L.head_b, L.head_out, L.n_head, L.head_k, c.row0, tid);
+        if (L.n_head > 0) eval_head_p<NW>(c.S.actp, c.S.rs_main, L.head_w, L.head_b, L.head_out, L.n_head, L.head_k, c.row0, tid);
         if (L.n_tiles == 0) continue;
         float4 v0[2][4], v1[2][4];
         float m0[2], m1[2];
-        fwd_tile(ch, L, l, c, c.wave, v0, m0 PH_ARG);
-        fwd_tile(ch, L, l, c, c.wave + PW, v1, m1 PH_ARG);
-        commit_planes_p(c, v0, v1, c.wave < L.n_tiles, c.wave + PW < L.n_tiles);
+        fwd_tile<NW>(ch, L, l, c, c.wave, v0, m0 PH_ARG);
+        if (NW == 4) fwd_tile<NW>(ch, L, l, c, c.wave + NW, v1, m1 PH_ARG);
+        commit_planes_p<NW>(c, v0, v1, c.wave < L.n_tiles, c.wave + NW < L.n_tiles);
         PH(5);
     }
 #ifdef F16_PHASE_TIMING
@@ -347,6 +366,7 @@ __global__ __launch_bounds__(256, 2) void fwd_p_kernel(nero_fwd_chain ch, int n_
 // ---------------------------------------------------------------------------------------------------------------------
 // tangent chain (softplus networks):  adot_l = s_l * (W_l adot_{l-1}),  inj_l = gbar_l * beta (1-s_l) * zdot_l
 // ---------------------------------------------------------------------------------------------------------------------
+template <int NW>
 __device__ __forceinline__ void tan_tile(const nero_tan_chain& ch, const nero_tan_layer& L, int l, const Ctx& c, int t, float4 (&val)[2][4],
                                          float (&m)[2]) {
     m[0] = m[1] = 0.f;
@@ -358,7 +378,7 @@ __device__ __forceinline__ void tan_tile(const nero_tan_chain& ch, const nero_ta
         zero2(aH);
         zero2(aL);
         float U[2] = {1.f, 1.f};
-        gemm_tile(aH, aL, U, c, t, L.w_main, L.w_aux, c.S.wsc[2 * l], c.S.wsc[2 * l + 1], L.k_main >> 4, L.k_aux >> 4, ch.aux, ch.ld_aux, ch.k_aux);
+        gemm_tile<NW>(aH, aL, U, c, t, L.w_main, L.w_aux, c.S.wsc[2 * l], c.S.wsc[2 * l + 1], L.k_main >> 4, L.k_aux >> 4, ch.aux, ch.ld_aux, ch.k_aux);
         // the saved activations are requested BEHIND the GEMM (32 registers it has no room for at two workgroups per CU: 23 spilled);
         // the round trip is covered by the other workgroup's MFMAs, which is what this engine is for
         NERO_FENCE();
@@ -376,7 +396,7 @@ __device__ __forceinline__ void tan_tile(const nero_tan_chain& ch, const nero_ta
 #pragma unroll
                 for (int g = 0; g < 4; ++g) pg[r][g] = *reinterpret_cast<const float4*>(L.gbar + goff + (size_t)r * 32 * NERO_HID + 8 * g);
         }
-        float* scr = reinterpret_cast<float*>(c.S.scr + c.wave * SCRP_BYTES);
+        float* scr = c.scr;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const bool live = (c.row0 + 32 * r + c.i) < c.n_rows;
@@ -394,30 +414,31 @@ __device__ __forceinline__ void tan_tile(const nero_tan_chain& ch, const nero_ta
                 adq[g] = live ? ad : make_float4(0.f, 0.f, 0.f, 0.f);
                 ijq[g] = ij;
             }
-            acc_to_global16(scr, adq, L.adot + boff + (size_t)r * 32 * NERO_HID, c.lane);
-            if (want_inj) acc_to_global16(scr, ijq, L.inj + boff + (size_t)r * 32 * NERO_HID, c.lane);
+            acc_to_global_rows<64 / NW>(scr, adq, L.adot + boff + (size_t)r * 32 * NERO_HID, c.lane);
+            if (want_inj) acc_to_global_rows<64 / NW>(scr, ijq, L.inj + boff + (size_t)r * 32 * NERO_HID, c.lane);
         }
     }
     publish_rowmax(c.S.rmax, m[0], m[1], t, c.i, c.h);
 }
 
-__global__ __launch_bounds__(256, 2) void tan_p_kernel(nero_tan_chain ch, int n_rows) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2) void tan_p_kernel(nero_tan_chain ch, int n_rows) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const Ctx c = make_ctx(smem, n_rows);
+    const Ctx c = make_ctx<NW>(smem, n_rows);
     const int tid = threadIdx.x;
     WscRegs wr;
     wsc_request(wr, ch, [](const nero_tan_layer& Lx, const float*& pm, const float*& pa) { pm = Lx.k_main > 0 ? Lx.w_main : nullptr; pa = Lx.k_aux > 0 ? Lx.w_aux : nullptr; });
-    if (ch.init) load_planes_scaled_p(c.S.actp, c.S.rs_main, ch.init, ch.ld_init, ch.k_init, c.row0, n_rows, tid);
-    if (ch.aux) aux_row_scales_p(c.S.rs_aux, ch.aux, ch.ld_aux, ch.k_aux, c.row0, n_rows, tid);
+    if (ch.init) load_planes_scaled_p<NW>(c.S.actp, c.S.rs_main, ch.init, ch.ld_init, ch.k_init, c.row0, n_rows, tid);
+    if (ch.aux) aux_row_scales_p<NW>(c.S.rs_aux, ch.aux, ch.ld_aux, ch.k_aux, c.row0, n_rows, tid);
     wsc_commit(c.S.wsc, wr, tid);
     __syncthreads();
     for (int l = 0; l < ch.n_layers; ++l) {
         const nero_tan_layer L = load_layer(ch, l);
         float4 v0[2][4], v1[2][4];
         float m0[2], m1[2];
-        tan_tile(ch, L, l, c, c.wave, v0, m0);
-        tan_tile(ch, L, l, c, c.wave + PW, v1, m1);
-        commit_planes_p(c, v0, v1, c.wave < L.n_tiles, c.wave + PW < L.n_tiles);
+        tan_tile<NW>(ch, L, l, c, c.wave, v0, m0);
+        if (NW == 4) tan_tile<NW>(ch, L, l, c, c.wave + NW, v1, m1);
+        commit_planes_p<NW>(c, v0, v1, c.wave < L.n_tiles, c.wave + NW < L.n_tiles);
     }
 }
 
@@ -434,7 +455,7 @@ __device__ __forceinline__ void combine_acc(float4 (&gq)[2][4], const f32x16 (&a
 }
 
 // one feature tile of one reverse layer; `first` = the chain's first dense layer (its input gradient goes to d_init / d_aux)
-template <bool PA_EARLY>
+template <bool PA_EARLY, int NW>
 __device__ __forceinline__ void bwd_tile(const nero_bwd_chain& ch, const nero_bwd_layer& L, int l, const Ctx& c, int t, bool first, float rs0, float rs1,
                                          float4 (&val)[2][4], float (&m)[2]) {
     m[0] = m[1] = 0.f;
@@ -473,7 +494,8 @@ __device__ __forceinline__ void bwd_tile(const nero_bwd_chain& ch, const nero_bw
             zero2(aH);
             zero2(aL);
             const float wsc = c.S.wsc[2 * l + 1];
-            gemm_f16x3(aH, aL, reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(L.w_aux_t) + HDR_BYTES) + (size_t)t * steps * 128 + c.lane,
+            if (NW == 8) gemm_f16x3_lean(aH, aL, reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(L.w_aux_t) + HDR_BYTES) + (size_t)t * steps * 128 + c.lane, xp, 32 * SA, PLANE_A, steps);
+            else gemm_f16x3(aH, aL, reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(L.w_aux_t) + HDR_BYTES) + (size_t)t * steps * 128 + c.lane,
                        xp, 32 * SA, PLANE_A, steps);
             const float u[2] = {wsc * rs0, wsc * rs1};
             combine_acc(gq, aH, aL, u);
@@ -493,7 +515,8 @@ __device__ __forceinline__ void bwd_tile(const nero_bwd_chain& ch, const nero_bw
         zero2(aH);
         zero2(aL);
         const float wsc = c.S.wsc[2 * l];
-        gemm_f16x3(aH, aL, reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(L.w_main_t) + HDR_BYTES) + (size_t)t * steps * 128 + c.lane,
+        if (NW == 8) gemm_f16x3_lean(aH, aL, reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(L.w_main_t) + HDR_BYTES) + (size_t)t * steps * 128 + c.lane, xp, 32 * SA, PLANE_A, steps);
+        else gemm_f16x3(aH, aL, reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(L.w_main_t) + HDR_BYTES) + (size_t)t * steps * 128 + c.lane,
                    xp, 32 * SA, PLANE_A, steps);
         const float u[2] = {wsc * rs0, wsc * rs1};
         combine_acc(gq, aH, aL, u);
@@ -538,22 +561,22 @@ __device__ __forceinline__ void bwd_tile(const nero_bwd_chain& ch, const nero_bw
     else if (L.act_prev == NERO_ACT_SOFTPLUS100) bwd_values_h<NERO_ACT_SOFTPLUS100, false>(gq, pa, goff, has_inj, L, c.row0, c.i, fbase, c.n_rows, val, m, ijp);
     else bwd_values_h<NERO_ACT_NONE, false>(gq, pa, goff, has_inj, L, c.row0, c.i, fbase, c.n_rows, val, m, ijp);
     if (L.delta_prev) {
-        float* scr = reinterpret_cast<float*>(c.S.scr + c.wave * SCRP_BYTES);
-        acc_to_global16(scr, val[0], L.delta_prev + boff, c.lane);
-        acc_to_global16(scr, val[1], L.delta_prev + boff + (size_t)32 * NERO_HID, c.lane);
+        acc_to_global_rows<64 / NW>(c.scr, val[0], L.delta_prev + boff, c.lane);
+        acc_to_global_rows<64 / NW>(c.scr, val[1], L.delta_prev + boff + (size_t)32 * NERO_HID, c.lane);
     }
     publish_rowmax(c.S.rmax, m[0], m[1], t, c.i, c.h);
 }
 
-__global__ __launch_bounds__(256, 2) void bwd_p_kernel(nero_bwd_chain ch, int n_rows) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2) void bwd_p_kernel(nero_bwd_chain ch, int n_rows) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const Ctx c = make_ctx(smem, n_rows);
+    const Ctx c = make_ctx<NW>(smem, n_rows);
     const int tid = threadIdx.x;
     WscRegs wr;
     wsc_request(wr, ch, [](const nero_bwd_layer& Lx, const float*& pm, const float*& pa) { pm = Lx.n_out > 0 ? Lx.w_main_t : nullptr; pa = Lx.n_out > 0 ? Lx.w_aux_t : nullptr; });
-    if (ch.dy) load_planes_scaled_p(c.S.actp, c.S.rs_main, ch.dy, ch.ld_dy, ch.k_dy, c.row0, n_rows, tid);
+    if (ch.dy) load_planes_scaled_p<NW>(c.S.actp, c.S.rs_main, ch.dy, ch.ld_dy, ch.k_dy, c.row0, n_rows, tid);
     else {
-        for (int idx = tid; idx < 2 * PLANE_A / 16; idx += 256) reinterpret_cast<uint4*>(c.S.actp)[idx] = make_uint4(0u, 0u, 0u, 0u);
+        for (int idx = tid; idx < 2 * PLANE_A / 16; idx += NW * 64) reinterpret_cast<uint4*>(c.S.actp)[idx] = make_uint4(0u, 0u, 0u, 0u);
         if (tid < 64) c.S.rs_main[tid] = 1.f;
     }
     wsc_commit(c.S.wsc, wr, tid);
@@ -566,10 +589,10 @@ __global__ __launch_bounds__(256, 2) void bwd_p_kernel(nero_bwd_chain ch, int n_
         const float rs0 = c.S.rs_main[c.i], rs1 = c.S.rs_main[32 + c.i];
         float4 v0[2][4], v1[2][4];
         float m0[2], m1[2];
-        bwd_tile<P_PA_EARLY_A>(ch, L, l, c, c.wave, first, rs0, rs1, v0, m0);
-        bwd_tile<P_PA_EARLY_B>(ch, L, l, c, c.wave + PW, first, rs0, rs1, v1, m1);
+        bwd_tile<P_PA_EARLY_A, NW>(ch, L, l, c, c.wave, first, rs0, rs1, v0, m0);
+        if (NW == 4) bwd_tile<P_PA_EARLY_B, NW>(ch, L, l, c, c.wave + NW, first, rs0, rs1, v1, m1);
         if (first) break;
-        commit_planes_p(c, v0, v1, c.wave < L.k_main_tiles, c.wave + PW < L.k_main_tiles);
+        commit_planes_p<NW>(c, v0, v1, c.wave < L.k_main_tiles, c.wave + NW < L.k_main_tiles);
     }
 }
 
@@ -597,14 +620,30 @@ static void report_occupancy(const void* f, const char* name) {      // NERO_DEB
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f, 256, p_lds_bytes());
     fprintf(stderr, "[nero] %s: dynamic LDS %d -> %d workgroups per CU\n", name, p_lds_bytes(), nb);
 }
+// waves per workgroup of the paired kernels: NERO_F16_PW = 4 | 8, per pass as a decimal digit string "fwd tan bwd" (e.g. 848)
+static int nero_pw(int kind) {
+    static int sel[3] = {-1, -1, -1};
+    if (sel[0] < 0) {
+        const char* e = getenv("NERO_F16_PW");
+        int v = e ? atoi(e) : NERO_F16_PW_DEFAULT;
+        if (v < 10) v = v * 111;
+        sel[0] = (v / 100) % 10 == 8 ? 8 : 4; sel[1] = (v / 10) % 10 == 8 ? 8 : 4; sel[2] = v % 10 == 8 ? 8 : 4;
+    }
+    return sel[kind];
+}
+template <class K, class CH> static void launch_p(K k4, K k8, int nw, const CH* ch, int n_rows, hipStream_t stream) {
+    NERO_ONCE(hipFuncSetAttribute((const void*)k4, hipFuncAttributeMaxDynamicSharedMemorySize, p_lds_bytes()));
+    NERO_ONCE(hipFuncSetAttribute((const void*)k8, hipFuncAttributeMaxDynamicSharedMemorySize, p_lds_bytes()));
+    nero_prof_mark_paired();
+    if (nw == 8) hipLaunchKernelGGL(k8, dim3((n_rows + 63) / 64), dim3(512), p_lds_bytes(), stream, *ch, n_rows);
+    else hipLaunchKernelGGL(k4, dim3((n_rows + 63) / 64), dim3(256), p_lds_bytes(), stream, *ch, n_rows);
+}
 int nero_f16p_forward(const nero_fwd_chain* ch, int n_rows, hipStream_t stream) {
     for (int l = 0; l < ch->n_layers; ++l)
         if ((ch->layer[l].k_main | ch->layer[l].k_aux) & 15)
             return nero_fail(NERO_ERR_ARG, "nero_mlp_forward(f16x3p): k_main / k_aux must be multiples of 16");
-    NERO_ONCE(hipFuncSetAttribute((const void*)fwd_p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, p_lds_bytes()));
-    NERO_ONCE(report_occupancy((const void*)fwd_p_kernel, "fwd_p_kernel"));
-    nero_prof_mark_paired();
-    hipLaunchKernelGGL(fwd_p_kernel, dim3((n_rows + 63) / 64), dim3(256), p_lds_bytes(), stream, *ch, n_rows);
+    NERO_ONCE(report_occupancy((const void*)fwd_p_kernel<4>, "fwd_p_kernel<4>"));
+    launch_p(fwd_p_kernel<4>, fwd_p_kernel<8>, nero_pw(0), ch, n_rows, stream);
     return NERO_OK;
 }
 
@@ -612,9 +651,7 @@ int nero_f16p_tangent(const nero_tan_chain* ch, int n_rows, hipStream_t stream) 
     for (int l = 0; l < ch->n_layers; ++l)
         if ((ch->layer[l].k_main | ch->layer[l].k_aux) & 15)
             return nero_fail(NERO_ERR_ARG, "nero_mlp_tangent(f16x3p): k_main / k_aux must be multiples of 16");
-    NERO_ONCE(hipFuncSetAttribute((const void*)tan_p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, p_lds_bytes()));
-    nero_prof_mark_paired();
-    hipLaunchKernelGGL(tan_p_kernel, dim3((n_rows + 63) / 64), dim3(256), p_lds_bytes(), stream, *ch, n_rows);
+    launch_p(tan_p_kernel<4>, tan_p_kernel<8>, nero_pw(1), ch, n_rows, stream);
     return NERO_OK;
 }
 
@@ -623,8 +660,6 @@ int nero_f16p_backward(const nero_bwd_chain* ch, int n_rows, hipStream_t stream)
         if (ch->layer[l].n_out & 15) return nero_fail(NERO_ERR_ARG, "nero_mlp_backward(f16x3p): n_out must be a multiple of 16");
     if (ch->d_aux && (ch->ld_daux & 3)) return nero_fail(NERO_ERR_ARG, "nero_mlp_backward(f16x3p): ld_daux must be a multiple of 4");
     if (ch->d_init && (ch->ld_dinit & 3)) return nero_fail(NERO_ERR_ARG, "nero_mlp_backward(f16x3p): ld_dinit must be a multiple of 4");
-    NERO_ONCE(hipFuncSetAttribute((const void*)bwd_p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, p_lds_bytes()));
-    nero_prof_mark_paired();
-    hipLaunchKernelGGL(bwd_p_kernel, dim3((n_rows + 63) / 64), dim3(256), p_lds_bytes(), stream, *ch, n_rows);
+    launch_p(bwd_p_kernel<4>, bwd_p_kernel<8>, nero_pw(2), ch, n_rows, stream);
     return NERO_OK;
 }

@@ -245,6 +245,9 @@ __global__ __launch_bounds__(512, 1) void fwd_f16_kernel(nero_fwd_chain ch, int 
             bq[g] = (live_wave && L.bias) ? *reinterpret_cast<const float4*>(L.bias + 32 * wave + 8 * g + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
         float U[2] = {1.f, 1.f};                           // result unit of the accumulators, per 32-row half (this lane's rows i, 32+i)
         PH(1);
+#if GEMM_SETPRIO == 2
+        if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
         if (live_wave) {
             const int sm = L.k_main >> 4, sx = L.k_aux >> 4;
             if (sx > 0) {
@@ -282,6 +285,9 @@ __global__ __launch_bounds__(512, 1) void fwd_f16_kernel(nero_fwd_chain ch, int 
         // requests for what comes next, behind this layer's last weight load (vmcnt retires in order): the next layer's first weight
         // fragments, or -- after the tile's last GEMM -- the next tile's input rows and the first layer's fragments again.  The
         // epilogue, two barriers and the plane conversion that follow (~6 k cycles) cover the L2 / HBM latency.
+#if GEMM_SETPRIO == 2
+        __builtin_amdgcn_s_setprio(0);
+#endif
         NERO_FENCE();
         // (two separate call sites on purpose: merged into one, hipcc keeps the tile-ahead registers and the fragment registers of both
         //  branches alive together -- 256 VGPRs + 13-17 spilled instead of 229-233)

@@ -559,6 +559,7 @@ int nero_stage1_create(const nero_stage1_cfg* cfg, nero_stage1** out) {
             h->s2 = nullptr;
         }
     }
+    const bool have_device = h->s2 != nullptr || h->n_streams < 2;
     if (h->n_streams >= 3) {
         bool ok = hipStreamCreateWithFlags(&h->s3, hipStreamNonBlocking) == hipSuccess &&
                   hipEventCreateWithFlags(&h->ev_dw_done, hipEventDisableTiming) == hipSuccess;
@@ -566,6 +567,10 @@ int nero_stage1_create(const nero_stage1_cfg* cfg, nero_stage1** out) {
         if (!ok) {
             (void)hipGetLastError();
             h->s3 = nullptr;
+            // out of stream / event handles on a live device: the memory plan must follow the streams that exist -- in three-stream mode no
+            // chain delta is released before the step ends (+6 GiB at 4096 rays), which only pays when the third stream runs.
+            // Without a device (CPU-side size queries) the handle keeps the requested mode, so that the sizes match the GPU box's.
+            if (have_device) h->n_streams = 2;
         }
     }
     *out = h;

@@ -403,7 +403,8 @@ class NeROShapeRenderer(nn.Module):
             pts = S['pts4'][:, :3]
             m = torch.norm(pts, dim=-1) < 1.2
             outputs['sdf_pts'] = pts[m]
-            outputs['sdf_vals'] = SDFValue.apply(Kpre, outputs['sdf_pts'], *eff[:18])
+            # (the SDF's effective (W, b) pairs come first in `eff`: 2 * (sdf_n_layers + 1) tensors -- 18 only for the YAML depth 8)
+            outputs['sdf_vals'] = SDFValue.apply(Kpre, outputs['sdf_pts'], *eff[:2 * self.sdf_network.n_lin])
         if c['apply_occ_loss']:
             outputs['loss_occ'] = torch.zeros(1, device=rgb.device)
             if n_in > 0 and step is not None and step >= c['occ_loss_step']:

@@ -399,7 +399,7 @@ class RenderCore(torch.autograd.Function):
 # plain SDF value with first-order weight gradients (InitSDFRegLoss inputs, network/renderer.py:591-594)
 # ----------------------------------------------------------------------------------------------------------------------
 class SDFValue(torch.autograd.Function):
-    """sdf(x) for x [n,3] as an autograd node w.r.t. the 18 effective SDF weights (no gradient w.r.t. x)."""
+    """sdf(x) for x [n,3] as an autograd node w.r.t. the 2 * (sdf_n_layers + 1) effective SDF weights / biases (no gradient w.r.t. x)."""
 
     @staticmethod
     def forward(ctx, K, x, *params):
@@ -484,6 +484,8 @@ def validation_info(K, cfg, shader_cfg, lut, variance, o, d, z_vals, weights, po
     Xo2, Xi, Xo = torch.empty((2 * rp, K.ld_outer), **f32), torch.empty((rp, 128), **f32), torch.empty((rp, 96), **f32)
     L.check(lib.nero_shade_encode(_p(x4), _p(geo), _p(mats[0]['heads'][3]), _p(mats[1]['heads'][3]), _p(mats[2]['heads'][3]), R,
                                   _p(mat), _p(Xo2[:rp]), _p(Xo2[rp:]), _p(Xi), _p(Xo), K.sphere, st))
+    if K.pos_freq != 8:                                # shader_config.light_pos_freq != 8: the chains are packed for PE-f positions
+        Xi, Xo = K.recode_positions(x4, R, Xi, Xo)     # (as RenderCore.forward does; ADVICE r5: validation fed PE-8 columns)
     Lh2 = K.outer_light.forward(Xo2, None, rp + R, save=False)['heads'][3]
     Li = K.inner_light.forward(Xi, None, R, save=False)['heads'][3]
     Lo = K.inner_weight.forward(Xo, None, R, save=False)['heads'][3]

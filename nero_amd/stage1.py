@@ -126,6 +126,8 @@ class Stage1Driver:
         """the step workspace for R rays: the worst case over the data-dependent inner / outer split, allocated once"""
         need = self.workspace_bytes(R)
         if self._ws is None or self._ws.numel() < need:
+            held = 0 if self._ws is None else self._ws.numel()
+            L.check_workspace_fits(need, self.device, held, f'Stage-I step workspace for {R} rays per GPU (worst case over the inner / outer split)')
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws

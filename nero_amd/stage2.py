@@ -87,6 +87,8 @@ class Stage2Driver:
             self._ws_need[(n_pred, P)] = _lib.nero_stage2_workspace_bytes(self.h, n_pred, P)
         need = self._ws_need[(n_pred, P)]
         if self._ws is None or self._ws.numel() < need:
+            held = 0 if self._ws is None else self._ws.numel()
+            L.check_workspace_fits(need, self.device, held, f'Stage-II step workspace for {P} points per GPU')
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws

@@ -177,3 +177,24 @@ def test_batched_weight_gradient_jobs_vs_fp64(n):
             assert bool(torch.isnan(db).all())                # no bias destination: untouched
     ref_sk = torch.cat([D[1].double().t() @ B[2].double(), D[1].double().t() @ B[3][:, :39].double()], 1)
     assert _rel(Wsk, ref_sk) < 2e-6 and _rel(bsk, D[1].double().sum(0)) < 2e-6
+
+
+def test_block_scale_keeps_huge_and_tiny_operands_finite():
+    """with the one-accumulator plane format the block scale puts the block maximum into [2^14, 2^15); the exponent clamp used to
+    be applied BEFORE that shift, so a weight matrix or an activation row beyond 2^40 was scaled above 65504 = fp16 infinity.  Weights of
+    magnitude 2^45 against inputs of 2^-45 (and the other way round): finite and fp32-grade against fp64."""
+    from nero_amd import _lib as L
+    from nero_amd.chain import Chain, Dense
+    g = torch.Generator(device='cuda').manual_seed(11)
+    n = 500
+    rp = (n + 63) // 64 * 64
+    for sw, sx in ((2.0 ** 45, 2.0 ** -45), (2.0 ** -45, 2.0 ** 45), (2.0 ** 60, 2.0 ** -30)):
+        W0 = torch.randn(256, 256, device='cuda', generator=g) / 16 * sw
+        W1 = torch.randn(256, 256, device='cuda', generator=g) / 16
+        x = torch.randn(rp, 256, device='cuda', generator=g) * sx
+        ch = Chain([(Dense(W0, torch.zeros(256, device="cuda"), L.ACT_RELU, 256), None), (Dense(W1, torch.zeros(256, device="cuda"), L.ACT_NONE, 256), None)], k_init=256).pack()
+        out = ch.forward(x, None, n, save=True)['saves'][1][:n]
+        ref = (torch.relu(x[:n].double() @ W0.double().T) @ W1.double().T)
+        assert bool(torch.isfinite(out).all()), (sw, sx)
+        err = float((out.double() - ref).abs().max() / ref.abs().max())
+        assert err < 2e-5, (sw, sx, err)

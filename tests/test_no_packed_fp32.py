@@ -51,16 +51,18 @@ def test_paired_chain_kernels_fit_two_workgroups_per_cu():
     path = os.path.join(ROOT, 'nero_amd', 'csrc', 'mlp_f16p.hip')
     p = subprocess.run(['hipcc'] + _flags() + ['-S', '--cuda-device-only', '-o', '-', path], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr[-2000:]
-    meta, cur = {}, None
-    for line in p.stdout.splitlines():
-        m = re.match(r'\s*\.name:\s+(\S+)', line)
-        if m and 'kernel' in m.group(1):
-            cur = m.group(1)
-            meta[cur] = {}
-        m = re.match(r'\s*\.(vgpr_count|vgpr_spill_count|private_segment_fixed_size|max_flat_workgroup_size):\s+(\d+)', line)
-        if m and cur:
-            meta[cur][m.group(1)] = int(m.group(2))
-    for k in ('fwd_p_kernel', 'tan_p_kernel'):
+    meta = {}
+    text = p.stdout[p.stdout.index('amdhsa.kernels:'):]
+    for entry in re.split(r'\n  - ', text)[1:]:          # one YAML list item per kernel (the field order inside an item is alphabetical)
+        nm = re.search(r'\.name:\s+(\S+)', entry)
+        if nm is None:                                    # (the amdhsa.version list behind the kernels)
+            continue
+        name = nm.group(1)
+        meta[name] = {m.group(1): int(m.group(2)) for m in
+                      re.finditer(r'\.(vgpr_count|vgpr_spill_count|private_segment_fixed_size|max_flat_workgroup_size):\s+(\d+)', entry)}
+    # (the 8-wave instantiations <8> -- four waves per SIMD at 128 registers, NERO_F16_PW=8 -- are a measured-and-dropped experiment of
+    #  round 6 and do spill; the default organisation is <4>)
+    for k in ('fwd_p_kernelILi4E', 'tan_p_kernelILi4E'):
         hit = [v for n, v in meta.items() if k in n]
         assert len(hit) == 1, (k, list(meta))
         v = hit[0]

