@@ -247,6 +247,16 @@ typedef struct {
  * advance (deviation_network.variance while step < freeze_inv_s_step, network/renderer.py:494-495). */
 typedef struct { float* p; const float* grad; float* m; float* v; int n; int step; } nero_adam_job;
 int nero_wn_forward_batch(const nero_wn_job* jobs /*host*/, int n_jobs, void* stream);
+/* The weight-norm backward ALONE, for hosts that keep their own optimiser (the drop-in renderers under torch.optim.Adam: round 6): given
+ * dL/dW_eff of every weight-normed matrix, dg = <dW, v> inv_norm and dv = g inv_norm (dW - <dW, v> inv_norm^2 v) in ONE launch -- what
+ * autograd does per Linear through torch._weight_norm_interface_backward (nn.utils.weight_norm, network/field.py:118-119, 323-331).
+ * inv_norm: the row norms nero_wn_forward_batch left behind. */
+typedef struct {
+    const float* v; const float* g; const float* inv_norm; const float* dW;
+    float* dv; float* dg;                /* out: [rows, cols], [rows]                                                                 */
+    int rows, cols;
+} nero_wn_grad_job;
+int nero_wn_backward_batch(const nero_wn_grad_job* jobs /*host*/, int n_jobs, void* stream);
 int nero_wn_adam_batch(const nero_wn_job* wn /*host*/, int n_wn, const nero_adam_job* plain /*host*/, int n_plain, float lr, float beta1,
                        float beta2, float eps, int step /*1-based*/, void* stream);
 

@@ -72,6 +72,10 @@ class WnJob(C.Structure):
                 ('v_v', _fp), ('m_g', _fp), ('v_g', _fp), ('rows', C.c_int), ('cols', C.c_int)]
 
 
+class WnGradJob(C.Structure):
+    _fields_ = [('v', _fp), ('g', _fp), ('inv_norm', _fp), ('dW', _fp), ('dv', _fp), ('dg', _fp), ('rows', C.c_int), ('cols', C.c_int)]
+
+
 class AdamJob(C.Structure):
     _fields_ = [('p', _fp), ('grad', _fp), ('m', _fp), ('v', _fp), ('n', C.c_int), ('step', C.c_int)]
 

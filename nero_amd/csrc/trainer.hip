@@ -84,6 +84,24 @@ __global__ __launch_bounds__(256) void wn_adam_kernel(WnBatch B, AdamHyper H) {
     }
 }
 
+// weight-norm backward alone (nero_wn_backward_batch): one wave per row
+struct WnGradBatch { nero_wn_grad_job job[NERO_MAX_WN_JOBS]; };
+__global__ __launch_bounds__(256) void wn_backward_kernel(WnGradBatch B) {
+    const nero_wn_grad_job& J = B.job[blockIdx.y];
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= J.rows) return;
+    const float* v = J.v + (size_t)row * J.cols;
+    const float* dW = J.dW + (size_t)row * J.cols;
+    float s = 0.f;
+    for (int k = lane; k < J.cols; k += 64) s = fmaf(dW[k], v[k], s);
+    s = wave_sum(s);
+    const float inv = J.inv_norm[row];
+    const float c1 = J.g[row] * inv, c2 = s * inv * inv;
+    float* dv = J.dv + (size_t)row * J.cols;
+    for (int k = lane; k < J.cols; k += 64) dv[k] = c1 * (dW[k] - c2 * v[k]);
+    if (lane == 0) J.dg[row] = s * inv;
+}
+
 // plain Adam: grid (blocks, n_jobs), grid-stride
 __global__ __launch_bounds__(256) void adam_kernel(AdamBatch B, AdamHyper H) {
     const nero_adam_job& J = B.job[blockIdx.y];
@@ -113,6 +131,21 @@ int nero_wn_forward_batch(const nero_wn_job* jobs, int n_jobs, void* stream) {
     }
     hipLaunchKernelGGL(wn_forward_kernel, dim3((max_rows + 3) / 4, n_jobs), dim3(256), 0, (hipStream_t)stream, B);
     return nero_check_launch("nero_wn_forward_batch");
+}
+
+int nero_wn_backward_batch(const nero_wn_grad_job* jobs, int n_jobs, void* stream) {
+    if (n_jobs <= 0) return NERO_OK;
+    if (!jobs || n_jobs > NERO_MAX_WN_JOBS) return nero_fail(NERO_ERR_ARG, "nero_wn_backward_batch: bad job count");
+    WnGradBatch B;
+    int max_rows = 1;
+    for (int i = 0; i < n_jobs; ++i) {
+        if (!jobs[i].v || !jobs[i].g || !jobs[i].inv_norm || !jobs[i].dW || !jobs[i].dv || !jobs[i].dg || jobs[i].rows <= 0 || jobs[i].cols <= 0)
+            return nero_fail(NERO_ERR_ARG, "nero_wn_backward_batch: bad job");
+        B.job[i] = jobs[i];
+        max_rows = jobs[i].rows > max_rows ? jobs[i].rows : max_rows;
+    }
+    hipLaunchKernelGGL(wn_backward_kernel, dim3((max_rows + 3) / 4, n_jobs), dim3(256), 0, (hipStream_t)stream, B);
+    return nero_check_launch("nero_wn_backward_batch");
 }
 
 int nero_wn_adam_batch(const nero_wn_job* wn, int n_wn, const nero_adam_job* plain, int n_plain, float lr, float beta1, float beta2,

@@ -7,9 +7,11 @@ unchanged, and they are constructed with the same torch initialisers in the same
 
 These modules never run a PyTorch forward: the arithmetic lives in the HIP library (nero_amd/csrc).  What they provide is
 `effective()` -- the per-step reparametrised weights W = g * v / ||v||_row as autograd tensors -- which `nero_amd.ops`
-packs into the kernels' MFMA operand layout; the weight-norm backward stays in PyTorch.
+packs into the kernels' MFMA operand layout.  The weight-norm forward / backward of ALL Linears is one batched autograd node on CUDA
+(nero_amd/wn_fused.py, round 6); on CPU modules it stays torch._weight_norm per Linear.
 """
 import math
+import threading
 
 import numpy as np
 import torch
@@ -22,11 +24,47 @@ def _wn_linear(d_in, d_out):
     return nn.utils.weight_norm(nn.Linear(d_in, d_out))
 
 
+_WN = threading.local()
+
+
 def _eff(lin):
-    """effective (weight, bias) of a Linear, weight-normed or plain."""
+    """effective (weight, bias) of a Linear, weight-normed or plain.  Inside batched_weight_norm() every weight-normed Linear of the model
+    goes through ONE autograd node (nero_amd/wn_fused.py) instead of one torch._weight_norm each."""
     if hasattr(lin, 'weight_g'):
+        st = getattr(_WN, 'st', None)
+        if st is not None:
+            if st['w'] is None:                        # first pass: collect the modules in call order
+                st['lins'].append(lin)
+                return lin.weight_v, lin.bias          # (placeholder of the right shape; this pass's results are discarded)
+            return st['w'][id(lin)], lin.bias
         return torch._weight_norm(lin.weight_v, lin.weight_g, 0), lin.bias
     return lin.weight, lin.bias
+
+
+def batched_weight_norm(collect_fn, owner=None):
+    """run `collect_fn()` (something that calls .effective() on the model's networks) with every weight-normed Linear's effective weight
+    coming from ONE batched autograd node -> collect_fn's result.  Falls back to the per-Linear torch path when the batch node is not
+    usable (CPU modules) or NERO_WN_BATCH=0.  owner: the module the list of weight-normed Linears is cached on (the module tree does not
+    change between steps; without the cache every step walks the networks twice)."""
+    import os
+    from . import wn_fused
+    if os.environ.get('NERO_WN_BATCH', '1') == '0' or getattr(_WN, 'st', None) is not None:
+        return collect_fn()
+    uniq = getattr(owner, '_wn_lins', None) if owner is not None else None
+    _WN.st = {'lins': [], 'w': None}
+    try:
+        if uniq is None:
+            collect_fn()
+            uniq = list({id(l): l for l in _WN.st['lins']}.values())
+            if owner is not None:
+                object.__setattr__(owner, '_wn_lins', uniq)            # (not a submodule / parameter: keep nn.Module's registries out of it)
+        if not wn_fused.usable(uniq):
+            _WN.st = None
+            return collect_fn()
+        _WN.st['w'] = dict(zip((id(l) for l in uniq), wn_fused.weight_norm_batch(uniq)))
+        return collect_fn()
+    finally:
+        _WN.st = None
 
 
 class SDFNetwork(nn.Module):

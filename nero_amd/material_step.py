@@ -68,6 +68,12 @@ MAT_NAMES = ('metallic', 'roughness', 'albedo')
 
 
 def flatten_material_effective(shader):
+    """(names, tensors) of the Stage-II shader's effective weights; the weight-normed Linears through ONE batched node (fields.batched_weight_norm)"""
+    from .fields import batched_weight_norm
+    return batched_weight_norm(lambda: _flatten_material_effective(shader), owner=shader)
+
+
+def _flatten_material_effective(shader):
     names, ts = [], []
 
     def add(prefix, wb):

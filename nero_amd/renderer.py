@@ -127,9 +127,34 @@ class NeROShapeRenderer(nn.Module):
         if self.train_batch_i + rn >= self.tbn:
             self._shuffle_train_batch()
         rays_o, rays_d, near, far, human_poses = self._process_ray_batch(batch, self.train_poses, self._train_human_poses)
-        outputs = self.render(rays_o, rays_d, near, far, human_poses, -1, self.get_anneal_val(step), is_train=True, step=step)
+        kern, drv = self._train_driver(step)
+        outputs = self.render(rays_o, rays_d, near, far, human_poses, -1, self.get_anneal_val(step), is_train=True, step=step, _kern=kern, _driver=drv)
         outputs['loss_rgb'] = self.compute_rgb_loss(outputs['ray_rgb'], batch['rgbs'])
         return outputs
+
+    def _train_driver(self, step):
+        """(kern, driver) for the drop-in training path (forward({'step': s}) under the caller's own optimiser, INTEGRATION.md option A): the
+        C-level step driver packed with this step's effective weights, so that sampling, render forward and render backward are one C call
+        each instead of ~180 ctypes launches sequenced from Python -- at the reference's own batch (512 rays) the Python-sequenced step was
+        HOST-bound (8.3 ms of interpreter time around 5.3 ms of GPU work: scripts/r06/dropin_profile.py).  Same kernels, same order, same
+        bits as the Python-sequenced step (tests/test_stage1_driver.py).  (None, None) when the driver does not apply: no gradients wanted,
+        the first 1000 steps (InitSDFRegLoss extras), non-YAML network shapes, another GEMM engine, a CPU module, NERO_DROPIN_DRIVER=0."""
+        import os
+        if not torch.is_grad_enabled() or step is None or step < 1000 or os.environ.get('NERO_DROPIN_DRIVER', '1') == '0':
+            return None, None
+        dev = next(self.parameters()).device
+        if dev.type != 'cuda':
+            return None, None
+        from . import stage1
+        from .shape_step import flatten_effective
+        if not stage1.supported(self.cfg, self.color_network.cfg):
+            return None, None
+        drv = getattr(self, '_train_drv', None)
+        if drv is None or not drv.matches_current_modes():
+            drv = self._train_drv = stage1.Stage1Driver(self.cfg, self.color_network.cfg, dev)
+        names, eff = flatten_effective(self)
+        drv.pack([t.detach().contiguous() for t in eff])
+        return (names, eff, None), drv
 
     def render_image(self, pose, K, h, w, step=300000, chunk=None, extras=False):
         """nvs / test_step inner loop (network/renderer.py:189-222, 301-307): render one h x w view in chunks of test_ray_num rays,

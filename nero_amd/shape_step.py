@@ -3,6 +3,7 @@ allocator, kernel sequencing, autograd glue).  Mirrors NeROShapeRenderer.sample_
 (network/renderer.py:403-443, 550-606) and AppShadingNetwork.forward (network/field.py:591-651); every arithmetic step
 is a call into libnero_hip.so (include/nero_hip.h).  See DESIGN.md §2 for the kernel sequence."""
 import ctypes as C
+import os
 
 import torch
 
@@ -96,7 +97,13 @@ class ShapeKernels:
 
 
 def flatten_effective(net):
-    """-> (names, tensors): effective weights of a NeROShapeRenderer as a flat list of autograd tensors."""
+    """-> (names, tensors): effective weights of a NeROShapeRenderer as a flat list of autograd tensors (every weight-normed Linear through
+    ONE batched weight-norm node: fields.batched_weight_norm)"""
+    from .fields import batched_weight_norm
+    return batched_weight_norm(lambda: _flatten_effective(net), owner=net)
+
+
+def _flatten_effective(net):
     names, ts = [], []
 
     def add(prefix, wb):
@@ -522,6 +529,27 @@ def occ_loss(S, occ_prob, cfg, variance, occ_keys=None):
     sctx = S['sctx']
     L.check(lib.nero_occ_candidates(_p(S['x4']), _p(sctx['sdf4']), _p(sctx['normal']), _p(S['inner_idx']), _p(S['d']), T,
                                     C.c_float(cfg['occ_sdf_thresh']), n_in, _p(flag), st))
+    cap = int(cfg['occ_loss_max_pn'])
+    if 1 <= cap <= 4096 and os.environ.get('NERO_OCC_DEVICE', '1') != '0':
+        # round 6: the candidate subset chosen ON THE DEVICE (nero_occ_select: what the fused trainer's glue has done since round 4) -- no
+        # torch.nonzero, i.e. no host read-back in the middle of the step: at the reference's own batch that stall was 1 ms of a 6 ms
+        # drop-in step (scripts/r06/dropin_profile.py).  The march covers the fixed capacity `cap`; unused slots carry index -1 and weight 0;
+        # the mean divides by the kept count as a device scalar.  Same subset rule as below -- argsort(keys[:total], stable)[:cap], sorted --
+        # with keys drawn for every inner sample instead of for the candidates (not seed-comparable with the tensor path; tests pass keys).
+        keys = occ_keys.to(dev).contiguous().float() if occ_keys is not None else torch.rand(n_in, **f32)
+        if keys.numel() < n_in:
+            keys = torch.cat([keys, torch.full((n_in - keys.numel(),), float('inf'), **f32)])
+        cand = torch.empty(cap, dtype=torch.int32, device=dev)
+        counts = torch.zeros(2, dtype=torch.int32, device=dev)
+        lib.nero_occ_select_workspace.restype = C.c_size_t
+        ws = torch.empty(lib.nero_occ_select_workspace(n_in), dtype=torch.uint8, device=dev)
+        L.check(lib.nero_occ_select(_p(flag), n_in, _p(keys), cap, _p(cand), _p(counts), C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel()), st))
+        pts, dirs = torch.empty((cap, 3), **f32), torch.empty((cap, 3), **f32)
+        L.check(lib.nero_occ_gather(_p(S['x4']), _p(S['geo']), _p(cand), cap, _p(pts), _p(dirs), st))
+        gt = secondary_occlusion(K, pts, dirs, variance, 64, 16)
+        valid = (cand >= 0)
+        diff = (occ_prob[cand.clamp(min=0).long()].reshape(-1) - gt.reshape(-1)).abs() * valid
+        return diff.sum() / counts[0].clamp(min=1).to(torch.float32), counts[0]
     cand = torch.nonzero(flag)[:, 0]
     Pn = cand.numel()
     if Pn > cfg['occ_loss_max_pn']:

@@ -1,0 +1,171 @@
+"""Golden vectors AT THE BENCHMARKED SIZE (round 6; VERDICT r5 missing 3 / weak 2): the UNMODIFIED reference run on 1024 rays x (64+64+32)
+samples -- one rank's shard of BASELINE configs[2], and the shape (sampler rounds of width 64 / 80 / 96 / 112) of configs[1] -- so that the
+HIP step is compared with the REFERENCE ITSELF at size, not only with the oracle (which is pinned to the reference at 48 rays x 16+16+8).
+
+Build container only (needs /root/reference):   python oracle/gen_golden_at_size.py [bell] [bear]          TEST INFRASTRUCTURE ONLY.
+The reference is Python and does not travel; what travels is tests/golden/at_size_<case>_1024.npz (inputs + the reference's outputs).
+
+Per case (bell = configs/shape/syn/bell.yaml, bear = configs/shape/real/bear.yaml with the human light), schedule step 25000, occlusion
+loss on, weights from seed 6033 + perturb_state(variance 0.5) exactly as bench.py builds them (checksums stored):
+  1. the reference's own sample_ray (perturb on, draws from seed 3) with torch.searchsorted / torch.sort and the instance's `upsample`
+     and the module's `sample_pdf` wrapped: z_vals of all 1024 rays, and for the first 256 rays the inputs (z, sdf, inv_s) and results (section
+     weights, searchsorted indices, new z, merge permutation) of every up-sampling round -- the teacher-forcing data of the bit-exact index checks at the real round widths;
+  2. render(is_train=True) + the trainer's loss assembly + backward, teacher-forced on those z_vals, in float32 (what the reference ships)
+     AND in float64 (the ground truth): ray_rgb, gradient_error, std, loss_occ, loss, and a fixed sample of 1024 entries of every parameter
+     gradient of both runs (sample_index below) with each tensor's largest float64 entry.
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from oracle import ref_shim  # noqa: E402
+from oracle.golden_util import perturb_state, synthetic_rays, state_checksums  # noqa: E402
+from oracle.gen_golden_grads import _ide_closures_to  # noqa: E402
+
+OUT = os.path.join(REPO, 'tests', 'golden')
+R, STEP, VARIANCE, SEED, N_TRACE, N_SAMPLE, OCC_KEYS_SEED = 1024, 25000, 0.5, 6033, 256, 1024, 11
+BASE = {'freeze_inv_s_step': 15000, 'apply_occ_loss': True, 'occ_loss_step': 20000}        # bench.py's BELL (configs/shape/syn/bell.yaml)
+CASES = {'bell': {}, 'bear': {'shader_config': {'human_light': True}}}
+
+
+def sample_index(n, k=N_SAMPLE):
+    return np.unique(np.round(np.linspace(0, n - 1, min(n, k))).astype(np.int64))
+
+
+def occ_keys():
+    return torch.rand(R * 160, generator=torch.Generator().manual_seed(OCC_KEYS_SEED))
+
+
+def build(renderer, cfg):
+    torch.set_default_dtype(torch.float32)
+    torch.manual_seed(SEED)
+    net = renderer.NeROShapeRenderer(cfg, training=False)
+    perturb_state(net, VARIANCE)
+    net.train()
+    return net
+
+
+def run_case(name, extra):
+    renderer, _ = ref_shim.load_reference()
+    cfg = {**BASE, **extra}
+    net = build(renderer, cfg)
+    rec = {}
+    for k, v in state_checksums({k: v.detach().clone() for k, v in net.state_dict().items()}).items():
+        rec['ck/' + k] = v
+    o, d, poses_img, gt = synthetic_rays(R, seed=1, window=200)
+    near, far = net.near_far_from_sphere(o, d)
+    hp = torch.cat([net.get_human_coordinate_poses(poses_img[i:i + 1].clone()) for i in range(R)], 0)     # (one pose at a time: gen_golden.py)
+    anneal = float(net.get_anneal_val(STEP))
+    torch.manual_seed(3)
+    rand1 = torch.rand([R, 1])
+    rand_bg = torch.rand([R, net.cfg['n_bg_samples']])
+
+    # ---- 1. the reference's sampler, every round recorded ---------------------------------------------------------------------------
+    rounds, searched, sorted_idx, pdf_weights = [], [], [], []
+    _ss, _sort, _up, _pdf = torch.searchsorted, torch.sort, net.upsample, renderer.sample_pdf
+
+    def pdf(bins, weights, *a, **k):                      # (network/renderer.py:384 calls the name `sample_pdf` of its own module namespace)
+        pdf_weights.append(weights.clone())
+        return _pdf(bins, weights, *a, **k)
+
+    def ss(*a, **k):
+        r = _ss(*a, **k)
+        searched.append(r.clone())
+        return r
+
+    def srt(*a, **k):
+        r = _sort(*a, **k)
+        sorted_idx.append(r[1].clone())
+        return r
+
+    def up(rays_o, rays_d, z_vals, sdf, n_importance, inv_s):
+        z_new = _up(rays_o, rays_d, z_vals, sdf, n_importance, inv_s)
+        rounds.append(dict(z=z_vals.clone(), sdf=sdf.reshape(z_vals.shape).clone(), inv_s=float(inv_s.reshape(-1)[0]), z_new=z_new.clone()))
+        assert float((inv_s - inv_s.reshape(-1)[0]).abs().max()) == 0.0
+        return z_new
+    t0 = time.time()
+    torch.manual_seed(3)
+    torch.searchsorted, torch.sort, net.upsample, renderer.sample_pdf = ss, srt, up, pdf
+    try:
+        with torch.no_grad():
+            z_ref = net.sample_ray(o, d, near, far, net.cfg['perturb'])
+    finally:
+        torch.searchsorted, torch.sort, renderer.sample_pdf = _ss, _sort, _pdf
+        del net.upsample
+    assert len(rounds) == len(searched) == len(sorted_idx) == len(pdf_weights) == net.cfg['up_sample_steps']
+    for i, (rd, a, b) in enumerate(zip(rounds, searched, sorted_idx)):
+        n = rd['z'].shape[1]
+        rec[f'tr/weights{i}'] = pdf_weights[i][:N_TRACE].numpy()
+        assert pdf_weights[i].shape[1] == n - 1
+        rec[f'tr/z{i}'] = rd['z'][:N_TRACE].numpy()
+        rec[f'tr/sdf{i}'] = rd['sdf'][:N_TRACE].numpy()
+        rec[f'tr/inv_s{i}'] = np.float32(rd['inv_s'])
+        rec[f'tr/z_new{i}'] = rd['z_new'][:N_TRACE].numpy()
+        rec[f'tr/inds{i}'] = a[:N_TRACE].numpy().astype(np.int16)
+        rec[f'tr/index{i}'] = b[:N_TRACE].numpy().astype(np.int16)
+        assert a.max() <= n and b.shape[1] == n + rd['z_new'].shape[1]
+    print(f'{name}: sampler {time.time() - t0:.1f} s, round widths {[r["z"].shape[1] for r in rounds]}, inv_s {[r["inv_s"] for r in rounds]}', flush=True)
+
+    # ---- 2. render + loss + backward on those z_vals, float32 and float64 -----------------------------------------------------------------
+    keys = occ_keys()
+    res = {}
+    for tag, dtype in (('32', torch.float32), ('64', torch.float64)):
+        t0 = time.time()
+        net = build(renderer, cfg)
+        torch.set_default_dtype(dtype)
+        try:
+            net = net.to(dtype)
+            _ide_closures_to(net, dtype)
+            zv = z_ref.to(dtype)
+            net.sample_ray = lambda *a, **k: zv           # teacher forcing (instance attribute: the reference's code is untouched)
+            _rp = torch.randperm
+            torch.randperm = lambda n, **k: torch.argsort(keys[:n], stable=True)
+            try:
+                torch.manual_seed(3)
+                out = net.render(o.to(dtype), d.to(dtype), near.to(dtype), far.to(dtype), hp.to(dtype), -1, anneal, is_train=True, step=STEP)
+            finally:
+                torch.randperm = _rp
+            loss_rgb = net.compute_rgb_loss(out['ray_rgb'], gt.to(dtype))
+            loss = loss_rgb.mean() + (out['gradient_error'] * 0.1).mean() + out['loss_occ'].mean()      # train/trainer.py:127-137
+            loss.backward()
+        finally:
+            torch.set_default_dtype(torch.float32)
+        res[tag] = dict(ray_rgb=out['ray_rgb'].detach(), gerr=out['gradient_error'].detach(), std=float(out['std']), loss_occ=float(out['loss_occ'].reshape(-1)[0]),
+                        loss=float(loss), grads={k: (p.grad.detach().double().reshape(-1) if p.grad is not None else torch.zeros(p.numel(), dtype=torch.float64))
+                                                 for k, p in net.named_parameters()})
+        print(f'{name}: float{tag} render + backward {time.time() - t0:.1f} s, loss {float(loss):.7f}, N_in {out["gradient_error"].shape[0]}, '
+              f'loss_occ {float(out["loss_occ"].reshape(-1)[0]):.6f}', flush=True)
+        del net, out, loss
+    assert res['32']['gerr'].shape == res['64']['gerr'].shape
+    rec.update(meta=json.dumps(dict(name=name, cfg=cfg, R=R, step=STEP, variance=VARIANCE, seed=SEED, anneal=anneal, occ_keys_seed=OCC_KEYS_SEED,
+                                    n_trace=N_TRACE, n_sample=N_SAMPLE)),
+               o=o.numpy(), d=d.numpy(), human_poses=hp.numpy(), gt=gt.numpy(), near=near.numpy(), far=far.numpy(), rand1=rand1.numpy(),
+               rand_bg=rand_bg.numpy(), z_vals=z_ref.numpy(),
+               ray_rgb32=res['32']['ray_rgb'].numpy(), ray_rgb64=res['64']['ray_rgb'].numpy(),
+               gradient_error32=res['32']['gerr'].numpy(), gradient_error64=res['64']['gerr'].numpy().astype(np.float32),
+               std32=np.float64(res['32']['std']), std64=np.float64(res['64']['std']),
+               loss_occ32=np.float64(res['32']['loss_occ']), loss_occ64=np.float64(res['64']['loss_occ']),
+               loss32=np.float64(res['32']['loss']), loss64=np.float64(res['64']['loss']))
+    worst = 0.0
+    for k in res['64']['grads']:
+        idx = sample_index(res['64']['grads'][k].numel())
+        g32, g64 = res['32']['grads'][k].numpy()[idx], res['64']['grads'][k].numpy()[idx]
+        rec['g32/' + k], rec['g64/' + k] = g32.astype(np.float32), g64.astype(np.float64)
+        rec['max64/' + k] = np.float64(res['64']['grads'][k].abs().max())
+        worst = max(worst, float(np.abs(g32 - g64).max()) / (float(rec['max64/' + k]) + 1e-300))
+    path = os.path.join(OUT, f'at_size_{name}_{R}.npz')
+    np.savez_compressed(path, **rec)
+    rgb_spread = float((res['32']['ray_rgb'].double() - res['64']['ray_rgb']).abs().max() / res['64']['ray_rgb'].abs().max())
+    print(f'{name}: wrote {path} ({os.path.getsize(path) / 1e6:.1f} MB); reference fp32-vs-fp64 spread: ray_rgb {rgb_spread:.2e}, worst gradient tensor {worst:.2e}', flush=True)
+
+
+if __name__ == '__main__':
+    want = sys.argv[1:] or list(CASES)
+    for n in want:
+        run_case(n, CASES[n])

@@ -225,3 +225,52 @@ def test_inference_cache_sees_fused_updates():
     ts.cursor = 0
     c = ts.forward_only(25000)
     assert torch.equal(b, c)
+
+
+@pytest.mark.gpu
+def test_batched_weight_norm_node_matches_torch_per_linear(monkeypatch):
+    """nero_amd/wn_fused.py (round 6): ALL weight-normed Linears of the drop-in renderer through ONE autograd node (nero_wn_forward_batch /
+    nero_wn_backward_batch) against torch._weight_norm per Linear (NERO_WN_BATCH=0, the reference's own formulation): effective weights,
+    the loss of a render step and every parameter gradient (weight_g, weight_v, bias -- the reference's state_dict names) agree to fp32
+    rounding; gradients ACCUMULATE across two backward passes without zero_grad; the state_dict is untouched."""
+    from nero_amd.renderer import NeROShapeRenderer
+    from nero_amd.shape_step import flatten_effective
+    from nero_amd.synthetic import perturb_state, synthetic_rays
+    from nero_amd.train import shape_training_loss
+    cfg = {'n_samples': 16, 'n_importance': 16, 'n_bg_samples': 8, 'freeze_inv_s_step': 15000, 'apply_occ_loss': True, 'occ_loss_step': 20000,
+           'shader_config': {'human_light': True}}
+    torch.manual_seed(6033)
+    net = NeROShapeRenderer(cfg, training=False)
+    perturb_state(net, 0.4)
+    net = net.cuda()
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    o, d, poses_img, gt = synthetic_rays(192, seed=1)
+    o, d, gt = o.cuda(), d.cuda(), gt.cuda()
+    near, far = net.near_far_from_sphere(o, d)
+    hp = torch.zeros(192, 3, 4, device='cuda')
+    zv = net.sample_ray(o, d, near, far, 0.0)
+
+    def run(batch, passes=1):
+        monkeypatch.setenv('NERO_WN_BATCH', '1' if batch else '0')
+        net.zero_grad(set_to_none=True)
+        names, eff = flatten_effective(net)
+        for _ in range(passes):
+            out = net.render(o, d, near, far, hp, -1, 0.5, is_train=True, step=25000, z_vals=zv)
+            loss = shape_training_loss(net, out, gt, 25000)
+            loss.backward()
+        torch.cuda.synchronize()
+        return [e.detach().clone() for e in eff], float(loss), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+    e0, l0, g0 = run(False)
+    e1, l1, g1 = run(True)
+    assert len(e0) == len(e1) and all(a.shape == b.shape for a, b in zip(e0, e1))
+    worst_w = max(float((a - b).abs().max() / (a.abs().max() + 1e-30)) for a, b in zip(e0, e1))
+    assert worst_w < 1e-6, worst_w
+    assert abs(l0 - l1) < 1e-6 * max(1.0, abs(l0)), (l0, l1)
+    assert set(g0) == set(g1) and len(g0) >= 3 * 37
+    worst_g = max(float((g0[k] - g1[k]).abs().max() / (g0[k].abs().max() + 1e-30)) for k in g0 if float(g0[k].abs().max()) > 0)
+    assert worst_g < 2e-4, worst_g                      # (two evaluations of the step with effective weights 1e-7 apart: ReLU ties aside, 1e-6)
+    _, _, g2 = run(True, passes=2)                       # accumulation: twice the gradient
+    worst_acc = max(float((g2[k] - 2 * g1[k]).abs().max() / (g1[k].abs().max() + 1e-30)) for k in g1 if float(g1[k].abs().max()) > 0)
+    assert worst_acc < 1e-5, worst_acc
+    sd1 = net.state_dict()
+    assert all(torch.equal(sd0[k], sd1[k]) for k in sd0)
