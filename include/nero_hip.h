@@ -191,6 +191,11 @@ int nero_mlp_backward(const nero_bwd_chain* chain /*host*/, int n_rows, void* st
  * Initial value: NERO_F16_PAIRED in the environment, default 3.  Process-wide, not thread-safe against concurrent launches.
  * (No reference counterpart: an execution detail of network/field.py's nn.Linear stacks.) */
 int nero_f16_paired(int mask);
+/* Forward chains that save nothing (no saved activations, no ReLU masks: the sampler's SDF evaluations, forward-only inference) on the
+ * row-owner kernel (round 6, mlp_f16r.hip): a wave owns 32 rows and all features, activation planes in registers, weights through an LDS-DMA
+ * ring.  Bit-identical results.  mask bit 0 = on for launches of >= 128 rows per CU, bit 1 = whatever the size; < 0 queries; returns the
+ * previous selection (default: NERO_F16_ROWOWNER or 0). */
+int nero_f16_rowowner(int mask);
 
 /* ---- weight-gradient GEMM ------------------------------------------------------------------------------------
  * dW[n][k] (+)= sum_r D0[r][n] * B0[r][k] (+ sum_r D1[r][n] * B1[r][k]),  db[n] (+)= sum_r D0[r][n]

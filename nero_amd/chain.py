@@ -55,6 +55,15 @@ def f16_paired(mask=-1):
     return int(L.lib.nero_f16_paired(int(mask)))
 
 
+def f16_rowowner(mask=-1):
+    """forward chains that save nothing on the row-owner kernel (include/nero_hip.h::nero_f16_rowowner, mlp_f16r.hip): bit 0 = launches of at
+    least 128 rows per CU, bit 1 = every launch; mask < 0 only queries.  Returns the previous mask.  Bit-identical results
+    (tests/test_rowowner_engine.py)."""
+    L.lib.nero_f16_rowowner.argtypes = [C.c_int]
+    L.lib.nero_f16_rowowner.restype = C.c_int
+    return int(L.lib.nero_f16_rowowner(int(mask)))
+
+
 # test hook (tests/test_parity_at_size.py, gate-teacher-forced gradient parity): when a list, every saving forward launch appends the
 # ReLU sign masks its kernel wrote (nero_fwd_layer.relu_mask: one word per (row, 32-column tile)) with the chain's signature
 MASK_CAPTURE = None

@@ -852,7 +852,32 @@ static void launch_fwd(const nero_fwd_chain* ch, int n_rows, int n_tiles, dim3 g
     hipLaunchKernelGGL((fwd_f16_kernel<WIDE, NVI>), grid, dim3(512), f16_lds_bytes(WIDE ? 1 : 0), stream, *ch, n_rows, n_tiles);
 }
 
+// NERO_F16_ROWOWNER: forward chains WITHOUT saves / masks on the row-owner kernel of mlp_f16r.hip (a wave owns 32 rows and all features, planes
+// in registers, weights through an LDS-DMA ring): 1 = launches of at least 128 rows per CU, 3 = every launch (tests), 0 = off.
+#ifndef NERO_F16_ROWOWNER_DEFAULT
+#define NERO_F16_ROWOWNER_DEFAULT 0
+#endif
+static int g_rowowner = -1;
+static int nero_rowowner_mask() {
+    if (g_rowowner < 0) { const char* e = getenv("NERO_F16_ROWOWNER"); g_rowowner = (e ? atoi(e) : NERO_F16_ROWOWNER_DEFAULT) & 3; }
+    return g_rowowner;
+}
+extern "C" int nero_f16_rowowner(int mask) {           // mask >= 0: select; returns the previous selection (include/nero_hip.h)
+    const int prev = nero_rowowner_mask();
+    if (mask >= 0) g_rowowner = mask & 3;
+    return prev;
+}
+
 int nero_f16_forward(const nero_fwd_chain* ch, int n_rows, hipStream_t stream) {
+    {
+        const int m = nero_rowowner_mask();
+        if ((m & 1) && ((m & 2) || n_rows >= 128 * nero_cu_count()) && nero_f16r_covers(ch)) {
+            for (int l = 0; l < ch->n_layers; ++l)
+                if ((ch->layer[l].k_main | ch->layer[l].k_aux) & 15)
+                    return nero_fail(NERO_ERR_ARG, "nero_mlp_forward(f16x3): k_main / k_aux must be multiples of 16");
+            return nero_f16r_forward(ch, n_rows, stream);
+        }
+    }
     if (nero_paired(0, n_rows) && !ch->aux_wide) return nero_f16p_forward(ch, n_rows, stream);
     const int n_tiles = (n_rows + 63) / 64, cus = nero_cu_count();
     const dim3 grid(nero_chain_grid(n_tiles, 0));

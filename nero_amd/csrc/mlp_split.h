@@ -22,6 +22,9 @@ int nero_f16_backward(const nero_bwd_chain* ch, int n_rows, hipStream_t stream);
 int nero_f16p_forward(const nero_fwd_chain* ch, int n_rows, hipStream_t stream);
 int nero_f16p_tangent(const nero_tan_chain* ch, int n_rows, hipStream_t stream);
 int nero_f16p_backward(const nero_bwd_chain* ch, int n_rows, hipStream_t stream);
+// forward chains that save nothing, with the chain walk re-cut so that a wave owns rows (mlp_f16r.hip; NERO_F16_ROWOWNER inside nero_f16_forward)
+bool nero_f16r_covers(const nero_fwd_chain* ch);
+int nero_f16r_forward(const nero_fwd_chain* ch, int n_rows, hipStream_t stream);
 int nero_f16_dw(const nero_dw_job* job, int n_rows, int rows_per_slice, int slices, float* partials, int n_pad, int k_pad,
                 hipStream_t stream);                                                    // mlp_f16dw.hip
 // several weight-gradient jobs over the SAME rows in one launch (grid.y = job): kernel argument of dw_f16_batch_kernel / dw_reduce_batch_kernel
