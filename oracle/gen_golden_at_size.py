@@ -2,7 +2,7 @@
 samples -- one rank's shard of BASELINE configs[2], and the shape (sampler rounds of width 64 / 80 / 96 / 112) of configs[1] -- so that the
 HIP step is compared with the REFERENCE ITSELF at size, not only with the oracle (which is pinned to the reference at 48 rays x 16+16+8).
 
-Build container only (needs /root/reference):   python oracle/gen_golden_at_size.py [bell] [bear]          TEST INFRASTRUCTURE ONLY.
+Build container only (needs /root/reference):   python oracle/gen_golden_at_size.py [bell] [bear] [mat_bell]          TEST INFRASTRUCTURE ONLY.
 The reference is Python and does not travel; what travels is tests/golden/at_size_<case>_1024.npz (inputs + the reference's outputs).
 
 Per case (bell = configs/shape/syn/bell.yaml, bear = configs/shape/real/bear.yaml with the human light), schedule step 25000, occlusion
@@ -165,7 +165,121 @@ def run_case(name, extra):
     print(f'{name}: wrote {path} ({os.path.getsize(path) / 1e6:.1f} MB); reference fp32-vs-fp64 spread: ray_rgb {rgb_spread:.2e}, worst gradient tensor {worst:.2e}', flush=True)
 
 
+# ---- Stage II at size: the reference's MCShadingNetwork on 1024 surface points x (128 + 128) Monte-Carlo directions ---------------------------
+MAT_P, MAT_STEP, MAT_RAY_STRIDE = 1024, 5000, 64
+MAT_CASES = {'mat_bell': dict(diffuse_sample_num=128, specular_sample_num=128, human_lights=False, outer_light_version='direction')}
+
+
+def material_inputs(Pn, seed=5):
+    """surface points = camera-ray hits on the golden mesh (tests/test_parity_at_size.py::_material_inputs, oracle/gen_golden.py::run_material_case)"""
+    from oracle.tracer_oracle import trace_bruteforce_margins
+    from tests.helpers import golden_mesh
+    v, f = golden_mesh()
+    o, d, poses_img, gt = synthetic_rays(6 * Pn, seed=seed, window=120)
+    pos, nrm, depth, tri, amb = trace_bruteforce_margins(v, f, o.numpy(), d.numpy())
+    sel = np.nonzero((tri >= 0) & ~amb)[0][:Pn]
+    assert sel.shape[0] == Pn
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    n = torch.nn.functional.normalize(-t(nrm[sel]), dim=-1)
+    g = torch.Generator().manual_seed(3)
+    return dict(pts=t(pos[sel]), view=-d[sel], normals=n, poses=poses_img[sel], gt=gt[sel], rand_d=torch.rand(Pn, 1, 1, generator=g),
+                rand_s=torch.rand(Pn, 1, 1, generator=g), reg_ang=torch.rand(Pn, 1, generator=g),
+                reg_eps=torch.normal(mean=0.0, std=0.05, size=[Pn, 1], generator=g))
+
+
+def run_material(name, shader_cfg):
+    """MCShadingNetwork.forward + material_regularization + the diffuse-light regulariser + backward of the UNMODIFIED reference, float32 and
+    float64, secondary rays answered by the float64 brute-force tracer oracle (C restatement) behind NeROMaterialRenderer.trace's contract;
+    the float64 run replays the float32 run's hits (its own rays would flip razor-edge hits).  Stored for the HIP test: inputs, the hits
+    (depth of every ray; position and normal of the hit rays), every 64th secondary ray, outputs, losses, gradient samples."""
+    import torch.nn as nn
+    from tests.helpers import CTracer, golden_mesh, tracer_contract
+    renderer, field = ref_shim.load_reference()
+    mesh = golden_mesh()
+    I = material_inputs(MAT_P)
+    rr = renderer.NeROShapeRenderer.__new__(renderer.NeROShapeRenderer)          # only for get_human_coordinate_poses (same code in both renderers)
+    rr.cfg = {'fixed_camera': False}
+    hp = torch.cat([renderer.NeROShapeRenderer.get_human_coordinate_poses(rr, I['poses'][i:i + 1].clone()) for i in range(MAT_P)], 0)
+    rec, res, src = {}, {}, None
+    for tag, dtype in (('32', torch.float32), ('64', torch.float64)):
+        t0 = time.time()
+        tr = CTracer(*mesh, replay=src)
+        src = src or tr
+
+        class Holder(nn.Module):
+            pass
+        torch.set_default_dtype(torch.float32)
+        torch.manual_seed(SEED)
+        net = Holder()
+        net.shader_network = field.MCShadingNetwork(shader_cfg, tracer_contract(tr))
+        perturb_state(net, None)
+        if tag == '32':
+            for k, v in state_checksums({k: v.detach().clone() for k, v in net.state_dict().items()}).items():
+                rec['ck/' + k] = v
+        torch.set_default_dtype(dtype)
+        try:
+            net = net.to(dtype)
+            _ide_closures_to(net, dtype)
+            sn = net.shader_network
+            f = lambda a: a.to(dtype)
+            queue = [f(I['rand_d']), f(I['rand_s']), f(I['reg_ang']), f(I['reg_eps'])]
+            _rand, _normal = torch.rand, torch.normal
+            torch.rand = lambda *a, **k: queue.pop(0)     # the stored draws, in the order the reference asks for them (oracle/gen_golden_grads.py)
+            torch.normal = lambda *a, **k: queue.pop(0)
+            try:
+                rgb, out = sn(f(I['pts']), f(I['view']), f(I['normals']), f(hp), MAT_STEP, True)
+                loss_rgb = torch.sqrt(torch.sum((f(I['gt']) - rgb) ** 2, dim=-1) + 1e-3)
+                reg = sn.material_regularization(f(I['pts']), f(I['normals']), out['metallic'], out['roughness'], out['albedo'], MAT_STEP)
+            finally:
+                torch.rand, torch.normal = _rand, _normal
+            assert not queue
+            dl = out['diffuse_light']
+            white = torch.sum(torch.abs(dl - torch.mean(dl, dim=-1, keepdim=True)), dim=-1) * 0.1
+            loss = loss_rgb.mean() + reg.mean() + white.mean()
+            loss.backward()
+        finally:
+            torch.set_default_dtype(torch.float32)
+        res[tag] = dict(rgb=rgb.detach(), reg=reg.detach(), white=white.detach(), loss=float(loss),
+                        out={k: out[k].detach() for k in ('albedo', 'roughness', 'metallic', 'diffuse_light', 'specular_light', 'specular_color')},
+                        grads={k: (p.grad.detach().double().reshape(-1) if p.grad is not None else torch.zeros(p.numel(), dtype=torch.float64))
+                               for k, p in net.named_parameters()})
+        print(f'{name}: float{tag} {time.time() - t0:.1f} s, loss {float(loss):.7f}, reg {float(reg.mean()):.3e}, tracer calls {len(src.raw)}', flush=True)
+    # the hits both runs saw
+    assert len(src.raw) == 1, len(src.raw)                 # get_lights traces all P x D secondary rays in one call (network/field.py:856-880)
+    pos, nrm, depth = src.raw[0]
+    ro, rd = src.rays[0]
+    hit = depth < 10
+    rec.update(meta=json.dumps(dict(name=name, shader_cfg=shader_cfg, P=MAT_P, step=MAT_STEP, seed=SEED, n_sample=N_SAMPLE, ray_stride=MAT_RAY_STRIDE,
+                                    n_rays=int(depth.shape[0]), n_hit=int(hit.sum()))),
+               pts=I['pts'].numpy(), view=I['view'].numpy(), normals=I['normals'].numpy(), human_poses=hp.numpy(), gt=I['gt'].numpy(),
+               rand_d=I['rand_d'].numpy(), rand_s=I['rand_s'].numpy(), reg_ang=I['reg_ang'].numpy(), reg_eps=I['reg_eps'].numpy(),
+               hit_depth=depth.astype(np.float32), hit_pos=pos[hit].astype(np.float32), hit_nrm=nrm[hit].astype(np.float32),
+               ray_o=ro[::MAT_RAY_STRIDE].astype(np.float32), ray_d=rd[::MAT_RAY_STRIDE].astype(np.float32))
+    for tag in ('32', '64'):
+        r = res[tag]
+        rec['rgb' + tag] = r['rgb'].numpy().astype(np.float32 if tag == '32' else np.float64)
+        rec['loss_mat_reg' + tag] = r['reg'].numpy().astype(np.float64)
+        rec['loss_white' + tag] = r['white'].numpy().astype(np.float64)
+        rec['loss' + tag] = np.float64(r['loss'])
+        for k, v in r['out'].items():
+            rec[f'out{tag}/{k}'] = v.numpy().astype(np.float32)
+    worst = 0.0
+    for k in res['64']['grads']:
+        idx = sample_index(res['64']['grads'][k].numel())
+        g32, g64 = res['32']['grads'][k].numpy()[idx], res['64']['grads'][k].numpy()[idx]
+        rec['g32/' + k], rec['g64/' + k] = g32.astype(np.float32), g64.astype(np.float64)
+        rec['max64/' + k] = np.float64(res['64']['grads'][k].abs().max())
+        worst = max(worst, float(np.abs(g32 - g64).max()) / (float(rec['max64/' + k]) + 1e-300))
+    path = os.path.join(OUT, f'at_size_{name}_{MAT_P}.npz')
+    np.savez_compressed(path, **rec)
+    print(f'{name}: wrote {path} ({os.path.getsize(path) / 1e6:.1f} MB); hit fraction {float(hit.mean()):.3f}; reference fp32-vs-fp64: rgb '
+          f'{float((res["32"]["rgb"].double() - res["64"]["rgb"]).abs().max() / res["64"]["rgb"].abs().max()):.2e}, worst gradient tensor {worst:.2e}', flush=True)
+
+
 if __name__ == '__main__':
-    want = sys.argv[1:] or list(CASES)
+    want = sys.argv[1:] or (list(CASES) + list(MAT_CASES))
     for n in want:
-        run_case(n, CASES[n])
+        if n in CASES:
+            run_case(n, CASES[n])
+        else:
+            run_material(n, MAT_CASES[n])
