@@ -455,7 +455,11 @@ __device__ __forceinline__ void combine_acc(float4 (&gq)[2][4], const f32x16 (&a
 }
 
 // one feature tile of one reverse layer; `first` = the chain's first dense layer (its input gradient goes to d_init / d_aux)
-template <bool PA_EARLY, int NW>
+// MASKS (round 6): a chain whose reverse pass needs NO saved activation and NO injection -- every act_prev is ReLU with sign words
+// (nero_bwd_layer.mask_prev) or the identity: the material / light predictors and the NeRF++ networks.  Compiled without the softplus path the
+// tile keeps 2 sign words instead of 32 activation registers, and the kernel fits its 256 registers without the 14-16 spills of the generic
+// bwd_p_kernel (which lost to the 512-thread kernel for exactly that reason).
+template <bool PA_EARLY, int NW, bool MASKS>
 __device__ __forceinline__ void bwd_tile(const nero_bwd_chain& ch, const nero_bwd_layer& L, int l, const Ctx& c, int t, bool first, float rs0, float rs1,
                                          float4 (&val)[2][4], float (&m)[2]) {
     m[0] = m[1] = 0.f;
@@ -464,14 +468,15 @@ __device__ __forceinline__ void bwd_tile(const nero_bwd_chain& ch, const nero_bw
     const size_t goff = (size_t)(c.row0 + c.i) * NERO_HID + fbase;
     const size_t boff = (size_t)c.row0 * NERO_HID + 32 * t;
     const int steps = L.n_out >> 4;
-    const bool has_inj = !first && L.inj != nullptr;
+    const bool has_inj = !MASKS && !first && L.inj != nullptr;
     const char* xp = c.S.actp + c.i * SA + 16 * c.h;
     // saved activations of this lane's outputs (ReLU: 1 / 0 from the sign words).  PA_EARLY: requested in FRONT of the main GEMM (32
     // registers through the k-loop, the HBM round trip under it); default: behind it (the round trip under the sibling workgroup's MFMAs)
     float4 pa[2][4];
     auto load_pa = [&]() {
         if (first || !live_t) return;
-        if (L.mask_prev && L.act_prev == NERO_ACT_RELU) {   // 4 bytes per (row, tile) instead of 128: only the sign is needed
+        if (MASKS && L.act_prev != NERO_ACT_RELU) return;   // (identity: the activation is not looked at)
+        if (MASKS || (L.mask_prev && L.act_prev == NERO_ACT_RELU)) {   // 4 bytes per (row, tile) instead of 128: only the sign is needed
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const unsigned bits = L.mask_prev[(size_t)(c.row0 + 32 * r + c.i) * 8 + t] >> (16 * c.h);
@@ -480,7 +485,7 @@ __device__ __forceinline__ void bwd_tile(const nero_bwd_chain& ch, const nero_bw
                     pa[r][g] = make_float4((bits >> (4 * g)) & 1u ? 1.f : 0.f, (bits >> (4 * g + 1)) & 1u ? 1.f : 0.f,
                                            (bits >> (4 * g + 2)) & 1u ? 1.f : 0.f, (bits >> (4 * g + 3)) & 1u ? 1.f : 0.f);
             }
-        } else {
+        } else if (!MASKS) {
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -558,7 +563,7 @@ __device__ __forceinline__ void bwd_tile(const nero_bwd_chain& ch, const nero_bw
 #pragma unroll
         for (int g = 0; g < 4; ++g) ijp[r][g] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (L.act_prev == NERO_ACT_RELU) bwd_values_h<NERO_ACT_RELU, false>(gq, pa, goff, has_inj, L, c.row0, c.i, fbase, c.n_rows, val, m, ijp);
-    else if (L.act_prev == NERO_ACT_SOFTPLUS100) bwd_values_h<NERO_ACT_SOFTPLUS100, false>(gq, pa, goff, has_inj, L, c.row0, c.i, fbase, c.n_rows, val, m, ijp);
+    else if (!MASKS && L.act_prev == NERO_ACT_SOFTPLUS100) bwd_values_h<NERO_ACT_SOFTPLUS100, false>(gq, pa, goff, has_inj, L, c.row0, c.i, fbase, c.n_rows, val, m, ijp);
     else bwd_values_h<NERO_ACT_NONE, false>(gq, pa, goff, has_inj, L, c.row0, c.i, fbase, c.n_rows, val, m, ijp);
     if (L.delta_prev) {
         acc_to_global_rows<64 / NW>(c.scr, val[0], L.delta_prev + boff, c.lane);
@@ -567,7 +572,7 @@ __device__ __forceinline__ void bwd_tile(const nero_bwd_chain& ch, const nero_bw
     publish_rowmax(c.S.rmax, m[0], m[1], t, c.i, c.h);
 }
 
-template <int NW>
+template <int NW, bool MASKS>
 __global__ __launch_bounds__(NW * 64, NW / 2) void bwd_p_kernel(nero_bwd_chain ch, int n_rows) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Ctx c = make_ctx<NW>(smem, n_rows);
@@ -589,8 +594,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void bwd_p_kernel(nero_bwd_chain c
         const float rs0 = c.S.rs_main[c.i], rs1 = c.S.rs_main[32 + c.i];
         float4 v0[2][4], v1[2][4];
         float m0[2], m1[2];
-        bwd_tile<P_PA_EARLY_A, NW>(ch, L, l, c, c.wave, first, rs0, rs1, v0, m0);
-        if (NW == 4) bwd_tile<P_PA_EARLY_B, NW>(ch, L, l, c, c.wave + NW, first, rs0, rs1, v1, m1);
+        bwd_tile<P_PA_EARLY_A, NW, MASKS>(ch, L, l, c, c.wave, first, rs0, rs1, v0, m0);
+        if (NW == 4) bwd_tile<P_PA_EARLY_B, NW, MASKS>(ch, L, l, c, c.wave + NW, first, rs0, rs1, v1, m1);
         if (first) break;
         commit_planes_p<NW>(c, v0, v1, c.wave < L.k_main_tiles, c.wave + NW < L.k_main_tiles);
     }
@@ -655,11 +660,23 @@ int nero_f16p_tangent(const nero_tan_chain* ch, int n_rows, hipStream_t stream) 
     return NERO_OK;
 }
 
+// a chain whose reverse walk looks at no saved activation and adds no injection (bwd_tile<.., MASKS>)
+bool nero_f16p_masks_only(const nero_bwd_chain* ch) {
+    for (int l = 0; l < ch->n_layers; ++l) {
+        const nero_bwd_layer& L = ch->layer[l];
+        if (L.inj || L.inj_adot) return false;
+        if (L.a_prev == nullptr) continue;                 // the first layer: no activation in front of it
+        if (L.act_prev == NERO_ACT_NONE) continue;
+        if (!(L.act_prev == NERO_ACT_RELU && L.mask_prev)) return false;
+    }
+    return true;
+}
 int nero_f16p_backward(const nero_bwd_chain* ch, int n_rows, hipStream_t stream) {
     for (int l = 0; l < ch->n_layers; ++l)
         if (ch->layer[l].n_out & 15) return nero_fail(NERO_ERR_ARG, "nero_mlp_backward(f16x3p): n_out must be a multiple of 16");
     if (ch->d_aux && (ch->ld_daux & 3)) return nero_fail(NERO_ERR_ARG, "nero_mlp_backward(f16x3p): ld_daux must be a multiple of 4");
     if (ch->d_init && (ch->ld_dinit & 3)) return nero_fail(NERO_ERR_ARG, "nero_mlp_backward(f16x3p): ld_dinit must be a multiple of 4");
-    launch_p(bwd_p_kernel<4>, bwd_p_kernel<8>, nero_pw(2), ch, n_rows, stream);
+    if (nero_f16p_masks_only(ch)) launch_p(bwd_p_kernel<4, true>, bwd_p_kernel<8, true>, nero_pw(2), ch, n_rows, stream);
+    else launch_p(bwd_p_kernel<4, false>, bwd_p_kernel<8, false>, nero_pw(2), ch, n_rows, stream);
     return NERO_OK;
 }

@@ -905,8 +905,16 @@ int nero_f16_tangent(const nero_tan_chain* ch, int n_rows, hipStream_t stream) {
     return NERO_OK;
 }
 
+// NERO_F16_PAIRED_MASKS (round 6; default 1): reverse chains that need sign words only (ReLU / identity: the predictors, the NeRF++ networks)
+// on the paired kernel's MASKS instantiation when the launch is large; the softplus chains keep the 512-thread kernel and its LDS-DMA.
+static bool nero_paired_masks(int n_rows) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("NERO_F16_PAIRED_MASKS"); on = e ? atoi(e) : 1; }
+    return on && ((on & 2) || (n_rows + 63) / 64 > 4 * nero_cu_count());
+}
 int nero_f16_backward(const nero_bwd_chain* ch, int n_rows, hipStream_t stream) {
     if (nero_paired(2, n_rows)) return nero_f16p_backward(ch, n_rows, stream);
+    if (nero_paired_masks(n_rows) && nero_f16p_masks_only(ch)) return nero_f16p_backward(ch, n_rows, stream);
     const dim3 grid((n_rows + 63) / 64), block(512);
     for (int l = 0; l < ch->n_layers; ++l)
         if (ch->layer[l].n_out & 15) return nero_fail(NERO_ERR_ARG, "nero_mlp_backward(f16x3): n_out must be a multiple of 16");

@@ -22,6 +22,7 @@ int nero_f16_backward(const nero_bwd_chain* ch, int n_rows, hipStream_t stream);
 int nero_f16p_forward(const nero_fwd_chain* ch, int n_rows, hipStream_t stream);
 int nero_f16p_tangent(const nero_tan_chain* ch, int n_rows, hipStream_t stream);
 int nero_f16p_backward(const nero_bwd_chain* ch, int n_rows, hipStream_t stream);
+bool nero_f16p_masks_only(const nero_bwd_chain* ch);     // ReLU / identity chain with sign words: the spill-free paired reverse kernel applies
 // forward chains that save nothing, with the chain walk re-cut so that a wave owns rows (mlp_f16r.hip; NERO_F16_ROWOWNER inside nero_f16_forward)
 bool nero_f16r_covers(const nero_fwd_chain* ch);
 int nero_f16r_forward(const nero_fwd_chain* ch, int n_rows, hipStream_t stream);
