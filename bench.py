@@ -414,7 +414,8 @@ def inference_bench(dev, cfg, variance, res_grid=256):
 def dropin_trainer_bench(dev, cfg, rays, variance, step0=25000, warmup=5, steps=20):
     """what INTEGRATION.md option A gives a user of the reference Trainer: NeROShapeRenderer.forward({'step': s}) (pool slicing,
     _process_ray_batch, render, loss_rgb: network/renderer.py:319-330) under a plain torch.optim.Adam loop with the reference's loss
-    assembly (train/trainer.py:120-140) -- torch weight-norm autograd, no fused optimiser, no flat bucket -- at `rays` = train_ray_num."""
+    assembly (train/trainer.py:120-140) -- torch owns the parameters, the autograd graph and the optimiser; no fused optimiser, no flat
+    bucket -- at `rays` = train_ray_num."""
     import numpy as np
     from nero_amd.renderer import NeROShapeRenderer
     from nero_amd.synthetic import look_at_pose, perturb_state
@@ -456,7 +457,7 @@ def dropin_trainer_bench(dev, cfg, rays, variance, step0=25000, warmup=5, steps=
     torch.cuda.empty_cache()
     return {'value': round(rays / dt, 1), 'unit': 'rays/s', 'ms_per_step': round(dt * 1e3, 3), 'rays': rays, 'steps': steps, 'warmup': warmup,
             'what': "NeROShapeRenderer.forward({'step': s}) + the reference's loss assembly + torch.optim.Adam(fused=True): the drop-in path of "
-                    'INTEGRATION.md option A (torch weight-norm autograd, no fused trainer kernels)'}
+                    'INTEGRATION.md option A (one batched weight-norm autograd node, the C step driver, torch's own optimiser)'}
 
 
 def spawn_ranks(n):
@@ -765,16 +766,17 @@ def main():
     if rank == 0:
         if world == 1 and not args.quick:          # (baselines, the small-batch / drop-in legs and the Stage-II legs: rank 0 at N = 1 only)
             def r512():
+                # (60 steps after 8: a 20-step sample of a 5 ms step is 0.1 s and scatters by +- 4 % from run to run -- scripts/r06/dropin_ab2.py)
                 t5 = ShapeTrainStep(cfg, rays_per_rank=512, device=dev, variance=VARIANCE, prime_fraction=0.0)
-                for i in range(5):
+                for i in range(8):
                     t5.step(args.train_step + i)
                 torch.cuda.synchronize()
                 t0_ = time.time()
-                for i in range(20):
-                    t5.step(args.train_step + 5 + i)
+                for i in range(60):
+                    t5.step(args.train_step + 8 + i)
                 torch.cuda.synchronize()
-                d_ = (time.time() - t0_) / 20
-                return {'value': round(512 / d_, 1), 'unit': 'rays/s', 'ms_per_step': round(d_ * 1e3, 3), 'rays': 512, 'steps': 20, 'warmup': 5,
+                d_ = (time.time() - t0_) / 60
+                return {'value': round(512 / d_, 1), 'unit': 'rays/s', 'ms_per_step': round(d_ * 1e3, 3), 'rays': 512, 'steps': 60, 'warmup': 8,
                         'what': "the reference's own train_ray_num = 512 (configs/shape/syn/bell.yaml:31) on the fused training step"}
             leg('r512', r512)
 
@@ -794,7 +796,7 @@ def main():
                         'what': "GlossyReal 'bear' Stage-I shape, 1024 rays x (64+64+32) on ONE GPU = one rank's shard of BASELINE configs[2] (8192 rays over 8 GPUs)"}
             leg('c3_shard_bear_1024_rays', c3_shard)
             leg('dropin_trainer', lambda: {'r4096': dropin_trainer_bench(dev, cfg, args.rays, VARIANCE, args.train_step),
-                                           'r512': dropin_trainer_bench(dev, cfg, 512, VARIANCE, args.train_step)})
+                                           'r512': dropin_trainer_bench(dev, cfg, 512, VARIANCE, args.train_step, warmup=8, steps=60)})
             leg('inference', lambda: inference_bench(dev, cfg, VARIANCE))
             leg('stage2', lambda: stage2_bench(dev))
             # (= one rank's shard of BASELINE configs[4]: bear Stage II, 16384 points x (256+256) over 8 GPUs -- the N = 1 denominator)

@@ -432,6 +432,10 @@ int nero_mat_loss_bwd(const nero_mat_loss_cfg* cfg, int P, int has_reg, const fl
  *   (ordinal = rank of the candidate among the candidates; ties to the lower ordinal): argsort(keys[:total], stable)[:cap], sorted.
  *   Nothing is read back: every launch covers the worst case n.  ws: nero_occ_select_workspace(n) bytes.
  * nero_occ_gather: pts / dirs [cap,3] = x4[cand, 0:3] / geo[cand, 4:7] (the reflected direction); unused slots: origin, +z.
+ * nero_occ_l1: loss[0] = sum over the used slots k of |occ_prob[cand[k]] - gt[k]| / max(counts[0], 1) -- F.l1_loss(occ_prob[cand], gt) of
+ *   network/renderer.py:546-547 on the fixed-capacity candidate list (one block, fixed summation tree); nero_occ_l1_backward: d_occ [n_in] =
+ *   d_loss[0] * sign(occ_prob[cand[k]] - gt[k]) / max(counts[0], 1) at the kept candidates, zero elsewhere (sign(0) = 0 as in ATen).  For
+ *   callers that assemble the loss themselves under autograd (the drop-in renderer); nero_shape_loss below holds the same term for the fused step.
  * nero_shape_loss: losses [4] = (total, mean loss_rgb, eik_weight * mean(gerr) * w[0], L1(occ_prob[cand], gt_occ) * w[1]);
  *   d_rgb [R,3], d_gerr [n_in], d_occ [n_in] (zero except at the kept candidates) = d total / d (ray_rgb, gradient_error, occ_prob).
  *   cand = NULL: no occlusion term (d_occ may be NULL).  weights: device [2] (data-parallel count weights) or NULL = (1, 1).
@@ -443,6 +447,9 @@ size_t nero_occ_select_workspace(int n);
 int nero_occ_select(const unsigned char* flag, int n, const float* keys, int cap, int* cand, int* counts, void* ws, size_t ws_bytes,
                     void* stream);
 int nero_occ_gather(const float* x4, const float* geo, const int* cand, int cap, float* pts, float* dirs, void* stream);
+int nero_occ_l1(const float* occ_prob, const int* cand, const int* counts, const float* gt, int cap, float* loss, void* stream);
+int nero_occ_l1_backward(const float* d_loss, const float* occ_prob, const int* cand, const int* counts, const float* gt, int cap, int n_in,
+                         float* d_occ, void* stream);
 int nero_shape_loss_partials(int R, int n_in);
 int nero_shape_loss(int R, int rgb_kind, const float* rgb, const float* gt, int n_in, const float* gerr, float eik_weight,
                     const float* occ_prob, const int* cand, const int* counts, const float* gt_occ, const float* weights, float* losses,

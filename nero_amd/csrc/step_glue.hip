@@ -8,6 +8,7 @@
 //                          the candidate count (network/renderer.py:535-541).  Launch sizes depend on n only.
 //   nero_occ_gather        surface points / reflected directions of the kept candidates into a FIXED-capacity batch (unused slots
 //                          get a harmless dummy ray: the march always runs `cap` rays, nothing waits for the count)
+//   nero_occ_l1 (+ _backward)  the occlusion L1 mean alone and its seed d_occ, for callers that assemble the loss under autograd (drop-in renderer)
 //   nero_shape_loss        loss_rgb (l2 / l1 / smooth_l1 / charbonier), the eikonal mean, the occlusion L1 mean, their weighted sum
 //                          (train/trainer.py:127-137, network/loss.py:8-55) AND the seeds of the backward pass: d_rgb, d_gerr, d_occ
 //   nero_var_grad          d loss / d variance from the driver's d loss / d inv_s        (inv_s = exp(10 variance), clipped)
@@ -135,6 +136,40 @@ __global__ __launch_bounds__(LB) void occ_gather_kernel(const float* __restrict_
     }
     pts[3 * k] = x4[4 * (size_t)i]; pts[3 * k + 1] = x4[4 * (size_t)i + 1]; pts[3 * k + 2] = x4[4 * (size_t)i + 2];
     dirs[3 * k] = geo[8 * (size_t)i + 4]; dirs[3 * k + 1] = geo[8 * (size_t)i + 5]; dirs[3 * k + 2] = geo[8 * (size_t)i + 6];
+}
+
+// ---- the occlusion L1 term alone, for callers that assemble the loss themselves (the drop-in renderer under autograd) -------------------------
+// loss[0] = sum_k |occ_prob[cand[k]] - gt[k]| over the used slots / max(kept, 1); ONE block, fixed tree: the value does not depend on scheduling
+__global__ __launch_bounds__(1024) void occ_l1_kernel(const float* __restrict__ occ_prob, const int* __restrict__ cand, const int* __restrict__ counts,
+                                                      const float* __restrict__ gt, int cap, float* __restrict__ loss) {
+    __shared__ float part[1024];
+    float a = 0.f;
+    for (int k = threadIdx.x; k < cap; k += 1024) {
+        const int i = cand[k];
+        if (i >= 0) a += fabsf(occ_prob[i] - gt[k]);
+    }
+    part[threadIdx.x] = a;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int kept = counts[0] > 1 ? counts[0] : 1;
+        loss[0] = part[0] / (float)kept;
+    }
+}
+__device__ __forceinline__ float sgn0(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+// d_occ[cand[k]] = d_loss[0] * sign(occ_prob[cand[k]] - gt[k]) / max(kept, 1) on a d_occ the caller zeroed (candidates are distinct samples)
+__global__ __launch_bounds__(LB) void occ_l1_bwd_kernel(const float* __restrict__ d_loss, const float* __restrict__ occ_prob,
+                                                        const int* __restrict__ cand, const int* __restrict__ counts, const float* __restrict__ gt,
+                                                        int cap, float* __restrict__ d_occ) {
+    const int k = blockIdx.x * LB + threadIdx.x;
+    if (k >= cap) return;
+    const int i = cand[k];
+    if (i < 0) return;
+    const int kept = counts[0] > 1 ? counts[0] : 1;
+    d_occ[i] = d_loss[0] * sgn0(occ_prob[i] - gt[k]) / (float)kept;
 }
 
 // ---- loss + backward seeds ------------------------------------------------------------------------------------------------------
@@ -290,6 +325,23 @@ int nero_occ_gather(const float* x4, const float* geo, const int* cand, int cap,
     if (!x4 || !geo || !cand || !pts || !dirs) return nero_fail(NERO_ERR_ARG, "nero_occ_gather: null pointer");
     hipLaunchKernelGGL(occ_gather_kernel, dim3((cap + LB - 1) / LB), dim3(LB), 0, (hipStream_t)stream, x4, geo, cand, cap, pts, dirs);
     return nero_check_launch("nero_occ_gather");
+}
+
+int nero_occ_l1(const float* occ_prob, const int* cand, const int* counts, const float* gt, int cap, float* loss, void* stream) {
+    if (cap <= 0 || cap > PICK_MAX) return nero_fail(NERO_ERR_ARG, "nero_occ_l1: cap must be in 1 ... 4096");
+    if (!occ_prob || !cand || !counts || !gt || !loss) return nero_fail(NERO_ERR_ARG, "nero_occ_l1: null pointer");
+    hipLaunchKernelGGL(occ_l1_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, occ_prob, cand, counts, gt, cap, loss);
+    return nero_check_launch("nero_occ_l1");
+}
+
+int nero_occ_l1_backward(const float* d_loss, const float* occ_prob, const int* cand, const int* counts, const float* gt, int cap, int n_in,
+                         float* d_occ, void* stream) {
+    if (cap <= 0 || n_in <= 0) return nero_fail(NERO_ERR_ARG, "nero_occ_l1_backward: cap and n_in must be positive");
+    if (!d_loss || !occ_prob || !cand || !counts || !gt || !d_occ) return nero_fail(NERO_ERR_ARG, "nero_occ_l1_backward: null pointer");
+    if (hipMemsetAsync(d_occ, 0, sizeof(float) * (size_t)n_in, (hipStream_t)stream) != hipSuccess)
+        return nero_fail(NERO_ERR_LAUNCH, "nero_occ_l1_backward: memset failed");
+    hipLaunchKernelGGL(occ_l1_bwd_kernel, dim3((cap + LB - 1) / LB), dim3(LB), 0, (hipStream_t)stream, d_loss, occ_prob, cand, counts, gt, cap, d_occ);
+    return nero_check_launch("nero_occ_l1_backward");
 }
 
 int nero_shape_loss_partials(int R, int n_in) {

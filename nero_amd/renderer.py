@@ -111,10 +111,15 @@ class NeROShapeRenderer(nn.Module):
         if idxs.dim() == 2:
             idxs = idxs[..., 0]                                   # the reference's pools carry idxs as [rn,1]
         Rm, t = poses[:, :, :3], poses[:, :, 3:]
-        rays_o = (Rm.permute(0, 2, 1) @ -t)[idxs, :, 0]
+        # camera centres per IMAGE: the same -R^T t the reference recomputes for all images on every call; cached while `poses` is unchanged
+        key = (poses.data_ptr(), poses._version, tuple(poses.shape))
+        cached = getattr(self, '_cam_centres', None)
+        if cached is None or cached[0] != key:
+            cached = self._cam_centres = (key, (Rm.permute(0, 2, 1) @ -t)[:, :, 0].contiguous())
+        rays_o = cached[1][idxs]
         rays_d = (Rm[idxs].permute(0, 2, 1) @ ray_batch['dirs'].unsqueeze(-1))[..., 0]
         rays_d = torch.nn.functional.normalize(rays_d, dim=-1)
-        near, far = self.near_far_from_sphere(rays_o, rays_d)
+        near, far = self._near_far(rays_o, rays_d)
         if human_poses_img is None:
             human_poses_img = self.get_human_coordinate_poses(poses)
         return rays_o, rays_d, near, far, human_poses_img[idxs]
@@ -315,6 +320,19 @@ class NeROShapeRenderer(nn.Module):
     def get_anneal_val(self, step):
         e = self.cfg['anneal_end']
         return 1.0 if e < 0 else float(np.min([1.0, step / e]))
+
+    def _near_far(self, rays_o, rays_d):
+        """near_far_from_sphere for the training / rendering batches: on the device one launch of nero_near_far_sphere -- the ten tensor
+        ops below fused, the three products added in ATen's order, bit-identical for the unit directions every caller passes
+        (tests/test_step_glue.py) -- instead of ten launches in a step that is launch-dominated at the reference's 512 rays"""
+        if rays_o.is_cuda and rays_o.dtype == torch.float32 and rays_o.dim() == 2 and not (rays_o.requires_grad or rays_d.requires_grad):
+            from . import stage1
+            R = rays_o.shape[0]
+            o, d = rays_o.contiguous(), rays_d.contiguous()
+            near, far = torch.empty((R, 1), dtype=torch.float32, device=o.device), torch.empty((R, 1), dtype=torch.float32, device=o.device)
+            stage1.L.check(stage1._lib.nero_near_far_sphere(stage1._p(o), stage1._p(d), R, stage1._p(near), stage1._p(far), stage1.L.stream_ptr()))
+            return near, far
+        return self.near_far_from_sphere(rays_o, rays_d)
 
     @staticmethod
     def near_far_from_sphere(rays_o, rays_d):

@@ -518,6 +518,28 @@ def validation_info(K, cfg, shader_cfg, lut, variance, o, d, z_vals, weights, po
     return out
 
 
+class OccL1(torch.autograd.Function):
+    """F.l1_loss(occ_prob[cand], gt) (network/renderer.py:546-547) on the fixed-capacity candidate list of nero_occ_select (unused slots: -1),
+    mean over the kept count (a device scalar): nero_occ_l1 / nero_occ_l1_backward, two launches where the tensor expression and its autograd
+    nodes were about twenty (round 6: a 512-ray drop-in step is dominated by such launches).  Gradient w.r.t. occ_prob only."""
+
+    @staticmethod
+    def forward(ctx, occ_prob, cand, counts, gt):
+        occ_prob, gt = occ_prob.contiguous(), gt.contiguous().reshape(-1)
+        loss = torch.empty(1, dtype=torch.float32, device=occ_prob.device)
+        L.check(L.lib.nero_occ_l1(_p(occ_prob), _p(cand), _p(counts), _p(gt), cand.numel(), _p(loss), _st()))
+        ctx.save_for_backward(occ_prob, cand, counts, gt)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        occ_prob, cand, counts, gt = ctx.saved_tensors
+        d = d_loss.contiguous().reshape(1).float()
+        d_occ = torch.empty_like(occ_prob)
+        L.check(L.lib.nero_occ_l1_backward(_p(d), _p(occ_prob), _p(cand), _p(counts), _p(gt), cand.numel(), occ_prob.numel(), _p(d_occ), _st()))
+        return d_occ, None, None, None
+
+
 def occ_loss(S, occ_prob, cfg, variance, occ_keys=None):
     """compute_occ_loss (network/renderer.py:522-548): surface subset -> march the reflected ray to the unit sphere
     (64 uniform + 16 importance z, no grad) -> L1(occ_prob, sum of section weights)."""
@@ -547,9 +569,7 @@ def occ_loss(S, occ_prob, cfg, variance, occ_keys=None):
         pts, dirs = torch.empty((cap, 3), **f32), torch.empty((cap, 3), **f32)
         L.check(lib.nero_occ_gather(_p(S['x4']), _p(S['geo']), _p(cand), cap, _p(pts), _p(dirs), st))
         gt = secondary_occlusion(K, pts, dirs, variance, 64, 16)
-        valid = (cand >= 0)
-        diff = (occ_prob[cand.clamp(min=0).long()].reshape(-1) - gt.reshape(-1)).abs() * valid
-        return diff.sum() / counts[0].clamp(min=1).to(torch.float32), counts[0]
+        return OccL1.apply(occ_prob, cand, counts, gt), counts[0]
     cand = torch.nonzero(flag)[:, 0]
     Pn = cand.numel()
     if Pn > cfg['occ_loss_max_pn']:

@@ -239,16 +239,28 @@ class RenderCoreC(torch.autograd.Function):
         gv = meta['grad_views'] or {}
         G = Grads()
         fresh = {}
+        missing = [k for k, name in enumerate(meta['names']) if name not in gv]
+        if missing:
+            # zeros (a network without samples this step -- n_in or n_out == 0 -- is not written), as views of ONE flat buffer: one fill
+            # launch instead of one per tensor (92 at the YAML shapes: a fifth of the launches of a 512-ray drop-in step; round 6).  Fresh
+            # every backward: torch keeps the views as the parameters' .grad
+            sizes = [1]
+            for k in missing:
+                n = 1
+                for s_ in meta['shapes'][k]:
+                    n *= s_
+                sizes.append(n)
+            parts = torch.zeros(sum(sizes), **f32).split(sizes)
+            dsum = parts[0]
+            for k, t in zip(missing, parts[1:]):
+                fresh[meta['names'][k]] = t.view(meta['shapes'][k])
+        else:
+            dsum = torch.zeros(1, **f32)
         for i in range(drv.n_lin):
             nw, nb = meta['names'][2 * i], meta['names'][2 * i + 1]
-            if nw in gv:
-                dW, db = gv[nw], gv[nb]
-            else:                                  # (zeros: a network without samples this step -- n_in or n_out == 0 -- is not written)
-                dW, db = torch.zeros(meta['shapes'][2 * i], **f32), torch.zeros(meta['shapes'][2 * i + 1], **f32)
-                fresh[nw], fresh[nb] = dW, db
+            dW, db = (gv[nw] if nw in gv else fresh[nw]), (gv[nb] if nb in gv else fresh[nb])
             assert dW.is_contiguous() and db.is_contiguous()
             G.lin[i].W, G.lin[i].b = dW.data_ptr(), db.data_ptr()
-        dsum = torch.zeros(1, **f32)
         d_gerr_c = d_gerr.contiguous() if (d_gerr is not None and n_in > 0) else None
         d_occ_c = d_occ.contiguous() if (d_occ is not None and n_in > 0) else None
         d_rgb_c = d_rgb.contiguous()          # (bound to a local: a temporary's block could be re-used by the next .contiguous() while the C call still reads it)

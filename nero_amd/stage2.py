@@ -108,14 +108,19 @@ class Stage2Driver:
 def _grad_table(names, shapes, gv, lo, hi, device):
     """pointer table for Linears lo..hi-1 of `names` (global Linear index = lo + position); fresh zero tensors where no bucket view exists"""
     G, fresh = Weights(), {}
-    f32 = dict(dtype=torch.float32, device=device)
+    missing = [k for k, name in enumerate(names) if name not in gv]
+    if missing:                                    # views of ONE zero buffer: one fill launch, not one per tensor (nero_amd.stage1.RenderCoreC.backward)
+        sizes = []
+        for k in missing:
+            n = 1
+            for s_ in shapes[k]:
+                n *= s_
+            sizes.append(n)
+        for k, t in zip(missing, torch.zeros(sum(sizes), dtype=torch.float32, device=device).split(sizes)):
+            fresh[names[k]] = t.view(shapes[k])
     for k in range(len(names) // 2):
         nw, nb = names[2 * k], names[2 * k + 1]
-        if nw in gv:
-            dW, db = gv[nw], gv[nb]
-        else:
-            dW, db = torch.zeros(shapes[2 * k], **f32), torch.zeros(shapes[2 * k + 1], **f32)
-            fresh[nw], fresh[nb] = dW, db
+        dW, db = (gv[nw] if nw in gv else fresh[nw]), (gv[nb] if nb in gv else fresh[nb])
         assert dW.is_contiguous() and db.is_contiguous()
         G.lin[lo + k].W, G.lin[lo + k].b = dW.data_ptr(), db.data_ptr()
     return G, fresh

@@ -40,6 +40,7 @@ torch.cuda.synchronize(); t0 = time.time()
 for i in range(20): one(8 + i, True)
 torch.cuda.synchronize(); dt = (time.time() - t0) / 20
 print(f'{rays} rays: {dt*1e3:.3f} ms/step wall; host time per call (ms):', {k: round(v / 20 * 1e3, 3) for k, v in T.items()}, 'host sum', round(sum(T.values()) / 20 * 1e3, 3))
+if os.environ.get('NO_CPROFILE'): sys.exit(0)
 pr = cProfile.Profile(); pr.enable()
 for i in range(20): one(40 + i)
 torch.cuda.synchronize(); pr.disable()

@@ -190,3 +190,30 @@ def test_glued_step_edge_batches(case, monkeypatch):
     assert abs(lt - lh) <= 2e-6 * max(1.0, abs(lt)) and lt == lt
     assert float((gt_ - gh).abs().max()) <= 1e-5 * float(gt_.abs().max()) + 1e-12
 
+
+
+@pytest.mark.parametrize('n_in,cap,kept', [(5000, 256, 256), (5000, 256, 100), (70000, 2048, 2048), (300, 64, 0), (4097, 4096, 4096)])
+def test_occ_l1_node_vs_tensor_expression(n_in, cap, kept):
+    """nero_occ_l1 / _backward (the drop-in renderer's occlusion term) = the tensor expression it replaced, with its autograd gradient:
+    mean over the kept slots of |occ_prob[cand] - gt|, sign(0) = 0, zero gradient away from the candidates"""
+    from nero_amd.shape_step import OccL1
+    g = torch.Generator().manual_seed(n_in + cap + kept)
+    occ = torch.rand(n_in, generator=g).cuda()
+    idx = torch.sort(torch.randperm(n_in, generator=g)[:kept])[0].int()
+    cand = torch.full((cap,), -1, dtype=torch.int32)
+    cand[:kept] = idx
+    cand = cand.cuda()
+    counts = torch.tensor([kept, kept + 5], dtype=torch.int32).cuda()
+    gt = torch.rand(cap, generator=g).cuda()
+    if kept > 2:
+        gt[1] = occ[cand[1].long()]                              # an exact tie: sub-gradient 0
+    a = occ.clone().requires_grad_(True)
+    loss = OccL1.apply(a, cand, counts, gt)
+    (loss * 0.7).backward()
+    b = occ.clone().requires_grad_(True)
+    valid = cand >= 0
+    ref = ((b[cand.clamp(min=0).long()] - gt).abs() * valid).sum() / counts[0].clamp(min=1).float()
+    (ref * 0.7).backward()
+    assert loss.shape == () and float((loss - ref).abs()) <= 2e-6 * max(1.0, float(ref.abs()))
+    assert torch.equal(a.grad != 0, b.grad != 0)
+    assert float((a.grad - b.grad).abs().max()) <= 1e-7 * max(1e-30, float(b.grad.abs().max())) + 1e-12
