@@ -8,7 +8,7 @@ does not travel, its outputs do).  1024 rays is one rank's shard of BASELINE con
 rays are those of configs[1].
 
   * weights: rebuilt from the seed, checked against the stored checksums -- the HIP model IS the reference's model;
-  * sampler: every round fed the REFERENCE's (z, sdf) of that round: section weights within 2e-5 of the reference's, searchsorted indices and the merge permutation BIT-EQUAL
+  * sampler: every round fed the REFERENCE's (z, sdf) of that round: section weights within 2e-5 of the reference's, searchsorted indices and the merge permutation BIT-EQUAL (the permutation up to exact ties, which the reference's unstable sort leaves open)
     through the exact-contract entry points (nero_sample_pdf on the reference's weights, nero_merge_sorted on its new z), at all four widths;
   * render step teacher-forced on the reference's z_vals: ray_rgb, gradient_error, std, loss_occ, loss within 1e-4 of the reference's float32
     run AND of its float64 run (north_star tolerance);
@@ -76,7 +76,7 @@ def test_sampler_rounds_on_the_references_own_inputs(case):
     nt = meta['n_trace']
     o, d = _t(z, 'o')[:nt].contiguous(), _t(z, 'd')[:nt].contiguous()
     st, P = L.stream_ptr(), C.c_void_p
-    widths, worst_w, flips, n_idx, plain = [], 0.0, 0, 0, 0
+    widths, worst_w, flips, n_idx, plain, ties = [], 0.0, 0, 0, 0, 0
     for i in range(4):
         zc, sc = _t(z, f'tr/z{i}'), _t(z, f'tr/sdf{i}')
         ref_new, ref_inds, ref_index = _t(z, f'tr/z_new{i}', 'cpu'), _t(z, f'tr/inds{i}', 'cpu').int(), _t(z, f'tr/index{i}', 'cpu').int()
@@ -113,11 +113,22 @@ def test_sampler_rounds_on_the_references_own_inputs(case):
         index = torch.empty(nt, n + m, dtype=torch.int32, device='cuda')
         zn = ref_new.cuda().contiguous()
         L.check(L.lib.nero_merge_sorted(P(zt.data_ptr()), n + m, n, P(None), 0, P(zn.data_ptr()), m, P(None), 0, nt, P(index.data_ptr()), st))
-        assert torch.equal(index.cpu(), ref_index), (case, i)
+        # ... up to EXACT ties: the reference sorts with torch.sort (network/renderer.py:398, not stable), so where a new z equals an existing one
+        # bit for bit (sample_pdf returns bins[below] itself when u sits on a cdf edge; the bear fixture has three such pairs, the bell fixture
+        # none) the order of the two equal entries is whatever the sort implementation leaves.  The kernel's rule is old before new, lower
+        # index first (a stable sort of the concatenation); everything else must be the reference's permutation, and the sorted values are
+        # identical either way
+        zall = torch.cat([zc.cpu(), ref_new], 1)
+        mine, ref = index.cpu().long(), ref_index.long()
+        assert torch.equal(torch.gather(zall, 1, mine), torch.gather(zall, 1, ref)), (case, i)
+        diff = mine != ref
+        ties += int(diff.sum())
+        assert int(diff.sum()) <= 8 and torch.equal(mine, torch.sort(zall, dim=1, stable=True)[1]), (case, i, int(diff.sum()))
     assert widths == [64, 80, 96, 112]
     assert worst_w < 2e-5 and flips / n_idx < 2e-3, (worst_w, flips, n_idx)
     parity_report(f'ref_at_size[{case}].sampler', rays=nt, widths=widths, indices_compared=n_idx, bit_equal_on_reference_weights=True,
-                  own_weights_index_flips=flips, worst_weight_rel_err=worst_w, new_z_within_2e_6=plain / n_idx)
+                  own_weights_index_flips=flips, worst_weight_rel_err=worst_w, new_z_within_2e_6=plain / n_idx,
+                  merge_entries_differing_at_exact_ties=ties)
     assert plain / n_idx > 0.995
 
 
