@@ -36,6 +36,8 @@ bash scripts/probe/run_rowowner_probe.sh > /dev/null 2>&1; cp gpurun_out/rowowne
 python scripts/r06/bench_rowowner.py 2>&1 | grep -v Warn | tail -6 > $O/three_organisations.txt
 python scripts/r06/dropin_ab.py 2>&1 | grep -v Warn | tail -24 > $O/dropin_ab.txt
 python scripts/r06/dropin_profile.py 512 2>&1 | grep "rays:" >> $O/dropin_ab.txt
+python scripts/r06/dropin_ab2.py 512 2>&1 | grep -v Warn | tail -2 >> $O/dropin_ab.txt
+TAG=_final bash scripts/r06/dropin_trace.sh > /dev/null 2>&1; cp gpurun_out/r06/dropin_trace_final.txt $O/dropin_trace.txt
 { for lib in "" 2acc; do echo "=== lib ${lib:-in-tree (one accumulator set, round 5/6 default)}"; if [ -n "$lib" ]; then export NERO_HIP_LIB=$PWD/build/variants/lib_$lib.so; else unset NERO_HIP_LIB; fi; python scripts/r06/smoke_diff.py 2>&1 | grep -v "Warn\|amdgpu.ids" | tail -14; done; unset NERO_HIP_LIB; } > $O/smoke_diff.txt 2>&1
 cp gpurun_out/parity_at_size.json $O/ 2>/dev/null
 ls -la $O | head -40; tail -3 $O/bench.err
