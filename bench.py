@@ -457,7 +457,7 @@ def dropin_trainer_bench(dev, cfg, rays, variance, step0=25000, warmup=5, steps=
     torch.cuda.empty_cache()
     return {'value': round(rays / dt, 1), 'unit': 'rays/s', 'ms_per_step': round(dt * 1e3, 3), 'rays': rays, 'steps': steps, 'warmup': warmup,
             'what': "NeROShapeRenderer.forward({'step': s}) + the reference's loss assembly + torch.optim.Adam(fused=True): the drop-in path of "
-                    'INTEGRATION.md option A (one batched weight-norm autograd node, the C step driver, torch's own optimiser)'}
+                    'INTEGRATION.md option A (one batched weight-norm autograd node, the C step driver, the optimiser of torch)'}
 
 
 def spawn_ranks(n):
