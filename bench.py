@@ -66,7 +66,7 @@ def hbm_traffic_per_launch(kernel, prefix='hbm_traffic_per_kernel'):
     """average HBM bytes per launch of `kernel` from the newest committed PMC summary (scripts/prof_traffic.sh), or None.
     -> (bytes, description of the source incl. the commit / library hash the counters were taken on and whether that library is
     the one running now)"""
-    for rnd in ('r05', 'r04', 'r03', 'r02', 'r01'):
+    for rnd in ('r06', 'r05', 'r04', 'r03', 'r02', 'r01'):
         name = f'{rnd}_{prefix}.csv'
         try:
             lines = open(os.path.join(ROOT, 'profiles', name)).read().splitlines()
