@@ -273,12 +273,18 @@ def stage2_step_bench(dev, kind, P_, Dd, Ds, mesh, rank=0, world=1, warmup=5, st
     tracer = ts.net.ray_tracer
     rec = {'n': 0, 'hit': 0, 'ms': 0.0, 'on': False}
 
-    class Timed:                                            # times nero_bvh_trace on the secondary rays of one untimed extra step
+    class Timed:                                            # times the tracer call of the step on the secondary rays of one untimed extra step
         def trace_grouped(self, ro, rd, group, heavy_from):
             return self.trace(ro, rd, (group, heavy_from))
 
-        def trace(self, ro, rd, order=None):
-            run = (lambda: tracer.trace_grouped(ro, rd, *order)) if order is not None else (lambda: tracer.trace(ro, rd))
+        def trace_masked(self, ro, rd, skip):               # (round 6: the step hands over the flags of its zero-weight rays -- not traversed)
+            return self.trace(ro, rd, None, skip)
+
+        def trace(self, ro, rd, order=None, skip=None):
+            if skip is not None:
+                run = lambda: tracer.trace_masked(ro, rd, skip)
+            else:
+                run = (lambda: tracer.trace_grouped(ro, rd, *order)) if order is not None else (lambda: tracer.trace(ro, rd))
             if not rec['on']:
                 return run()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -310,14 +316,19 @@ def stage2_step_bench(dev, kind, P_, Dd, Ds, mesh, rank=0, world=1, warmup=5, st
     torch.cuda.synchronize()
     D = Dd + Ds
     h = rec['hit'] / max(rec['n'], 1)
+    # rows of the light MLPs per ray: the step's own counts (round 6: rays whose estimator weight is exactly zero -- GGX directions below the
+    # shading horizon under the Schlick geometry term, nero_mc_dead_rays -- are neither traced nor shaded; NERO_MC_SKIP_DEAD=0 keeps them)
+    n_miss_rows, n_hit_rows, n_rays = getattr(ts.drv, 'last_counts', None) or (round((1 - h) * rec['n']), rec['hit'], max(rec['n'], 1))
+    m_frac, h_frac = n_miss_rows / n_rays, n_hit_rows / n_rays
     c_miss = (168704 if kind == 'bear' else C_OUTER) + (138240 if kind == 'bear' else 0)        # C_outer (+ C_human)
-    flop_pt = 2 * 3 * (2 * C_MAT + D * ((1 - h) * c_miss + h * C_INNER))
+    flop_pt = 2 * 3 * (2 * C_MAT + D * (m_frac * c_miss + h_frac * C_INNER))
     peak = PEAK_OF_MODE[CH.GEMM_MODE['fwd']]
     out = {'model': kind, 'points_per_gpu': P_, 'directions': f'{Dd}+{Ds}', 'n_gpus': world, 'trainer': 'fused (nero_wn_forward_batch / nero_wn_adam_batch)',
            'ms_per_step': round(wall * 1e3, 3), 'ms_per_step_this_rank': round(wall_local * 1e3, 3), 'ms_per_step_median': round(ms[len(ms) // 2], 3),
            'points_per_s': round(P_ * world / wall, 1), 'light_rays_per_s': round(P_ * world * D / wall, 1),
            'tracer_rays_per_s': round(rec['n'] / (rec['ms'] * 1e-3), 1) if rec['ms'] > 0 else None, 'tracer_ms': round(rec['ms'], 3),
-           'hit_fraction': round(h, 4), 'mlp_mflop_per_point': round(flop_pt / 1e6, 1),
+           'hit_fraction': round(h_frac, 4), 'miss_fraction': round(m_frac, 4), 'zero_weight_ray_fraction': round(1.0 - m_frac - h_frac, 4),
+           'mlp_mflop_per_point': round(flop_pt / 1e6, 1),
            'mlp_flop_frac': round(flop_pt * P_ / wall / peak, 4), 'mlp_flop_frac_peak_tflops': round(peak / 1e12, 1),
            'warmup': warmup, 'steps': steps}
     if prof and rank == 0:

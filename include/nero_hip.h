@@ -375,6 +375,12 @@ int nero_bvh_trace(void* handle, const float* rays_o, const float* rays_d, int n
  * otherwise the natural order. */
 int nero_bvh_trace_grouped(void* handle, const float* rays_o, const float* rays_d, int n, float* positions, float* face_normals, float* depth,
                            int group, int heavy_from, void* stream);
+/* nero_bvh_trace for a caller that knows some rays' results will not be used (round 6): skip [n] bytes, non-zero = do not traverse; such a
+ * ray is reported as a miss (depth 10, zero normal).  Every other ray's outputs are nero_bvh_trace's bit for bit; skip = NULL: the same call.
+ * Stage II passes the flags of nero_mc_dead_rays: GGX-sampled directions below the shading horizon, whose estimator weight is exactly zero
+ * (field.py:892-903, 979-987 with geometry_type 'schlick') and which are the longest rays of the launch (they cross the inside of the mesh). */
+int nero_bvh_trace_masked(void* handle, const float* rays_o, const float* rays_d, int n, const unsigned char* skip, float* positions,
+                          float* face_normals, float* depth, void* stream);
 int nero_bvh_destroy(void* handle);
 /* which kernel nero_bvh_trace launches: 1 = memory requests of a traversal step overlapped, stack in LDS (default when the tree is no
  * deeper than the 24-entry LDS stack), 0 = private stack, one request after the other.  Same visit order and arithmetic per ray:
@@ -393,6 +399,15 @@ int nero_mc_point_setup(const float* pts, const float* view, const float* normal
  * = (n_miss, n_hit) on the device; miss_idx / hit_idx need room for n entries each; tmp: nero_mc_split_tmp_ints(n) int32 of scratch. */
 int nero_mc_split_tmp_ints(int n);
 int nero_mc_split(const float* depth, int n, int* slot, int* miss_idx, int* hit_idx, int* counts, int* tmp, void* stream);
+/* DEAD rays (round 6).  With geometry_type 'schlick' (the reference's default, field.py:702; the only one its configurations use) a direction
+ * below the shading horizon has NoL = saturate(n.w) = 0, hence G = 0 and an estimator weight D G / (4 NoV p + 1e-5) of EXACTLY zero, with
+ * zero derivatives (the clamp passes no gradient for n.w < 0): the ray contributes nothing to any output or gradient of shade_mixed
+ * (field.py:950-1012), whatever it hits.  nero_mc_dead_rays: dead [P*D] bytes = 1 for the GGX-sampled rows with n.w < -1e-6 (0 everywhere for
+ * geometry_type 1, whose weight at NoL = 0 is small but not zero).  nero_mc_split_dead: nero_mc_split with a third class -- flagged rays get
+ * slot = INT_MIN and enter neither list (counts[0] + counts[1] = n - #dead); the estimator kernels read L = 0 for them; dead = NULL: nero_mc_split. */
+int nero_mc_dead_rays(const float* pt, const float* dirs, int P, int Dd, int Ds, int geometry_type, unsigned char* dead, void* stream);
+int nero_mc_split_dead(const float* depth, const unsigned char* dead, int n, int* slot, int* miss_idx, int* hit_idx, int* counts, int* tmp,
+                       void* stream);
 
 /* ---- Stage-II training glue (nero_amd/csrc/mat_loss.hip): what NeROMaterialRenderer.train_step does between the MLP / shading kernels,
  * as single launches.
@@ -579,6 +594,10 @@ int nero_stage2_predict_fwd(nero_stage2* h, const float* x, int n, float* raw5, 
  * the fixed (azimuth, elevation) tables (field.py:741-749) -> origins, dirs [P*(Dd+Ds),3] (caller-owned, kept alive until shade_bwd) */
 int nero_stage2_rays(nero_stage2* h, int P, const float* pts, const float* view, const float* normals, const float* mat5, const float* rand_d,
                      const float* rand_s, const float* tab_d, const float* tab_s, float* origins, float* dirs, void* stream);
+/* the flags of the rays of the last nero_stage2_rays call whose estimator weight is exactly zero (nero_mc_dead_rays; device pointer, [P*D]
+ * bytes, valid until the next nero_stage2_rays), for the caller's tracer (nero_bvh_trace_masked); NULL when nothing is skipped (geometry_type 1,
+ * or NERO_MC_SKIP_DEAD=0 at nero_stage2_create).  nero_stage2_shade_fwd leaves the flagged rays out of both light MLPs whatever the tracer reported. */
+const unsigned char* nero_stage2_dead_rays(nero_stage2* h);
 /* pos / face_normals [P*D,3], depth [P*D] of the traced rays (depth >= 10 = miss; kept alive until shade_bwd); poses [P,3,4] or NULL
  * -> rgb (linear), mean diffuse light, mean weighted specular light, specular part: [P,3] each */
 int nero_stage2_shade_fwd(nero_stage2* h, const float* pos, const float* face_normals, const float* depth, const float* poses, float* rgb,

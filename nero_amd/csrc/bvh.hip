@@ -153,7 +153,8 @@ __device__ __forceinline__ void write_hit(const Tri* __restrict__ tris, int r, c
 
 __global__ __launch_bounds__(256) void trace_kernel(const Node* __restrict__ nodes, const Tri* __restrict__ tris, int root,
                                                     const float* __restrict__ ro, const float* __restrict__ rd, int n,
-                                                    float* __restrict__ pos, float* __restrict__ nrm, float* __restrict__ depth) {
+                                                    float* __restrict__ pos, float* __restrict__ nrm, float* __restrict__ depth,
+                                                    const unsigned char* __restrict__ skip) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     const float o[3] = {ro[r * 3], ro[r * 3 + 1], ro[r * 3 + 2]};
@@ -165,8 +166,8 @@ __global__ __launch_bounds__(256) void trace_kernel(const Node* __restrict__ nod
     int best = -1;
     int stack[64];
     int sp = 0;
-    int cur = root;
-    if (cur < 0) { leaf_test(tris, cur, o, d, tbest, best); cur = NONE; }
+    int cur = (skip != nullptr && skip[r] != 0) ? NONE : root;          // a skipped ray reports a miss without a single node visit
+    if (cur != NONE && cur < 0) { leaf_test(tris, cur, o, d, tbest, best); cur = NONE; }
     while (cur != NONE) {
         const Node nd = nodes[cur];
         float tl, tr;
@@ -242,7 +243,7 @@ constexpr int PL_STACK = 24;               // LDS stack entries per ray (6 KB pe
 __global__ __launch_bounds__(PL_THREADS) void trace_overlap_kernel(const Node* __restrict__ nodes, const Tri* __restrict__ tris, int root,
                                                                    const float* __restrict__ ro, const float* __restrict__ rd, int n,
                                                                    float* __restrict__ pos, float* __restrict__ nrm, float* __restrict__ depth,
-                                                                   int gchunks, int heavy0, int n_groups) {
+                                                                   int gchunks, int heavy0, int n_groups, const unsigned char* __restrict__ skip) {
     __shared__ int lds_stack[PL_STACK * PL_THREADS];
     int* const st = lds_stack + threadIdx.x;                                   // entry s of this lane: st[s * PL_THREADS]
     int chunk = blockIdx.x;
@@ -259,9 +260,10 @@ __global__ __launch_bounds__(PL_THREADS) void trace_overlap_kernel(const Node* _
 #pragma unroll
     for (int a = 0; a < 3; ++a) inv[a] = 1.0f / (fabsf(d[a]) > 1e-20f ? d[a] : (d[a] < 0.f ? -1e-20f : 1e-20f));
     float tbest = MISS_DEPTH;
-    int best = -1, sp = 0, cur = root;
-    NodeQ nd;
-    if (cur < 0) { leaf_test(tris, cur, o, d, tbest, best); cur = NONE; }
+    int best = -1, sp = 0, cur = (skip != nullptr && skip[r] != 0) ? NONE : root;      // (a skipped ray: a miss without a node visit)
+    NodeQ nd = {};
+    if (cur == NONE) {}
+    else if (cur < 0) { leaf_test(tris, cur, o, d, tbest, best); cur = NONE; }
     else nd = load_node(nodes, cur);
     // ONE leaf section per step: the second leaf of a node is tested at the start of the lane's next step, before its next node -- the
     // same order of visits, but a wavefront executes the triangle code once per step instead of twice (0.57 -> 0.52 ms per 1 M rays)
@@ -373,12 +375,31 @@ int nero_bvh_trace(void* handle, const float* rays_o, const float* rays_d, int n
     Handle* h = (Handle*)handle;
     if (h->mode == 0) {
         hipLaunchKernelGGL(trace_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->b.d_nodes, h->b.d_tris, h->root,
-                           rays_o, rays_d, n, positions, face_normals, depth);
+                           rays_o, rays_d, n, positions, face_normals, depth, nullptr);
         return nero_check_launch("nero_bvh_trace");
     }
     hipLaunchKernelGGL(trace_overlap_kernel, dim3((n + PL_THREADS - 1) / PL_THREADS), dim3(PL_THREADS), 0, (hipStream_t)stream, h->b.d_nodes, h->b.d_tris,
-                       h->root, rays_o, rays_d, n, positions, face_normals, depth, 0, 0, 0);
+                       h->root, rays_o, rays_d, n, positions, face_normals, depth, 0, 0, 0, nullptr);
     return nero_check_launch("nero_bvh_trace");
+}
+
+// nero_bvh_trace for a caller that knows some rays' results will not be used: skip [n] bytes, non-zero = do not traverse -- the ray is
+// reported as a miss (depth 10, zero normal) at the cost of one byte read.  Stage II (round 6): the GGX-sampled directions below the shading
+// horizon carry an estimator weight of exactly zero (nero_mc_dead_rays) and are the longest rays of the launch (they cross the inside of
+// the mesh).  Every other ray's outputs are those of nero_bvh_trace bit for bit.  skip = NULL: nero_bvh_trace.
+int nero_bvh_trace_masked(void* handle, const float* rays_o, const float* rays_d, int n, const unsigned char* skip, float* positions,
+                          float* face_normals, float* depth, void* stream) {
+    if (!handle || !rays_o || !rays_d || !positions || !face_normals || !depth) return nero_fail(NERO_ERR_ARG, "nero_bvh_trace_masked: bad argument");
+    if (n == 0) return NERO_OK;
+    Handle* h = (Handle*)handle;
+    if (h->mode == 0) {
+        hipLaunchKernelGGL(trace_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->b.d_nodes, h->b.d_tris, h->root,
+                           rays_o, rays_d, n, positions, face_normals, depth, skip);
+        return nero_check_launch("nero_bvh_trace_masked");
+    }
+    hipLaunchKernelGGL(trace_overlap_kernel, dim3((n + PL_THREADS - 1) / PL_THREADS), dim3(PL_THREADS), 0, (hipStream_t)stream, h->b.d_nodes, h->b.d_tris,
+                       h->root, rays_o, rays_d, n, positions, face_normals, depth, 0, 0, 0, skip);
+    return nero_check_launch("nero_bvh_trace_masked");
 }
 
 // nero_bvh_trace with a launch-order hint for rays that come in groups of `group` (Stage II: the D = Dd + Ds directions of a surface
@@ -393,7 +414,7 @@ int nero_bvh_trace_grouped(void* handle, const float* rays_o, const float* rays_
                     n > 0 && n % group == 0;
     if (!ok) return nero_bvh_trace(handle, rays_o, rays_d, n, positions, face_normals, depth, stream);
     hipLaunchKernelGGL(trace_overlap_kernel, dim3(n / PL_THREADS), dim3(PL_THREADS), 0, (hipStream_t)stream, h->b.d_nodes, h->b.d_tris, h->root,
-                       rays_o, rays_d, n, positions, face_normals, depth, group / PL_THREADS, heavy_from / PL_THREADS, n / group);
+                       rays_o, rays_d, n, positions, face_normals, depth, group / PL_THREADS, heavy_from / PL_THREADS, n / group, nullptr);
     return nero_check_launch("nero_bvh_trace_grouped");
 }
 

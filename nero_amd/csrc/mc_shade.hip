@@ -293,11 +293,23 @@ __device__ __forceinline__ void brdf_terms(const float* q, const float* w, bool 
 
 struct Lights { const float* outer_raw; const float* inner_raw; const float* human_raw; const float* hmask; float emax, imax; int geom; };
 
+// DEAD rays (round 6).  With the Schlick-GGX geometry term (the reference's default and the only one its configurations use, field.py:702) a
+// direction below the shading horizon has NoL = saturate(n.w) = 0, so G = g(NoV) g(0) = 0 and its estimator weight D G / (4 NoV p + 1e-5) is
+// EXACTLY zero; the clamp passes no gradient for n.w < 0, so every derivative of the weight is zero too.  Such a ray (always a GGX-sampled
+// one: the cosine-weighted diffuse directions lie above the horizon) contributes exactly nothing to any output or gradient of shade_mixed
+// (field.py:950-1012) whatever light it would fetch -- and it is the expensive kind: it starts at the surface and runs through the inside of
+// the mesh (hundreds of dependent BVH steps; every one of them hits, i.e. it is a row of the inner-light MLP).  nero_mc_dead_rays flags
+// them (n.w < -1e-6: a margin that no difference in contraction between two kernels can cross), the tracer skips flagged rays, the split
+// gives them the slot below -- neither a miss row nor a hit row -- and the estimator reads L = 0 for them.
+constexpr int DEAD_SLOT = -2147483647 - 1;
+
 // L = near * ( miss: outer (1-hw) + hl hw ; hit: inner )      (get_lights, field.py:866-879)
 __device__ __forceinline__ void light_value(int s, const Lights& P_, float near, float* L, float* outer, float* hl, float& hw, float& hw_raw) {
     hw = 0.f; hw_raw = 0.f;
     for (int c = 0; c < 3; ++c) { outer[c] = 0.f; hl[c] = 0.f; }
-    if (s >= 0) {
+    if (s == DEAD_SLOT) {
+        for (int c = 0; c < 3; ++c) L[c] = 0.f;
+    } else if (s >= 0) {
         for (int c = 0; c < 3; ++c) outer[c] = expf(fminf(P_.outer_raw[(size_t)s * 4 + c], P_.emax));
         if (P_.human_raw) {
             const float hm = P_.hmask[s];
@@ -398,8 +410,9 @@ __global__ __launch_bounds__(64) void mc_combine_bwd_kernel(const float* __restr
             da[c] += dF0 * m;
             if (diffuse) { da[c] += gd[c] * (1.f - m) * L[c]; dm -= gd[c] * a * L[c]; }
         }
-        // raw head gradients: L = near * (outer (1-hw) + hl hw) with outer = exp(min(raw, cap)), or near * inner
-        if (s >= 0) {
+        // raw head gradients: L = near * (outer (1-hw) + hl hw) with outer = exp(min(raw, cap)), or near * inner (a dead ray has no row)
+        if (s == DEAD_SLOT) {
+        } else if (s >= 0) {
             float o4[3], h4[4] = {0.f, 0.f, 0.f, 0.f};
             float dhw = 0.f;
             for (int c = 0; c < 3; ++c) {
@@ -496,7 +509,8 @@ __global__ __launch_bounds__(64) void mc_dir_bwd_kernel(const float* __restrict_
         float dw[3] = {d_wspec[((size_t)p * Ds + js) * 3], d_wspec[((size_t)p * Ds + js) * 3 + 1], d_wspec[((size_t)p * Ds + js) * 3 + 2]};
         const int s = slot[row];
         float dk_unused = 0.f;
-        if (s >= 0) {
+        if (s == DEAD_SLOT) {                                  // no light row: nothing comes back through the light inputs (d_wspec is zero as well)
+        } else if (s >= 0) {
             const int ldm = sphere ? 144 : 72;
             const float* gm = dX_miss + (size_t)s * ldm;
             ide_backward<false>(w[0], w[1], w[2], 0.f, [&](int c) { return gm[c]; }, dw[0], dw[1], dw[2], dk_unused);
@@ -560,67 +574,102 @@ __global__ __launch_bounds__(64) void mc_dir_bwd_kernel(const float* __restrict_
 }
 
 
+// dead[row] = 1 for a specular direction below the shading horizon by more than the margin (see DEAD_SLOT above), 0 otherwise
+__global__ void mc_dead_rays_kernel(const float* __restrict__ pt, const float* __restrict__ dirs, int P_, int Dd, int Ds,
+                                    unsigned char* __restrict__ dead) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    const int D = Dd + Ds;
+    if (row >= P_ * D) return;
+    const int p = row / D, j = row - p * D;
+    const float* n = pt + (size_t)p * 32 + 3;
+    const float w[3] = {dirs[(size_t)row * 3], dirs[(size_t)row * 3 + 1], dirs[(size_t)row * 3 + 2]};
+    dead[row] = (j >= Dd && dot3(n, w) < -1e-6f) ? 1 : 0;
+}
+
 // ---- hit / miss split of the P*D secondary rays (get_lights, network/field.py:861-877: lights[miss] = outer(...), lights[hit] =
 // inner(...)): ordered compaction of the ray ids by `depth < 10` into two index lists + the slot map the combine kernels read.
 // Three launches: per-block ballot counts, one-block exclusive scan, ordered scatter (position = block base + wave base + population
 // count of the lower lanes) -- the order torch.nonzero produces, without its host round trip for the sizes of intermediate tensors.
 constexpr int SPLIT_BLOCK = 1024;                  // rays per 256-thread block (4 per thread, wave-contiguous chunks of 64)
-__global__ __launch_bounds__(256) void mc_split_count_kernel(const float* __restrict__ depth, int n, int* __restrict__ block_hits) {
-    __shared__ int wsum[4];
+// three classes when `dead` is given: dead rays (flagged; neither list), hits (depth < 10, not dead), misses (the rest).  tmp holds two
+// per-block count arrays of nb + 1 ints: hits at [0, nb), dead rays at [nb + 1, 2 nb + 1).
+__device__ __forceinline__ bool is_dead(const unsigned char* dead, int i) { return dead != nullptr && dead[i] != 0; }
+__global__ __launch_bounds__(256) void mc_split_count_kernel(const float* __restrict__ depth, const unsigned char* __restrict__ dead, int n, int nb,
+                                                             int* __restrict__ tmp) {
+    __shared__ int wsum[4], wdead[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int c = 0;
+    int c = 0, cd = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int i = blockIdx.x * SPLIT_BLOCK + (wv * 4 + k) * 64 + lane;
-        c += __popcll(__ballot(i < n && depth[i] < 10.0f));
+        const bool dd = i < n && is_dead(dead, i);
+        c += __popcll(__ballot(i < n && !dd && depth[i] < 10.0f));
+        cd += __popcll(__ballot(dd));
     }
-    if (lane == 0) wsum[wv] = c;
+    if (lane == 0) { wsum[wv] = c; wdead[wv] = cd; }
     __syncthreads();
-    if (threadIdx.x == 0) block_hits[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (threadIdx.x == 0) {
+        tmp[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        tmp[nb + 1 + blockIdx.x] = wdead[0] + wdead[1] + wdead[2] + wdead[3];
+    }
 }
-// exclusive scan of block_hits[0..nb) in place (one 1024-thread block, any nb); counts = (n_miss, n_hit)
-__global__ __launch_bounds__(1024) void mc_split_scan_kernel(int* __restrict__ block_hits, int nb, int n, int* __restrict__ counts) {
+// exclusive scans of both count arrays in place (one 1024-thread block, any nb); counts = (n_miss, n_hit)
+__global__ __launch_bounds__(1024) void mc_split_scan_kernel(int* __restrict__ tmp, int nb, int n, int* __restrict__ counts) {
     __shared__ int part[1024];
     const int tid = threadIdx.x;
     const int per = (nb + 1023) / 1024;
-    int s = 0;
-    for (int k = 0; k < per; ++k) { const int b = tid * per + k; if (b < nb) s += block_hits[b]; }
-    part[tid] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int v = tid >= off ? part[tid - off] : 0;
+    int totals[2] = {0, 0};
+    for (int a = 0; a < 2; ++a) {
+        int* const arr = tmp + a * (nb + 1);
+        int s = 0;
+        for (int k = 0; k < per; ++k) { const int b = tid * per + k; if (b < nb) s += arr[b]; }
         __syncthreads();
-        part[tid] += v;
+        part[tid] = s;
         __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int v = tid >= off ? part[tid - off] : 0;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        int base = part[tid] - s;
+        for (int k = 0; k < per; ++k) {
+            const int b = tid * per + k;
+            if (b < nb) { const int c = arr[b]; arr[b] = base; base += c; }
+        }
+        totals[a] = part[1023];
     }
-    int base = part[tid] - s;
-    for (int k = 0; k < per; ++k) {
-        const int b = tid * per + k;
-        if (b < nb) { const int c = block_hits[b]; block_hits[b] = base; base += c; }
-    }
-    if (tid == 1023) { counts[0] = n - part[1023]; counts[1] = part[1023]; }
+    if (tid == 1023) { counts[0] = n - totals[0] - totals[1]; counts[1] = totals[0]; }
 }
-__global__ __launch_bounds__(256) void mc_split_scatter_kernel(const float* __restrict__ depth, int n, const int* __restrict__ block_base,
-                                                               int* __restrict__ slot, int* __restrict__ miss_idx, int* __restrict__ hit_idx) {
+__global__ __launch_bounds__(256) void mc_split_scatter_kernel(const float* __restrict__ depth, const unsigned char* __restrict__ dead, int n, int nb,
+                                                               const int* __restrict__ tmp, int* __restrict__ slot, int* __restrict__ miss_idx,
+                                                               int* __restrict__ hit_idx) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const unsigned long long lower = (1ull << lane) - 1ull;
-    // hits before this wave's first chunk inside the block: the chunks are wave-contiguous, so count the earlier waves' chunks directly
-    int hits_before = block_base[blockIdx.x];
+    // hits / dead rays before this wave's first chunk inside the block: the chunks are wave-contiguous, so count the earlier waves' chunks directly
+    int hits_before = tmp[blockIdx.x], dead_before = tmp[nb + 1 + blockIdx.x];
     for (int c = 0; c < wv * 4; ++c) {
         const int i = blockIdx.x * SPLIT_BLOCK + c * 64 + lane;
-        hits_before += __popcll(__ballot(i < n && depth[i] < 10.0f));
+        const bool dd = i < n && is_dead(dead, i);
+        hits_before += __popcll(__ballot(i < n && !dd && depth[i] < 10.0f));
+        dead_before += __popcll(__ballot(dd));
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int i0 = blockIdx.x * SPLIT_BLOCK + (wv * 4 + k) * 64;
         const int i = i0 + lane;
-        const bool valid = i < n, hit = valid && depth[i] < 10.0f;
-        const unsigned long long mh = __ballot(hit);
+        const bool valid = i < n, dd = valid && is_dead(dead, i), hit = valid && !dd && depth[i] < 10.0f;
+        const unsigned long long mh = __ballot(hit), md = __ballot(dd);
         if (valid) {
-            if (hit) { const int q = hits_before + __popcll(mh & lower); hit_idx[q] = i; slot[i] = -q - 1; }
-            else { const int q = (i0 - hits_before) + (lane - __popcll(mh & lower)); miss_idx[q] = i; slot[i] = q; }   // misses before i = i - hits before i
+            if (dd) slot[i] = DEAD_SLOT;
+            else if (hit) { const int q = hits_before + __popcll(mh & lower); hit_idx[q] = i; slot[i] = -q - 1; }
+            else {                                                       // misses before i = i - hits before i - dead rays before i
+                const int q = (i0 - hits_before - dead_before) + (lane - __popcll(mh & lower) - __popcll(md & lower));
+                miss_idx[q] = i; slot[i] = q;
+            }
         }
         hits_before += __popcll(mh);
+        dead_before += __popcll(md);
     }
 }
 }  // namespace
@@ -701,16 +750,33 @@ int nero_mc_dir_bwd(const float* pt, const float* dirs, const float* face_normal
 }
 
 
-int nero_mc_split_tmp_ints(int n) { return (n + SPLIT_BLOCK - 1) / SPLIT_BLOCK + 1; }
+int nero_mc_split_tmp_ints(int n) { return 2 * ((n + SPLIT_BLOCK - 1) / SPLIT_BLOCK + 1); }
 
-int nero_mc_split(const float* depth, int n, int* slot, int* miss_idx, int* hit_idx, int* counts, int* tmp, void* stream) {
+int nero_mc_dead_rays(const float* pt, const float* dirs, int P, int Dd, int Ds, int geometry_type, unsigned char* dead, void* stream) {
+    if (!pt || !dirs || !dead || P < 0 || Dd < 0 || Ds < 0) return nero_fail(NERO_ERR_ARG, "nero_mc_dead_rays: bad argument");
+    const int N = P * (Dd + Ds);
+    if (N == 0) return NERO_OK;
+    if (geometry_type != 0) {                       // the height-correlated Smith term keeps a small non-zero weight at NoL = 0 (field.py:905-913): nothing is dead
+        if (hipMemsetAsync(dead, 0, (size_t)N, (hipStream_t)stream) != hipSuccess) return nero_fail(NERO_ERR_LAUNCH, "nero_mc_dead_rays: memset failed");
+        return NERO_OK;
+    }
+    hipLaunchKernelGGL(mc_dead_rays_kernel, GRID1D(N), pt, dirs, P, Dd, Ds, dead);
+    return nero_check_launch("nero_mc_dead_rays");
+}
+
+int nero_mc_split_dead(const float* depth, const unsigned char* dead, int n, int* slot, int* miss_idx, int* hit_idx, int* counts, int* tmp,
+                       void* stream) {
     if (!depth || !slot || !miss_idx || !hit_idx || !counts || !tmp || n < 0) return nero_fail(NERO_ERR_ARG, "nero_mc_split: bad argument");
     if (n == 0) { (void)hipMemsetAsync(counts, 0, 8, (hipStream_t)stream); return NERO_OK; }
     const int nb = (n + SPLIT_BLOCK - 1) / SPLIT_BLOCK;
-    hipLaunchKernelGGL(mc_split_count_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, depth, n, tmp);
+    hipLaunchKernelGGL(mc_split_count_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, depth, dead, n, nb, tmp);
     hipLaunchKernelGGL(mc_split_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, tmp, nb, n, counts);
-    hipLaunchKernelGGL(mc_split_scatter_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, depth, n, tmp, slot, miss_idx, hit_idx);
+    hipLaunchKernelGGL(mc_split_scatter_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, depth, dead, n, nb, tmp, slot, miss_idx, hit_idx);
     return nero_check_launch("nero_mc_split");
+}
+
+int nero_mc_split(const float* depth, int n, int* slot, int* miss_idx, int* hit_idx, int* counts, int* tmp, void* stream) {
+    return nero_mc_split_dead(depth, nullptr, n, slot, miss_idx, hit_idx, counts, tmp, stream);
 }
 
 }  // extern "C"

@@ -63,6 +63,10 @@ struct nero_stage2 {
     int P = 0, n_miss = 0, n_hit = 0;
     float *pt = nullptr, *Xm = nullptr, *Xh = nullptr, *Xhum = nullptr, *hmask = nullptr;
     int *slot = nullptr, *miss_idx = nullptr, *hit_idx = nullptr, *counts = nullptr;
+    // rays whose estimator weight is exactly zero (mc_shade.hip, DEAD_SLOT): flagged in nero_stage2_rays, skipped by the tracer the caller hands
+    // the flags to, left out of both light MLPs.  NERO_MC_SKIP_DEAD=0 (read at create) keeps every ray, as rounds 1-5 did.
+    bool skip_dead = true;
+    unsigned char* dead = nullptr;
     Fwd f_out, f_in, f_hum;
     const float *dirs = nullptr, *depth = nullptr, *fnrm = nullptr, *poses = nullptr, *tab_s = nullptr;
     // a second stream for the HIT rows (inner-light MLP) beside the MISS rows (outer / human light): the two row sets share nothing
@@ -293,6 +297,8 @@ int nero_stage2_create(const nero_stage2_cfg* cfg, nero_stage2** out) {
     build_chains(h, &zero);
     const char* e = getenv("NERO_STREAMS");
     h->n_streams = e ? atoi(e) : NERO_STREAMS_DEFAULT;
+    const char* sd = getenv("NERO_MC_SKIP_DEAD");
+    h->skip_dead = !(sd && atoi(sd) == 0);
     if (hipGetDevice(&h->device) != hipSuccess) { h->device = -1; (void)hipGetLastError(); }
     if (h->n_streams >= 2) {
         if (hipStreamCreateWithFlags(&h->s2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -353,6 +359,7 @@ size_t nero_stage2_workspace_bytes(nero_stage2* h, int n_pred, int P) {
         tmp.P = P;
         tmp.pt = A.f32((size_t)P * 32);
         tmp.slot = A.i32(N); tmp.miss_idx = A.i32(N); tmp.hit_idx = A.i32(N); tmp.counts = A.i32(2);
+        (void)A.i32((N + 3) / 4);                                      // the dead-ray flags (bytes)
         (void)A.i32(nero_mc_split_tmp_ints(N));
         tmp.n_hit = hits[k]; tmp.n_miss = N - hits[k];
         (void)do_shade_lights(&tmp, A, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
@@ -387,12 +394,19 @@ int nero_stage2_rays(nero_stage2* h, int P, const float* pts, const float* view,
     h->P = P;
     h->pt = A.f32((size_t)P * 32);
     h->slot = A.i32(N); h->miss_idx = A.i32(N); h->hit_idx = A.i32(N); h->counts = A.i32(2);
+    h->dead = reinterpret_cast<unsigned char*>(A.i32((N + 3) / 4));
     if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage2_rays: workspace too small");
     RC(nero_mc_point_setup(pts, view, normals, mat5, rand_d, rand_s, P, h->pt, stream));
     RC(nero_mc_dirs(h->pt, tab_d, tab_s, P, c.diffuse_sample_num, c.specular_sample_num, dirs, origins, stream));
+    if (h->skip_dead && c.geometry_type == 0)
+        RC(nero_mc_dead_rays(h->pt, dirs, P, c.diffuse_sample_num, c.specular_sample_num, c.geometry_type, h->dead, stream));
     h->dirs = dirs; h->tab_s = tab_s;
     h->shade_mark = A.mark();
     return NERO_OK;
+}
+
+const unsigned char* nero_stage2_dead_rays(nero_stage2* h) {
+    return (h && h->P > 0 && h->skip_dead && h->cfg.geometry_type == 0) ? h->dead : nullptr;
 }
 
 int nero_stage2_shade_fwd(nero_stage2* h, const float* pos, const float* face_normals, const float* depth, const float* poses, float* rgb,
@@ -405,7 +419,7 @@ int nero_stage2_shade_fwd(nero_stage2* h, const float* pos, const float* face_no
     const int N = h->P * (h->cfg.diffuse_sample_num + h->cfg.specular_sample_num);
     int* tmp = A.i32(nero_mc_split_tmp_ints(N));
     if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage2_shade_fwd: workspace too small");
-    RC(nero_mc_split(depth, N, h->slot, h->miss_idx, h->hit_idx, h->counts, tmp, stream));
+    RC(nero_mc_split_dead(depth, (h->skip_dead && h->cfg.geometry_type == 0) ? h->dead : nullptr, N, h->slot, h->miss_idx, h->hit_idx, h->counts, tmp, stream));
     int counts[2] = {0, 0};
     if (hipMemcpyAsync(counts, h->counts, 8, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess || hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
         return nero_fail(NERO_ERR_LAUNCH, "nero_stage2_shade_fwd: reading the ray counts failed");

@@ -186,18 +186,31 @@ class MCShade(torch.autograd.Function):
         L.check(lib.nero_mc_dirs(_p(pt), _p(K.tab_d), _p(K.tab_s), Pn, Dd, Ds, _p(dirs), _p(orig), st))
         # closest hit, depth >= 10 <=> miss.  A tracer that takes a launch-order hint starts the specular chunks of every point first
         # (nero_bvh_trace_grouped: same outputs); any other RayTracer-shaped object (tests, a reference-side tracer) gets the plain call
+        # Round 6: rays whose estimator weight is exactly zero (GGX directions below the shading horizon under the Schlick geometry term:
+        # mc_shade.hip, DEAD_SLOT) are flagged, not traversed by a tracer that takes the flags, and left out of both light MLPs
+        N = Pn * D
+        geom = GEOMETRY_TYPES[cfg['geometry_type']]
+        dead = None
+        if geom == 0 and os.environ.get('NERO_MC_SKIP_DEAD', '1') != '0':
+            dead = torch.empty(N, dtype=torch.uint8, device=dev)
+            L.check(lib.nero_mc_dead_rays(_p(pt), _p(dirs), Pn, Dd, Ds, geom, _p(dead), st))
         tg = getattr(tracer, 'trace_grouped', None)
-        if tg is not None and os.environ.get('NERO_TRACE_ORDER', 'natural') == 'grouped':
+        tm = getattr(tracer, 'trace_masked', None)
+        if tm is not None and dead is not None:
+            pos, fnrm, depth = tm(orig, dirs, dead)
+        elif tg is not None and os.environ.get('NERO_TRACE_ORDER', 'natural') == 'grouped':
             pos, fnrm, depth = tg(orig, dirs, D, Dd)
         else:
             pos, fnrm, depth = tracer.trace(orig, dirs)
         # hit / miss split on the device (ordered compaction, nero_mc_split): the index lists torch.nonzero would give + the slot map
-        N = Pn * D
         depth = depth.contiguous().reshape(-1)
         i32 = dict(dtype=torch.int32, device=dev)
         slot, miss_idx, hit_idx, counts = torch.empty(N, **i32), torch.empty(N, **i32), torch.empty(N, **i32), torch.empty(2, **i32)
         tmp = torch.empty(lib.nero_mc_split_tmp_ints(N), **i32)
-        L.check(lib.nero_mc_split(_p(depth), N, _p(slot), _p(miss_idx), _p(hit_idx), _p(counts), _p(tmp), st))
+        L.check(lib.nero_mc_split_dead(_p(depth), _p(dead), N, _p(slot), _p(miss_idx), _p(hit_idx), _p(counts), _p(tmp), st))
+        from . import chain as CH
+        if CH.MASK_CAPTURE is not None:                 # (tests: which rays own a row of which light MLP -- the capture's masks are per ROW)
+            CH.MASK_CAPTURE.append({'kind': 'mc_split', 'slot': slot.clone(), 'depth': depth.clone()})
         n_miss, n_hit = (int(v) for v in counts.cpu())               # the step's host synchronisation: sizes of the light-MLP launches
         rpm, rph = row_pad(n_miss), row_pad(n_hit)
         Xm, Xh = torch.empty((max(rpm, 64), 144 if K.sphere else 72), **f32), torch.empty((max(rph, 64), 128), **f32)

@@ -40,7 +40,12 @@ class RayTracer:
         group started first (Stage II: the specular directions of a surface point).  Same outputs as trace()."""
         return self.trace(rays_o, rays_d, inplace, _order=(int(group), int(heavy_from)))
 
-    def trace(self, rays_o, rays_d, inplace=False, _order=None):
+    def trace_masked(self, rays_o, rays_d, skip, inplace=False):
+        """trace() that does not traverse the rays flagged in `skip` (uint8 tensor [n] or a device pointer; nero_bvh_trace_masked): they are
+        reported as misses.  Every other ray: the outputs of trace() bit for bit."""
+        return self.trace(rays_o, rays_d, inplace, _skip=skip)
+
+    def trace(self, rays_o, rays_d, inplace=False, _order=None, _skip=None):
         rays_o = rays_o.float().contiguous()
         rays_d = rays_d.float().contiguous()
         if not rays_o.is_cuda:
@@ -56,7 +61,14 @@ class RayTracer:
         depth = torch.empty(n, dtype=torch.float32, device=rays_o.device)
         if inplace:                      # the kernel reads o/d before it writes: each thread owns its ray
             pass
-        if _order is not None:
+        if _skip is not None:
+            sp = _skip.data_ptr() if torch.is_tensor(_skip) else int(_skip)
+            if torch.is_tensor(_skip):
+                assert _skip.dtype == torch.uint8 and _skip.is_cuda and _skip.numel() == n and _skip.is_contiguous()
+            L.check(L.lib.nero_bvh_trace_masked(self._handle(), C.c_void_p(rays_o.data_ptr()), C.c_void_p(rays_d.data_ptr()), n, C.c_void_p(sp),
+                                                C.c_void_p(positions.data_ptr()), C.c_void_p(face_normals.data_ptr()),
+                                                C.c_void_p(depth.data_ptr()), L.stream_ptr()))
+        elif _order is not None:
             L.check(L.lib.nero_bvh_trace_grouped(self._handle(), C.c_void_p(rays_o.data_ptr()), C.c_void_p(rays_d.data_ptr()), n,
                                                  C.c_void_p(positions.data_ptr()), C.c_void_p(face_normals.data_ptr()),
                                                  C.c_void_p(depth.data_ptr()), _order[0], _order[1], L.stream_ptr()))

@@ -37,6 +37,8 @@ _lib.nero_stage2_destroy.argtypes = [_fp]
 _lib.nero_stage2_pack.argtypes = [_fp, C.POINTER(Weights), _fp, _fp]
 _lib.nero_stage2_predict_fwd.argtypes = [_fp, _fp, C.c_int, _fp, _fp, C.c_size_t, _fp]
 _lib.nero_stage2_rays.argtypes = [_fp, C.c_int] + [_fp] * 11
+_lib.nero_stage2_dead_rays.restype = C.c_void_p
+_lib.nero_stage2_dead_rays.argtypes = [_fp]
 _lib.nero_stage2_shade_fwd.argtypes = [_fp] + [_fp] * 8 + [C.POINTER(C.c_int), C.POINTER(C.c_int), _fp]
 _lib.nero_stage2_shade_bwd.argtypes = [_fp, _fp, _fp, C.POINTER(Weights), _fp, _fp]
 _lib.nero_stage2_predict_bwd.argtypes = [_fp, _fp, C.POINTER(Weights), _fp]
@@ -170,8 +172,15 @@ class MCShadeC(torch.autograd.Function):
                                       _p(dirs), L.stream_ptr()))
         # closest hit, depth >= 10 <=> miss.  A tracer that takes a launch-order hint starts the specular chunks of every point first
         # (nero_bvh_trace_grouped: same outputs); any other RayTracer-shaped object (tests, a reference-side tracer) gets the plain call
+        # Round 6: the driver flags the rays whose estimator weight is exactly zero (GGX directions below the shading horizon under the
+        # Schlick geometry term: mc_shade.hip, DEAD_SLOT); a tracer that takes the flags does not traverse them (they are the longest rays of
+        # the launch), and shade_fwd leaves them out of both light MLPs whatever the tracer reported
         tg = getattr(tracer, 'trace_grouped', None)
-        if tg is not None and os.environ.get('NERO_TRACE_ORDER', 'natural') == 'grouped':
+        tm = getattr(tracer, 'trace_masked', None)
+        dead = _lib.nero_stage2_dead_rays(drv.h)
+        if tm is not None and dead:
+            pos, fnrm, depth = tm(orig, dirs, dead)
+        elif tg is not None and os.environ.get('NERO_TRACE_ORDER', 'natural') == 'grouped':
             pos, fnrm, depth = tg(orig, dirs, D, drv.Dd)
         else:
             pos, fnrm, depth = tracer.trace(orig, dirs)
@@ -180,6 +189,7 @@ class MCShadeC(torch.autograd.Function):
         n_miss, n_hit = C.c_int(0), C.c_int(0)
         L.check(_lib.nero_stage2_shade_fwd(drv.h, _p(pos), _p(fnrm), _p(depth), _p(poses), _p(rgb), _p(dl), _p(sl), _p(sp), C.byref(n_miss),
                                            C.byref(n_hit), L.stream_ptr()))
+        drv.last_counts = (n_miss.value, n_hit.value, Pn * D)       # (miss rows, hit rows, rays: the rest are zero-weight rays nobody shades)
         ctx.drv, ctx.names, ctx.gv, ctx.shapes, ctx.P = drv, names, (gv or {}), [tuple(p.shape) for p in params], Pn
         ctx.keep = (pts, view, normals, mat5, rd, rs, poses, orig, dirs, pos, fnrm, depth)
         ctx.mark_non_differentiable(sl, sp)

@@ -323,11 +323,31 @@ def forced_gates_from_capture(capture, stage, n_primary, human=False, k_inner_li
     def put(key, words, r0, n, n_out):
         gates[key] = decode_relu_masks(words[r0:], n, n_out)
 
-    def put_pred(prefix, rec, splits):
+    # Stage II, round 6: the HIP step leaves the rays whose estimator weight is exactly zero (nero_mc_dead_rays) out of both light MLPs, the
+    # oracle -- like the reference -- shades every ray.  The capture's 'mc_split' record (slot + the depth the tracer returned, per ray) says
+    # which of the oracle's rows the HIP rows are; the oracle's extra rows get open gates (their outputs are multiplied by a weight of 0.0
+    # and receive a gradient of 0.0, so the choice cannot matter).  Needs a tracer that reports the true hit of a dead ray too (tests.helpers.CTracer).
+    split = next((r for r in capture if r.get('kind') == 'mc_split'), None)
+    live_of = {}
+    if split is not None:
+        live = split['slot'] != -2 ** 31
+        hit = split['depth'] < 10
+        live_of = {'hit': live[hit], 'miss': live[~hit]}
+
+    def put_pred(prefix, rec, splits, rows=None):
         for call, (r0, n) in enumerate(splits):
             for i in range(3):
-                put(f'{prefix}@{call}/{i}', rec['masks'][i], r0, n, rec['n_out'][i])
+                key = f'{prefix}@{call}/{i}'
+                put(key, rec['masks'][i], r0, n, rec['n_out'][i])
+                sel = live_of.get(rows)
+                if sel is not None and not bool(sel.all()):
+                    assert int(sel.sum()) == n, (key, int(sel.sum()), n)
+                    full = torch.ones((sel.numel(), rec['n_out'][i]), dtype=gates[key].dtype, device=gates[key].device)
+                    full[sel.to(gates[key].device)] = gates[key]
+                    gates[key] = full
     for rec in capture:
+        if rec.get('kind') == 'mc_split':
+            continue
         k, ka, n = rec['k_init'], rec['k_aux'], rec['n_rows']
         if stage == 1 and rec['aux_wide'] and k == 88:                       # NeRF++ trunk
             for i in range(8):
@@ -349,13 +369,13 @@ def forced_gates_from_capture(capture, stage, n_primary, human=False, k_inner_li
             if stage == 1:                                                   # rows [0, rpi): IDE(n, 1) diffuse; [rpi, rpi + n_in): IDE(refl, rough)
                 put_pred(f'{pre}.outer_light', rec, [(0, n_primary), (row_pad(n_primary), n_primary)])
             else:
-                put_pred(f'{pre}.outer_light', rec, [(0, n)])
+                put_pred(f'{pre}.outer_light', rec, [(0, n)], rows='miss')
         elif k == k_inner_light:
-            put_pred(f'{pre}.inner_light', rec, [(0, n)])
+            put_pred(f'{pre}.inner_light', rec, [(0, n)], rows='hit' if stage == 2 else None)
         elif k == k_inner_weight and stage == 1:
             put_pred(f'{pre}.inner_weight', rec, [(0, n)])
         elif k == 24:
-            put_pred(f'{pre}.human_light_predictor' if stage == 1 else f'{pre}.human_light', rec, [(0, n)])
+            put_pred(f'{pre}.human_light_predictor' if stage == 1 else f'{pre}.human_light', rec, [(0, n)], rows='miss' if stage == 2 else None)
         else:
             raise AssertionError(('unrecognised chain in the mask capture', k, ka, rec['aux_wide'], n))
     return gates

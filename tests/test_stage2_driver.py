@@ -114,3 +114,68 @@ def test_c_driven_material_training_steps(monkeypatch):
                            pool_points=512, device='cuda:0')
     losses = [float(ts.step(5000 + i)['loss']) for i in range(4)]
     assert all(l == l for l in losses) and ts.drv is not None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n', [1, 64, 1000, 1025, 300001])
+def test_mc_split_with_dead_rays_matches_torch_nonzero(n):
+    """nero_mc_split_dead (round 6): flagged rays enter neither list and get slot INT_MIN; the other two classes keep torch.nonzero's order"""
+    from nero_amd import _lib as L
+    g = torch.Generator().manual_seed(n + 7)
+    depth = torch.where(torch.rand(n, generator=g) < 0.4, torch.rand(n, generator=g) * 2.0, torch.full((n,), 10.0)).cuda()
+    dead = (torch.rand(n, generator=g) < 0.15).to(torch.uint8).cuda()
+    i32 = dict(dtype=torch.int32, device='cuda')
+    slot, mi, hi, counts = torch.full((n,), 12345, **i32), torch.empty(n, **i32), torch.empty(n, **i32), torch.empty(2, **i32)
+    tmp = torch.empty(L.lib.nero_mc_split_tmp_ints(n), **i32)
+    P = C.c_void_p
+    L.check(L.lib.nero_mc_split_dead(P(depth.data_ptr()), P(dead.data_ptr()), n, P(slot.data_ptr()), P(mi.data_ptr()), P(hi.data_ptr()),
+                                     P(counts.data_ptr()), P(tmp.data_ptr()), L.stream_ptr()))
+    live = dead == 0
+    hit = (depth < 10) & live
+    want_m, want_h = torch.nonzero(~hit & live)[:, 0].int(), torch.nonzero(hit)[:, 0].int()
+    n_miss, n_hit = (int(v) for v in counts.cpu())
+    assert (n_miss, n_hit) == (want_m.numel(), want_h.numel()) and n_miss + n_hit == int(live.sum())
+    assert torch.equal(mi[:n_miss], want_m) and torch.equal(hi[:n_hit], want_h)
+    want_slot = torch.full((n,), -2 ** 31, **i32)
+    want_slot[want_m.long()] = torch.arange(n_miss, **i32)
+    want_slot[want_h.long()] = -torch.arange(n_hit, **i32) - 1
+    assert torch.equal(slot, want_slot)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('drv', ['py', 'c'])
+def test_skipping_the_zero_weight_rays_changes_nothing(drv, monkeypatch):
+    """Round 6: GGX directions below the shading horizon carry an estimator weight of exactly zero under the Schlick geometry term
+    (network/field.py:892-903, 979-987); the step neither traces nor shades them.  Against NERO_MC_SKIP_DEAD=0 (every ray traced and shaded,
+    rounds 1-5): the same outputs and loss to fp32 rounding of the sums that lost zero terms -- here: bit-equal outputs -- and the same
+    gradients to the rounding of weight-gradient sums whose row blocks moved (1e-5 of each tensor's largest entry); fewer MLP rows."""
+    from nero_amd.synthetic import icosphere
+    from nero_amd.train import MaterialTrainStep
+    v, f = icosphere(4, 0.5, 0.2)
+    mesh = (v, np.ascontiguousarray(f[:, ::-1]))
+    scfg = dict(diffuse_sample_num=64, specular_sample_num=64, human_lights=True, outer_light_version='sphere_direction')
+    P_ = 192
+    g = torch.Generator().manual_seed(5)
+    rands = {'rand_d': torch.rand(P_, 1, 1, generator=g).cuda(), 'rand_s': torch.rand(P_, 1, 1, generator=g).cuda(),
+             'reg_ang': torch.rand(P_, 1, generator=g).cuda(), 'reg_eps': torch.normal(mean=0.0, std=0.05, size=[P_, 1], generator=g).cuda()}
+    monkeypatch.setenv('NERO_STEP_DRIVER', drv)
+    res = {}
+    for skip in ('0', '1'):
+        monkeypatch.setenv('NERO_MC_SKIP_DEAD', skip)
+        ts = MaterialTrainStep({'shader_cfg': scfg, 'database_name': 'real/bear'}, mesh, points_per_rank=P_, pool_points=4 * P_, device='cuda:0',
+                               fused_glue=False)
+        info = ts.forward_backward(5000, rands)
+        torch.cuda.synchronize()
+        res[skip] = (float(info['loss']), {k: v.detach().clone() for k, v in info['out'].items() if torch.is_tensor(v)}, ts.bucket.flat.clone(),
+                     [p.numel() for p in ts.bucket.params])
+    (l0, o0, f0, sizes), (l1, o1, f1, _) = res['0'], res['1']
+    assert abs(l0 - l1) <= 1e-6 * max(1.0, abs(l0))
+    for k in o0:
+        if o0[k].dtype.is_floating_point:
+            assert float((o0[k] - o1[k]).abs().max()) <= 1e-6 * max(1.0, float(o0[k].abs().max())), k
+    off = 0
+    for n_ in sizes:
+        a, b = f0[off:off + n_], f1[off:off + n_]
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-12
+        off += n_
+    assert float(f0.abs().max()) > 0

@@ -106,3 +106,30 @@ def test_grouped_launch_order_is_bit_identical_to_the_natural_order(n_pts, group
         odd = rt.trace_grouped(o[:n], d[:n], g, hf)
         for a, b in zip(plain, odd):
             assert torch.equal(a[:n], b)
+
+
+@pytest.mark.parametrize('mode', [0, 1])
+def test_masked_trace_skips_the_flagged_rays_only(mode):
+    """nero_bvh_trace_masked (round 6): a flagged ray is reported as a miss (depth 10, zero normal) without a node visit; every other ray's
+    position, normal and depth are those of nero_bvh_trace bit for bit -- in both traversal kernels, with an odd ray count"""
+    from nero_amd import _lib as L
+    from nero_amd.raytracing import RayTracer
+    from nero_amd.synthetic import icosphere, secondary_rays
+    v, f = icosphere(5, 0.5, 0.2)
+    f = np.ascontiguousarray(f[:, ::-1])
+    rt = RayTracer(v, f)
+    L.check(L.lib.nero_bvh_set_traversal(rt._handle(), mode))
+    o, d = secondary_rays(v, f, 301, 64, seed=3)
+    o, d = o[:-17].cuda().contiguous(), d[:-17].cuda().contiguous()
+    n = o.shape[0]
+    plain = [x.clone() for x in rt.trace(o, d)]
+    skip = (torch.rand(n, generator=torch.Generator().manual_seed(1)) < 0.3).to(torch.uint8).cuda()
+    pos, nrm, depth = rt.trace_masked(o, d, skip)
+    keep = skip == 0
+    assert 0.05 < float((plain[2] < 10).float().mean()) < 0.95 and int((plain[2][~keep] < 10).sum()) > 0
+    for a, b in zip(plain, (pos, nrm, depth)):
+        assert torch.equal(a[keep], b[keep])
+    assert bool((depth[~keep] == 10.0).all()) and bool((nrm[~keep] == 0).all())
+    none = rt.trace_masked(o, d, torch.zeros(n, dtype=torch.uint8, device='cuda'))
+    for a, b in zip(plain, none):
+        assert torch.equal(a, b)
