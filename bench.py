@@ -502,7 +502,11 @@ def run_stage2(args, dev, rank, world, sync, max_over_ranks, rank_table=None):
            'data': 'synthetic',
            'config': {'workload': f"Glossy{'Real' if args.config == 'bear' else 'Synthetic'} '{args.config}' Stage-II material, {P_} surface points x "
                                   f'({Dd}+{Ds}) MC light directions per GPU, {int(mesh[1].shape[0])}-triangle mesh, step 5000',
-                      'points_per_gpu': P_, 'parallelism': f'dp{world}', 'optimizer': 'adam(fused)'},
+                      'points_per_gpu': P_, 'parallelism': f'dp{world}', 'optimizer': 'adam(fused)',
+                      'zero_weight_rays': ('neither traced nor shaded: GGX directions below the shading horizon have an estimator weight of exactly 0.0 '
+                                           'under the Schlick geometry term (network/field.py:892-903, 987) -- same outputs and gradients; '
+                                           'NERO_MC_SKIP_DEAD=0 processes every ray' if os.environ.get('NERO_MC_SKIP_DEAD', '1') != '0'
+                                           else 'processed like every other ray (NERO_MC_SKIP_DEAD=0)')},
            'stage2': r, **ranks}
     if 'roofline' in r:
         res['roofline'] = r['roofline']
