@@ -171,7 +171,10 @@ def run_case(name, extra):
 
 # ---- Stage II at size: the reference's MCShadingNetwork on 1024 surface points x (128 + 128) Monte-Carlo directions ---------------------------
 MAT_P, MAT_STEP, MAT_RAY_STRIDE = 1024, 5000, 64
-MAT_CASES = {'mat_bell': dict(diffuse_sample_num=128, specular_sample_num=128, human_lights=False, outer_light_version='direction')}
+MAT_CASES = {'mat_bell': dict(diffuse_sample_num=128, specular_sample_num=128, human_lights=False, outer_light_version='direction'),
+             # configs/material/real/bear.yaml's light model (the photographer's light + sphere-direction outer light), own weights and points
+             'mat_bear': dict(diffuse_sample_num=128, specular_sample_num=128, human_lights=True, outer_light_version='sphere_direction')}
+MAT_SEEDS = {'mat_bell': dict(seed=SEED, input_seed=5), 'mat_bear': dict(seed=SEED + 1, input_seed=6)}
 
 
 def material_inputs(Pn, seed=5):
@@ -200,7 +203,8 @@ def run_material(name, shader_cfg):
     from tests.helpers import CTracer, golden_mesh, tracer_contract
     renderer, field = ref_shim.load_reference()
     mesh = golden_mesh()
-    I = material_inputs(MAT_P)
+    seeds = MAT_SEEDS[name]
+    I = material_inputs(MAT_P, seed=seeds['input_seed'])
     rr = renderer.NeROShapeRenderer.__new__(renderer.NeROShapeRenderer)          # only for get_human_coordinate_poses (same code in both renderers)
     rr.cfg = {'fixed_camera': False}
     hp = torch.cat([renderer.NeROShapeRenderer.get_human_coordinate_poses(rr, I['poses'][i:i + 1].clone()) for i in range(MAT_P)], 0)
@@ -213,7 +217,7 @@ def run_material(name, shader_cfg):
         class Holder(nn.Module):
             pass
         torch.set_default_dtype(torch.float32)
-        torch.manual_seed(SEED)
+        torch.manual_seed(seeds['seed'])
         net = Holder()
         net.shader_network = field.MCShadingNetwork(shader_cfg, tracer_contract(tr))
         perturb_state(net, None)
@@ -253,7 +257,7 @@ def run_material(name, shader_cfg):
     pos, nrm, depth = src.raw[0]
     ro, rd = src.rays[0]
     hit = depth < 10
-    rec.update(meta=json.dumps(dict(name=name, shader_cfg=shader_cfg, P=MAT_P, step=MAT_STEP, seed=SEED, n_sample=N_SAMPLE, ray_stride=MAT_RAY_STRIDE,
+    rec.update(meta=json.dumps(dict(name=name, shader_cfg=shader_cfg, P=MAT_P, step=MAT_STEP, **seeds, n_sample=N_SAMPLE, ray_stride=MAT_RAY_STRIDE,
                                     n_rays=int(depth.shape[0]), n_hit=int(hit.sum()))),
                pts=I['pts'].numpy(), view=I['view'].numpy(), normals=I['normals'].numpy(), human_poses=hp.numpy(), gt=I['gt'].numpy(),
                rand_d=I['rand_d'].numpy(), rand_s=I['rand_s'].numpy(), reg_ang=I['reg_ang'].numpy(), reg_eps=I['reg_eps'].numpy(),

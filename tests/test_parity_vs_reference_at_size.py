@@ -218,15 +218,18 @@ class _FixtureTracer:
         return f(pos), f(nrm), f(self.depth)
 
 
-def test_stage2_step_on_the_references_hits():
+@pytest.mark.parametrize('case', ['mat_bell', 'mat_bear'])
+def test_stage2_step_on_the_references_hits(case):
+    """mat_bell: configs/material/syn/bell.yaml's light model; mat_bear: configs/material/real/bear.yaml's (the photographer's light on the
+    camera plane + the sphere-direction outer light), its own weights and surface points"""
     from nero_amd.renderer import NeROMaterialRenderer
     from nero_amd.synthetic import perturb_state
     from oracle.gen_golden_at_size import sample_index
     from oracle.golden_util import state_checksums
     from tests.helpers import MatHolder, golden_mesh
-    path = os.path.join(GOLDEN, 'at_size_mat_bell_1024.npz')
+    path = os.path.join(GOLDEN, f'at_size_{case}_1024.npz')
     if not os.path.exists(path):
-        pytest.skip(f'{path} not generated (python oracle/gen_golden_at_size.py mat_bell in the build container)')
+        pytest.skip(f'{path} not generated (python oracle/gen_golden_at_size.py {case} in the build container)')
     z = np.load(path)
     meta = json.loads(str(z['meta']))
     cfg = meta['shader_cfg']
@@ -235,7 +238,7 @@ def test_stage2_step_on_the_references_hits():
     perturb_state(ref, None)
     for k, v in state_checksums({k: v.detach().clone() for k, v in ref.state_dict().items()}).items():
         assert np.allclose(v, z['ck/' + k], rtol=1e-9, atol=1e-9), k
-    net = NeROMaterialRenderer({'shader_cfg': cfg, 'database_name': 'syn/bell'}, mesh=golden_mesh())
+    net = NeROMaterialRenderer({'shader_cfg': cfg, 'database_name': 'real/bear' if cfg['human_lights'] else 'syn/bell'}, mesh=golden_mesh())
     net.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
     net = net.cuda()
     tr = net.ray_tracer = _FixtureTracer(z, meta)
@@ -286,6 +289,6 @@ def test_stage2_step_on_the_references_hits():
     rep['gradients'] = dict(n_tensors=len(err), n_plain=len(plain), n_clause_a=len(a), n_clause_b=len(b), clause_a=a, clause_b=b,
                             median_err=float(np.median(vals)), max_err=float(vals.max()), median_reference_fp32_floor=float(np.median(list(floor_t.values()))),
                             worst=sorted(((k, err[k], floor[_mlp_of(k)]) for k in err), key=lambda t: -t[1])[:5])
-    parity_report('ref_at_size[mat_bell].stage2_step', **rep)
+    parity_report(f'ref_at_size[{case}].stage2_step', **rep)
     assert not bad, bad
     assert len(a) <= MAX_CLAUSE_A and len(b) <= MAX_CLAUSE_B, (len(a), len(b))
