@@ -318,16 +318,19 @@ def stage2_step_bench(dev, kind, P_, Dd, Ds, mesh, rank=0, world=1, warmup=5, st
     h = rec['hit'] / max(rec['n'], 1)
     # rows of the light MLPs per ray: the step's own counts (round 6: rays whose estimator weight is exactly zero -- GGX directions below the
     # shading horizon under the Schlick geometry term, nero_mc_dead_rays -- are neither traced nor shaded; NERO_MC_SKIP_DEAD=0 keeps them)
-    n_miss_rows, n_hit_rows, n_rays = getattr(ts.drv, 'last_counts', None) or (round((1 - h) * rec['n']), rec['hit'], max(rec['n'], 1))
+    n_miss_rows, n_hit_rows, n_rays, n_hum_rows = getattr(ts.drv, 'last_counts', None) or (round((1 - h) * rec['n']), rec['hit'], max(rec['n'], 1), None)
     m_frac, h_frac = n_miss_rows / n_rays, n_hit_rows / n_rays
-    c_miss = (168704 if kind == 'bear' else C_OUTER) + (138240 if kind == 'bear' else 0)        # C_outer (+ C_human)
-    flop_pt = 2 * 3 * (2 * C_MAT + D * (m_frac * c_miss + h_frac * C_INNER))
+    # (bear: the human-light MLP owns a row only for the miss rays that reach the photographer's region of the camera plane -- its output is
+    #  multiplied by that mask, network/field.py:829; NERO_MC_SKIP_DEAD=0: for every miss ray, as rounds 1-5)
+    u_frac = (n_hum_rows / n_rays) if (kind == 'bear' and n_hum_rows is not None) else (m_frac if kind == 'bear' else 0.0)
+    c_outer = 168704 if kind == 'bear' else C_OUTER                                             # C_outer, C_human
+    flop_pt = 2 * 3 * (2 * C_MAT + D * (m_frac * c_outer + u_frac * 138240 + h_frac * C_INNER))
     peak = PEAK_OF_MODE[CH.GEMM_MODE['fwd']]
     out = {'model': kind, 'points_per_gpu': P_, 'directions': f'{Dd}+{Ds}', 'n_gpus': world, 'trainer': 'fused (nero_wn_forward_batch / nero_wn_adam_batch)',
            'ms_per_step': round(wall * 1e3, 3), 'ms_per_step_this_rank': round(wall_local * 1e3, 3), 'ms_per_step_median': round(ms[len(ms) // 2], 3),
            'points_per_s': round(P_ * world / wall, 1), 'light_rays_per_s': round(P_ * world * D / wall, 1),
            'tracer_rays_per_s': round(rec['n'] / (rec['ms'] * 1e-3), 1) if rec['ms'] > 0 else None, 'tracer_ms': round(rec['ms'], 3),
-           'hit_fraction': round(h_frac, 4), 'miss_fraction': round(m_frac, 4), 'zero_weight_ray_fraction': round(1.0 - m_frac - h_frac, 4),
+           'hit_fraction': round(h_frac, 4), 'miss_fraction': round(m_frac, 4), 'zero_weight_ray_fraction': round(1.0 - m_frac - h_frac, 4), 'human_light_row_fraction': round(u_frac, 4),
            'mlp_mflop_per_point': round(flop_pt / 1e6, 1),
            'mlp_flop_frac': round(flop_pt * P_ / wall / peak, 4), 'mlp_flop_frac_peak_tflops': round(peak / 1e12, 1),
            'warmup': warmup, 'steps': steps}

@@ -491,6 +491,26 @@ int nero_mc_combine_bwd(const float* pt, const float* dirs, const float* depth, 
 int nero_mc_dir_bwd(const float* pt, const float* dirs, const float* face_normals, const int* slot, const float* tab_s,
                     const float* dX_miss, const float* dX_hit, const float* d_wspec, int P, int Dd, int Ds, float* d_mat5, int sphere,
                     const float* dXh /*or NULL*/, const float* poses /*[P,3,4] or NULL*/, void* stream);
+/* Round 6: the photographer's light exists only where a ray reaches his region of the camera plane -- get_human_light multiplies the MLP's
+ * output by that mask (field.py:819-829), so every other row of the human-light MLP is exactly dead.  nero_mc_human_flags: hum [P*D] bytes =
+ * the mask per ray (hits & |0.3 inter_xy| < 1.5 & dist > 0).  nero_mc_split_classes: nero_mc_split_dead (dead may be NULL) with the miss
+ * list PARTITIONED by `hum`: the misses with hum != 0 first (ray order), then the others (ray order); counts3 int32 [3] = (n_miss, n_hit, n_hum).
+ * The human-light MLP then runs on the miss rows [0, n_hum); the _h entry points take n_hum and read human_raw / hmask / dXh / write d_human_raw
+ * for those rows only (the plain entry points: for every miss row). */
+int nero_mc_human_flags(const float* pt, const float* dirs, const float* poses, int P, int D, unsigned char* hum, void* stream);
+int nero_mc_split_classes(const float* depth, const unsigned char* dead, const unsigned char* hum, int n, int* slot, int* miss_idx, int* hit_idx,
+                          int* counts3, int* tmp, void* stream);
+int nero_mc_combine_fwd_h(const float* pt, const float* dirs, const float* depth, const int* slot, const float* outer_raw,
+                          const float* inner_raw, const float* human_raw, const float* hmask, int n_hum, float exp_max, float inner_exp_max, int P,
+                          int Dd, int Ds, int geometry_type, float* rgb_lin, float* dl_mean, float* sl_mean, float* spec_lin /*or NULL*/,
+                          void* stream);
+int nero_mc_combine_bwd_h(const float* pt, const float* dirs, const float* depth, const int* slot, const float* outer_raw,
+                          const float* inner_raw, const float* human_raw, const float* hmask, int n_hum, float exp_max, float inner_exp_max, int P,
+                          int Dd, int Ds, int geometry_type, const float* d_rgb, const float* d_dl, float* d_outer_raw, float* d_inner_raw,
+                          float* d_human_raw, float* d_mat5, float* d_wspec, void* stream);
+int nero_mc_dir_bwd_h(const float* pt, const float* dirs, const float* face_normals, const int* slot, const float* tab_s,
+                      const float* dX_miss, const float* dX_hit, const float* d_wspec, int P, int Dd, int Ds, float* d_mat5, int sphere,
+                      const float* dXh /*or NULL*/, const float* poses /*[P,3,4] or NULL*/, int n_hum, void* stream);
 
 /* ---- C-level driver of the Stage-I render step (nero_stage1_render_fwd / _bwd, nero_workspace_bytes) -------------------
  * One call each for sample_ray (network/renderer.py:403-443), render / render_core (:445-463, 550-606: the drop-in boundary) and
@@ -598,6 +618,10 @@ int nero_stage2_rays(nero_stage2* h, int P, const float* pts, const float* view,
  * bytes, valid until the next nero_stage2_rays), for the caller's tracer (nero_bvh_trace_masked); NULL when nothing is skipped (geometry_type 1,
  * or NERO_MC_SKIP_DEAD=0 at nero_stage2_create).  nero_stage2_shade_fwd leaves the flagged rays out of both light MLPs whatever the tracer reported. */
 const unsigned char* nero_stage2_dead_rays(nero_stage2* h);
+/* rows of the last nero_stage2_shade_fwd: miss rows (outer light), hit rows (inner light), and how many of the miss rows own a row of the
+ * human-light MLP (round 6: the rays that reach the photographer's region of the camera plane; 0 without human_lights).  Rays that are none of
+ * these are the zero-weight rays nobody shades. */
+int nero_stage2_counts(nero_stage2* h, int* n_miss, int* n_hit, int* n_hum);
 /* pos / face_normals [P*D,3], depth [P*D] of the traced rays (depth >= 10 = miss; kept alive until shade_bwd); poses [P,3,4] or NULL
  * -> rgb (linear), mean diffuse light, mean weighted specular light, specular part: [P,3] each */
 int nero_stage2_shade_fwd(nero_stage2* h, const float* pos, const float* face_normals, const float* depth, const float* poses, float* rgb,

@@ -291,7 +291,7 @@ __device__ __forceinline__ void brdf_terms(const float* q, const float* w, bool 
     b.W = b.N / b.Q;
 }
 
-struct Lights { const float* outer_raw; const float* inner_raw; const float* human_raw; const float* hmask; float emax, imax; int geom; };
+struct Lights { const float* outer_raw; const float* inner_raw; const float* human_raw; const float* hmask; float emax, imax; int geom; int n_hum; };
 
 // DEAD rays (round 6).  With the Schlick-GGX geometry term (the reference's default and the only one its configurations use, field.py:702) a
 // direction below the shading horizon has NoL = saturate(n.w) = 0, so G = g(NoV) g(0) = 0 and its estimator weight D G / (4 NoV p + 1e-5) is
@@ -311,7 +311,7 @@ __device__ __forceinline__ void light_value(int s, const Lights& P_, float near,
         for (int c = 0; c < 3; ++c) L[c] = 0.f;
     } else if (s >= 0) {
         for (int c = 0; c < 3; ++c) outer[c] = expf(fminf(P_.outer_raw[(size_t)s * 4 + c], P_.emax));
-        if (P_.human_raw) {
+        if (P_.human_raw && s < P_.n_hum) {                 // (miss rows [0, n_hum) own a row of the human-light MLP: nero_mc_split_classes)
             const float hm = P_.hmask[s];
             for (int c = 0; c < 3; ++c) hl[c] = expf(fminf(P_.human_raw[(size_t)s * 4 + c], 0.f)) * hm;
             hw_raw = expf(fminf(P_.human_raw[(size_t)s * 4 + 3], 0.f)) * hm;
@@ -418,13 +418,13 @@ __global__ __launch_bounds__(64) void mc_combine_bwd_kernel(const float* __restr
             for (int c = 0; c < 3; ++c) {
                 const float dl_ = dL[c] * near;
                 o4[c] = LP.outer_raw[(size_t)s * 4 + c] <= LP.emax ? dl_ * (1.f - hw) * ou[c] : 0.f;
-                if (LP.human_raw) {
+                if (LP.human_raw && s < LP.n_hum) {
                     h4[c] = LP.human_raw[(size_t)s * 4 + c] <= 0.f ? dl_ * hw * hl[c] : 0.f;
                     dhw += dl_ * (hl[c] - ou[c]);
                 }
             }
             reinterpret_cast<float4*>(d_outer_raw)[s] = make_float4(o4[0], o4[1], o4[2], 0.f);
-            if (LP.human_raw) {
+            if (LP.human_raw && s < LP.n_hum) {
                 const float g = (hwr >= 0.f && hwr <= 1.f) ? dhw : 0.f;
                 h4[3] = LP.human_raw[(size_t)s * 4 + 3] <= 0.f ? g * hwr : 0.f;
                 reinterpret_cast<float4*>(d_human_raw)[s] = make_float4(h4[0], h4[1], h4[2], h4[3]);
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(64) void mc_dir_bwd_kernel(const float* __restrict_
                                                         const float* __restrict__ tab_s, const float* __restrict__ dX_miss,
                                                         const float* __restrict__ dX_hit, const float* __restrict__ d_wspec,
                                                         int P_, int Dd, int Ds, float* __restrict__ d_mat5, int sphere,
-                                                        const float* __restrict__ dXh, const float* __restrict__ poses) {
+                                                        const float* __restrict__ dXh, const float* __restrict__ poses, int n_hum) {
     const int p = blockIdx.x, lane = threadIdx.x;
     if (p >= P_) return;
     const int D = Dd + Ds;
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(64) void mc_dir_bwd_kernel(const float* __restrict_
                 const float dd = dot3(ds, w) * (se.dtx / se.s - 1.f);
                 for (int c = 0; c < 3; ++c) dw[c] += se.dist * ds[c] + dd * se.pp[c];
             }
-            if (dXh) {
+            if (dXh && s < n_hum) {
                 // IPE(mean, 0) of the human-plane hit: mean = 0.3 h inter_xy
                 const float* pose = poses + (size_t)p * 12;
                 const HumanGeom hg = human_geom(pose, q + 29, w);
@@ -574,6 +574,17 @@ __global__ __launch_bounds__(64) void mc_dir_bwd_kernel(const float* __restrict_
 }
 
 
+// hum[row] = 1 when the ray reaches the photographer's region of the camera plane (get_human_light, field.py:819-824: hits & |mean| < 1.5 &
+// dist > 0) -- the human-light MLP's output is multiplied by this mask (field.py:829), so every other row of that MLP is exactly dead
+__global__ void mc_human_flags_kernel(const float* __restrict__ pt, const float* __restrict__ dirs, const float* __restrict__ poses, int P_, int D,
+                                      unsigned char* __restrict__ hum) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= P_ * D) return;
+    const int p = row / D;
+    const HumanGeom g = human_geom(poses + (size_t)p * 12, pt + (size_t)p * 32 + 29, dirs + (size_t)row * 3);
+    hum[row] = g.h != 0.f ? 1 : 0;
+}
+
 // dead[row] = 1 for a specular direction below the shading horizon by more than the margin (see DEAD_SLOT above), 0 otherwise
 __global__ void mc_dead_rays_kernel(const float* __restrict__ pt, const float* __restrict__ dirs, int P_, int Dd, int Ds,
                                     unsigned char* __restrict__ dead) {
@@ -591,35 +602,44 @@ __global__ void mc_dead_rays_kernel(const float* __restrict__ pt, const float* _
 // Three launches: per-block ballot counts, one-block exclusive scan, ordered scatter (position = block base + wave base + population
 // count of the lower lanes) -- the order torch.nonzero produces, without its host round trip for the sizes of intermediate tensors.
 constexpr int SPLIT_BLOCK = 1024;                  // rays per 256-thread block (4 per thread, wave-contiguous chunks of 64)
-// three classes when `dead` is given: dead rays (flagged; neither list), hits (depth < 10, not dead), misses (the rest).  tmp holds two
-// per-block count arrays of nb + 1 ints: hits at [0, nb), dead rays at [nb + 1, 2 nb + 1).
+// Classes: dead rays (flagged by `dead`; neither list), hits (depth < 10, not dead), misses (the rest).  With `hum` the miss list is
+// PARTITIONED: the misses that reach the photographer's region (hum[i] != 0) first, in ray order, then the other misses, in ray order -- the
+// human-light MLP then runs on the miss rows [0, n_hum) only (its output is multiplied by that mask: field.py:829).  Without `hum` the miss list
+// is in ray order (what torch.nonzero yields).  tmp: three per-block count arrays of nb + 1 ints -- hits, dead rays, human misses.
 __device__ __forceinline__ bool is_dead(const unsigned char* dead, int i) { return dead != nullptr && dead[i] != 0; }
-__global__ __launch_bounds__(256) void mc_split_count_kernel(const float* __restrict__ depth, const unsigned char* __restrict__ dead, int n, int nb,
-                                                             int* __restrict__ tmp) {
-    __shared__ int wsum[4], wdead[4];
+struct RayClass { bool dead, hit, hmiss; };
+__device__ __forceinline__ RayClass ray_class(const float* __restrict__ depth, const unsigned char* __restrict__ dead,
+                                              const unsigned char* __restrict__ hum, int i, int n) {
+    RayClass c;
+    c.dead = i < n && is_dead(dead, i);
+    c.hit = i < n && !c.dead && depth[i] < 10.0f;
+    c.hmiss = i < n && !c.dead && !c.hit && hum != nullptr && hum[i] != 0;
+    return c;
+}
+__global__ __launch_bounds__(256) void mc_split_count_kernel(const float* __restrict__ depth, const unsigned char* __restrict__ dead,
+                                                             const unsigned char* __restrict__ hum, int n, int nb, int* __restrict__ tmp) {
+    __shared__ int wsum[3][4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int c = 0, cd = 0;
+    int c[3] = {0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int i = blockIdx.x * SPLIT_BLOCK + (wv * 4 + k) * 64 + lane;
-        const bool dd = i < n && is_dead(dead, i);
-        c += __popcll(__ballot(i < n && !dd && depth[i] < 10.0f));
-        cd += __popcll(__ballot(dd));
+        const RayClass rc = ray_class(depth, dead, hum, i, n);
+        c[0] += __popcll(__ballot(rc.hit));
+        c[1] += __popcll(__ballot(rc.dead));
+        c[2] += __popcll(__ballot(rc.hmiss));
     }
-    if (lane == 0) { wsum[wv] = c; wdead[wv] = cd; }
+    if (lane == 0) for (int a = 0; a < 3; ++a) wsum[a][wv] = c[a];
     __syncthreads();
-    if (threadIdx.x == 0) {
-        tmp[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        tmp[nb + 1 + blockIdx.x] = wdead[0] + wdead[1] + wdead[2] + wdead[3];
-    }
+    if (threadIdx.x < 3) tmp[threadIdx.x * (nb + 1) + blockIdx.x] = wsum[threadIdx.x][0] + wsum[threadIdx.x][1] + wsum[threadIdx.x][2] + wsum[threadIdx.x][3];
 }
-// exclusive scans of both count arrays in place (one 1024-thread block, any nb); counts = (n_miss, n_hit)
-__global__ __launch_bounds__(1024) void mc_split_scan_kernel(int* __restrict__ tmp, int nb, int n, int* __restrict__ counts) {
+// exclusive scans of the three count arrays in place (one 1024-thread block, any nb); counts = (n_miss, n_hit[, n_hum])
+__global__ __launch_bounds__(1024) void mc_split_scan_kernel(int* __restrict__ tmp, int nb, int n, int* __restrict__ counts, int three) {
     __shared__ int part[1024];
     const int tid = threadIdx.x;
     const int per = (nb + 1023) / 1024;
-    int totals[2] = {0, 0};
-    for (int a = 0; a < 2; ++a) {
+    int totals[3] = {0, 0, 0};
+    for (int a = 0; a < 3; ++a) {
         int* const arr = tmp + a * (nb + 1);
         int s = 0;
         for (int k = 0; k < per; ++k) { const int b = tid * per + k; if (b < nb) s += arr[b]; }
@@ -639,37 +659,47 @@ __global__ __launch_bounds__(1024) void mc_split_scan_kernel(int* __restrict__ t
         }
         totals[a] = part[1023];
     }
-    if (tid == 1023) { counts[0] = n - totals[0] - totals[1]; counts[1] = totals[0]; }
+    if (tid == 1023) {
+        counts[0] = n - totals[0] - totals[1]; counts[1] = totals[0];
+        tmp[3 * (nb + 1) - 1] = totals[2];                                 // (the scatter kernel's base of the plain misses; the slot behind the third array)
+        if (three) counts[2] = totals[2];
+    }
 }
-__global__ __launch_bounds__(256) void mc_split_scatter_kernel(const float* __restrict__ depth, const unsigned char* __restrict__ dead, int n, int nb,
+__global__ __launch_bounds__(256) void mc_split_scatter_kernel(const float* __restrict__ depth, const unsigned char* __restrict__ dead,
+                                                               const unsigned char* __restrict__ hum, int n, int nb,
                                                                const int* __restrict__ tmp, int* __restrict__ slot, int* __restrict__ miss_idx,
                                                                int* __restrict__ hit_idx) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const unsigned long long lower = (1ull << lane) - 1ull;
-    // hits / dead rays before this wave's first chunk inside the block: the chunks are wave-contiguous, so count the earlier waves' chunks directly
-    int hits_before = tmp[blockIdx.x], dead_before = tmp[nb + 1 + blockIdx.x];
+    const int n_hum = tmp[3 * (nb + 1) - 1];
+    // hits / dead rays / human misses before this wave's first chunk inside the block: the chunks are wave-contiguous, so count the earlier
+    // waves' chunks directly
+    int hits_before = tmp[blockIdx.x], dead_before = tmp[nb + 1 + blockIdx.x], hm_before = tmp[2 * (nb + 1) + blockIdx.x];
     for (int c = 0; c < wv * 4; ++c) {
         const int i = blockIdx.x * SPLIT_BLOCK + c * 64 + lane;
-        const bool dd = i < n && is_dead(dead, i);
-        hits_before += __popcll(__ballot(i < n && !dd && depth[i] < 10.0f));
-        dead_before += __popcll(__ballot(dd));
+        const RayClass rc = ray_class(depth, dead, hum, i, n);
+        hits_before += __popcll(__ballot(rc.hit));
+        dead_before += __popcll(__ballot(rc.dead));
+        hm_before += __popcll(__ballot(rc.hmiss));
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int i0 = blockIdx.x * SPLIT_BLOCK + (wv * 4 + k) * 64;
         const int i = i0 + lane;
-        const bool valid = i < n, dd = valid && is_dead(dead, i), hit = valid && !dd && depth[i] < 10.0f;
-        const unsigned long long mh = __ballot(hit), md = __ballot(dd);
-        if (valid) {
-            if (dd) slot[i] = DEAD_SLOT;
-            else if (hit) { const int q = hits_before + __popcll(mh & lower); hit_idx[q] = i; slot[i] = -q - 1; }
-            else {                                                       // misses before i = i - hits before i - dead rays before i
-                const int q = (i0 - hits_before - dead_before) + (lane - __popcll(mh & lower) - __popcll(md & lower));
+        const RayClass rc = ray_class(depth, dead, hum, i, n);
+        const unsigned long long mh = __ballot(rc.hit), md = __ballot(rc.dead), mm = __ballot(rc.hmiss);
+        if (i < n) {
+            if (rc.dead) slot[i] = DEAD_SLOT;
+            else if (rc.hit) { const int q = hits_before + __popcll(mh & lower); hit_idx[q] = i; slot[i] = -q - 1; }
+            else if (rc.hmiss) { const int q = hm_before + __popcll(mm & lower); miss_idx[q] = i; slot[i] = q; }
+            else {                                                       // plain misses before i = i - hits - dead rays - human misses before i
+                const int q = n_hum + (i0 - hits_before - dead_before - hm_before) + (lane - __popcll(mh & lower) - __popcll(md & lower) - __popcll(mm & lower));
                 miss_idx[q] = i; slot[i] = q;
             }
         }
         hits_before += __popcll(mh);
         dead_before += __popcll(md);
+        hm_before += __popcll(mm);
     }
 }
 }  // namespace
@@ -716,41 +746,60 @@ int nero_mc_encode_hit(const float* dirs, const float* pos, const float* face_no
     return nero_check_launch("nero_mc_encode_hit");
 }
 
-int nero_mc_combine_fwd(const float* pt, const float* dirs, const float* depth, const int* slot, const float* outer_raw,
-                        const float* inner_raw, const float* human_raw, const float* hmask, float exp_max, float inner_exp_max, int P,
-                        int Dd, int Ds, int geometry_type, float* rgb_lin, float* dl_mean, float* sl_mean, float* spec_lin, void* stream) {
+// (_h: the human-light MLP owns a row for the miss rows [0, n_hum) only -- nero_mc_split_classes; the plain entry points: for every miss row)
+int nero_mc_combine_fwd_h(const float* pt, const float* dirs, const float* depth, const int* slot, const float* outer_raw,
+                          const float* inner_raw, const float* human_raw, const float* hmask, int n_hum, float exp_max, float inner_exp_max, int P,
+                          int Dd, int Ds, int geometry_type, float* rgb_lin, float* dl_mean, float* sl_mean, float* spec_lin, void* stream) {
     if (P == 0) return NERO_OK;
     if (geometry_type != 0 && geometry_type != 1) return nero_fail(NERO_ERR_UNSUPPORTED, "nero_mc_combine_fwd: unknown geometry_type");
-    Lights LP{outer_raw, inner_raw, human_raw, hmask, exp_max, inner_exp_max, geometry_type};
+    Lights LP{outer_raw, inner_raw, human_raw, hmask, exp_max, inner_exp_max, geometry_type, n_hum};
     hipLaunchKernelGGL(mc_combine_fwd_kernel, dim3(P), dim3(64), 0, (hipStream_t)stream, pt, dirs, depth, slot, LP, P, Dd, Ds, rgb_lin,
                        dl_mean, sl_mean, spec_lin);
     return nero_check_launch("nero_mc_combine_fwd");
 }
-
-int nero_mc_combine_bwd(const float* pt, const float* dirs, const float* depth, const int* slot, const float* outer_raw,
+int nero_mc_combine_fwd(const float* pt, const float* dirs, const float* depth, const int* slot, const float* outer_raw,
                         const float* inner_raw, const float* human_raw, const float* hmask, float exp_max, float inner_exp_max, int P,
-                        int Dd, int Ds, int geometry_type, const float* d_rgb, const float* d_dl, float* d_outer_raw, float* d_inner_raw,
-                        float* d_human_raw, float* d_mat5, float* d_wspec, void* stream) {
+                        int Dd, int Ds, int geometry_type, float* rgb_lin, float* dl_mean, float* sl_mean, float* spec_lin, void* stream) {
+    return nero_mc_combine_fwd_h(pt, dirs, depth, slot, outer_raw, inner_raw, human_raw, hmask, 0x7fffffff, exp_max, inner_exp_max, P, Dd, Ds,
+                                 geometry_type, rgb_lin, dl_mean, sl_mean, spec_lin, stream);
+}
+
+int nero_mc_combine_bwd_h(const float* pt, const float* dirs, const float* depth, const int* slot, const float* outer_raw,
+                          const float* inner_raw, const float* human_raw, const float* hmask, int n_hum, float exp_max, float inner_exp_max, int P,
+                          int Dd, int Ds, int geometry_type, const float* d_rgb, const float* d_dl, float* d_outer_raw, float* d_inner_raw,
+                          float* d_human_raw, float* d_mat5, float* d_wspec, void* stream) {
     if (P == 0) return NERO_OK;
     if (geometry_type != 0 && geometry_type != 1) return nero_fail(NERO_ERR_UNSUPPORTED, "nero_mc_combine_bwd: unknown geometry_type");
-    Lights LP{outer_raw, inner_raw, human_raw, hmask, exp_max, inner_exp_max, geometry_type};
+    Lights LP{outer_raw, inner_raw, human_raw, hmask, exp_max, inner_exp_max, geometry_type, n_hum};
     hipLaunchKernelGGL(mc_combine_bwd_kernel, dim3(P), dim3(64), 0, (hipStream_t)stream, pt, dirs, depth, slot, LP, P, Dd, Ds, d_rgb,
                        d_dl, d_outer_raw, d_inner_raw, d_human_raw, d_mat5, d_wspec);
     return nero_check_launch("nero_mc_combine_bwd");
 }
+int nero_mc_combine_bwd(const float* pt, const float* dirs, const float* depth, const int* slot, const float* outer_raw,
+                        const float* inner_raw, const float* human_raw, const float* hmask, float exp_max, float inner_exp_max, int P,
+                        int Dd, int Ds, int geometry_type, const float* d_rgb, const float* d_dl, float* d_outer_raw, float* d_inner_raw,
+                        float* d_human_raw, float* d_mat5, float* d_wspec, void* stream) {
+    return nero_mc_combine_bwd_h(pt, dirs, depth, slot, outer_raw, inner_raw, human_raw, hmask, 0x7fffffff, exp_max, inner_exp_max, P, Dd, Ds,
+                                 geometry_type, d_rgb, d_dl, d_outer_raw, d_inner_raw, d_human_raw, d_mat5, d_wspec, stream);
+}
 
-int nero_mc_dir_bwd(const float* pt, const float* dirs, const float* face_normals, const int* slot, const float* tab_s,
-                    const float* dX_miss, const float* dX_hit, const float* d_wspec, int P, int Dd, int Ds, float* d_mat5, int sphere,
-                    const float* dXh, const float* poses, void* stream) {
+int nero_mc_dir_bwd_h(const float* pt, const float* dirs, const float* face_normals, const int* slot, const float* tab_s,
+                      const float* dX_miss, const float* dX_hit, const float* d_wspec, int P, int Dd, int Ds, float* d_mat5, int sphere,
+                      const float* dXh, const float* poses, int n_hum, void* stream) {
     CHECK_T();
     if (P == 0) return NERO_OK;
     hipLaunchKernelGGL(mc_dir_bwd_kernel, dim3(P), dim3(64), 0, (hipStream_t)stream, pt, dirs, face_normals, slot, tab_s, dX_miss, dX_hit,
-                       d_wspec, P, Dd, Ds, d_mat5, sphere, dXh, poses);
+                       d_wspec, P, Dd, Ds, d_mat5, sphere, dXh, poses, n_hum);
     return nero_check_launch("nero_mc_dir_bwd");
+}
+int nero_mc_dir_bwd(const float* pt, const float* dirs, const float* face_normals, const int* slot, const float* tab_s,
+                    const float* dX_miss, const float* dX_hit, const float* d_wspec, int P, int Dd, int Ds, float* d_mat5, int sphere,
+                    const float* dXh, const float* poses, void* stream) {
+    return nero_mc_dir_bwd_h(pt, dirs, face_normals, slot, tab_s, dX_miss, dX_hit, d_wspec, P, Dd, Ds, d_mat5, sphere, dXh, poses, 0x7fffffff, stream);
 }
 
 
-int nero_mc_split_tmp_ints(int n) { return 2 * ((n + SPLIT_BLOCK - 1) / SPLIT_BLOCK + 1); }
+int nero_mc_split_tmp_ints(int n) { return 3 * ((n + SPLIT_BLOCK - 1) / SPLIT_BLOCK + 1); }
 
 int nero_mc_dead_rays(const float* pt, const float* dirs, int P, int Dd, int Ds, int geometry_type, unsigned char* dead, void* stream) {
     if (!pt || !dirs || !dead || P < 0 || Dd < 0 || Ds < 0) return nero_fail(NERO_ERR_ARG, "nero_mc_dead_rays: bad argument");
@@ -764,19 +813,36 @@ int nero_mc_dead_rays(const float* pt, const float* dirs, int P, int Dd, int Ds,
     return nero_check_launch("nero_mc_dead_rays");
 }
 
-int nero_mc_split_dead(const float* depth, const unsigned char* dead, int n, int* slot, int* miss_idx, int* hit_idx, int* counts, int* tmp,
-                       void* stream) {
+int nero_mc_human_flags(const float* pt, const float* dirs, const float* poses, int P, int D, unsigned char* hum, void* stream) {
+    if (!pt || !dirs || !poses || !hum || P < 0 || D < 1) return nero_fail(NERO_ERR_ARG, "nero_mc_human_flags: bad argument");
+    if (P == 0) return NERO_OK;
+    hipLaunchKernelGGL(mc_human_flags_kernel, GRID1D(P * D), pt, dirs, poses, P, D, hum);
+    return nero_check_launch("nero_mc_human_flags");
+}
+
+static int split_impl(const float* depth, const unsigned char* dead, const unsigned char* hum, int n, int* slot, int* miss_idx, int* hit_idx,
+                      int* counts, int three, int* tmp, void* stream) {
     if (!depth || !slot || !miss_idx || !hit_idx || !counts || !tmp || n < 0) return nero_fail(NERO_ERR_ARG, "nero_mc_split: bad argument");
-    if (n == 0) { (void)hipMemsetAsync(counts, 0, 8, (hipStream_t)stream); return NERO_OK; }
+    if (n == 0) { (void)hipMemsetAsync(counts, 0, three ? 12 : 8, (hipStream_t)stream); return NERO_OK; }
     const int nb = (n + SPLIT_BLOCK - 1) / SPLIT_BLOCK;
-    hipLaunchKernelGGL(mc_split_count_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, depth, dead, n, nb, tmp);
-    hipLaunchKernelGGL(mc_split_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, tmp, nb, n, counts);
-    hipLaunchKernelGGL(mc_split_scatter_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, depth, dead, n, nb, tmp, slot, miss_idx, hit_idx);
+    hipLaunchKernelGGL(mc_split_count_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, depth, dead, hum, n, nb, tmp);
+    hipLaunchKernelGGL(mc_split_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, tmp, nb, n, counts, three);
+    hipLaunchKernelGGL(mc_split_scatter_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, depth, dead, hum, n, nb, tmp, slot, miss_idx, hit_idx);
     return nero_check_launch("nero_mc_split");
 }
 
+int nero_mc_split_classes(const float* depth, const unsigned char* dead, const unsigned char* hum, int n, int* slot, int* miss_idx, int* hit_idx,
+                          int* counts3, int* tmp, void* stream) {
+    return split_impl(depth, dead, hum, n, slot, miss_idx, hit_idx, counts3, 1, tmp, stream);
+}
+
+int nero_mc_split_dead(const float* depth, const unsigned char* dead, int n, int* slot, int* miss_idx, int* hit_idx, int* counts, int* tmp,
+                       void* stream) {
+    return split_impl(depth, dead, nullptr, n, slot, miss_idx, hit_idx, counts, 0, tmp, stream);
+}
+
 int nero_mc_split(const float* depth, int n, int* slot, int* miss_idx, int* hit_idx, int* counts, int* tmp, void* stream) {
-    return nero_mc_split_dead(depth, nullptr, n, slot, miss_idx, hit_idx, counts, tmp, stream);
+    return split_impl(depth, nullptr, nullptr, n, slot, miss_idx, hit_idx, counts, 0, tmp, stream);
 }
 
 }  // extern "C"

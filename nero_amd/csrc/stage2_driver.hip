@@ -67,6 +67,10 @@ struct nero_stage2 {
     // the flags to, left out of both light MLPs.  NERO_MC_SKIP_DEAD=0 (read at create) keeps every ray, as rounds 1-5 did.
     bool skip_dead = true;
     unsigned char* dead = nullptr;
+    // the human-light MLP's output is multiplied by the plane-hit mask of its ray (field.py:829): with the flags of nero_mc_human_flags the
+    // miss list is partitioned (nero_mc_split_classes) and that MLP runs on the miss rows [0, n_hum) only.  Off with skip_dead: n_hum = n_miss.
+    unsigned char* hum = nullptr;
+    int n_hum = 0;
     Fwd f_out, f_in, f_hum;
     const float *dirs = nullptr, *depth = nullptr, *fnrm = nullptr, *poses = nullptr, *tab_s = nullptr;
     // a second stream for the HIT rows (inner-light MLP) beside the MISS rows (outer / human light): the two row sets share nothing
@@ -196,11 +200,12 @@ int do_shade_lights(nero_stage2* h, Arena& A, const float* pos, float* rgb, floa
     if (n_miss > 0) {
         LAUNCH(nero_mc_encode_miss(h->dirs, h->miss_idx, h->pt, D, c.sphere_direction, n_miss, h->Xm, stream));
         RC(h->outer_light.forward(A, h->M, h->Xm, h->kout, nullptr, 0, n_miss, true, h->f_out, stream));
-        if (c.human_lights) {
-            h->Xhum = A.f32((size_t)rpm * 24); h->hmask = A.f32(rpm);
+        if (c.human_lights && h->n_hum > 0) {                 // (the miss rows [0, n_hum): the rays that reach the photographer's region)
+            const int rpu = rpad(h->n_hum) > 64 ? rpad(h->n_hum) : 64;
+            h->Xhum = A.f32((size_t)rpu * 24); h->hmask = A.f32(rpu);
             if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage2_shade_fwd: workspace too small");
-            LAUNCH(nero_mc_human_encode(h->dirs, h->miss_idx, h->pt, D, h->poses, n_miss, h->Xhum, h->hmask, stream));
-            RC(h->human_light.forward(A, h->M, h->Xhum, 24, nullptr, 0, n_miss, true, h->f_hum, stream));
+            LAUNCH(nero_mc_human_encode(h->dirs, h->miss_idx, h->pt, D, h->poses, h->n_hum, h->Xhum, h->hmask, stream));
+            RC(h->human_light.forward(A, h->M, h->Xhum, 24, nullptr, 0, h->n_hum, true, h->f_hum, stream));
         }
     }
     hipStream_t side = (hipStream_t)stream;
@@ -210,9 +215,9 @@ int do_shade_lights(nero_stage2* h, Arena& A, const float* pos, float* rgb, floa
         RC(h->inner_light.forward(A, h->M, h->Xh, 128, nullptr, 0, n_hit, true, h->f_in, (void*)side));
     }
     if (!A.dry) join_side(h, side, (hipStream_t)stream);
-    LAUNCH(nero_mc_combine_fwd(h->pt, h->dirs, h->depth, h->slot, n_miss > 0 ? h->f_out.heads[3] : nullptr, n_hit > 0 ? h->f_in.heads[3] : nullptr,
-                               (n_miss > 0 && c.human_lights) ? h->f_hum.heads[3] : nullptr, h->hmask, c.light_exp_max, c.inner_light_exp_max,
-                               h->P, c.diffuse_sample_num, c.specular_sample_num, c.geometry_type, rgb, dl, sl, sp, stream));
+    LAUNCH(nero_mc_combine_fwd_h(h->pt, h->dirs, h->depth, h->slot, n_miss > 0 ? h->f_out.heads[3] : nullptr, n_hit > 0 ? h->f_in.heads[3] : nullptr,
+                                 (n_miss > 0 && c.human_lights && h->n_hum > 0) ? h->f_hum.heads[3] : nullptr, h->hmask, h->n_hum, c.light_exp_max,
+                                 c.inner_light_exp_max, h->P, c.diffuse_sample_num, c.specular_sample_num, c.geometry_type, rgb, dl, sl, sp, stream));
     return NERO_OK;
 }
 
@@ -222,8 +227,10 @@ int do_shade_bwd(nero_stage2* h, Arena& A, const float* d_rgb, const float* d_dl
     const nero_linear_grad* g = G->lin;
     const int n_miss = h->n_miss, n_hit = h->n_hit, P = h->P, Dd = c.diffuse_sample_num, Ds = c.specular_sample_num;
     const int rm = rpad(n_miss) > 64 ? rpad(n_miss) : 64, rh = rpad(n_hit) > 64 ? rpad(n_hit) : 64;
-    const bool hum = c.human_lights && n_miss > 0;
-    float* d_hr = c.human_lights ? A.f32((size_t)rm * 4) : nullptr;
+    const int n_hum = h->n_hum;
+    const bool hum = c.human_lights && n_miss > 0 && n_hum > 0;
+    const int ru = rpad(n_hum) > 64 ? rpad(n_hum) : 64;
+    float* d_hr = c.human_lights ? A.f32((size_t)ru * 4) : nullptr;
     float* d_or = A.f32((size_t)rm * 4);
     float* d_ir = A.f32((size_t)rh * 4);
     float* d_w = A.f32((size_t)P * Ds * 3);
@@ -233,17 +240,17 @@ int do_shade_bwd(nero_stage2* h, Arena& A, const float* d_rgb, const float* d_dl
     float* partials_h = two ? A.f32((size_t)nero_dw_workspace_floats(n_hit > 1 ? n_hit : 1)) : partials;     // (the hit branch's own partial sums)
     float* dXm = n_miss > 0 ? A.f32((size_t)rpad(n_miss) * h->kout) : nullptr;
     float* dXh = n_hit > 0 ? A.f32((size_t)rpad(n_hit) * 128) : nullptr;
-    float* dXhum = hum ? A.f32((size_t)rpad(n_miss) * 24) : nullptr;
+    float* dXhum = hum ? A.f32((size_t)rpad(n_hum) * 24) : nullptr;
     if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage2_shade_bwd: workspace too small");
     if (!A.dry) {
-        if (d_hr) (void)hipMemsetAsync(d_hr, 0, (size_t)rm * 16, hs);
+        if (d_hr) (void)hipMemsetAsync(d_hr, 0, (size_t)ru * 16, hs);
         (void)hipMemsetAsync(d_or, 0, (size_t)rm * 16, hs);
         (void)hipMemsetAsync(d_ir, 0, (size_t)rh * 16, hs);
         (void)hipMemsetAsync(d_w, 0, (size_t)P * Ds * 12, hs);
     }
-    LAUNCH(nero_mc_combine_bwd(h->pt, h->dirs, h->depth, h->slot, n_miss > 0 ? h->f_out.heads[3] : nullptr, n_hit > 0 ? h->f_in.heads[3] : nullptr,
-                               hum ? h->f_hum.heads[3] : nullptr, h->hmask, c.light_exp_max, c.inner_light_exp_max, P, Dd, Ds, c.geometry_type,
-                               d_rgb, d_dl, d_or, d_ir, d_hr, d_mat5, d_w, stream));
+    LAUNCH(nero_mc_combine_bwd_h(h->pt, h->dirs, h->depth, h->slot, n_miss > 0 ? h->f_out.heads[3] : nullptr, n_hit > 0 ? h->f_in.heads[3] : nullptr,
+                                 hum ? h->f_hum.heads[3] : nullptr, h->hmask, n_hum, c.light_exp_max, c.inner_light_exp_max, P, Dd, Ds, c.geometry_type,
+                                 d_rgb, d_dl, d_or, d_ir, d_hr, d_mat5, d_w, stream));
     const float* hd[MAXL] = {};
     // the hit branch (inner light) starts behind the estimator's backward, beside the miss branch
     const hipStream_t side = (n_miss > 0 && n_hit > 0) ? fork_side(h, A, hs) : hs;
@@ -259,8 +266,8 @@ int do_shade_bwd(nero_stage2* h, Arena& A, const float* d_rgb, const float* d_dl
             predictor_grads(h->human_light, g + M_HUMAN, 24);
             hd[3] = d_hr;
             Bwd hb;
-            RC(h->human_light.backward(A, h->M, h->f_hum, n_miss, nullptr, 0, hd, true, false, nullptr, dXhum, 24, false, false, hb, stream));
-            RC(h->human_light.weight_grads(A, h->M, h->f_hum, hb, n_miss, h->Xhum, 24, nullptr, 0, hd, nullptr, nullptr, partials, stream));
+            RC(h->human_light.backward(A, h->M, h->f_hum, n_hum, nullptr, 0, hd, true, false, nullptr, dXhum, 24, false, false, hb, stream));
+            RC(h->human_light.weight_grads(A, h->M, h->f_hum, hb, n_hum, h->Xhum, 24, nullptr, 0, hd, nullptr, nullptr, partials, stream));
             if (!two) A.release(mk);
         }
     }
@@ -275,7 +282,7 @@ int do_shade_bwd(nero_stage2* h, Arena& A, const float* d_rgb, const float* d_dl
         if (!two) A.release(mk);
     }
     if (!A.dry) join_side(h, side, hs);
-    LAUNCH(nero_mc_dir_bwd(h->pt, h->dirs, h->fnrm, h->slot, h->tab_s, dXm, dXh, d_w, P, Dd, Ds, d_mat5, c.sphere_direction, dXhum, h->poses, stream));
+    LAUNCH(nero_mc_dir_bwd_h(h->pt, h->dirs, h->fnrm, h->slot, h->tab_s, dXm, dXh, d_w, P, Dd, Ds, d_mat5, c.sphere_direction, dXhum, h->poses, n_hum, stream));
     return nero_check_launch("nero_stage2_shade_bwd");
 }
 
@@ -358,10 +365,11 @@ size_t nero_stage2_workspace_bytes(nero_stage2* h, int n_pred, int P) {
         (void)do_predict_fwd(&tmp, A, nullptr, n_pred, nullptr, nullptr);
         tmp.P = P;
         tmp.pt = A.f32((size_t)P * 32);
-        tmp.slot = A.i32(N); tmp.miss_idx = A.i32(N); tmp.hit_idx = A.i32(N); tmp.counts = A.i32(2);
+        tmp.slot = A.i32(N); tmp.miss_idx = A.i32(N); tmp.hit_idx = A.i32(N); tmp.counts = A.i32(4);
         (void)A.i32((N + 3) / 4);                                      // the dead-ray flags (bytes)
+        if (tmp.cfg.human_lights) (void)A.i32((N + 3) / 4);            // the human-plane flags (bytes)
         (void)A.i32(nero_mc_split_tmp_ints(N));
-        tmp.n_hit = hits[k]; tmp.n_miss = N - hits[k];
+        tmp.n_hit = hits[k]; tmp.n_miss = N - hits[k]; tmp.n_hum = tmp.n_miss;
         (void)do_shade_lights(&tmp, A, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
         const size_t mk = A.mark();
         (void)do_shade_bwd(&tmp, A, nullptr, nullptr, &G, nullptr, nullptr);
@@ -393,8 +401,9 @@ int nero_stage2_rays(nero_stage2* h, int P, const float* pts, const float* view,
     const int N = P * (c.diffuse_sample_num + c.specular_sample_num);
     h->P = P;
     h->pt = A.f32((size_t)P * 32);
-    h->slot = A.i32(N); h->miss_idx = A.i32(N); h->hit_idx = A.i32(N); h->counts = A.i32(2);
+    h->slot = A.i32(N); h->miss_idx = A.i32(N); h->hit_idx = A.i32(N); h->counts = A.i32(4);
     h->dead = reinterpret_cast<unsigned char*>(A.i32((N + 3) / 4));
+    h->hum = c.human_lights ? reinterpret_cast<unsigned char*>(A.i32((N + 3) / 4)) : nullptr;
     if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage2_rays: workspace too small");
     RC(nero_mc_point_setup(pts, view, normals, mat5, rand_d, rand_s, P, h->pt, stream));
     RC(nero_mc_dirs(h->pt, tab_d, tab_s, P, c.diffuse_sample_num, c.specular_sample_num, dirs, origins, stream));
@@ -402,6 +411,14 @@ int nero_stage2_rays(nero_stage2* h, int P, const float* pts, const float* view,
         RC(nero_mc_dead_rays(h->pt, dirs, P, c.diffuse_sample_num, c.specular_sample_num, c.geometry_type, h->dead, stream));
     h->dirs = dirs; h->tab_s = tab_s;
     h->shade_mark = A.mark();
+    return NERO_OK;
+}
+
+int nero_stage2_counts(nero_stage2* h, int* n_miss, int* n_hit, int* n_hum) {
+    if (!h) return nero_fail(NERO_ERR_ARG, "nero_stage2_counts: bad argument");
+    if (n_miss) *n_miss = h->n_miss;
+    if (n_hit) *n_hit = h->n_hit;
+    if (n_hum) *n_hum = h->cfg.human_lights ? h->n_hum : 0;
     return NERO_OK;
 }
 
@@ -419,11 +436,15 @@ int nero_stage2_shade_fwd(nero_stage2* h, const float* pos, const float* face_no
     const int N = h->P * (h->cfg.diffuse_sample_num + h->cfg.specular_sample_num);
     int* tmp = A.i32(nero_mc_split_tmp_ints(N));
     if (A.failed) return nero_fail(NERO_ERR_ARG, "nero_stage2_shade_fwd: workspace too small");
-    RC(nero_mc_split_dead(depth, (h->skip_dead && h->cfg.geometry_type == 0) ? h->dead : nullptr, N, h->slot, h->miss_idx, h->hit_idx, h->counts, tmp, stream));
-    int counts[2] = {0, 0};
-    if (hipMemcpyAsync(counts, h->counts, 8, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess || hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+    const unsigned char* dead = (h->skip_dead && h->cfg.geometry_type == 0) ? h->dead : nullptr;
+    const bool part = h->skip_dead && h->cfg.human_lights && h->hum;       // (the miss list partitioned by the human-plane mask)
+    if (part) RC(nero_mc_human_flags(h->pt, h->dirs, poses, h->P, h->cfg.diffuse_sample_num + h->cfg.specular_sample_num, h->hum, stream));
+    RC(nero_mc_split_classes(depth, dead, part ? h->hum : nullptr, N, h->slot, h->miss_idx, h->hit_idx, h->counts, tmp, stream));
+    int counts[3] = {0, 0, 0};
+    if (hipMemcpyAsync(counts, h->counts, 12, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess || hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
         return nero_fail(NERO_ERR_LAUNCH, "nero_stage2_shade_fwd: reading the ray counts failed");
     h->n_miss = counts[0]; h->n_hit = counts[1];
+    h->n_hum = part ? counts[2] : counts[0];
     if (n_miss_out) *n_miss_out = counts[0];
     if (n_hit_out) *n_hit_out = counts[1];
     h->depth = depth; h->fnrm = face_normals; h->poses = poses;

@@ -205,40 +205,49 @@ class MCShade(torch.autograd.Function):
         # hit / miss split on the device (ordered compaction, nero_mc_split): the index lists torch.nonzero would give + the slot map
         depth = depth.contiguous().reshape(-1)
         i32 = dict(dtype=torch.int32, device=dev)
-        slot, miss_idx, hit_idx, counts = torch.empty(N, **i32), torch.empty(N, **i32), torch.empty(N, **i32), torch.empty(2, **i32)
+        slot, miss_idx, hit_idx, counts = torch.empty(N, **i32), torch.empty(N, **i32), torch.empty(N, **i32), torch.empty(3, **i32)
         tmp = torch.empty(lib.nero_mc_split_tmp_ints(N), **i32)
-        L.check(lib.nero_mc_split_dead(_p(depth), _p(dead), N, _p(slot), _p(miss_idx), _p(hit_idx), _p(counts), _p(tmp), st))
+        poses = poses.detach().contiguous().float() if (poses is not None and K.human_light is not None) else None
+        if K.human_light is not None and poses is None:
+            raise ValueError('shader_cfg.human_lights needs human_poses [P,3,4]')
+        # the human-light MLP's output is multiplied by the plane-hit mask of its ray (field.py:829): the miss list is partitioned by that mask
+        # (nero_mc_split_classes) and the MLP runs on the miss rows [0, n_hum) only
+        hum = None
+        if K.human_light is not None and os.environ.get('NERO_MC_SKIP_DEAD', '1') != '0':
+            hum = torch.empty(N, dtype=torch.uint8, device=dev)
+            L.check(lib.nero_mc_human_flags(_p(pt), _p(dirs), _p(poses), Pn, D, _p(hum), st))
+        L.check(lib.nero_mc_split_classes(_p(depth), _p(dead), _p(hum), N, _p(slot), _p(miss_idx), _p(hit_idx), _p(counts), _p(tmp), st))
+        n_miss, n_hit, n_hum = (int(v) for v in counts.cpu())        # the step's host synchronisation: sizes of the light-MLP launches
+        if hum is None:
+            n_hum = n_miss if K.human_light is not None else 0
         from . import chain as CH
         if CH.MASK_CAPTURE is not None:                 # (tests: which rays own a row of which light MLP -- the capture's masks are per ROW)
-            CH.MASK_CAPTURE.append({'kind': 'mc_split', 'slot': slot.clone(), 'depth': depth.clone()})
-        n_miss, n_hit = (int(v) for v in counts.cpu())               # the step's host synchronisation: sizes of the light-MLP launches
+            CH.MASK_CAPTURE.append({'kind': 'mc_split', 'slot': slot.clone(), 'depth': depth.clone(), 'n_hum': n_hum})
         rpm, rph = row_pad(n_miss), row_pad(n_hit)
         Xm, Xh = torch.empty((max(rpm, 64), 144 if K.sphere else 72), **f32), torch.empty((max(rph, 64), 128), **f32)
         fo = fi = fh = None
         outer_raw = inner_raw = human_raw = hmask = Xhum = None
-        poses = poses.detach().contiguous().float() if (poses is not None and K.human_light is not None) else None
-        if K.human_light is not None and poses is None:
-            raise ValueError('shader_cfg.human_lights needs human_poses [P,3,4]')
         if n_miss > 0:
             L.check(lib.nero_mc_encode_miss(_p(dirs), _p(miss_idx), _p(pt), D, K.sphere, n_miss, _p(Xm), st))
             fo = K.outer_light.forward(Xm, None, n_miss)
             outer_raw = fo['heads'][3]
-            if K.human_light is not None:
-                Xhum, hmask = torch.empty((rpm, 24), **f32), torch.empty(rpm, **f32)
-                L.check(lib.nero_mc_human_encode(_p(dirs), _p(miss_idx), _p(pt), D, _p(poses), n_miss, _p(Xhum), _p(hmask), st))
-                fh = K.human_light.forward(Xhum, None, n_miss)
+            if K.human_light is not None and n_hum > 0:
+                rpu = max(row_pad(n_hum), 64)
+                Xhum, hmask = torch.empty((rpu, 24), **f32), torch.empty(rpu, **f32)
+                L.check(lib.nero_mc_human_encode(_p(dirs), _p(miss_idx), _p(pt), D, _p(poses), n_hum, _p(Xhum), _p(hmask), st))
+                fh = K.human_light.forward(Xhum, None, n_hum)
                 human_raw = fh['heads'][3]
         if n_hit > 0:
             L.check(lib.nero_mc_encode_hit(_p(dirs), _p(pos), _p(fnrm), _p(hit_idx), n_hit, _p(Xh), st))
             fi = K.inner_light.forward(Xh, None, n_hit)
             inner_raw = fi['heads'][3]
         rgb, dl, sl, sp = (torch.empty((Pn, 3), **f32) for _ in range(4))
-        L.check(lib.nero_mc_combine_fwd(_p(pt), _p(dirs), _p(depth), _p(slot), _p(outer_raw), _p(inner_raw), _p(human_raw), _p(hmask),
+        L.check(lib.nero_mc_combine_fwd_h(_p(pt), _p(dirs), _p(depth), _p(slot), _p(outer_raw), _p(inner_raw), _p(human_raw), _p(hmask), n_hum,
                                         C.c_float(cfg['light_exp_max']), C.c_float(cfg['inner_light_exp_max']), Pn, Dd, Ds,
                                         GEOMETRY_TYPES[cfg['geometry_type']], _p(rgb), _p(dl), _p(sl), _p(sp), st))
         ctx.S = dict(K=K, names=names, P=Pn, pt=pt, dirs=dirs, depth=depth, fnrm=fnrm, slot=slot, Xm=Xm, Xh=Xh, fo=fo, fi=fi,
                      fh=fh, Xhum=Xhum, hmask=hmask, poses=poses, gv=(gv or {}),
-                     n_miss=n_miss, n_hit=n_hit, shapes=[tuple(p.shape) for p in params])
+                     n_miss=n_miss, n_hit=n_hit, n_hum=n_hum, shapes=[tuple(p.shape) for p in params])
         ctx.mark_non_differentiable(sl, sp)
         return rgb, dl, sl, sp
 
@@ -251,17 +260,17 @@ class MCShade(torch.autograd.Function):
         lib, st = L.lib, _st()
         f32 = dict(dtype=torch.float32, device=dev)
         Dd, Ds = cfg['diffuse_sample_num'], cfg['specular_sample_num']
-        n_miss, n_hit = S['n_miss'], S['n_hit']
+        n_miss, n_hit, n_hum = S['n_miss'], S['n_hit'], S['n_hum']
         fo, fi, fh = S['fo'], S['fi'], S['fh']
-        d_hr = torch.zeros((max(row_pad(n_miss), 64), 4), **f32) if fh else None
+        d_hr = torch.zeros((max(row_pad(n_hum), 64), 4), **f32) if fh else None
         d_or = torch.zeros((max(row_pad(n_miss), 64), 4), **f32)
         d_ir = torch.zeros((max(row_pad(n_hit), 64), 4), **f32)
         d_mat5 = torch.empty((Pn, 5), **f32)
         d_w = torch.zeros((Pn * Ds, 3), **f32)
         d_rgb_c, d_dl_c = d_rgb.contiguous(), (d_dl.contiguous() if d_dl is not None else None)     # locals: both live across the C call
-        L.check(lib.nero_mc_combine_bwd(_p(S['pt']), _p(S['dirs']), _p(S['depth']), _p(S['slot']),
+        L.check(lib.nero_mc_combine_bwd_h(_p(S['pt']), _p(S['dirs']), _p(S['depth']), _p(S['slot']),
                                         _p(fo['heads'][3] if fo else None), _p(fi['heads'][3] if fi else None),
-                                        _p(fh['heads'][3] if fh else None), _p(S['hmask']),
+                                        _p(fh['heads'][3] if fh else None), _p(S['hmask']), n_hum,
                                         C.c_float(cfg['light_exp_max']), C.c_float(cfg['inner_light_exp_max']), Pn, Dd, Ds,
                                         GEOMETRY_TYPES[cfg['geometry_type']], _p(d_rgb_c), _p(d_dl_c),
                                         _p(d_or), _p(d_ir), _p(d_hr), _p(d_mat5), _p(d_w), st))
@@ -284,15 +293,15 @@ class MCShade(torch.autograd.Function):
             put('outer_light', K.outer_light.weight_grads(fo, ob, n_miss, S['Xm'], None, head_dys={3: d_or}, workspace=ws, outs=outs_of('outer_light')))
             dXm = ob['d_init']
             if fh:
-                hb = K.human_light.backward(fh, n_miss, head_dys={3: d_hr}, need_dinit=True)
-                put('human_light', K.human_light.weight_grads(fh, hb, n_miss, S['Xhum'], None, head_dys={3: d_hr}, workspace=ws, outs=outs_of('human_light')))
+                hb = K.human_light.backward(fh, n_hum, head_dys={3: d_hr}, need_dinit=True)
+                put('human_light', K.human_light.weight_grads(fh, hb, n_hum, S['Xhum'], None, head_dys={3: d_hr}, workspace=ws, outs=outs_of('human_light')))
                 dXhum = hb['d_init']
         if n_hit > 0:
             ib = K.inner_light.backward(fi, n_hit, head_dys={3: d_ir}, need_dinit=True)
             put('inner_light', K.inner_light.weight_grads(fi, ib, n_hit, S['Xh'], None, head_dys={3: d_ir}, workspace=ws, outs=outs_of('inner_light')))
             dXh = ib['d_init']
-        L.check(lib.nero_mc_dir_bwd(_p(S['pt']), _p(S['dirs']), _p(S['fnrm']), _p(S['slot']), _p(K.tab_s), _p(dXm), _p(dXh), _p(d_w),
-                                    Pn, Dd, Ds, _p(d_mat5), K.sphere, _p(dXhum), _p(S['poses']), st))
+        L.check(lib.nero_mc_dir_bwd_h(_p(S['pt']), _p(S['dirs']), _p(S['fnrm']), _p(S['slot']), _p(K.tab_s), _p(dXm), _p(dXh), _p(d_w),
+                                      Pn, Dd, Ds, _p(d_mat5), K.sphere, _p(dXhum), _p(S['poses']), n_hum, st))
         grads = []
         for nm, shape in zip(S['names'], S['shapes']):
             if nm in inplace:

@@ -38,6 +38,7 @@ _lib.nero_stage2_pack.argtypes = [_fp, C.POINTER(Weights), _fp, _fp]
 _lib.nero_stage2_predict_fwd.argtypes = [_fp, _fp, C.c_int, _fp, _fp, C.c_size_t, _fp]
 _lib.nero_stage2_rays.argtypes = [_fp, C.c_int] + [_fp] * 11
 _lib.nero_stage2_dead_rays.restype = C.c_void_p
+_lib.nero_stage2_counts.argtypes = [_fp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
 _lib.nero_stage2_dead_rays.argtypes = [_fp]
 _lib.nero_stage2_shade_fwd.argtypes = [_fp] + [_fp] * 8 + [C.POINTER(C.c_int), C.POINTER(C.c_int), _fp]
 _lib.nero_stage2_shade_bwd.argtypes = [_fp, _fp, _fp, C.POINTER(Weights), _fp, _fp]
@@ -189,7 +190,9 @@ class MCShadeC(torch.autograd.Function):
         n_miss, n_hit = C.c_int(0), C.c_int(0)
         L.check(_lib.nero_stage2_shade_fwd(drv.h, _p(pos), _p(fnrm), _p(depth), _p(poses), _p(rgb), _p(dl), _p(sl), _p(sp), C.byref(n_miss),
                                            C.byref(n_hit), L.stream_ptr()))
-        drv.last_counts = (n_miss.value, n_hit.value, Pn * D)       # (miss rows, hit rows, rays: the rest are zero-weight rays nobody shades)
+        n_hum = C.c_int(0)
+        _lib.nero_stage2_counts(drv.h, None, None, C.byref(n_hum))
+        drv.last_counts = (n_miss.value, n_hit.value, Pn * D, n_hum.value)  # (miss rows, hit rows, rays -- the rest are zero-weight rays nobody shades --, human-light rows)
         ctx.drv, ctx.names, ctx.gv, ctx.shapes, ctx.P = drv, names, (gv or {}), [tuple(p.shape) for p in params], Pn
         ctx.keep = (pts, view, normals, mat5, rd, rs, poses, orig, dirs, pos, fnrm, depth)
         ctx.mark_non_differentiable(sl, sp)

@@ -328,23 +328,33 @@ def forced_gates_from_capture(capture, stage, n_primary, human=False, k_inner_li
     # which of the oracle's rows the HIP rows are; the oracle's extra rows get open gates (their outputs are multiplied by a weight of 0.0
     # and receive a gradient of 0.0, so the choice cannot matter).  Needs a tracer that reports the true hit of a dead ray too (tests.helpers.CTracer).
     split = next((r for r in capture if r.get('kind') == 'mc_split'), None)
-    live_of = {}
-    if split is not None:
-        live = split['slot'] != -2 ** 31
-        hit = split['depth'] < 10
-        live_of = {'hit': live[hit], 'miss': live[~hit]}
+    DEAD = -2 ** 31
+
+    def expand(g, rows):
+        """HIP rows -> the oracle's rows of the same MLP.  The oracle's rows are the hit rays ('hit') resp. the miss rays ('miss', 'hum') in
+        ray order; a ray's HIP row is its slot (hits: -slot - 1; round 6: the miss list is partitioned by the human-plane mask, and only the
+        miss rows [0, n_hum) own a row of the human-light MLP)"""
+        if split is None or rows is None:
+            return g
+        slot, hit = split['slot'].long(), split['depth'] < 10
+        sl = slot[hit] if rows == 'hit' else slot[~hit]
+        if rows == 'hit':
+            ok, idx = (sl != DEAD) & (sl < 0), -sl - 1
+        else:
+            ok, idx = (sl != DEAD) & (sl >= 0), sl
+            if rows == 'hum':
+                ok = ok & (sl < int(split.get('n_hum', 1 << 30)))
+        assert int(ok.sum()) == g.shape[0], (rows, int(ok.sum()), tuple(g.shape))
+        full = torch.ones((sl.numel(), g.shape[1]), dtype=g.dtype, device=g.device)
+        full[ok.to(g.device)] = g[idx[ok].to(g.device)]
+        return full
 
     def put_pred(prefix, rec, splits, rows=None):
         for call, (r0, n) in enumerate(splits):
             for i in range(3):
                 key = f'{prefix}@{call}/{i}'
                 put(key, rec['masks'][i], r0, n, rec['n_out'][i])
-                sel = live_of.get(rows)
-                if sel is not None and not bool(sel.all()):
-                    assert int(sel.sum()) == n, (key, int(sel.sum()), n)
-                    full = torch.ones((sel.numel(), rec['n_out'][i]), dtype=gates[key].dtype, device=gates[key].device)
-                    full[sel.to(gates[key].device)] = gates[key]
-                    gates[key] = full
+                gates[key] = expand(gates[key], rows)
     for rec in capture:
         if rec.get('kind') == 'mc_split':
             continue
@@ -375,7 +385,7 @@ def forced_gates_from_capture(capture, stage, n_primary, human=False, k_inner_li
         elif k == k_inner_weight and stage == 1:
             put_pred(f'{pre}.inner_weight', rec, [(0, n)])
         elif k == 24:
-            put_pred(f'{pre}.human_light_predictor' if stage == 1 else f'{pre}.human_light', rec, [(0, n)], rows='miss' if stage == 2 else None)
+            put_pred(f'{pre}.human_light_predictor' if stage == 1 else f'{pre}.human_light', rec, [(0, n)], rows='hum' if stage == 2 else None)
         else:
             raise AssertionError(('unrecognised chain in the mask capture', k, ka, rec['aux_wide'], n))
     return gates

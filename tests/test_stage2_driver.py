@@ -179,3 +179,33 @@ def test_skipping_the_zero_weight_rays_changes_nothing(drv, monkeypatch):
         assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-12
         off += n_
     assert float(f0.abs().max()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n', [1, 64, 1000, 1025, 300001])
+def test_mc_split_classes_partitions_the_miss_list_by_the_human_mask(n):
+    """nero_mc_split_classes (round 6): dead rays in neither list, hits in ray order, the miss list = the misses that reach the photographer's
+    region (ray order) followed by the other misses (ray order); counts = (n_miss, n_hit, n_hum)"""
+    from nero_amd import _lib as L
+    g = torch.Generator().manual_seed(n + 11)
+    depth = torch.where(torch.rand(n, generator=g) < 0.4, torch.rand(n, generator=g) * 2.0, torch.full((n,), 10.0)).cuda()
+    dead = (torch.rand(n, generator=g) < 0.15).to(torch.uint8).cuda()
+    hum = (torch.rand(n, generator=g) < 0.5).to(torch.uint8).cuda()
+    i32 = dict(dtype=torch.int32, device='cuda')
+    slot, mi, hi, counts = torch.full((n,), 12345, **i32), torch.empty(n, **i32), torch.empty(n, **i32), torch.empty(3, **i32)
+    tmp = torch.empty(L.lib.nero_mc_split_tmp_ints(n), **i32)
+    P = C.c_void_p
+    L.check(L.lib.nero_mc_split_classes(P(depth.data_ptr()), P(dead.data_ptr()), P(hum.data_ptr()), n, P(slot.data_ptr()), P(mi.data_ptr()),
+                                        P(hi.data_ptr()), P(counts.data_ptr()), P(tmp.data_ptr()), L.stream_ptr()))
+    live = dead == 0
+    hit = (depth < 10) & live
+    miss = ~hit & live
+    want_h = torch.nonzero(hit)[:, 0].int()
+    want_m = torch.cat([torch.nonzero(miss & (hum != 0))[:, 0], torch.nonzero(miss & (hum == 0))[:, 0]]).int()
+    n_miss, n_hit, n_hum = (int(v) for v in counts.cpu())
+    assert (n_miss, n_hit, n_hum) == (want_m.numel(), want_h.numel(), int((miss & (hum != 0)).sum()))
+    assert torch.equal(mi[:n_miss], want_m) and torch.equal(hi[:n_hit], want_h)
+    want_slot = torch.full((n,), -2 ** 31, **i32)
+    want_slot[want_m.long()] = torch.arange(n_miss, **i32)
+    want_slot[want_h.long()] = -torch.arange(n_hit, **i32) - 1
+    assert torch.equal(slot, want_slot)
