@@ -27,3 +27,6 @@ print(f'rays {rays}, samples per ray {T}, inner samples {n_in} ({n_in / rays:.1f
 for thr in (0.0, 1e-30, 1e-20, 1e-12, 1e-9, 1e-7):
     print(f'  inner samples with weight <= {thr:g}: {float((wi <= thr).float().mean()):.4f}')
 print('  all samples with weight == 0:', float((w == 0).float().mean()))
+occ = out['_occ_prob'].reshape(-1)
+print(f'  occlusion probability of the specular query (clamped to [0, 1] before it blends indirect and direct light, field.py:572-575): '
+      f'<= 0 (indirect-light MLP row exactly dead): {float((occ <= 0).float().mean()):.4f}; >= 1 (direct-light row of the specular query dead): {float((occ >= 1).float().mean()):.4f}')
