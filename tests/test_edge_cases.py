@@ -148,3 +148,40 @@ def test_stage2_every_secondary_ray_hits_the_mesh():
     rec = _stage2_teacher_forced('edge_s2_all_hit', 72, dict(diffuse_sample_num=16, specular_sample_num=32, **BELL2), inputs=I,
                                  mesh=(v, np.ascontiguousarray(f)), small_batch=True)
     assert rec['hit_fraction'] == 1.0
+
+
+@pytest.mark.parametrize('far', [True, False])
+def test_stage2_human_light_rows_follow_the_plane_mask(far, monkeypatch):
+    """Round 6: the human-light MLP owns a row only for the miss rays that reach the photographer's region of the camera plane.  far=True: the
+    cameras are moved 2000 units away, no ray reaches the region -> zero human-light rows, the step runs, the human-light weights get an exactly
+    zero gradient; far=False: some rows.  Both: the same loss / outputs / gradients as the step that gives every miss ray a row (NERO_MC_SKIP_DEAD=0)."""
+    from nero_amd.train import MaterialTrainStep
+    from tests.helpers import golden_mesh
+    N = 64
+    I = _material_inputs(N)
+    poses = I['poses'].clone()
+    if far:
+        poses[:, :, 3] = poses[:, :, 3] * 2000.0
+    scfg = dict(diffuse_sample_num=32, specular_sample_num=32, **BEAR2)
+    res = {}
+    for skip in ('1', '0'):
+        monkeypatch.setenv('NERO_MC_SKIP_DEAD', skip)
+        pool = {'pts': I['pts'], 'view': I['view'], 'normals': I['normals'], 'rgb': I['gt']}
+        pool = {k: v.contiguous().cuda() for k, v in pool.items()}
+        pool['img_idx'] = torch.arange(N, device='cuda')
+        ts = MaterialTrainStep({'shader_cfg': scfg, 'database_name': 'real/bear'}, golden_mesh(), points_per_rank=N, device='cuda:0',
+                               pool=(pool, poses.contiguous().cuda()))
+        rands = {k: I[k].cuda() for k in ('rand_d', 'rand_s', 'reg_ang', 'reg_eps')}
+        info = ts.forward_backward(5000, rands)
+        torch.cuda.synchronize()
+        n_miss, n_hit, n_rays, n_hum = ts.drv.last_counts
+        res[skip] = (float(info['loss']), info['out']['rgb_pr'].clone(), ts.bucket.flat.clone(), (n_miss, n_hit, n_hum), [p.numel() for p in ts.bucket.params])
+    (l1, r1, g1, c1, sizes), (l0, r0, g0, c0, _) = res['1'], res['0']
+    assert c0[2] == c0[0]                                        # every miss ray owns a row when nothing is skipped
+    assert (c1[2] == 0) if far else (0 < c1[2] < c1[0]), c1
+    assert abs(l1 - l0) <= 1e-6 * max(1.0, abs(l0)) and float((r1 - r0).abs().max()) <= 1e-6
+    off = 0
+    for n_ in sizes:
+        a, b = g0[off:off + n_], g1[off:off + n_]
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-12
+        off += n_
