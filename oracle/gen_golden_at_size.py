@@ -114,6 +114,27 @@ def run_case(name, extra):
         rec[f'tr/inds{i}'] = a[:N_TRACE].numpy().astype(np.int16)
         rec[f'tr/index{i}'] = b[:N_TRACE].numpy().astype(np.int16)
         assert a.max() <= n and b.shape[1] == n + rd['z_new'].shape[1]
+    # the reference's sampler once more in float64 on the SAME draws (torch.rand answers with the stored float32 draws): how far the reference's
+    # own float32 z_vals are from the exact ones -- the floor of every free-running comparison (tests: test_free_running_sampler_...)
+    net64 = build(renderer, cfg, seeds['seed'])
+    torch.set_default_dtype(torch.float64)
+    _rand = torch.rand
+    try:
+        net64 = net64.double()
+        queue = [rand1.double(), rand_bg.double()]
+        torch.rand = lambda *a, **k: queue.pop(0)
+        with torch.no_grad():
+            z_ref64 = net64.sample_ray(o.double(), d.double(), near.double(), far.double(), net64.cfg['perturb'])
+        assert not queue
+    finally:
+        torch.rand = _rand
+        torch.set_default_dtype(torch.float32)
+    del net64
+    rec['z_vals64'] = z_ref64.numpy().astype(np.float32)
+    nb_ = net.cfg['n_bg_samples']
+    dz_ = (z_ref64[:, :-nb_] - z_ref.double()[:, :-nb_]).abs()
+    print(f'{name}: reference sampler float32 vs float64: {float((dz_ < 1e-5).double().mean()):.4f} of the inner z equal to 1e-5, '
+          f'{float((dz_.max(-1)[0] < 1e-5).double().mean()):.4f} of the rays entirely', flush=True)
     print(f'{name}: sampler {time.time() - t0:.1f} s, round widths {[r["z"].shape[1] for r in rounds]}, inv_s {[r["inv_s"] for r in rounds]}', flush=True)
 
     # ---- 2. render + loss + backward on those z_vals, float32 and float64 -----------------------------------------------------------------
