@@ -277,12 +277,12 @@ def stage2_step_bench(dev, kind, P_, Dd, Ds, mesh, rank=0, world=1, warmup=5, st
         def trace_grouped(self, ro, rd, group, heavy_from):
             return self.trace(ro, rd, (group, heavy_from))
 
-        def trace_masked(self, ro, rd, skip):               # (round 6: the step hands over the flags of its zero-weight rays -- not traversed)
-            return self.trace(ro, rd, None, skip)
+        def trace_masked(self, ro, rd, skip, chunk_order=None):     # (round 6: the flags of the step's zero-weight rays -- not traversed -- and its launch order)
+            return self.trace(ro, rd, None, skip, chunk_order)
 
-        def trace(self, ro, rd, order=None, skip=None):
-            if skip is not None:
-                run = lambda: tracer.trace_masked(ro, rd, skip)
+        def trace(self, ro, rd, order=None, skip=None, chunk_order=None):
+            if skip is not None or chunk_order is not None:
+                run = lambda: tracer.trace_masked(ro, rd, skip, chunk_order=chunk_order)
             else:
                 run = (lambda: tracer.trace_grouped(ro, rd, *order)) if order is not None else (lambda: tracer.trace(ro, rd))
             if not rec['on']:

@@ -381,6 +381,12 @@ int nero_bvh_trace_grouped(void* handle, const float* rays_o, const float* rays_
  * (field.py:892-903, 979-987 with geometry_type 'schlick') and which are the longest rays of the launch (they cross the inside of the mesh). */
 int nero_bvh_trace_masked(void* handle, const float* rays_o, const float* rays_d, int n, const unsigned char* skip, float* positions,
                           float* face_normals, float* depth, void* stream);
+/* nero_bvh_trace_masked (skip may be NULL) with an explicit LAUNCH ORDER: rays in groups of n_order * 64; phase p of the launch holds chunk
+ * order[p] of every group (a permutation of 0 .. n_order-1, n_order <= 32, n % (64 n_order) == 0; anything else falls back to the natural order).
+ * Outputs identical to nero_bvh_trace_masked's.  Stage II starts the chunks in DESCENDING order: the later entries of both direction tables
+ * (field.py:741-749) are the grazing directions, the long traversals; with them first the launch no longer ends on a handful of waves. */
+int nero_bvh_trace_ordered(void* handle, const float* rays_o, const float* rays_d, int n, const unsigned char* skip, const int* order, int n_order,
+                           float* positions, float* face_normals, float* depth, void* stream);
 int nero_bvh_destroy(void* handle);
 /* which kernel nero_bvh_trace launches: 1 = memory requests of a traversal step overlapped, stack in LDS (default when the tree is no
  * deeper than the 24-entry LDS stack), 0 = private stack, one request after the other.  Same visit order and arithmetic per ray:

@@ -230,6 +230,7 @@ __device__ __forceinline__ void leaf_test_batched(const Tri* __restrict__ tris, 
 // boxes of a node tested and sorted per step, hit leaves queued one per step; its visit logic checked on the CPU against this kernel's:
 // same closest triangle on every ray) -- half the dependent steps per ray (36 -> 20), but 101 VGPRs and twice the box work per step:
 // 0.57 ms per 1 M synthetic rays against 0.51, 0.83 against 0.73 on the rays of a training step.
+struct ChunkOrder { int n; unsigned char c[32]; };            // n = 0: no explicit order
 constexpr int PL_THREADS = 64;
 constexpr int PL_STACK = 24;               // LDS stack entries per ray (6 KB per workgroup); deeper trees take trace_kernel
 
@@ -243,11 +244,14 @@ constexpr int PL_STACK = 24;               // LDS stack entries per ray (6 KB pe
 __global__ __launch_bounds__(PL_THREADS) void trace_overlap_kernel(const Node* __restrict__ nodes, const Tri* __restrict__ tris, int root,
                                                                    const float* __restrict__ ro, const float* __restrict__ rd, int n,
                                                                    float* __restrict__ pos, float* __restrict__ nrm, float* __restrict__ depth,
-                                                                   int gchunks, int heavy0, int n_groups, const unsigned char* __restrict__ skip) {
+                                                                   int gchunks, int heavy0, int n_groups, const unsigned char* __restrict__ skip,
+                                                                   ChunkOrder ord) {
     __shared__ int lds_stack[PL_STACK * PL_THREADS];
     int* const st = lds_stack + threadIdx.x;                                   // entry s of this lane: st[s * PL_THREADS]
     int chunk = blockIdx.x;
-    if (gchunks > 0 && chunk < n_groups * gchunks) {
+    if (ord.n > 0) {                                     // phase p = all groups' chunk ord.c[p]: the workgroups of a phase start together
+        if (chunk < n_groups * ord.n) chunk = (chunk % n_groups) * ord.n + ord.c[chunk / n_groups];
+    } else if (gchunks > 0 && chunk < n_groups * gchunks) {
         const int nh = gchunks - heavy0, heavy_total = n_groups * nh;
         if (chunk < heavy_total) chunk = (chunk / nh) * gchunks + heavy0 + chunk % nh;
         else { const int b = chunk - heavy_total; chunk = (b / heavy0) * gchunks + b % heavy0; }
@@ -379,7 +383,7 @@ int nero_bvh_trace(void* handle, const float* rays_o, const float* rays_d, int n
         return nero_check_launch("nero_bvh_trace");
     }
     hipLaunchKernelGGL(trace_overlap_kernel, dim3((n + PL_THREADS - 1) / PL_THREADS), dim3(PL_THREADS), 0, (hipStream_t)stream, h->b.d_nodes, h->b.d_tris,
-                       h->root, rays_o, rays_d, n, positions, face_normals, depth, 0, 0, 0, nullptr);
+                       h->root, rays_o, rays_d, n, positions, face_normals, depth, 0, 0, 0, nullptr, ChunkOrder{});
     return nero_check_launch("nero_bvh_trace");
 }
 
@@ -398,7 +402,7 @@ int nero_bvh_trace_masked(void* handle, const float* rays_o, const float* rays_d
         return nero_check_launch("nero_bvh_trace_masked");
     }
     hipLaunchKernelGGL(trace_overlap_kernel, dim3((n + PL_THREADS - 1) / PL_THREADS), dim3(PL_THREADS), 0, (hipStream_t)stream, h->b.d_nodes, h->b.d_tris,
-                       h->root, rays_o, rays_d, n, positions, face_normals, depth, 0, 0, 0, skip);
+                       h->root, rays_o, rays_d, n, positions, face_normals, depth, 0, 0, 0, skip, ChunkOrder{});
     return nero_check_launch("nero_bvh_trace_masked");
 }
 
@@ -414,8 +418,32 @@ int nero_bvh_trace_grouped(void* handle, const float* rays_o, const float* rays_
                     n > 0 && n % group == 0;
     if (!ok) return nero_bvh_trace(handle, rays_o, rays_d, n, positions, face_normals, depth, stream);
     hipLaunchKernelGGL(trace_overlap_kernel, dim3(n / PL_THREADS), dim3(PL_THREADS), 0, (hipStream_t)stream, h->b.d_nodes, h->b.d_tris, h->root,
-                       rays_o, rays_d, n, positions, face_normals, depth, group / PL_THREADS, heavy_from / PL_THREADS, n / group, nullptr);
+                       rays_o, rays_d, n, positions, face_normals, depth, group / PL_THREADS, heavy_from / PL_THREADS, n / group, nullptr, ChunkOrder{});
     return nero_check_launch("nero_bvh_trace_grouped");
+}
+
+// nero_bvh_trace_masked with an explicit LAUNCH ORDER (round 6).  The rays come in groups of n_order * 64 (Stage II: the D directions of a
+// surface point); phase p of the launch holds chunk order[p] (64 rays) of EVERY group, so the workgroups of the chunks named first start first.
+// Stage II passes the chunks in descending order: both direction tables run from the pole of their lobe outwards (field.py:741-749), the
+// later entries of a table are the grazing directions -- the long traversals -- and a launch that ends with them runs its last
+// hundreds of microseconds on a handful of resident waves (tracer 0.69 -> 0.57 ms per C4 step).  Same rays, same arithmetic, same outputs at the
+// same addresses.  order: a permutation of 0 .. n_order-1, n_order <= 32, n % (64 n_order) == 0, LDS-stack kernel only; anything else: natural order.
+int nero_bvh_trace_ordered(void* handle, const float* rays_o, const float* rays_d, int n, const unsigned char* skip, const int* order, int n_order,
+                           float* positions, float* face_normals, float* depth, void* stream) {
+    if (!handle || !rays_o || !rays_d || !positions || !face_normals || !depth) return nero_fail(NERO_ERR_ARG, "nero_bvh_trace_ordered: bad argument");
+    Handle* h = (Handle*)handle;
+    bool ok = h->mode != 0 && order && n_order > 0 && n_order <= 32 && n > 0 && n % (n_order * PL_THREADS) == 0;
+    ChunkOrder ord{};
+    unsigned seen = 0;
+    for (int i = 0; ok && i < n_order; ++i) {
+        if (order[i] < 0 || order[i] >= n_order || (seen >> order[i] & 1u)) ok = false;
+        else { seen |= 1u << order[i]; ord.c[i] = (unsigned char)order[i]; }
+    }
+    if (!ok) return nero_bvh_trace_masked(handle, rays_o, rays_d, n, skip, positions, face_normals, depth, stream);
+    ord.n = n_order;
+    hipLaunchKernelGGL(trace_overlap_kernel, dim3(n / PL_THREADS), dim3(PL_THREADS), 0, (hipStream_t)stream, h->b.d_nodes, h->b.d_tris, h->root,
+                       rays_o, rays_d, n, positions, face_normals, depth, 0, 0, n / (n_order * PL_THREADS), skip, ord);
+    return nero_check_launch("nero_bvh_trace_ordered");
 }
 
 int nero_bvh_set_traversal(void* handle, int mode) {

@@ -196,9 +196,11 @@ class MCShade(torch.autograd.Function):
             L.check(lib.nero_mc_dead_rays(_p(pt), _p(dirs), Pn, Dd, Ds, geom, _p(dead), st))
         tg = getattr(tracer, 'trace_grouped', None)
         tm = getattr(tracer, 'trace_masked', None)
-        if tm is not None and dead is not None:
-            pos, fnrm, depth = tm(orig, dirs, dead)
-        elif tg is not None and os.environ.get('NERO_TRACE_ORDER', 'natural') == 'grouped':
+        from .stage2 import descending_chunks
+        order = descending_chunks(D) if tm is not None else None
+        if tm is not None and (dead is not None or order is not None):
+            pos, fnrm, depth = tm(orig, dirs, dead, chunk_order=order)
+        elif tg is not None and os.environ.get('NERO_TRACE_ORDER', 'descending') == 'grouped':
             pos, fnrm, depth = tg(orig, dirs, D, Dd)
         else:
             pos, fnrm, depth = tracer.trace(orig, dirs)

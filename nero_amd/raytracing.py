@@ -40,12 +40,14 @@ class RayTracer:
         group started first (Stage II: the specular directions of a surface point).  Same outputs as trace()."""
         return self.trace(rays_o, rays_d, inplace, _order=(int(group), int(heavy_from)))
 
-    def trace_masked(self, rays_o, rays_d, skip, inplace=False):
-        """trace() that does not traverse the rays flagged in `skip` (uint8 tensor [n] or a device pointer; nero_bvh_trace_masked): they are
-        reported as misses.  Every other ray: the outputs of trace() bit for bit."""
-        return self.trace(rays_o, rays_d, inplace, _skip=skip)
+    def trace_masked(self, rays_o, rays_d, skip, inplace=False, chunk_order=None):
+        """trace() that does not traverse the rays flagged in `skip` (uint8 tensor [n] or a device pointer, or None; nero_bvh_trace_masked): they
+        are reported as misses.  Every other ray: the outputs of trace() bit for bit.  chunk_order: a permutation of range(k) -- the rays come
+        in groups of 64 k and the launch starts chunk chunk_order[0] of every group first, then chunk_order[1], ... (nero_bvh_trace_ordered:
+        same outputs, another launch order)."""
+        return self.trace(rays_o, rays_d, inplace, _skip=skip, _chunks=chunk_order)
 
-    def trace(self, rays_o, rays_d, inplace=False, _order=None, _skip=None):
+    def trace(self, rays_o, rays_d, inplace=False, _order=None, _skip=None, _chunks=None):
         rays_o = rays_o.float().contiguous()
         rays_d = rays_d.float().contiguous()
         if not rays_o.is_cuda:
@@ -61,7 +63,13 @@ class RayTracer:
         depth = torch.empty(n, dtype=torch.float32, device=rays_o.device)
         if inplace:                      # the kernel reads o/d before it writes: each thread owns its ray
             pass
-        if _skip is not None:
+        if _chunks is not None:
+            sp = None if _skip is None else (_skip.data_ptr() if torch.is_tensor(_skip) else int(_skip))
+            arr = (C.c_int * len(_chunks))(*[int(c) for c in _chunks])
+            L.check(L.lib.nero_bvh_trace_ordered(self._handle(), C.c_void_p(rays_o.data_ptr()), C.c_void_p(rays_d.data_ptr()), n, C.c_void_p(sp), arr,
+                                                 len(_chunks), C.c_void_p(positions.data_ptr()), C.c_void_p(face_normals.data_ptr()),
+                                                 C.c_void_p(depth.data_ptr()), L.stream_ptr()))
+        elif _skip is not None:
             sp = _skip.data_ptr() if torch.is_tensor(_skip) else int(_skip)
             if torch.is_tensor(_skip):
                 assert _skip.dtype == torch.uint8 and _skip.is_cuda and _skip.numel() == n and _skip.is_contiguous()

@@ -152,6 +152,16 @@ class PredictMaterialsC(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(fresh.get(nm) for nm in ctx.names)
 
 
+def descending_chunks(D):
+    """launch order of the 64-ray chunks of a surface point's D secondary rays for RayTracer.trace_masked: descending.  Both direction tables run
+    from the pole of their lobe outwards (network/field.py:741-749), so the later entries -- of the cosine table and of the GGX table alike -- are
+    the grazing directions, the long BVH traversals; started first, they no longer end the launch on a handful of resident waves (tracer
+    0.69 -> 0.57 ms per C4 step; same outputs).  None when D is not a whole number of chunks (<= 32), or with NERO_TRACE_ORDER=natural."""
+    if D % 64 or D // 64 > 32 or D // 64 < 2 or os.environ.get('NERO_TRACE_ORDER', 'descending') == 'natural':
+        return None
+    return list(range(D // 64 - 1, -1, -1))
+
+
 class MCShadeC(torch.autograd.Function):
     """nero_amd.material_step.MCShade through nero_stage2_rays / _shade_fwd / _shade_bwd"""
 
@@ -179,9 +189,10 @@ class MCShadeC(torch.autograd.Function):
         tg = getattr(tracer, 'trace_grouped', None)
         tm = getattr(tracer, 'trace_masked', None)
         dead = _lib.nero_stage2_dead_rays(drv.h)
-        if tm is not None and dead:
-            pos, fnrm, depth = tm(orig, dirs, dead)
-        elif tg is not None and os.environ.get('NERO_TRACE_ORDER', 'natural') == 'grouped':
+        order = descending_chunks(D) if tm is not None else None
+        if tm is not None and (dead or order is not None):
+            pos, fnrm, depth = tm(orig, dirs, dead, chunk_order=order)
+        elif tg is not None and os.environ.get('NERO_TRACE_ORDER', 'descending') == 'grouped':
             pos, fnrm, depth = tg(orig, dirs, D, drv.Dd)
         else:
             pos, fnrm, depth = tracer.trace(orig, dirs)

@@ -133,3 +133,32 @@ def test_masked_trace_skips_the_flagged_rays_only(mode):
     none = rt.trace_masked(o, d, torch.zeros(n, dtype=torch.uint8, device='cuda'))
     for a, b in zip(plain, none):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('n_pts,k,order', [(300, 4, [3, 2, 1, 0]), (97, 12, list(range(11, -1, -1))), (64, 2, [1, 0]), (50, 4, [2, 0, 3, 1])])
+def test_ordered_launch_is_bit_identical_to_the_natural_order(n_pts, k, order):
+    """nero_bvh_trace_ordered (round 6): phase p of the launch holds chunk order[p] of every group of 64 k rays -- same rays, same arithmetic,
+    same outputs at the same addresses as nero_bvh_trace / _masked, with and without a skip mask; an order that is not a permutation, or a ray
+    count that is not a whole number of groups, falls back to the natural order"""
+    from nero_amd.raytracing import RayTracer
+    from nero_amd.synthetic import icosphere, secondary_rays
+    v, f = icosphere(5, 0.5, 0.2)
+    f = np.ascontiguousarray(f[:, ::-1])
+    rt = RayTracer(v, f)
+    o, d = secondary_rays(v, f, n_pts, 64 * k, seed=n_pts)
+    o, d = o.cuda().contiguous(), d.cuda().contiguous()
+    n = o.shape[0]
+    plain = [x.clone() for x in rt.trace(o, d)]
+    assert 0.05 < float((plain[2] < 10).float().mean()) < 0.95
+    got = rt.trace_masked(o, d, None, chunk_order=order)
+    for a, b in zip(plain, got):
+        assert torch.equal(a, b), int((a != b).sum())
+    skip = (torch.rand(n, generator=torch.Generator().manual_seed(k)) < 0.25).to(torch.uint8).cuda()
+    masked = [x.clone() for x in rt.trace_masked(o, d, skip)]
+    both = rt.trace_masked(o, d, skip, chunk_order=order)
+    for a, b in zip(masked, both):
+        assert torch.equal(a, b)
+    for bad, m in (([0] * k, n), (order, n - 64)):                  # not a permutation / not whole groups: natural order, same result
+        odd = rt.trace_masked(o[:m], d[:m], None, chunk_order=bad)
+        for a, b in zip(plain, odd):
+            assert torch.equal(a[:m], b)
